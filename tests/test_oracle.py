@@ -1,0 +1,319 @@
+"""CPU tests that PIN the oracle (oracle/lsq_oracle.c) before anything is compared against it:
+
+* hand-derived known-answer trajectories KAT-DL / KAT-LM,
+* scipy's LSMR (same Fong-Saunders algorithm) and the LAPACK routines Julia dispatches to
+  (dgeqp3, dgelsy == ldiv!(::QRPivoted), dpotrf, dpstrf),
+* the outcome pins of the reference's own tests (ssr <= 1e-3 on MINPACK, ssr <= 12 & converged
+  on the factor model, |x - x*| <= 1e-6 & g_converged on the bounds problems).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg.lapack as lapack
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import problems as P
+from oracle import oracle as O
+
+EPS = np.finfo(float).eps
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def run(p, optimizer, solver, sparse=False, **kw):
+    name, f, g, x0 = p[:4]
+    n = len(x0)
+    out = np.zeros(64)
+    f(out, x0)  # size the output like optimize() does (types.jl:183)
+    m = n
+    if sparse:
+        J = O.Mat(csc=(*P.full_csc_pattern(m, n), np.zeros(m * n)))
+    else:
+        J = O.Mat(dense=np.zeros((m, n)))
+    ff, gg = P.wrap_dense(f, g, m, n)
+    return O.optimize(optimizer, solver, J, x0, ff, gg, **kw)
+
+
+# ------------------------------------------------------------------------- known-answer tests
+def test_kat_dogleg_rosenbrock():
+    """SURVEY 8c KAT-DL: README Rosenbrock, x0 = 0, Dogleg(QR()), Delta0 = 1."""
+    r = run(P.readme_rosenbrock(), O.DOGLEG, O.QR, iterations=2)
+    t = r.trace
+    assert t["rho"][0] == pytest.approx(-9999.0, rel=1e-13)
+    assert t["delta"][0] == 0.5 and t["accept"][0] == 0
+    assert t["rho"][1] == pytest.approx(-624.25 / 0.75, rel=1e-13)
+    assert t["delta"][1] == 0.25 and t["accept"][1] == 0
+    assert np.all(t["x"] == 0.0)          # both steps rejected, x restored exactly
+    assert t["ssr"][1] == 1.0 and t["gnorm"][0] == 1.0
+    assert r.f_calls == 3 and r.g_calls == 1  # reuse=true: Jacobian not re-evaluated
+    assert r.mul_calls == 2 + 1 + 1 + 1       # J'f, J dgr, ldiv (1), J dx ; then J dx
+
+
+def test_kat_lm_rosenbrock():
+    """SURVEY 8c KAT-LM: same problem, LevenbergMarquardt() (dense => QR), Delta0 = 10."""
+    r = run(P.readme_rosenbrock(), O.LM, O.QR, iterations=1)
+    t = r.trace
+    # damp = (0.1, 1000) => dx = (-1/1.1, 0); trial ssr ~ 6830.14; predicted 0.0082645
+    assert t["rho"][0] == pytest.approx((1 - (1 - 1 / 1.1) ** 2 - 1e4 * (1 / 1.1) ** 4) /
+                                        abs(1 - (1 - 1 / 1.1) ** 2), rel=1e-12)
+    assert t["rho"][0] == pytest.approx(-6886.05, rel=1e-5)
+    assert t["delta"][0] == 5.0 and t["accept"][0] == 0
+    assert r.g_calls == 1 and r.f_calls == 2
+
+
+# ------------------------------------------------------------------------------- kernels
+def rand_csc(m, n, density, seed):
+    rng = np.random.default_rng(seed)
+    S = sp.random(m, n, density=density, format="csc", random_state=rng,
+                  data_rvs=rng.standard_normal)
+    S.sort_indices()
+    return S
+
+
+def test_sparse_kernels_match_scipy():
+    S = rand_csc(300, 70, 0.08, 1)
+    A = O.Mat.from_scipy(S)
+    rng = np.random.default_rng(2)
+    x, y = rng.standard_normal(70), rng.standard_normal(300)
+    assert np.allclose(O.colsumabs2(A), np.asarray(S.multiply(S).sum(axis=0)).ravel(), rtol=1e-14)
+    assert np.allclose(O.rowsumabs2(A), np.asarray(S.multiply(S).sum(axis=1)).ravel(), rtol=1e-14)
+    y0 = rng.standard_normal(300)
+    assert np.allclose(O.mul(A, x, 1.5, -0.5, y0), 1.5 * S @ x - 0.5 * y0, rtol=1e-13, atol=1e-13)
+    x0 = rng.standard_normal(70)
+    assert np.allclose(O.mulT(A, y, -2.0, 0.25, x0), -2 * S.T @ y + 0.25 * x0, rtol=1e-13, atol=1e-13)
+    # beta == 0 overwrites (kills NaN), like _rmul_or_fill! [stdlib]
+    assert np.all(np.isfinite(O.mul(A, x, 1.0, 0.0, np.full(300, np.nan))))
+
+
+def test_dense_kernels():
+    rng = np.random.default_rng(3)
+    D = rng.standard_normal((40, 7))
+    A = O.Mat(dense=D)
+    x, y = rng.standard_normal(7), rng.standard_normal(40)
+    assert np.allclose(O.colsumabs2(A), (D * D).sum(0))
+    assert np.allclose(O.mul(A, x), D @ x)
+    assert np.allclose(O.mulT(A, y), D.T @ y)
+    w = rng.random(7)
+    assert O.wdot(x, x, w) == pytest.approx(np.sum(w * x * x))
+
+
+def test_projected_gradient():
+    g = np.array([1.0, -2.0, 3.0])
+    x = np.array([0.0, 5.0, 1.0])
+    assert O.maxabs_projected_gradient(g, x) == 3.0
+    # x0 at lower bound with g>0 dropped; x1 at upper bound with g<0 dropped
+    assert O.maxabs_projected_gradient(g, x, lower=[0, -9, 1], upper=[9, 5, 9]) == 0.0
+    assert O.maxabs_projected_gradient(g, x, lower=[0, -9, -9]) == 3.0
+
+
+# ------------------------------------------------------------------------------- LSMR
+@pytest.mark.parametrize("m,n,seed", [(200, 50, 0), (120, 50, 1), (400, 30, 2)])
+def test_lsmr_matches_scipy(m, n, seed):
+    """Same algorithm as scipy.sparse.linalg.lsmr; scipy lets later tests override istop while
+    the reference breaks on first hit (lsmr.jl:224-231) -- same exit iteration."""
+    S = rand_csc(m, n, 0.2, seed)
+    b = np.random.default_rng(seed + 10).standard_normal(m)
+    r = O.lsmr(O.Mat.from_scipy(S), b, atol=1e-10, btol=1e-10)
+    xs, istop, itn, normr, normar, *_ = spla.lsmr(S, b, atol=1e-10, btol=1e-10, conlim=1e8,
+                                                   maxiter=max(m, n))
+    assert r["iter"] == itn
+    # run to atol=btol=1e-10: the two implementations agree to the solve tolerance
+    assert np.allclose(r["x"], xs, rtol=1e-6, atol=1e-9)
+    assert r["normr"] == pytest.approx(normr, rel=1e-7)
+
+
+def test_lsmr_damped_preconditioned_operator():
+    """LM path (iterative_lsmr.jl:238-259): lsmr on [J; diag(sqrt(damp))] P vs scipy on the explicit
+    matrix, btol = 0.5."""
+    m, n = 120, 40
+    S = rand_csc(m, n, 0.15, 5)
+    rng = np.random.default_rng(6)
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.1
+    st, x, nmul, dsq = O.ldiv(O.LSMR, O.Mat.from_scipy(S), y, damp)
+    assert st == 0 and np.allclose(dsq, np.sqrt(damp))  # damp clobbered (:252)
+    P_ = 1 / np.sqrt(np.asarray(S.multiply(S).sum(0)).ravel() + damp)
+    Aexp = sp.vstack([S, sp.diags(np.sqrt(damp))]) @ sp.diags(P_)
+    xs, istop, itn, *_ = spla.lsmr(Aexp, np.concatenate([y, np.zeros(n)]), atol=1e-6, btol=0.5,
+                                   conlim=1e8, maxiter=m + n)
+    assert nmul == 2 * itn
+    assert np.allclose(x, P_ * xs, rtol=1e-9, atol=1e-12)
+
+
+def test_lsmr_zero_rhs_and_undamped():
+    S = rand_csc(60, 20, 0.3, 7)
+    A = O.Mat.from_scipy(S)
+    st, x, nmul = O.ldiv(O.LSMR, A, np.zeros(60))
+    assert nmul == 0 and np.all(x == 0)  # ||A'b|| == 0 early exit (lsmr.jl:115)
+    y = np.random.default_rng(8).standard_normal(60)
+    st, x, nmul = O.ldiv(O.LSMR, A, y)
+    xl = np.linalg.lstsq(S.toarray(), y, rcond=None)[0]
+    assert np.allclose(x, xl, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- Cholesky
+def test_potrf_pstrf_match_lapack():
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((30, 12))
+    A = B.T @ B + 0.1 * np.eye(12)
+    info, U = O.potrf_upper(A)
+    Ul, il = lapack.dpotrf(A, lower=0)
+    assert info == 0 and il == 0 and np.allclose(U, np.triu(Ul), rtol=1e-12)
+    info, U, piv, rank = O.pstrf_upper(A)
+    Ul, pl, rl, il = lapack.dpstrf(A, lower=0)
+    assert info == il == 0 and rank == rl == 12
+    assert np.array_equal(piv + 1, pl) and np.allclose(U, np.triu(Ul), rtol=1e-11)
+    # not positive definite -> PosDefException position
+    A2 = A.copy()
+    A2[5, 5] = -1.0
+    assert O.potrf_upper(A2)[0] == lapack.dpotrf(A2, lower=0)[1] == 6
+    # rank deficient -> RankDeficientException
+    B = rng.standard_normal((30, 5))
+    A3 = (B @ rng.standard_normal((5, 12)))
+    A3 = A3.T @ A3
+    assert O.pstrf_upper(A3, tol=-1.0)[3] == lapack.dpstrf(A3, lower=0, tol=-1.0)[2] == 5
+
+
+def test_ldiv_cholesky():
+    rng = np.random.default_rng(12)
+    D = rng.standard_normal((50, 9))
+    y = rng.standard_normal(50)
+    damp = rng.random(9)
+    st, x, nmul, _ = O.ldiv(O.CHOLESKY, O.Mat(dense=D), y, damp)
+    assert st == 0 and nmul == 1
+    assert np.allclose(x, np.linalg.solve(D.T @ D + np.diag(damp), D.T @ y), rtol=1e-10)
+    st, x, nmul = O.ldiv(O.CHOLESKY, O.Mat(dense=D), y)
+    assert st == 0 and np.allclose(x, np.linalg.lstsq(D, y, rcond=None)[0], rtol=1e-9)
+    D[:, 3] = D[:, 1]  # exactly rank deficient -> RankDeficientException (Dogleg) ...
+    assert O.ldiv(O.CHOLESKY, O.Mat(dense=D), y)[0] == O.ERANK
+    D[:, 3] = 0.0      # ... zero column: J'J singular, undamped potrf hits a zero pivot
+    assert O.ldiv(O.CHOLESKY, O.Mat(dense=D), y, np.zeros(9))[0] == O.ENOTPD
+
+
+# ------------------------------------------------------------------------------- pivoted QR
+@pytest.mark.parametrize("m,n,rank", [(40, 10, 10), (12, 12, 12), (30, 12, 7), (9, 6, 5), (20, 8, 1),
+                                      (6, 10, 6), (6, 10, 4)])
+def test_qr_solve_matches_gelsy(m, n, rank):
+    """orc_geqp3 + orc_qrp_solve == LAPACK dgelsy with rcond = min(m,n)*eps, which is the
+    algorithm of LinearAlgebra.ldiv!(::QRPivoted, b) [stdlib] (dense_qr.jl:37,83)."""
+    rng = np.random.default_rng(100 + m + n + rank)
+    A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n))
+    b = rng.standard_normal(m)
+    x, rk, jp, fac, tau = O.qr_solve(A, b)
+    qr_l, jp_l, tau_l, _, info = lapack.dgeqp3(A)
+    # pivots / R rows beyond the numerical rank are round-off noise: compare the leading part
+    assert np.array_equal(jp[:rank] + 1, jp_l[:rank])
+    assert np.allclose(np.triu(fac[:rank])[:, :rank], np.triu(qr_l[:rank])[:, :rank], rtol=1e-9, atol=1e-11)
+    lu = max(m, n)
+    bb = np.zeros((lu, 1))
+    bb[:m, 0] = b
+    lw = lapack.dgelsy_lwork(m, n, 1, min(m, n) * EPS)[0]
+    _, xg, _, rk_l, info = lapack.dgelsy(A, bb, np.zeros(n, dtype=np.int32), min(m, n) * EPS,
+                                         int(lw))
+    assert rk == rk_l == rank
+    assert np.allclose(x, xg[:n, 0], rtol=1e-8, atol=1e-10)
+    # minimum-norm property
+    assert np.allclose(x, np.linalg.pinv(A, rcond=1e-10) @ b, rtol=1e-7, atol=1e-9)
+
+
+def test_qr_zero_matrix_returns_zero():
+    x, rk, *_ = O.qr_solve(np.zeros((5, 3)), np.ones(5))
+    assert rk == 0 and np.all(x == 0)
+
+
+def test_ldiv_qr_damped_stacked():
+    rng = np.random.default_rng(13)
+    D = rng.standard_normal((30, 6))
+    y = rng.standard_normal(30)
+    damp = rng.random(6) + 0.01
+    st, x, nmul, dafter = O.ldiv(O.QR, O.Mat(dense=D), y, damp)
+    assert st == 0 and nmul == 1 and np.array_equal(dafter, damp)  # QR does not clobber damp
+    assert np.allclose(x, np.linalg.solve(D.T @ D + np.diag(damp), D.T @ y), rtol=1e-10)
+
+
+# ------------------------------------------------------- outcome pins of the reference's tests
+GRID = [(O.DOGLEG, O.QR, False), (O.LM, O.QR, False), (O.DOGLEG, O.LSMR, False),
+        (O.LM, O.LSMR, False), (O.DOGLEG, O.LSMR, True), (O.LM, O.LSMR, True)]
+
+
+@pytest.mark.parametrize("optimizer,solver,sparse", GRID)
+def test_minpack_outcomes(optimizer, solver, sparse):
+    """test/nonlinearsolvers.jl:505-537: ssr <= 1e-3 on all 21 instances."""
+    for p in P.minpack_all():
+        r = run(p, optimizer, solver, sparse, trace=False)
+        assert r.status == 0 and r.ssr <= 1e-3, (P.label(p), r.ssr)
+
+
+@pytest.mark.parametrize("optimizer", [O.DOGLEG, O.LM])
+def test_minpack_cholesky_outcomes(optimizer):
+    """test/nonlinearsolvers.jl:573-595: converged and ssr <= 1e-3 on the 18-instance list."""
+    for p in P.minpack_cholesky():
+        r = run(p, optimizer, O.CHOLESKY, trace=False)
+        assert r.status == 0 and r.converged and r.ssr <= 1e-3, (P.label(p), r.ssr)
+
+
+@pytest.mark.parametrize("optimizer", [O.DOGLEG, O.LM])
+def test_factor_model(optimizer):
+    """test/nonlinearleastsquares.jl:96-110: J'J singular; ssr <= 12 and converged for dense QR
+    (pins the minimum-norm behaviour of the pivoted-QR solve) and sparse LSMR."""
+    name, f, g, x0 = P.factor_dense()
+    ff, gg = P.wrap_dense(f, g, 9, 6)
+    r = O.optimize(optimizer, O.QR, O.Mat(dense=np.zeros((9, 6))), x0, ff, gg)
+    assert r.converged and r.ssr <= 12
+    name, f, gs, x0, pat = P.factor_sparse()
+    r = O.optimize(optimizer, O.LSMR, O.Mat(csc=(*pat, np.zeros(18))), x0, f, gs)
+    assert r.converged and r.ssr <= 12
+
+
+@pytest.mark.parametrize("optimizer", [O.DOGLEG, O.LM])
+def test_bounds(optimizer):
+    """test/bounds.jl:7-38 (with analytic Jacobians instead of finite differences)."""
+    def go(p, **kw):
+        name, f, g, x0 = p
+        ff, gg = P.wrap_dense(f, g, 2, 2)
+        return O.optimize(optimizer, O.QR, O.Mat(dense=np.zeros((2, 2))), x0, ff, gg, **kw)
+
+    r = go(P.readme_rosenbrock(), lower=[0.0, 0.0])
+    assert r.converged and np.all(r.minimizer >= -1e-8)
+    assert np.linalg.norm(r.minimizer - [1, 1]) <= 1e-6
+    r = go(P.bound_lower_active(), lower=[1.0, -100.0], x_tol=1e-50, f_tol=1e-50)
+    assert r.converged and r.g_converged and np.linalg.norm(r.minimizer - [1, 3]) <= 1e-6
+    r = go(P.bound_upper_active(), upper=[2.0, 100.0], x_tol=1e-50, f_tol=1e-50)
+    assert r.converged and r.g_converged and np.linalg.norm(r.minimizer - [2, 2]) <= 1e-6
+    # levenberg_marquardt.jl:49-51 / dogleg.jl:52-54: infeasible start is an ArgumentError
+    assert go(P.readme_rosenbrock(), lower=[1.0, 1.0]).status == O.EBOUNDS
+
+
+def test_nonfinite_x_raises():
+    """utils.jl:70-75 IsFiniteException."""
+    name, f, g, x0 = P.readme_rosenbrock()
+    ff, gg = P.wrap_dense(f, g, 2, 2)
+    r = O.optimize(O.LM, O.QR, O.Mat(dense=np.zeros((2, 2))), [np.nan, 0.0], ff, gg)
+    assert r.status == O.ENONFINITE and r.bad_index == 0
+
+
+def test_qr_on_sparse_rejected():
+    """types.jl:115-117."""
+    name, f, gs, x0, pat = P.factor_sparse()
+    r = O.optimize(O.DOGLEG, O.QR, O.Mat(csc=(*pat, np.zeros(18))), x0, f, gs)
+    assert r.status == O.EDIM
+
+
+# ----------------------------------------------------------------- committed golden trajectories
+def test_golden_trajectories():
+    """tests/golden/minpack_oracle.json (made by tests/golden/make_golden.py FROM THE ORACLE; it
+    guards the oracle against regressions -- it is not a Julia run)."""
+    with open(os.path.join(GOLDEN, "minpack_oracle.json")) as fh:
+        gold = json.load(fh)
+    names = {"dogleg": O.DOGLEG, "lm": O.LM, "qr": O.QR, "cholesky": O.CHOLESKY, "lsmr": O.LSMR}
+    probs = {P.label(p): p for p in P.minpack_all()}
+    assert len(gold["runs"]) >= 100
+    for rec in gold["runs"]:
+        r = run(probs[rec["problem"]], names[rec["optimizer"]], names[rec["solver"]],
+                rec["sparse"], trace=False)
+        assert r.iterations == rec["iterations"], rec
+        assert (r.f_calls, r.g_calls, r.mul_calls) == (rec["f_calls"], rec["g_calls"], rec["mul_calls"])
+        assert r.converged == rec["converged"]
+        assert np.allclose(r.minimizer, rec["x"], rtol=1e-9, atol=1e-11)
