@@ -1,0 +1,190 @@
+/*
+ * lsqhip.h -- C ABI of the MI355X (gfx950) nonlinear-least-squares hot path.
+ *
+ * This is the drop-in boundary for LeastSquaresOptim.jl's linear-algebra inner loop.  The reference
+ * has no FFI layer: its plug points are Julia multiple dispatch on AbstractAllocatedSolver and a
+ * duck-typed operator interface.  Every entry point below names the reference interface it
+ * replaces (file:line relative to the reference repo); INTEGRATION.md shows the `ccall` shim a
+ * maintainer would add on the Julia side.
+ *
+ * Conventions: plain pointers and sizes only; `double*` arguments named d_* are DEVICE pointers
+ * (fp64), h_* are host pointers; matrices are column-major; indices are 0-based int32; every call
+ * returns an lsq_status (0 = ok) and never aborts; lsq_last_error() gives the message.
+ * All work is enqueued on the context's HIP stream; calls that return host scalars synchronise it.
+ */
+#ifndef LSQHIP_H
+#define LSQHIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LSQ_OK = 0,
+    LSQ_EDIM = 1,       /* DimensionMismatch / ArgumentError (types.jl:14-15, dense_qr.jl:10,61) */
+    LSQ_ENOTPD = 2,     /* PosDefException from cholesky! (dense_cholesky.jl:57) */
+    LSQ_ERANK = 3,      /* RankDeficientException from pivoted cholesky! (dense_cholesky.jl:33) */
+    LSQ_ENONFINITE = 4, /* IsFiniteException (utils.jl:63-75) */
+    LSQ_EBOUNDS = 5,    /* "Initial guess must be within bounds" (levenberg_marquardt.jl:51) */
+    LSQ_EHIP = 6,       /* a HIP runtime call failed */
+    LSQ_EARG = 7,       /* invalid argument (e.g. QR on a sparse Jacobian, types.jl:115-117) */
+    LSQ_ECALLBACK = 8   /* a user callback reported failure */
+} lsq_status;
+
+typedef struct lsq_ctx lsq_ctx;       /* one per device/stream; not thread-safe */
+typedef struct lsq_mat lsq_mat;       /* Jacobian: dense column-major or CSC (+CSR mirror) */
+typedef struct lsq_solver lsq_solver; /* AbstractAllocatedSolver (types.jl:138-139) */
+typedef struct lsq_model lsq_model;   /* built-in device-side f!/g! (synthetic benchmarks) */
+
+typedef enum { LSQ_QR = 0, LSQ_CHOLESKY = 1, LSQ_LSMR = 2 } lsq_solver_kind;       /* types.jl:79-86 */
+typedef enum { LSQ_DOGLEG = 0, LSQ_LEVENBERG_MARQUARDT = 1 } lsq_optimizer_kind;   /* types.jl:90-98 */
+
+const char *lsq_last_error(void);
+int lsq_version(void);
+
+/* ---- context & raw device memory (Julia GC owns nothing here; explicit create/destroy) ---- */
+int lsq_ctx_create(int device, void *hip_stream_or_null, lsq_ctx **out);
+int lsq_ctx_destroy(lsq_ctx *ctx);
+int lsq_ctx_sync(lsq_ctx *ctx);
+void *lsq_ctx_stream(lsq_ctx *ctx);
+int lsq_malloc(lsq_ctx *ctx, size_t bytes, void **d_out);
+int lsq_free(lsq_ctx *ctx, void *d_ptr);
+int lsq_h2d(lsq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int lsq_d2h(lsq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int lsq_d2d(lsq_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+
+/* ---- Jacobian handles ---- */
+/* Dense m x n, column-major, device-owned (the `J::Matrix` of types.jl:36). */
+int lsq_dense_create(lsq_ctx *ctx, int m, int n, lsq_mat **out);
+/* CSC pattern given once (SparseMatrixCSC with a FIXED pattern, as the reference's sparse g!
+ * requires: test/nonlinearleastsquares.jl:47-86).  Builds the CSR mirror + CSC->CSR value map. */
+int lsq_csc_create(lsq_ctx *ctx, int m, int n, const int *h_colptr, const int *h_rowval, lsq_mat **out);
+int lsq_mat_destroy(lsq_mat *J);
+int lsq_mat_size(const lsq_mat *J, int *m, int *n, long long *nnz);
+/* Upload values after a host-side g!(J, x): dense m*n column-major, or nzval in CSC order. */
+int lsq_mat_set_values(lsq_mat *J, const double *h_values);
+int lsq_mat_get_values(const lsq_mat *J, double *h_values);
+/* Device pointer to the values a device-side g! writes (dense buffer / CSC nzval) ... */
+double *lsq_mat_values(lsq_mat *J);
+/* ... after which the CSR mirror must be refreshed (no-op for dense). */
+int lsq_mat_refresh(lsq_mat *J);
+
+/* ---- operator interface (README.md:37-47; used at lsmr.jl:73,76,118,122 and by the optimizers) ---- */
+/* mul!(y, J, x, alpha, beta) / mul!(x, J', y, alpha, beta): trans = 0 / 1.
+ * Replaces SparseArrays/BLAS mul! at levenberg_marquardt.jl:102,114; dogleg.jl:99,109,171;
+ * iterative_lsmr.jl:32,40,91,106. */
+int lsq_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);
+/* colsumabs2!(out, J): utils.jl:139-151 */
+int lsq_colsumabs2(lsq_mat *J, double *d_out);
+
+/* BLAS-1 on device vectors (what lsmr.jl:30-44 and the optimizer loops need from a vector type) */
+int lsq_axpy(lsq_ctx *ctx, int n, double a, const double *d_x, double *d_y);       /* axpy!   */
+int lsq_scal(lsq_ctx *ctx, int n, double a, double *d_x);                          /* rmul!   */
+int lsq_copy(lsq_ctx *ctx, int n, const double *d_x, double *d_y);                 /* copyto! */
+int lsq_fill(lsq_ctx *ctx, int n, double a, double *d_x);                          /* fill!   */
+int lsq_sumsq(lsq_ctx *ctx, int n, const double *d_x, double *h_out);              /* sum(abs2, x) */
+int lsq_sum(lsq_ctx *ctx, int n, const double *d_x, double *h_out);                /* sum(x)  */
+int lsq_nrm2(lsq_ctx *ctx, int n, const double *d_x, double *h_out);               /* norm(x) */
+int lsq_wdot(lsq_ctx *ctx, int n, const double *d_x, const double *d_y, const double *d_w,
+             double *h_out);                                                       /* utils.jl:165-175 */
+int lsq_amax(lsq_ctx *ctx, int n, const double *d_x, double *h_out);               /* maximum(abs, x) */
+/* maxabs_projected_gradient (utils.jl:39-55); d_lower / d_upper may be NULL */
+int lsq_amax_projected(lsq_ctx *ctx, int n, const double *d_g, const double *d_x,
+                       const double *d_lower, const double *d_upper, double *h_out);
+int lsq_clamp(lsq_ctx *ctx, int n, double lo, double hi, double *d_x);             /* clamp!  */
+int lsq_ediv(lsq_ctx *ctx, int n, const double *d_x, const double *d_y, double *d_out); /* map!(/, ..) */
+/* box step clipping dx = min(dx, x-lower), dx = max(dx, x-upper) (levenberg_marquardt.jl:89-98) */
+int lsq_box_clip(lsq_ctx *ctx, int n, double *d_dx, const double *d_x, const double *d_lower,
+                 const double *d_upper);
+/* first non-finite index or -1 (check_isfinite, utils.jl:70-75) */
+int lsq_first_nonfinite(lsq_ctx *ctx, int n, const double *d_x, int *h_index);
+
+/* ---- linear least-squares solvers: THE plug point ---- */
+/* AbstractAllocatedSolver(nls, optimizer): dense_qr.jl:25-28,50-54; dense_cholesky.jl:19-21;
+ * iterative_lsmr.jl:173-177,233-236.  `for_lm` selects the damped (LevenbergMarquardt) flavour. */
+int lsq_solver_create(lsq_ctx *ctx, lsq_mat *J, int solver_kind, int for_lm, lsq_solver **out);
+int lsq_solver_destroy(lsq_solver *s);
+/* ldiv!(x, J, y, A) -> (x, nmul)       Dogleg: dense_qr.jl:30, dense_cholesky.jl:29,
+ *                                              iterative_lsmr.jl:179.  y is preserved. */
+int lsq_ldiv(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_x, int *nmul);
+/* ldiv!(x, J, y, damp, A) -> (x, nmul) LM: dense_qr.jl:56, dense_cholesky.jl:43,
+ *                                          iterative_lsmr.jl:238.  damp MAY be clobbered (LSMR
+ *                                          leaves sqrt(damp) in it, iterative_lsmr.jl:252). */
+int lsq_ldiv_damped(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x,
+                    int *nmul);
+/* diagnostics of the last solve: LSMR istop / iterations, QR numerical rank */
+int lsq_solver_info(const lsq_solver *s, int *lsmr_iter, int *lsmr_istop, int *qr_rank);
+
+/* ---- whole trust-region loop on device buffers (host control, device arrays) ---- */
+/* f!(out, x) and g!(J, x) on DEVICE pointers; g writes lsq_mat_values(J) (the library refreshes
+ * the CSR mirror afterwards).  Return non-zero to abort with LSQ_ECALLBACK. */
+typedef int (*lsq_f_callback)(double *d_out, const double *d_x, void *user);
+typedef int (*lsq_g_callback)(lsq_mat *J, const double *d_x, void *user);
+/* optional global reduction hook for sharded problems: called once per outer
+ * iteration with vals = {ssr_local, maxabs_gr_local, converged_local}; the implementation
+ * (RCCL all-reduce via torch.distributed in bench.py) overwrites them with the global
+ * {sum, max, min}.  NULL = single problem. */
+typedef int (*lsq_allreduce_callback)(double *h_vals, int count, void *user);
+
+typedef struct {
+    double x_tol, f_tol, g_tol; /* 1e-8 defaults of levenberg_marquardt.jl:41 / dogleg.jl:43 */
+    int iterations;             /* 1000 */
+    double delta;               /* <= 0: 10.0 for LM, 1.0 for Dogleg */
+    const double *h_lower;      /* NULL or n (host) */
+    const double *h_upper;      /* NULL or n (host) */
+    lsq_allreduce_callback allreduce;
+    void *allreduce_user;
+    /* optional trace buffers (host), capacity trace_cap iterations */
+    int trace_cap;
+    double *trace_ssr, *trace_gnorm, *trace_delta, *trace_rho;
+    int *trace_inner, *trace_accept;
+    double *trace_x;            /* trace_cap * n, or NULL */
+} lsq_options;
+
+typedef struct {
+    int optimizer;              /* lsq_optimizer_kind actually used */
+    double ssr;
+    int iterations;
+    int converged, x_converged, f_converged, g_converged;
+    int f_calls, g_calls, mul_calls;
+    int status;
+    int bad_index;              /* for LSQ_ENONFINITE */
+    double seconds;             /* wall time of the loop (host clock, includes syncs) */
+    long long lsmr_iterations;  /* total inner iterations */
+} lsq_result;
+
+void lsq_options_default(lsq_options *opt);
+/* optimize!(LeastSquaresProblemAllocated; kwargs...) -- levenberg_marquardt.jl:39-144,
+ * dogleg.jl:41-203.  d_x (n) and d_fcur (m) are updated in place like nls.x / nls.y. */
+int lsq_optimize(lsq_ctx *ctx, int optimizer, int solver_kind, lsq_mat *J, double *d_x,
+                 double *d_fcur, lsq_f_callback f, lsq_g_callback g, void *user,
+                 const lsq_options *opt, lsq_result *res);
+
+/* ---- built-in device-side model for the synthetic benchmarks:
+ *      r(x) = A tanh(x) - b,  J = A diag(1 - tanh(x)^2); A has J's pattern. ---- */
+int lsq_model_tanh_create(lsq_ctx *ctx, lsq_mat *J, const double *h_Avalues, const double *h_b,
+                          lsq_model **out);
+int lsq_model_destroy(lsq_model *md);
+lsq_f_callback lsq_model_f(void);
+lsq_g_callback lsq_model_g(void);
+
+/* ---- deterministic synthetic inputs (host side; counter-based RNG) ---- */
+/* CSC with exactly `per_col` distinct sorted rows per column, values N(0,1)/sqrt(per_col). */
+int lsq_synth_sparse(int m, int n, int per_col, unsigned long long seed, int *h_colptr,
+                     int *h_rowval, double *h_nzval);
+/* dense column-major N(0,1)/sqrt(m) */
+int lsq_synth_dense(int m, int n, unsigned long long seed, double *h_values);
+/* x_true ~ U(-1,1) (n) and noise ~ N(0,1) (m) streams */
+int lsq_synth_uniform(int n, unsigned long long seed, double lo, double hi, double *h_out);
+int lsq_synth_normal(int n, unsigned long long seed, double *h_out);
+
+/* ---- measurement helpers ---- */
+/* Times `reps` launches of y <- alpha*J*x + beta*y (trans=0) or the transpose (trans=1) with HIP
+ * events on the context stream; returns the average milliseconds per launch. */
+int lsq_bench_mul(lsq_mat *J, int trans, int reps, const double *d_x, double *d_y, double beta,
+                  float *h_ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,13 @@
+"""MI355X-native hot path of LeastSquaresOptim.jl: host mirror of the reference API over the C ABI
+(include/lsqhip.h) of hand-written gfx950 HIP kernels.  Import as `lsq_amd` (root shim)."""
+from . import _lib
+from ._lib import (ArgumentError, DimensionMismatch, HipError, IsFiniteException, LsqError,
+                   PosDefException, RankDeficientException, build, declared_symbols, lib)
+from .api import (AllocatedSolver, Cholesky, Context, DeviceMatrix, DeviceVector, Dogleg, LSMR,
+                  LeastSquaresProblem, LeastSquaresResult, LevenbergMarquardt, OptimizationState, QR,
+                  colsumabs2_, converged, default_context, default_optimizer, default_solver,
+                  maxabs, maxabs_projected_gradient, mul_, norm, optimize, optimize_, sumsq, wdot,
+                  wnorm)
+from . import synthetic
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,524 @@
+"""Host-side mirror of the reference's user API for the hot path (types.jl:7-269):
+
+    LeastSquaresProblem(x=..., f_=..., g_=..., J=..., y=..., output_length=...)
+    optimize_(nls, Dogleg(QR()) | LevenbergMarquardt(LSMR()) | ..., x_tol=..., lower=..., ...)
+    optimize(f, x, optimizer, ...)
+
+(`f_`/`g_`/`optimize_` stand for Julia's `f!`/`g!`/`optimize!`).  The trust-region control runs
+on the host, every m-/n-/nnz-length array lives on the MI355X and every arithmetic step is a
+hand-written HIP kernel reached through the C ABI of include/lsqhip.h.  The Julia side of the same
+boundary is shown in INTEGRATION.md.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ArgumentError, DimensionMismatch, check, lib)
+
+try:  # scipy is only needed to accept csc_matrix Jacobians
+    import scipy.sparse as _sp
+except Exception:  # pragma: no cover
+    _sp = None
+
+
+# ------------------------------------------------------------------------------------------------
+# solver / optimizer selectors (types.jl:76-98)
+# ------------------------------------------------------------------------------------------------
+class AbstractSolver:
+    pass
+
+
+class QR(AbstractSolver):
+    kind = _lib.QR
+
+
+class Cholesky(AbstractSolver):
+    kind = _lib.CHOLESKY
+
+
+class LSMR(AbstractSolver):
+    kind = _lib.LSMR
+
+    def __init__(self, preconditioner=None, P=None):
+        if preconditioner is not None or P is not None:
+            raise NotImplementedError(
+                "custom LSMR preconditioners stay a host callback in the reference "
+                "(types.jl:82-86); only the default Jacobi preconditioner "
+                "(iterative_lsmr.jl:129-141) is implemented on the device")
+
+
+class AbstractOptimizer:
+    def __init__(self, solver=None):
+        if isinstance(solver, type):
+            solver = solver()
+        self.solver = solver
+
+
+class Dogleg(AbstractOptimizer):
+    kind = _lib.DOGLEG
+    name = "Dogleg"
+
+
+class LevenbergMarquardt(AbstractOptimizer):
+    kind = _lib.LEVENBERG_MARQUARDT
+    name = "LevenbergMarquardt"
+
+
+def _is_sparse(J):
+    return _sp is not None and _sp.issparse(J)
+
+
+def default_solver(solver, J):
+    """types.jl:114-121"""
+    if solver is None:
+        return LSMR() if _is_sparse(J) else QR()
+    if isinstance(solver, QR) and _is_sparse(J):
+        raise ArgumentError(_lib.EARG, "solver QR() is not available for sparse Jacobians. "
+                                       "Choose between Cholesky() and LSMR()")
+    return solver
+
+
+def default_optimizer(optimizer, solver):
+    """types.jl:123-127"""
+    if isinstance(optimizer, Dogleg):
+        return Dogleg(solver)
+    if isinstance(optimizer, LevenbergMarquardt):
+        return LevenbergMarquardt(solver)
+    if isinstance(solver, LSMR):
+        return LevenbergMarquardt(solver)
+    return Dogleg(solver)
+
+
+# ------------------------------------------------------------------------------------------------
+# device context and buffers
+# ------------------------------------------------------------------------------------------------
+class Context:
+    """One per device/stream (SURVEY 8b 'Threading'); fails loudly without a HIP device."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        check(lib().lsq_ctx_create(int(device), stream, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def sync(self):
+        check(lib().lsq_ctx_sync(self.h))
+
+    def close(self):
+        if self.h:
+            lib().lsq_ctx_destroy(self.h)
+            self.h = None
+
+
+_DEFAULT_CTX = {}
+
+
+def default_context(device=0):
+    if device not in _DEFAULT_CTX:
+        _DEFAULT_CTX[device] = Context(device)
+    return _DEFAULT_CTX[device]
+
+
+class DeviceVector:
+    """fp64 vector in HBM (the `HipVector` of SURVEY 8b)."""
+
+    def __init__(self, ctx, n, data=None):
+        self.ctx, self.n = ctx, int(n)
+        p = C.c_void_p()
+        check(lib().lsq_malloc(ctx.h, max(self.n, 1) * 8, C.byref(p)))
+        self.ptr = p
+        if data is not None:
+            self.set(data)
+        else:
+            check(lib().lsq_fill(ctx.h, self.n, 0.0, self.ptr))
+
+    def set(self, data):
+        a = np.ascontiguousarray(data, dtype=np.float64)
+        if a.size != self.n:
+            raise DimensionMismatch(_lib.EDIM, "vector has length %d, expected %d" % (a.size, self.n))
+        check(lib().lsq_h2d(self.ctx.h, self.ptr, a.ctypes.data_as(C.c_void_p), self.n * 8))
+
+    def get(self):
+        out = np.empty(self.n)
+        check(lib().lsq_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.n * 8))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().lsq_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(v):
+    return None if v is None else v.ptr
+
+
+class DeviceMatrix:
+    """Jacobian handle: dense column-major or CSC (+ CSR mirror) -- `HipDense` / `HipCSC`."""
+
+    def __init__(self, ctx, J):
+        self.ctx = ctx
+        h = C.c_void_p()
+        L = lib()
+        if _is_sparse(J):
+            S = J.tocsc()
+            S.sort_indices()
+            self.sparse = True
+            self.m, self.n = S.shape
+            self.colptr = np.ascontiguousarray(S.indptr, dtype=np.int32)
+            self.rowval = np.ascontiguousarray(S.indices, dtype=np.int32)
+            check(L.lsq_csc_create(ctx.h, self.m, self.n, self.colptr.ctypes.data_as(_lib.c_ip),
+                                   self.rowval.ctypes.data_as(_lib.c_ip), C.byref(h)))
+            self.h = h
+            self.nnz = int(S.nnz)
+            self.set_values(S.data)
+        else:
+            A = np.asarray(J, dtype=np.float64)
+            if A.ndim != 2:
+                raise DimensionMismatch(_lib.EDIM, "J must be a matrix")
+            self.sparse = False
+            self.m, self.n = A.shape
+            check(L.lsq_dense_create(ctx.h, self.m, self.n, C.byref(h)))
+            self.h = h
+            self.nnz = self.m * self.n
+            self.set_values(np.asfortranarray(A).reshape(-1, order="F"))
+
+    def set_values(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        if v.size != self.nnz:
+            raise DimensionMismatch(_lib.EDIM, "expected %d values, got %d" % (self.nnz, v.size))
+        check(lib().lsq_mat_set_values(self.h, v.ctypes.data_as(_lib.c_dp)))
+
+    def values(self):
+        out = np.empty(self.nnz)
+        check(lib().lsq_mat_get_values(self.h, out.ctypes.data_as(_lib.c_dp)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib().lsq_mat_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# --- operator interface (README.md:37-47) on device objects -------------------------------------
+def mul_(y, J, x, alpha=1.0, beta=0.0, trans=False):
+    """mul!(y, J, x, alpha, beta) / mul!(y, J', x, alpha, beta)"""
+    check(lib().lsq_mul(J.h, 1 if trans else 0, float(alpha), x.ptr, float(beta), y.ptr))
+    return y
+
+
+def colsumabs2_(out, J):
+    check(lib().lsq_colsumabs2(J.h, out.ptr))
+    return out
+
+
+def _scalar(fn, ctx, n, *ptrs):
+    r = C.c_double(0.0)
+    check(fn(ctx.h, n, *ptrs, C.byref(r)))
+    return r.value
+
+
+def sumsq(x):
+    return _scalar(lib().lsq_sumsq, x.ctx, x.n, x.ptr)
+
+
+def norm(x):
+    return _scalar(lib().lsq_nrm2, x.ctx, x.n, x.ptr)
+
+
+def wdot(x, y, w):
+    return _scalar(lib().lsq_wdot, x.ctx, x.n, x.ptr, y.ptr, w.ptr)
+
+
+def wnorm(x, w):
+    return float(np.sqrt(wdot(x, x, w)))
+
+
+def maxabs(x):
+    return _scalar(lib().lsq_amax, x.ctx, x.n, x.ptr)
+
+
+def maxabs_projected_gradient(g, x, lower=None, upper=None):
+    return _scalar(lib().lsq_amax_projected, g.ctx, g.n, g.ptr, x.ptr, _ptr(lower), _ptr(upper))
+
+
+class AllocatedSolver:
+    """AbstractAllocatedSolver(nls, optimizer) + ldiv! (the L2 plug point)."""
+
+    def __init__(self, J, solver, for_lm):
+        h = C.c_void_p()
+        check(lib().lsq_solver_create(J.ctx.h, J.h, solver.kind, 1 if for_lm else 0, C.byref(h)))
+        self.h, self.J = h, J
+
+    def ldiv_(self, x, y, damp=None):
+        """ldiv!(x, J, y[, damp], A) -> (x, nmul)"""
+        n = C.c_int(0)
+        if damp is None:
+            check(lib().lsq_ldiv(self.h, self.J.h, y.ptr, x.ptr, C.byref(n)))
+        else:
+            check(lib().lsq_ldiv_damped(self.h, self.J.h, y.ptr, damp.ptr, x.ptr, C.byref(n)))
+        return x, n.value
+
+    def info(self):
+        it, st, rk = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().lsq_solver_info(self.h, C.byref(it), C.byref(st), C.byref(rk)))
+        return dict(lsmr_iter=it.value, lsmr_istop=st.value, qr_rank=rk.value)
+
+    def free(self):
+        if self.h:
+            lib().lsq_solver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# problem / result types
+# ------------------------------------------------------------------------------------------------
+class OptimizationState:
+    def __init__(self, iteration, value, g_norm):
+        self.iteration, self.value, self.g_norm = iteration, value, g_norm
+
+    def __repr__(self):
+        return "%6d   %14e   %14e" % (self.iteration, self.value, self.g_norm)
+
+
+class LeastSquaresProblem:
+    """types.jl:7-68.  J may be a numpy matrix (dense) or a scipy.sparse CSC matrix with a FIXED
+    pattern whose `.data` g_ overwrites (test/nonlinearleastsquares.jl:47-86)."""
+
+    def __init__(self, x=None, y=None, f_=None, g_=None, J=None, output_length=0, autodiff="central"):
+        if x is None:
+            raise ValueError("initial x required")
+        if f_ is None:
+            raise ValueError("initial f! required")
+        self.x = np.array(x, dtype=np.float64)
+        if y is None:
+            if output_length == 0:
+                if J is None:
+                    raise ValueError("specify J or output_length")
+                output_length = J.shape[0]           # types.jl:46 (size(J, 1))
+            y = np.zeros(output_length)
+        self.y = np.asarray(y, dtype=np.float64)
+        if J is None:
+            J = np.zeros((len(self.y), len(self.x)), order="F")
+        if _is_sparse(J):
+            J = J.tocsc()
+            J.sort_indices()  # g_ writes J.data in this (canonical CSC) order
+        else:
+            J = np.asfortranarray(J, dtype=np.float64)
+        if len(self.x) != J.shape[1]:
+            raise DimensionMismatch(_lib.EDIM, "x must have length size(J, 2)")
+        if len(self.y) != J.shape[0]:
+            raise DimensionMismatch(_lib.EDIM, "y must have length size(J, 1)")
+        self.J = J
+        self.f_ = f_
+        if g_ is None:
+            if autodiff == "central":
+                g_ = _central_difference_jacobian(f_, len(self.y))
+            elif autodiff == "forward":
+                raise NotImplementedError("autodiff=:forward (ForwardDiff) is off the hot path and "
+                                          "never exercised by the reference's tests")
+            else:
+                raise ValueError("Invalid automatic differentiation method.")  # DomainError
+        self.g_ = g_
+
+
+def _central_difference_jacobian(f_, m):
+    """FiniteDiff-style central differences (types.jl:55-58) -- host side, off the hot path."""
+    eps3 = np.finfo(float).eps ** (1.0 / 3.0)
+
+    def g_(J, x):
+        if _is_sparse(J):
+            raise ArgumentError(_lib.EARG, "autodiff Jacobians are dense only (types.jl:57)")
+        fp, fm = np.zeros(m), np.zeros(m)
+        xp = np.array(x, dtype=np.float64)
+        for j in range(len(x)):
+            h = max(eps3 * abs(x[j]), eps3)
+            xj = xp[j]
+            xp[j] = xj + h
+            f_(fp, xp)
+            xp[j] = xj - h
+            f_(fm, xp)
+            xp[j] = xj
+            J[:, j] = (fp - fm) / (2 * h)
+
+    return g_
+
+
+class LeastSquaresResult:
+    """types.jl:220-269"""
+
+    def __repr__(self):
+        ok = self.x_converged or self.f_converged or self.g_converged
+        return ("Results of Optimization Algorithm\n * Status: %s\n\n * Candidate solution\n"
+                "    Final objective value:     %.6e\n\n * Found with\n    Algorithm:     %s\n\n"
+                " * Convergence measures\n    |x - x'|               %s %.1e\n"
+                "    |f(x) - f(x')| / |f(x)| %s %.1e\n    |g(x)|                 %s %.1e\n\n"
+                " * Work counters\n    Iterations:    %d\n    f(x) calls:    %d\n"
+                "    J(x) calls:    %d\n    mul! calls:    %d\n" % (
+                    "success" if ok else "failure (reached maximum number of iterations)",
+                    self.ssr, self.optimizer, "<=" if self.x_converged else "!<=", self.x_tol,
+                    "<=" if self.f_converged else "!<=", self.f_tol,
+                    "<=" if self.g_converged else "!<=", self.g_tol,
+                    self.iterations, self.f_calls, self.g_calls, self.mul_calls))
+
+
+def converged(r):
+    return r.x_converged or r.f_converged or r.g_converged
+
+
+def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_tol, f_tol, g_tol,
+                iterations, delta, lower, upper, trace, n, allreduce=None):
+    L = lib()
+    opt = _lib.Options()
+    L.lsq_options_default(C.byref(opt))
+    opt.x_tol, opt.f_tol, opt.g_tol = float(x_tol), float(f_tol), float(g_tol)
+    opt.iterations = int(iterations)
+    opt.delta = float(delta) if delta is not None else -1.0
+    keep = []
+    if lower is not None and len(lower):
+        lo = np.ascontiguousarray(lower, dtype=np.float64)
+        if len(lo) != n:
+            raise ArgumentError(_lib.EARG, "Bounds must either be empty or of the same length as "
+                                           "the number of parameters.")
+        opt.h_lower = lo.ctypes.data_as(_lib.c_dp)
+        keep.append(lo)
+    if upper is not None and len(upper):
+        hi = np.ascontiguousarray(upper, dtype=np.float64)
+        if len(hi) != n:
+            raise ArgumentError(_lib.EARG, "Bounds must either be empty or of the same length as "
+                                           "the number of parameters.")
+        opt.h_upper = hi.ctypes.data_as(_lib.c_dp)
+        keep.append(hi)
+    if allreduce is not None:
+        opt.allreduce = allreduce
+        keep.append(allreduce)
+    tr = None
+    if trace:
+        cap = int(iterations)
+        tr = dict(ssr=np.zeros(cap), gnorm=np.zeros(cap), delta=np.zeros(cap), rho=np.zeros(cap),
+                  inner=np.zeros(cap, dtype=np.int32), accept=np.zeros(cap, dtype=np.int32),
+                  x=np.zeros((cap, n)))
+        opt.trace_cap = cap
+        opt.trace_ssr = tr["ssr"].ctypes.data_as(_lib.c_dp)
+        opt.trace_gnorm = tr["gnorm"].ctypes.data_as(_lib.c_dp)
+        opt.trace_delta = tr["delta"].ctypes.data_as(_lib.c_dp)
+        opt.trace_rho = tr["rho"].ctypes.data_as(_lib.c_dp)
+        opt.trace_inner = tr["inner"].ctypes.data_as(_lib.c_ip)
+        opt.trace_accept = tr["accept"].ctypes.data_as(_lib.c_ip)
+        opt.trace_x = tr["x"].ctypes.data_as(_lib.c_dp)
+    res = _lib.Result()
+    st = L.lsq_optimize(ctx.h, optimizer_kind, solver_kind, Jd.h, dx.ptr, dy.ptr, fcb, gcb, user,
+                        C.byref(opt), C.byref(res))
+    if tr is not None:
+        k = res.iterations
+        tr = {key: v[:k].copy() for key, v in tr.items()}
+    return st, res, tr
+
+
+def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iterations=1000, delta=None,
+              store_trace=False, show_trace=False, show_every=1, lower=(), upper=(), ctx=None,
+              full_trace=False):
+    """optimize!(nls, optimizer; kwargs...)  -- types.jl:207-209 then
+    levenberg_marquardt.jl:39-144 / dogleg.jl:41-203.  Mutates nls.x, nls.y, nls.J in place."""
+    ctx = ctx or default_context()
+    solver = default_solver(optimizer.solver if optimizer is not None else None, nls.J)
+    optimizer = default_optimizer(optimizer, solver)
+    n, m = len(nls.x), len(nls.y)
+    Jd = DeviceMatrix(ctx, nls.J)
+    dx, dy = DeviceVector(ctx, n, nls.x), DeviceVector(ctx, m, nls.y)
+    L = lib()
+    xh, yh = np.zeros(n), np.zeros(m)
+    err = []
+
+    def fcb(d_out, d_x, _):
+        try:
+            check(L.lsq_d2h(ctx.h, xh.ctypes.data_as(C.c_void_p), d_x, n * 8))
+            nls.f_(yh, xh)
+            check(L.lsq_h2d(ctx.h, d_out, yh.ctypes.data_as(C.c_void_p), m * 8))
+            return 0
+        except Exception as e:  # surfaced after the C call returns
+            err.append(e)
+            return 1
+
+    def gcb(Jh, d_x, _):
+        try:
+            check(L.lsq_d2h(ctx.h, xh.ctypes.data_as(C.c_void_p), d_x, n * 8))
+            nls.g_(nls.J, xh)
+            vals = nls.J.data if Jd.sparse else nls.J.reshape(-1, order="F")
+            vals = np.ascontiguousarray(vals, dtype=np.float64)
+            check(L.lsq_h2d(ctx.h, L.lsq_mat_values(Jh), vals.ctypes.data_as(C.c_void_p), vals.size * 8))
+            return 0
+        except Exception as e:
+            err.append(e)
+            return 1
+
+    F, G = _lib.F_CALLBACK(fcb), _lib.G_CALLBACK(gcb)
+    tracing = store_trace or show_trace or full_trace
+    st, res, tr = _run_native(ctx, optimizer.kind, solver.kind, Jd, dx, dy, F, G, None, x_tol, f_tol,
+                              g_tol, iterations, delta, lower, upper, tracing, n)
+    if err:
+        raise err[0]
+    if st == _lib.ENONFINITE:
+        e = _lib.IsFiniteException(st, lib().lsq_last_error().decode())
+        e.indices = [res.bad_index]
+        raise e
+    check(st)
+    nls.x[:] = dx.get()
+    nls.y[:] = dy.get()
+    r = LeastSquaresResult()
+    r.optimizer = optimizer.name
+    r.minimizer = nls.x
+    r.ssr = float(res.ssr)
+    r.iterations = res.iterations
+    r.converged = bool(res.converged)
+    r.x_converged, r.f_converged, r.g_converged = bool(res.x_converged), bool(res.f_converged), bool(res.g_converged)
+    r.x_tol, r.f_tol, r.g_tol = float(x_tol), float(f_tol), float(g_tol)
+    r.f_calls, r.g_calls, r.mul_calls = res.f_calls, res.g_calls, res.mul_calls
+    r.jacobian = nls.J
+    r.seconds = res.seconds
+    r.trace = tr
+    states = []
+    if tracing and tr is not None:
+        # utils.jl:86-131: state 0 is (0, ssr0, Inf); we record the per-iteration states
+        for k in range(res.iterations):
+            states.append(OptimizationState(k + 1, tr["ssr"][k], tr["gnorm"][k]))
+        if show_trace:
+            print("Iter     Function value   Gradient norm ")
+            print("------   --------------   --------------")
+            for s_ in states:
+                if s_.iteration % show_every == 0:
+                    print(s_)
+    r.tr = states if store_trace else []
+    Jd.free()
+    return r
+
+
+def optimize(f, x, optimizer, autodiff="central", **kwargs):
+    """optimize(f, x, optimizer; kwargs...) -- types.jl:182-184 (x is copied; f returns a vector)."""
+    x0 = np.array(x, dtype=np.float64)
+    out0 = np.atleast_1d(np.asarray(f(x0), dtype=np.float64))
+
+    def f_(out, xx):
+        out[:] = np.atleast_1d(f(xx))
+
+    nls = LeastSquaresProblem(x=x0.copy(), f_=f_, output_length=len(out0), autodiff=autodiff)
+    return optimize_(nls, optimizer, **kwargs)

@@ -1,0 +1,185 @@
+// Internal declarations shared by the HIP translation units of liblsqhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/lsqhip.h"
+
+void lsq_set_error(const char *fmt, ...);
+
+#define LSQ_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            lsq_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                          __LINE__);                                                       \
+            return LSQ_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+#define LSQ_TRY(call)                 \
+    do {                              \
+        int s__ = (call);             \
+        if (s__ != LSQ_OK) return s__; \
+    } while (0)
+
+constexpr int LSQ_NT = 256;             // threads per block for streaming kernels (4 waves)
+constexpr int LSQ_MAX_PARTIALS = 1 << 16;
+constexpr int LSQ_NSLOTS = 64;          // device scalar slots
+
+// Host-visible mailbox (pinned, coherent): the device publishes inner-loop progress here so the
+// host never calls hipStreamSynchronize inside LSMR.
+struct LsqMailbox {
+    volatile int iter;
+    volatile int istop;
+    volatile int done;
+    volatile int seq;
+};
+
+struct lsq_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    double *d_slots;      // LSQ_NSLOTS device scalars (results of reductions)
+    double *h_slots;      // pinned host mirror
+    double *d_partials;   // LSQ_MAX_PARTIALS block partials
+    unsigned *d_counters; // LSQ_NSLOTS arrival counters (zero between kernels)
+    LsqMailbox *h_mail;   // pinned + mapped
+    LsqMailbox *d_mail;   // device address of h_mail
+    int num_cus;
+    unsigned mail_epoch;  // bumps per inner solve; tags mailbox words
+};
+
+// ---------------------------------------------------------------------------------------------
+// sparse / dense matrix handle
+// ---------------------------------------------------------------------------------------------
+enum { LSQ_MAT_DENSE = 0, LSQ_MAT_CSC = 1 };
+enum { LSQ_PLAN_STREAM = 0, LSQ_PLAN_WAVE = 1, LSQ_PLAN_BLOCK = 2 };
+
+// One direction of a sparse product: segments (rows for J*x via the CSR mirror, columns for
+// J'*y via CSC) with the launch plan chosen once per pattern from the segment-length profile.
+struct LsqSegs {
+    int nseg = 0;          // number of segments (m for CSR, n for CSC)
+    long long nnz = 0;
+    int *d_ptr = nullptr;  // nseg+1
+    int *d_idx = nullptr;  // nnz (gather index)
+    double *d_val = nullptr;
+    int plan = LSQ_PLAN_STREAM;
+    int ntiles = 0;        // stream plan: number of tiles
+    int *d_tiles = nullptr; // ntiles+1 segment boundaries of the tiles
+};
+
+struct lsq_mat {
+    lsq_ctx *ctx;
+    int kind;
+    int m, n;
+    long long nnz;
+    // dense
+    double *d_dense = nullptr;
+    // sparse
+    LsqSegs csc;           // columns; d_val is the user-visible nzval (CSC order)
+    LsqSegs csr;           // rows; d_val refreshed from csc.d_val through d_map
+    int *d_map = nullptr;  // csr position -> csc position
+    bool csr_fresh = false;
+    unsigned long long version = 0;  // bumps whenever values change
+    // cached colsumabs2 (utils.jl:139-151 is called twice per LM iteration by the reference)
+    double *d_colsum = nullptr;
+    unsigned long long colsum_version = ~0ull;
+};
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // lane 0 holds the sum
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// Sum over the block in a fixed order (deterministic); result valid in thread 0.
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double *sh /* NT/64 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += sh[i];
+    }
+    __syncthreads();
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ double block_max(double v, double *sh) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        r = sh[0];
+#pragma unroll
+        for (int i = 1; i < NT / 64; ++i) r = fmax(r, sh[i]);
+    }
+    __syncthreads();
+    return r;
+}
+
+// Two-stage grid reduction without a second launch: every block publishes its partial with an
+// agent-scope (write-through) store, drains it, then takes a ticket; the block that draws the
+// last ticket re-reads all partials with agent-scope loads IN INDEX ORDER (run-to-run
+// deterministic) and calls fin(total) from thread 0.  The counter is left at zero.
+// Returns true in every thread of the last block (after fin has run).
+template <int NT, bool IS_MAX = false, class Fin>
+__device__ __forceinline__ bool grid_reduce(double block_val, double *partials, unsigned *counter,
+                                            int nblocks, double *sh, Fin fin) {
+    __shared__ int s_last;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partials[b], block_val, RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned t = __hip_atomic_fetch_add(counter, 1u, RLX_AGENT);
+        s_last = (t == (unsigned)(nblocks - 1));
+    }
+    __syncthreads();
+    if (!s_last) return false;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += NT) {
+        double p = __hip_atomic_load(&partials[i], RLX_AGENT);
+        acc = IS_MAX ? fmax(acc, p) : acc + p;
+    }
+    double tot = IS_MAX ? block_max<NT>(acc, sh) : block_sum<NT>(acc, sh);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(counter, 0u, RLX_AGENT);
+        fin(tot);
+    }
+    return true;
+}
+
+static inline int lsq_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// internal entry points shared between translation units
+int lsq_sparse_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);
+int lsq_dense_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);
+int lsq_dense_colsumabs2(lsq_mat *J, double *d_out);
+int lsq_sparse_colsumabs2(lsq_mat *J, double *d_out);
+int lsq_ensure_csr(lsq_mat *J);
+int lsq_permute_to_csr(lsq_mat *J, const double *d_csc_vals, double *d_csr_vals);
+const double *lsq_cached_colsum(lsq_mat *J);  // nullptr on failure (error set)
+// reads slot values to host (synchronises the stream)
+int lsq_read_slots(lsq_ctx *ctx, int first, int count, double *h_out);

@@ -1,0 +1,635 @@
+// Dense Jacobian path: GEMVs / colsumabs2, the normal-equation + Cholesky solver
+// (dense_cholesky.jl:29-59) and the column-pivoted Householder QR solver with the rank-revealing
+// minimum-norm solve (dense_qr.jl:30-88; LinearAlgebra.ldiv!(::QRPivoted, b) [stdlib] = xGELSY).
+// Everything here runs on the device; the host only reads back status words.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "lsq_solver.h"
+#include "lsq_spmv.h"
+
+// ---------------------------------------------------------------------------------------------
+// generic dense products
+// ---------------------------------------------------------------------------------------------
+struct EpiAxpbyD {
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    double alpha, beta;
+    double *y;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int s, double dot, double &) const {
+        y[s] = (beta == 0.0) ? alpha * dot : alpha * dot + beta * y[s];
+    }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+
+int lsq_dense_mul(lsq_mat *J, int trans, double alpha, const double *x, double beta, double *y) {
+    EpiAxpbyD e{nullptr, 0, alpha, beta, y, nullptr, nullptr};
+    return launch_product(J, trans, x, e);
+}
+
+struct EpiStoreD {
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    double *out;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int s, double dot, double &) const { out[s] = dot; }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+
+int lsq_dense_colsumabs2(lsq_mat *J, double *out) {  // utils.jl:139-144
+    if (J->n <= 0) return LSQ_OK;
+    EpiStoreD e{nullptr, 0, out, nullptr, nullptr};
+    int grid = J->n > LSQ_MAX_GRID ? LSQ_MAX_GRID : J->n;
+    hipLaunchKernelGGL((k_dense_t<EpiStoreD, true>), dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream,
+                       J->d_dense, J->m, J->n, nullptr, e);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// normal equations  C = J'J (+ diag damp), upper triangle  (dense_cholesky.jl:31,48,51-53)
+// ---------------------------------------------------------------------------------------------
+constexpr int SY_T = 32;   // output tile
+constexpr int SY_K = 32;   // k-chunk
+__global__ void __launch_bounds__(256)
+k_syrk_upper(const double *__restrict__ A, int m, int n, double *__restrict__ C, const double *__restrict__ damp) {
+    // tile (bi, bj) with bj >= bi, enumerated linearly
+    __shared__ double sa[SY_T][SY_K + 1];
+    __shared__ double sb[SY_T][SY_K + 1];
+    const int nt = (n + SY_T - 1) / SY_T;
+    int t = blockIdx.x, bi = 0;
+    while (t >= nt - bi) { t -= nt - bi; ++bi; }
+    const int bj = bi + t;
+    const int i0 = bi * SY_T, j0 = bj * SY_T;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16x16 threads, 2x2 outputs each
+    double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    for (int k0 = 0; k0 < m; k0 += SY_K) {
+        // 32 columns x 32 k per operand = 1024 elements, 4 per thread, coalesced along k
+        for (int e = threadIdx.x; e < SY_T * SY_K; e += 256) {
+            int col = e / SY_K, kk = e % SY_K;
+            int k = k0 + kk;
+            sa[col][kk] = (k < m && i0 + col < n) ? A[(size_t)(i0 + col) * m + k] : 0.0;
+            sb[col][kk] = (k < m && j0 + col < n) ? A[(size_t)(j0 + col) * m + k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < SY_K; ++kk) {
+            double a0 = sa[ty][kk], a1 = sa[ty + 16][kk];
+            double b0 = sb[tx][kk], b1 = sb[tx + 16][kk];
+            c00 += a0 * b0; c01 += a0 * b1; c10 += a1 * b0; c11 += a1 * b1;
+        }
+        __syncthreads();
+    }
+    auto put = [&](int i, int j, double v) {
+        if (i < n && j < n && i <= j) {
+            if (i == j && damp) v += damp[i];
+            C[(size_t)j * n + i] = v;
+        }
+    };
+    put(i0 + ty, j0 + tx, c00);
+    put(i0 + ty, j0 + tx + 16, c01);
+    put(i0 + ty + 16, j0 + tx, c10);
+    put(i0 + ty + 16, j0 + tx + 16, c11);
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-workgroup Cholesky (upper) + solve.  PIVOT = false: dpotf2 (cholesky!(Symmetric(C)),
+// dense_cholesky.jl:57); PIVOT = true: dpstf2 with tol = 0 (cholesky!(.., Val(true)), :33).
+// info: 0 ok; k > 0 not positive definite at k (unpivoted) / rank deficient with rank k-1... see
+// below.  The right-hand side is solved in place (U'U x = b, with the permutation for PIVOT).
+// ---------------------------------------------------------------------------------------------
+constexpr int CH_NT = 1024;
+template <bool PIVOT>
+__global__ void __launch_bounds__(CH_NT)
+k_chol_solve(double *__restrict__ A, int n, double *__restrict__ b, int *__restrict__ info,
+             int *__restrict__ piv, double *__restrict__ work /* 2n */, double *__restrict__ tmp /* n */) {
+    __shared__ double sh[CH_NT / 64];
+    __shared__ double s_ajj;
+    __shared__ int s_pvt;
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_fail = 0;
+    if (PIVOT) {
+        for (int i = tid; i < n; i += CH_NT) { piv[i] = i; work[i] = 0.0; }
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        double *cj = A + (size_t)j * n;
+        double ajj;
+        if (PIVOT) {
+            // dpstf2: running column dot products, pivot = argmax of the updated diagonal
+            for (int i = j + tid; i < n; i += CH_NT) {
+                if (j > 0) { double a = A[(size_t)i * n + (j - 1)]; work[i] += a * a; }
+                work[n + i] = A[(size_t)i * n + i] - work[i];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int p = j;
+                for (int i = j + 1; i < n; ++i)
+                    if (work[n + i] > work[n + p]) p = i;
+                s_pvt = p;
+                s_ajj = work[n + p];
+                if (s_ajj <= 0.0 || isnan(s_ajj)) { s_fail = 1; *info = j + 1; }
+            }
+            __syncthreads();
+            if (s_fail) return;
+            const int p = s_pvt;
+            if (p != j) {
+                if (tid == 0) A[(size_t)p * n + p] = A[(size_t)j * n + j];
+                for (int i = tid; i < j; i += CH_NT) {
+                    double t = A[(size_t)j * n + i]; A[(size_t)j * n + i] = A[(size_t)p * n + i]; A[(size_t)p * n + i] = t;
+                }
+                for (int k = p + 1 + tid; k < n; k += CH_NT) {
+                    double t = A[(size_t)k * n + j]; A[(size_t)k * n + j] = A[(size_t)k * n + p]; A[(size_t)k * n + p] = t;
+                }
+                for (int i = j + 1 + tid; i < p; i += CH_NT) {
+                    double t = A[(size_t)i * n + j]; A[(size_t)i * n + j] = A[(size_t)p * n + i]; A[(size_t)p * n + i] = t;
+                }
+                if (tid == 0) {
+                    double t = work[j]; work[j] = work[p]; work[p] = t;
+                    int ti = piv[p]; piv[p] = piv[j]; piv[j] = ti;
+                }
+            }
+            __syncthreads();
+            ajj = sqrt(s_ajj);
+            if (tid == 0) cj[j] = ajj;
+        } else {
+            double acc = 0.0;
+            for (int i = tid; i < j; i += CH_NT) acc += cj[i] * cj[i];
+            double tot = 0.0;
+            {
+                double v = wave_sum(acc);
+                if ((tid & 63) == 0) sh[tid >> 6] = v;
+                __syncthreads();
+                if (tid == 0) {
+                    for (int w = 0; w < CH_NT / 64; ++w) tot += sh[w];
+                    double d = cj[j] - tot;
+                    s_ajj = d;
+                    if (d <= 0.0 || isnan(d)) { s_fail = 1; *info = j + 1; cj[j] = d; }
+                    else cj[j] = sqrt(d);
+                }
+                __syncthreads();
+            }
+            if (s_fail) return;
+            ajj = sqrt(s_ajj);
+        }
+        // row j of U: A[j,k] = (A[j,k] - sum_{i<j} A[i,j] A[i,k]) / ajj   for k > j
+        // one wave per column k so the dot product reads are contiguous
+        const int lane = tid & 63, w = tid >> 6;
+        for (int k = j + 1 + w; k < n; k += CH_NT / 64) {
+            double *ck = A + (size_t)k * n;
+            double acc = 0.0;
+            for (int i = lane; i < j; i += 64) acc += cj[i] * ck[i];
+            acc = wave_sum(acc);
+            if (lane == 0) ck[j] = (ck[j] - acc) / ajj;
+        }
+        __syncthreads();
+    }
+    // solve U'U x = P'b
+    double *z = b;
+    if (PIVOT) {
+        for (int i = tid; i < n; i += CH_NT) tmp[i] = b[piv[i]];  // permute!(B, piv)
+        __syncthreads();
+        z = tmp;
+    }
+    // forward: U' y = z  (row i of U' = column i of U: contiguous)
+    for (int i = 0; i < n; ++i) {
+        const double *ci = A + (size_t)i * n;
+        double acc = 0.0;
+        for (int k = tid; k < i; k += CH_NT) acc += ci[k] * z[k];
+        double v = wave_sum(acc);
+        if ((tid & 63) == 0) sh[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < CH_NT / 64; ++w) tot += sh[w];
+            z[i] = (z[i] - tot) / ci[i];
+        }
+        __syncthreads();
+    }
+    // backward: U x = y, column-oriented
+    for (int i = n - 1; i >= 0; --i) {
+        const double *ci = A + (size_t)i * n;
+        if (tid == 0) z[i] = z[i] / ci[i];
+        __syncthreads();
+        const double zi = z[i];
+        for (int k = tid; k < i; k += CH_NT) z[k] -= zi * ci[k];
+        __syncthreads();
+    }
+    if (PIVOT) {
+        for (int i = tid; i < n; i += CH_NT) b[piv[i]] = tmp[i];  // invpermute!
+    }
+    if (tid == 0 && !s_fail) *info = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-workgroup column-pivoted Householder QR (dgeqp3 semantics via the dlaqp2 recurrence)
+// followed by the xGELSY solve.  A is M x n (lda = M), b has length >= max(M, n).
+// ---------------------------------------------------------------------------------------------
+constexpr int QR_NT = 1024;
+
+__device__ __forceinline__ double blk_sum_qr(double v, double *sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < QR_NT / 64; ++w) r += sh[w];
+    __syncthreads();
+    return r;  // every thread gets the total
+}
+
+// LAPACK dlaic1 (incremental condition estimation); alpha = x'w is supplied by the caller.
+__device__ void laic1_dev(int job, double alpha, double sest, double gamma, double *sestpr, double *s,
+                          double *c) {
+    const double eps = DBL_EPSILON / 2;
+    double absalp = fabs(alpha), absgam = fabs(gamma), absest = fabs(sest);
+    double s1, s2, tmp, b, cc, t, zeta1, zeta2, sine, cosine;
+    if (job == 1) {
+        if (sest == 0.0) {
+            s1 = fmax(absgam, absalp);
+            if (s1 == 0.0) { *s = 0; *c = 1; *sestpr = 0; }
+            else { *s = alpha / s1; *c = gamma / s1; tmp = sqrt(*s * *s + *c * *c); *s /= tmp; *c /= tmp; *sestpr = s1 * tmp; }
+        } else if (absgam <= eps * absest) {
+            *s = 1; *c = 0; tmp = fmax(absest, absalp); s1 = absest / tmp; s2 = absalp / tmp;
+            *sestpr = tmp * sqrt(s1 * s1 + s2 * s2);
+        } else if (absalp <= eps * absest) {
+            s1 = absgam; s2 = absest;
+            if (s1 <= s2) { *s = 1; *c = 0; *sestpr = s2; } else { *s = 0; *c = 1; *sestpr = s1; }
+        } else if (absest <= eps * absalp || absest <= eps * absgam) {
+            s1 = absgam; s2 = absalp;
+            if (s1 <= s2) { tmp = s1 / s2; *s = sqrt(1 + tmp * tmp); *sestpr = s2 * *s; *c = (gamma / s2) / *s; *s = copysign(1.0, alpha) / *s; }
+            else { tmp = s2 / s1; *c = sqrt(1 + tmp * tmp); *sestpr = s1 * *c; *s = (alpha / s1) / *c; *c = copysign(1.0, gamma) / *c; }
+        } else {
+            zeta1 = alpha / absest; zeta2 = gamma / absest;
+            b = (1 - zeta1 * zeta1 - zeta2 * zeta2) * 0.5; cc = zeta1 * zeta1;
+            t = b > 0 ? cc / (b + sqrt(b * b + cc)) : sqrt(b * b + cc) - b;
+            sine = -zeta1 / t; cosine = -zeta2 / (1 + t);
+            tmp = sqrt(sine * sine + cosine * cosine);
+            *s = sine / tmp; *c = cosine / tmp; *sestpr = sqrt(t + 1) * absest;
+        }
+    } else {
+        if (sest == 0.0) {
+            *sestpr = 0;
+            if (fmax(absgam, absalp) == 0.0) { sine = 1; cosine = 0; } else { sine = -gamma; cosine = alpha; }
+            s1 = fmax(fabs(sine), fabs(cosine));
+            *s = sine / s1; *c = cosine / s1; tmp = sqrt(*s * *s + *c * *c); *s /= tmp; *c /= tmp;
+        } else if (absgam <= eps * absest) {
+            *s = 0; *c = 1; *sestpr = absgam;
+        } else if (absalp <= eps * absest) {
+            s1 = absgam; s2 = absest;
+            if (s1 <= s2) { *s = 0; *c = 1; *sestpr = s1; } else { *s = 1; *c = 0; *sestpr = s2; }
+        } else if (absest <= eps * absalp || absest <= eps * absgam) {
+            s1 = absgam; s2 = absalp;
+            if (s1 <= s2) { tmp = s1 / s2; *c = sqrt(1 + tmp * tmp); *sestpr = absest * (tmp / *c); *s = -(gamma / s2) / *c; *c = copysign(1.0, alpha) / *c; }
+            else { tmp = s2 / s1; *s = sqrt(1 + tmp * tmp); *sestpr = absest / *s; *c = (alpha / s1) / *s; *s = -copysign(1.0, gamma) / *s; }
+        } else {
+            zeta1 = alpha / absest; zeta2 = gamma / absest;
+            double norma = fmax(1 + zeta1 * zeta1 + fabs(zeta1 * zeta2), fabs(zeta1 * zeta2) + zeta2 * zeta2);
+            double test = 1 + 2 * (zeta1 - zeta2) * (zeta1 + zeta2);
+            if (test >= 0) {
+                b = (zeta1 * zeta1 + zeta2 * zeta2 + 1) * 0.5; cc = zeta2 * zeta2;
+                t = cc / (b + sqrt(fabs(b * b - cc)));
+                sine = zeta1 / (1 - t); cosine = -zeta2 / t;
+                *sestpr = sqrt(t + 4 * eps * eps * norma) * absest;
+            } else {
+                b = (zeta2 * zeta2 + zeta1 * zeta1 - 1) * 0.5; cc = zeta1 * zeta1;
+                t = b >= 0 ? -cc / (b + sqrt(b * b + cc)) : b - sqrt(b * b + cc);
+                sine = -zeta1 / t; cosine = -zeta2 / (1 + t);
+                *sestpr = sqrt(1 + t + 4 * eps * eps * norma) * absest;
+            }
+            tmp = sqrt(sine * sine + cosine * cosine);
+            *s = sine / tmp; *c = cosine / tmp;
+        }
+    }
+}
+
+// ws layout (doubles): vn1[n] vn2[n] tau[mn] wmin[mn] wmax[mn] tz[n] perm[n] ; jp (ints) separate
+__global__ void __launch_bounds__(QR_NT)
+k_qrcp_solve(double *__restrict__ A, int M, int n, double *__restrict__ b, int lenb, double *__restrict__ x,
+             double *__restrict__ ws, int *__restrict__ jp, double *__restrict__ Cz /* n*n scratch */,
+             double rcond, int *__restrict__ rank_out) {
+    __shared__ double sh[QR_NT / 64];
+    __shared__ double s_val;
+    __shared__ double s_val2;
+    __shared__ int s_idx;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NW = QR_NT / 64;
+    const int mn = M < n ? M : n;
+    double *vn1 = ws, *vn2 = ws + n, *tau = ws + 2 * n, *wmin = tau + mn, *wmax = wmin + mn;
+    double *tz = wmax + mn, *perm = tz + n;
+    const double tol3z = sqrt(DBL_EPSILON / 2);
+    // column norms
+    for (int j = wv; j < n; j += NW) {
+        const double *c = A + (size_t)j * M;
+        double acc = 0.0;
+        for (int k = lane; k < M; k += 64) acc += c[k] * c[k];
+        acc = wave_sum(acc);
+        if (lane == 0) { double v = sqrt(acc); vn1[j] = v; vn2[j] = v; jp[j] = j; }
+    }
+    __syncthreads();
+    for (int i = 0; i < mn; ++i) {
+        if (tid == 0) {  // idamax: first maximum
+            int p = i;
+            for (int j = i + 1; j < n; ++j)
+                if (vn1[j] > vn1[p]) p = j;
+            s_idx = p;
+        }
+        __syncthreads();
+        const int p = s_idx;
+        double *ci = A + (size_t)i * M;
+        if (p != i) {
+            double *cp = A + (size_t)p * M;
+            for (int k = tid; k < M; k += QR_NT) { double t = cp[k]; cp[k] = ci[k]; ci[k] = t; }
+            if (tid == 0) { int t = jp[p]; jp[p] = jp[i]; jp[i] = t; vn1[p] = vn1[i]; vn2[p] = vn2[i]; }
+        }
+        __syncthreads();
+        // dlarfg on A(i:M, i)
+        double acc = 0.0;
+        for (int k = i + 1 + tid; k < M; k += QR_NT) acc += ci[k] * ci[k];
+        double xn = sqrt(blk_sum_qr(acc, sh));
+        if (tid == 0) {
+            double alpha = ci[i];
+            if (xn == 0.0) { s_val = 0.0; s_val2 = 0.0; }
+            else {
+                double beta = -copysign(hypot(alpha, xn), alpha);
+                s_val = (beta - alpha) / beta;       // tau
+                s_val2 = 1.0 / (alpha - beta);       // scale
+                ci[i] = beta;
+            }
+            tau[i] = s_val;
+        }
+        __syncthreads();
+        const double ti = s_val, sc = s_val2;
+        if (ti != 0.0)
+            for (int k = i + 1 + tid; k < M; k += QR_NT) ci[k] *= sc;
+        __syncthreads();
+        // apply H(i) to the trailing columns (one wave per column), then downdate the norms
+        for (int j = i + 1 + wv; j < n; j += NW) {
+            double *cj = A + (size_t)j * M;
+            double cji = cj[i];                      // same address in every lane
+            if (ti != 0.0) {
+                double w = 0.0;
+                for (int k = i + 1 + lane; k < M; k += 64) w += ci[k] * cj[k];
+                w = wave_sum(w);
+                w = __shfl(w, 0, 64) + cji;          // v_i = 1
+                const double tw = ti * w;
+                for (int k = i + 1 + lane; k < M; k += 64) cj[k] -= ci[k] * tw;
+                cji -= tw;
+                if (lane == 0) cj[i] = cji;
+            }
+            const double v1 = vn1[j];
+            if (v1 != 0.0) {  // wave-uniform; each lane re-reads only elements it wrote itself
+                double r = fabs(cji) / v1;
+                double temp = fmax(1.0 - r * r, 0.0);
+                double q = v1 / vn2[j];
+                double temp2 = temp * q * q;
+                if (temp2 <= tol3z) {
+                    double nv = 0.0;
+                    if (i < M - 1) {
+                        double a2 = 0.0;
+                        for (int k = i + 1 + lane; k < M; k += 64) a2 += cj[k] * cj[k];
+                        a2 = wave_sum(a2);
+                        nv = sqrt(__shfl(a2, 0, 64));
+                    }
+                    if (lane == 0) { vn1[j] = nv; vn2[j] = nv; }
+                } else if (lane == 0) {
+                    vn1[j] = v1 * sqrt(temp);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- rank detection (dlaic1), LinearAlgebra.ldiv!(::QRPivoted, B, rcond) [stdlib] ----
+    int rnk = 0;
+    {
+        double smax = fabs(A[0]), smin = smax;
+        if (smax == 0.0) {
+            for (int k = tid; k < n; k += QR_NT) x[k] = 0.0;
+            if (tid == 0) *rank_out = 0;
+            return;
+        }
+        if (tid == 0) { wmin[0] = 1.0; wmax[0] = 1.0; }
+        __syncthreads();
+        rnk = 1;
+        while (rnk < mn) {
+            const int i = rnk;
+            const double *col = A + (size_t)i * M;
+            double a1 = 0.0, a2 = 0.0;
+            for (int k = tid; k < rnk; k += QR_NT) { a1 += wmin[k] * col[k]; a2 += wmax[k] * col[k]; }
+            a1 = blk_sum_qr(a1, sh);
+            a2 = blk_sum_qr(a2, sh);
+            double sminpr, s1, c1, smaxpr, s2, c2;
+            laic1_dev(2, a1, smin, col[i], &sminpr, &s1, &c1);   // every thread computes the same
+            laic1_dev(1, a2, smax, col[i], &smaxpr, &s2, &c2);
+            if (smaxpr * rcond > sminpr) break;
+            for (int k = tid; k < rnk; k += QR_NT) { wmin[k] *= s1; wmax[k] *= s2; }
+            if (tid == 0) { wmin[i] = c1; wmax[i] = c2; }
+            smin = sminpr; smax = smaxpr;
+            rnk += 1;
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    // ---- Q'b (dorm2r 'L','T'): H(0), H(1), ... in order ----
+    for (int i = 0; i < mn; ++i) {
+        const double *ci = A + (size_t)i * M;
+        double acc = 0.0;
+        for (int k = i + 1 + tid; k < M; k += QR_NT) acc += ci[k] * b[k];
+        double s = (blk_sum_qr(acc, sh) + b[i]) * tau[i];
+        __syncthreads();
+        for (int k = i + 1 + tid; k < M; k += QR_NT) b[k] -= ci[k] * s;
+        if (tid == 0) b[i] -= s;
+        __syncthreads();
+    }
+    if (rnk < n) {
+        // RZ factorisation of R(0:rnk, :) (dlatrz) into the scratch copy Cz (rnk x n, ld = rnk)
+        const int l = n - rnk;
+        for (int e = tid; e < rnk * n; e += QR_NT) {
+            int r = e % rnk, cidx = e / rnk;
+            Cz[e] = (r <= cidx) ? A[(size_t)cidx * M + r] : 0.0;
+        }
+        __syncthreads();
+        for (int i = rnk - 1; i >= 0; --i) {
+            double acc = 0.0;
+            for (int k = tid; k < l; k += QR_NT) { double v = Cz[(size_t)(n - l + k) * rnk + i]; acc += v * v; }
+            double xn = sqrt(blk_sum_qr(acc, sh));
+            if (tid == 0) {
+                double alpha = Cz[(size_t)i * rnk + i];
+                if (xn == 0.0) { s_val = 0.0; s_val2 = 0.0; }
+                else {
+                    double beta = -copysign(hypot(alpha, xn), alpha);
+                    s_val = (beta - alpha) / beta;
+                    s_val2 = 1.0 / (alpha - beta);
+                    Cz[(size_t)i * rnk + i] = beta;
+                }
+                tz[i] = s_val;
+            }
+            __syncthreads();
+            const double ti = s_val, sc = s_val2;
+            if (ti != 0.0)
+                for (int k = tid; k < l; k += QR_NT) Cz[(size_t)(n - l + k) * rnk + i] *= sc;
+            __syncthreads();
+            if (ti != 0.0)
+                for (int r = tid; r < i; r += QR_NT) {  // dlarz 'R' on rows 0..i-1
+                    double w = Cz[(size_t)i * rnk + r];
+                    for (int k = 0; k < l; ++k) w += Cz[(size_t)(n - l + k) * rnk + r] * Cz[(size_t)(n - l + k) * rnk + i];
+                    Cz[(size_t)i * rnk + r] -= ti * w;
+                    for (int k = 0; k < l; ++k) Cz[(size_t)(n - l + k) * rnk + r] -= ti * w * Cz[(size_t)(n - l + k) * rnk + i];
+                }
+            __syncthreads();
+        }
+        for (int i = rnk - 1; i >= 0; --i) {  // T z = (Q'b)(0:rnk), column-oriented
+            if (tid == 0) b[i] = b[i] / Cz[(size_t)i * rnk + i];
+            __syncthreads();
+            const double bi = b[i];
+            for (int k = tid; k < i; k += QR_NT) b[k] -= bi * Cz[(size_t)i * rnk + k];
+            __syncthreads();
+        }
+        for (int k = rnk + tid; k < n; k += QR_NT) b[k] = 0.0;
+        __syncthreads();
+        for (int i = 0; i < rnk; ++i) {  // Z'b (dormr3 'L','T')
+            double acc = 0.0;
+            for (int k = tid; k < l; k += QR_NT) acc += Cz[(size_t)(n - l + k) * rnk + i] * b[n - l + k];
+            double w = (blk_sum_qr(acc, sh) + b[i]) * tz[i];
+            __syncthreads();
+            for (int k = tid; k < l; k += QR_NT) b[n - l + k] -= Cz[(size_t)(n - l + k) * rnk + i] * w;
+            if (tid == 0) b[i] -= w;
+            __syncthreads();
+        }
+    } else {
+        for (int i = n - 1; i >= 0; --i) {
+            const double *ci = A + (size_t)i * M;
+            if (tid == 0) b[i] = b[i] / ci[i];
+            __syncthreads();
+            const double bi = b[i];
+            for (int k = tid; k < i; k += QR_NT) b[k] -= bi * ci[k];
+            __syncthreads();
+        }
+    }
+    for (int k = tid; k < n; k += QR_NT) perm[jp[k]] = b[k];
+    __syncthreads();
+    for (int k = tid; k < n; k += QR_NT) x[k] = perm[k];
+    if (tid == 0) *rank_out = rnk;
+    (void)lenb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers: stacked matrix [J; diag(sqrt(damp))] and right-hand side (y, 0)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(LSQ_NT)
+k_stack(const double *__restrict__ J, int m, int n, const double *__restrict__ damp, double *__restrict__ Q) {
+    const int M = damp ? m + n : m;
+    const long long tot = (long long)M * n;
+    for (long long e = blockIdx.x * (long long)LSQ_NT + threadIdx.x; e < tot; e += (long long)gridDim.x * LSQ_NT) {
+        int r = (int)(e % M), c = (int)(e / M);
+        double v;
+        if (r < m) v = J[(size_t)c * m + r];
+        else v = (r - m == c) ? sqrt(damp[c]) : 0.0;  // dense_qr.jl:72-74
+        Q[e] = v;
+    }
+}
+__global__ void __launch_bounds__(LSQ_NT)
+k_rhs(const double *__restrict__ y, int m, int len, double *__restrict__ u) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < len; i += gridDim.x * LSQ_NT) u[i] = i < m ? y[i] : 0.0;
+}
+
+int lsq_dense_solver_alloc(lsq_solver *s) {
+    const int m = s->m, n = s->n;
+    const size_t n1 = n > 0 ? n : 1;
+    LSQ_HIP(hipMalloc(&s->d_info, 4 * sizeof(int)));
+    if (s->kind == LSQ_CHOLESKY) {
+        LSQ_HIP(hipMalloc(&s->d_chol, n1 * n1 * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->d_rhs, n1 * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->d_work, 4 * n1 * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->d_tau, n1 * sizeof(int) + 16));  // pivots
+    } else {
+        const size_t M = s->for_lm ? (size_t)m + n : (size_t)m;       // dense_qr.jl:25-28, 50-54
+        const size_t lu = s->for_lm ? M : (size_t)std::max(m, n);
+        LSQ_HIP(hipMalloc(&s->d_qr, (M * n1 + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->d_qu, (lu + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->d_work, (8 * n1 + 3 * M + 64) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->d_tau, n1 * sizeof(int) + 16));         // jpvt
+        LSQ_HIP(hipMalloc(&s->d_T, n1 * n1 * sizeof(double)));        // RZ scratch
+    }
+    return LSQ_OK;
+}
+
+void lsq_dense_solver_free(lsq_solver *s) {
+    hipFree(s->d_info); hipFree(s->d_chol); hipFree(s->d_rhs); hipFree(s->d_work); hipFree(s->d_tau);
+    hipFree(s->d_qr); hipFree(s->d_qu); hipFree(s->d_T);
+}
+
+// dense_cholesky.jl:29-35 (d_damp == nullptr: pivoted) and :43-59 (damped, unpivoted)
+int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_damp, double *d_x, int *nmul) {
+    lsq_ctx *c = s->ctx;
+    const int m = J->m, n = J->n;
+    if (J->kind != LSQ_MAT_DENSE) {
+        lsq_set_error("Cholesky() has no method for sparse Jacobians (dense_cholesky.jl:19)");
+        return LSQ_EARG;
+    }
+    if (n != s->n || m != s->m) { lsq_set_error("cholesky: size mismatch"); return LSQ_EDIM; }
+    if (n > 0) {
+        const int nt = (n + SY_T - 1) / SY_T;
+        hipLaunchKernelGGL(k_syrk_upper, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, J->d_dense, m, n,
+                           s->d_chol, d_damp);
+        LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
+        int *piv = (int *)s->d_tau;
+        if (d_damp)
+            hipLaunchKernelGGL((k_chol_solve<false>), dim3(1), dim3(CH_NT), 0, c->stream, s->d_chol, n, d_x,
+                               s->d_info, piv, s->d_work, s->d_work + 2 * n);
+        else
+            hipLaunchKernelGGL((k_chol_solve<true>), dim3(1), dim3(CH_NT), 0, c->stream, s->d_chol, n, d_x,
+                               s->d_info, piv, s->d_work, s->d_work + 2 * n);
+        LSQ_HIP(hipGetLastError());
+        int info = 0;
+        LSQ_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        LSQ_HIP(hipStreamSynchronize(c->stream));
+        if (info != 0) {
+            if (d_damp) {
+                lsq_set_error("PosDefException: matrix is not positive definite; Cholesky failed at %d", info);
+                return LSQ_ENOTPD;
+            }
+            lsq_set_error("RankDeficientException(%d)", info - 1);
+            return LSQ_ERANK;
+        }
+    }
+    if (nmul) *nmul = 1;
+    return LSQ_OK;
+}
+
+// dense_qr.jl:30-42 (d_damp == nullptr) and :56-88
+int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_damp, double *d_x, int *nmul) {
+    lsq_ctx *c = s->ctx;
+    const int m = J->m, n = J->n;
+    if (J->kind != LSQ_MAT_DENSE) {
+        lsq_set_error("solver QR() is not available for sparse Jacobians. Choose between Cholesky() and LSMR()");
+        return LSQ_EARG;  // types.jl:115-117
+    }
+    if (n != s->n || m != s->m || (d_damp != nullptr) != (s->for_lm != 0)) {
+        lsq_set_error("qr: solver/Jacobian mismatch (length(u) should equal length(x) + length(y))");
+        return LSQ_EDIM;
+    }
+    const int M = d_damp ? m + n : m;
+    const int lu = d_damp ? M : std::max(m, n);
+    if (n > 0 && M > 0) {
+        long long tot = (long long)M * n;
+        int grid = (int)std::min<long long>((tot + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
+        hipLaunchKernelGGL(k_stack, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, m, n, d_damp, s->d_qr);
+        hipLaunchKernelGGL(k_rhs, dim3(lsq_div_up(lu, LSQ_NT)), dim3(LSQ_NT), 0, c->stream, d_y, m, lu, s->d_qu);
+        const int mn = std::min(M, n);
+        hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
+                           s->d_work, (int *)s->d_tau, s->d_T, (double)mn * DBL_EPSILON, s->d_info);
+        LSQ_HIP(hipGetLastError());
+    }
+    s->last_rank = -1;  // fetched lazily by lsq_solver_info
+    if (nmul) *nmul = 1;
+    return LSQ_OK;
+}

@@ -1,0 +1,409 @@
+// Device-resident LSMR (Fong & Saunders) on the damped, Jacobi-preconditioned operator
+//     A = [J; diag(sqrt(damp))] * diag(P)          b = (y, 0)
+// replacing lsmr.jl:53-238 driven by iterative_lsmr.jl:179-198 (Dogleg) / :238-259 (LM).
+//
+// One inner iteration = three launches, zero host synchronisations:
+//   K1  u~ <- J t - cu*u~   (+ damped rows, + sum u~^2 -> beta)          t = P.*v, cu = alpha/beta
+//   K2  v~ <- P.*(J'u~ + d.*ux~)/beta - beta*v  (+ sum v~^2 -> alpha, + the two Givens chains,
+//        ||r||, ||A||, cond(A) estimates: ~60 scalar flops in the last block)
+//   K3  v <- v~/alpha; hbar, x, h updates; t <- P.*v; sum x^2 -> ||x||; the 7 stopping rules
+// The PreconditionedMatrix / DampenedMatrix / MyAdjoint / InverseDiagonal wrappers
+// (iterative_lsmr.jl:12-122) become epilogue arithmetic; u is kept UNNORMALISED (its 1/beta is
+// folded into the consumer), which removes the rmul! passes over the m-vector (lsmr.jl:121).
+// The recurrence lives in device memory; the host learns about termination through a pinned
+// mailbox word and runs at most LSQ_LOOKAHEAD iterations ahead (kernels of a finished solve exit
+// on their first instruction).  Stopping rules are evaluated every iteration, so `iter` (and
+// mul_calls = 2*iter, lsmr.jl:236) is the count the reference would report.
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+
+#include "lsq_solver.h"
+#include "lsq_spmv.h"
+
+static constexpr int LSQ_LOOKAHEAD_DEFAULT = 2;
+
+// mailbox word: [63:41] epoch | [40] done | [39:32] istop | [31:0] iter
+__device__ __forceinline__ void publish(LsqMailbox *mail, const LsmrState *st) {
+    unsigned long long w = ((unsigned long long)(st->epoch & 0x7fffffu) << 41) |
+                           ((unsigned long long)(st->done ? 1 : 0) << 40) |
+                           ((unsigned long long)(st->istop & 0xff) << 32) | (unsigned)st->iter;
+    __hip_atomic_store((unsigned long long *)mail, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- setup: P, sqrt(damp) (iterative_lsmr.jl:129-141, 251-252) ------------------------------
+__global__ void __launch_bounds__(LSQ_NT)
+k_lsmr_prep(int n, const double *__restrict__ colsum, double *__restrict__ damp, double *__restrict__ P,
+            double *__restrict__ dg, double *__restrict__ ux) {
+    for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT) {
+        double s = colsum[j];
+        if (damp) {
+            double d = damp[j];
+            s += d;                  // axpy!(1, damp, out._)  -- damp is still dtd/Delta here
+            double r = sqrt(d);      // map!(sqrt, damp, damp)
+            dg[j] = r;
+            damp[j] = r;             // the reference clobbers the caller's damp (:252)
+            ux[j] = 0.0;             // zerosvector (:246)
+        }
+        P[j] = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+    }
+}
+
+// ---- beta_1 = ||b|| and state reset (lsmr.jl:73-75 with x == 0) ------------------------------
+__global__ void __launch_bounds__(LSQ_NT)
+k_lsmr_begin(int m, const double *__restrict__ y, LsmrState *st, LsqMailbox *mail, double *partials,
+             unsigned *counter, double atol, double btol, double ctol, int maxiter, unsigned epoch) {
+    __shared__ double sh[LSQ_NT / 64];
+    double acc = 0.0;
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < m; i += (long long)gridDim.x * LSQ_NT) {
+        double v = y[i];
+        acc += v * v;
+    }
+    double bv = block_sum<LSQ_NT>(acc, sh);
+    grid_reduce<LSQ_NT>(bv, partials, counter, gridDim.x, sh, [=](double t) {
+        double beta = sqrt(t);
+        st->beta = beta;
+        st->beta_zero = !(beta > 0.0);
+        st->inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
+        st->iter = 0;
+        st->istop = 0;
+        st->done = 0;
+        st->first = 1;
+        st->atol = atol;
+        st->btol = btol;
+        st->ctol = ctol;
+        st->maxiter = maxiter;
+        st->epoch = epoch;
+    });
+    (void)mail;
+}
+
+// ---- K1: u~ <- J t - cu u~ --------------------------------------------------------------------
+struct EpiU {
+    static constexpr bool REDUCE = true;
+    const int *done;
+    int extra_blocks;
+    LsmrState *st;
+    const double *uold;
+    double *unew;
+    // damped rows
+    int n;
+    const double *dg;
+    const double *t;
+    double *ux;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int s, double dot, double &racc) const {
+        double un = dot - st->cu * uold[s];
+        unew[s] = un;
+        racc += un * un;
+    }
+    __device__ void extra(int blk, double &racc) const {  // DampenedMatrix rows, iterative_lsmr.jl:92
+        int j = blk * LSQ_NT + threadIdx.x;
+        if (j < n) {
+            double un = t[j] * dg[j] - st->cu * ux[j];
+            ux[j] = un;
+            racc += un * un;
+        }
+    }
+    __device__ void finalize(double total) const {  // lsmr.jl:119-121, DampenedVector norm il:72
+        double beta = sqrt(total);
+        st->beta = beta;
+        st->beta_zero = !(beta > 0.0);
+        st->inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
+    }
+};
+
+// ---- K2: v~ <- P (J'u~ + d ux~)/beta - beta v, alpha, rotations -------------------------------
+struct EpiV {
+    static constexpr bool REDUCE = true;
+    const int *done;
+    int extra_blocks;
+    LsmrState *st;
+    LsqMailbox *mail;
+    const double *P;
+    const double *dg;
+    const double *ux;   // null during setup (zerosvector)
+    double *v;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int j, double dot, double &racc) const {
+        if (st->beta_zero) return;  // lsmr.jl:120
+        double w = dot;
+        if (dg && ux) w += ux[j] * dg[j];           // iterative_lsmr.jl:107
+        w *= st->inv_beta;                          // u = u~/beta
+        if (P) w *= P[j];                           // :41
+        double vn = st->first ? w : w - st->beta * v[j];  // :42-49 (beta == 0 => fill!)
+        v[j] = vn;
+        racc += vn * vn;
+    }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double total) const;
+};
+
+__device__ void EpiV::finalize(double total) const {
+    LsmrState &s = *st;
+    if (!s.beta_zero) {
+        s.alpha = sqrt(total);                       // lsmr.jl:77,123
+        s.vscale = s.alpha > 0.0 ? 1.0 / s.alpha : 1.0;
+    } else {
+        if (s.first) s.alpha = 0.0;
+        s.vscale = 1.0;
+    }
+    const double alpha = s.alpha, beta = s.beta;
+    if (s.first) {                                   // lsmr.jl:82-113
+        s.zetabar = alpha * beta;
+        s.alphabar = alpha;
+        s.rho = 1.0; s.rhobar = 1.0; s.cbar = 1.0; s.sbar = 0.0;
+        s.betadd = beta; s.betad = 0.0; s.rhodold = 1.0; s.tautildeold = 0.0;
+        s.thetatilde = 0.0; s.zeta = 0.0; s.d = 0.0;
+        s.normA = -1.0; s.condA = -1.0; s.normx = -1.0;
+        s.normA2 = alpha * alpha;
+        s.maxrbar = 0.0; s.minrbar = 1e100;
+        s.normb = beta; s.normr = beta; s.normAr = alpha * beta;
+        s.cu = beta > 0.0 ? alpha / beta : alpha;
+        if (!(s.normAr != 0.0)) {                    // lsmr.jl:115: exit if b = 0 or A'b = 0
+            s.done = 1;
+            publish(mail, st);
+        }
+        return;
+    }
+    const double lambda = 0.0;
+    // lsmr.jl:127-130
+    double alphahat = sqrt(s.alphabar * s.alphabar + lambda * lambda);
+    double chat = s.alphabar / alphahat, shat = lambda / alphahat;
+    // :132-138
+    double rhoold = s.rho;
+    double rho = sqrt(alphahat * alphahat + beta * beta);
+    double c = alphahat / rho, sn = beta / rho;
+    double thetanew = sn * alpha;
+    s.alphabar = c * alpha;
+    // :140-149
+    double rhobarold = s.rhobar, zetaold = s.zeta;
+    double thetabar = s.sbar * rho;
+    double rhotemp = s.cbar * rho;
+    double rhobar = sqrt((s.cbar * rho) * (s.cbar * rho) + thetanew * thetanew);
+    s.cbar = s.cbar * rho / rhobar;
+    s.sbar = thetanew / rhobar;
+    s.zeta = s.cbar * s.zetabar;
+    s.zetabar = -s.sbar * s.zetabar;
+    s.rho = rho; s.rhobar = rhobar;
+    // :152-156 coefficients of the vector updates
+    s.c1 = -thetabar * rho / (rhoold * rhobarold);
+    s.c2 = s.zeta / (rho * rhobar);
+    s.c3 = -thetanew / rho;
+    // :164-184 estimate of ||r||
+    double betaacute = chat * s.betadd, betacheck = -shat * s.betadd;
+    double betahat = c * betaacute;
+    s.betadd = -sn * betaacute;
+    double thetatildeold = s.thetatilde;
+    double rhotildeold = sqrt(s.rhodold * s.rhodold + thetabar * thetabar);
+    double ctildeold = s.rhodold / rhotildeold, stildeold = thetabar / rhotildeold;
+    s.thetatilde = stildeold * rhobar;
+    s.rhodold = ctildeold * rhobar;
+    s.betad = -stildeold * s.betad + ctildeold * betahat;
+    s.tautildeold = (zetaold - thetatildeold * s.tautildeold) / rhotildeold;
+    double taud = (s.zeta - s.thetatilde * s.tautildeold) / s.rhodold;
+    s.d = s.d + betacheck * betacheck;
+    s.normr = sqrt(s.d + (s.betad - taud) * (s.betad - taud) + s.betadd * s.betadd);
+    // :187-189 ||A||
+    s.normA2 = s.normA2 + beta * beta;
+    s.normA = sqrt(s.normA2);
+    s.normA2 = s.normA2 + alpha * alpha;
+    // :192-196 cond(A)
+    s.maxrbar = fmax(s.maxrbar, rhobarold);
+    if (s.iter + 1 > 1) s.minrbar = fmin(s.minrbar, rhobarold);
+    s.condA = fmax(s.maxrbar, rhotemp) / fmin(s.minrbar, rhotemp);
+    s.normAr = fabs(s.zetabar);                      // :205
+    s.cu = beta > 0.0 ? alpha / beta : alpha;        // next K1: u~_new = A v - (alpha/beta) u~
+}
+
+// ---- K3: n-vector updates, ||x||, stopping rules ----------------------------------------------
+__global__ void __launch_bounds__(LSQ_NT)
+k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *__restrict__ P, double *__restrict__ v,
+              double *__restrict__ h, double *__restrict__ hbar, double *__restrict__ x,
+              double *__restrict__ t, double *partials, unsigned *counter) {
+    __shared__ double sh[LSQ_NT / 64];
+    if (st->done) return;
+    const bool first = st->first;
+    const double vs = st->vscale, c1 = st->c1, c2 = st->c2, c3 = st->c3;
+    double acc = 0.0;
+    for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT) {
+        double vj = v[j] * vs;                       // lsmr.jl:78,124 rmul!(v, inv(alpha))
+        v[j] = vj;
+        if (first) {                                 // :89-90, iterative_lsmr.jl:183,242
+            h[j] = vj;
+            hbar[j] = 0.0;
+            x[j] = 0.0;
+        } else {
+            double hb = hbar[j] * c1 + h[j];         // :152-153
+            hbar[j] = hb;
+            double xj = x[j] + c2 * hb;              // :154
+            x[j] = xj;
+            h[j] = h[j] * c3 + vj;                   // :155-156
+            acc += xj * xj;
+        }
+        t[j] = P ? vj * P[j] : vj;                   // iterative_lsmr.jl:31 ldiv!(tmp, P, a)
+    }
+    double bv = block_sum<LSQ_NT>(acc, sh);
+    grid_reduce<LSQ_NT>(bv, partials, counter, gridDim.x, sh, [=](double total) {
+        LsmrState &s = *st;
+        if (s.first) {
+            s.first = 0;
+            publish(mail, st);
+            return;
+        }
+        s.iter += 1;
+        s.normx = sqrt(total);                       // lsmr.jl:206
+        double test1 = s.normr / s.normb;
+        double test2 = s.normAr / (s.normA * s.normr);
+        double test3 = 1.0 / s.condA;
+        double t1 = test1 / (1.0 + s.normA * s.normx / s.normb);
+        double rtol = s.btol + s.atol * s.normA * s.normx / s.normb;
+        int istop = 0;                               // :224-231, first hit wins
+        if (s.iter >= s.maxiter) istop = 7;
+        else if (1.0 + test3 <= 1.0) istop = 6;
+        else if (1.0 + test2 <= 1.0) istop = 5;
+        else if (1.0 + t1 <= 1.0) istop = 4;
+        else if (test3 <= s.ctol) istop = 3;
+        else if (test2 <= s.atol) istop = 2;
+        else if (test1 <= rtol) istop = 1;
+        s.istop = istop;
+        if (istop) s.done = 1;
+        publish(mail, st);
+    });
+}
+
+// ---- x <- P .* x (iterative_lsmr.jl:195-196, 256-257) ----------------------------------------
+__global__ void __launch_bounds__(LSQ_NT)
+k_lsmr_finish(int n, const LsmrState *st, const double *__restrict__ P, const double *__restrict__ xs,
+              double *__restrict__ x) {
+    const bool zero = (st->iter == 0);  // A'b == 0: x stays the zero start
+    for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT)
+        x[j] = zero ? 0.0 : xs[j] * P[j];
+}
+
+int lsq_lsmr_alloc(lsq_solver *s) {
+    size_t nb = (size_t)(s->n > 0 ? s->n : 1) * sizeof(double);
+    LSQ_HIP(hipMalloc(&s->d_state, sizeof(LsmrState)));
+    LSQ_HIP(hipMemset(s->d_state, 0, sizeof(LsmrState)));
+    LSQ_HIP(hipMalloc(&s->d_u, (size_t)(s->m > 0 ? s->m : 1) * sizeof(double)));
+    LSQ_HIP(hipMalloc(&s->d_ux, nb));
+    LSQ_HIP(hipMalloc(&s->d_v, nb));
+    LSQ_HIP(hipMalloc(&s->d_h, nb));
+    LSQ_HIP(hipMalloc(&s->d_hbar, nb));
+    LSQ_HIP(hipMalloc(&s->d_t, nb));
+    LSQ_HIP(hipMalloc(&s->d_P, nb));
+    LSQ_HIP(hipMalloc(&s->d_dg, nb));
+    LSQ_HIP(hipMalloc(&s->d_rhs, nb));  // LSMR iterate (un-preconditioned space)
+    return LSQ_OK;
+}
+
+void lsq_lsmr_free(lsq_solver *s) {
+    hipFree(s->d_state); hipFree(s->d_u); hipFree(s->d_ux); hipFree(s->d_v); hipFree(s->d_h);
+    hipFree(s->d_hbar); hipFree(s->d_t); hipFree(s->d_P); hipFree(s->d_dg); hipFree(s->d_rhs);
+}
+
+static inline int nvec_grid(const lsq_ctx *c, int n) {
+    int g = lsq_div_up(n > 0 ? n : 1, LSQ_NT);
+    int cap = c->num_cus * 4;
+    return g > cap ? cap : g;
+}
+
+// d_damp == nullptr: undamped (Dogleg, atol = btol = 1e-6); else LM (btol = 0.5).
+int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul) {
+    lsq_ctx *c = s->ctx;
+    const int m = J->m, n = J->n;
+    if (m != s->m || n != s->n) {
+        lsq_set_error("lsmr: solver allocated for %dx%d, Jacobian is %dx%d", s->m, s->n, m, n);
+        return LSQ_EDIM;
+    }
+    static const int lookahead = [] {
+        const char *e = getenv("LSQ_LOOKAHEAD");
+        int v = e ? atoi(e) : LSQ_LOOKAHEAD_DEFAULT;
+        return v < 1 ? 1 : v;
+    }();
+    const bool damped = d_damp != nullptr;
+    const double atol = 1e-6, btol = damped ? 0.5 : 1e-6, conlim = 1e8;  // lsmr.jl:54, il:255
+    const long long rows = damped ? (long long)m + n : m;
+    const int maxiter = (int)std::max<long long>(rows, n);               // lsmr.jl:55
+    const unsigned epoch = (++c->mail_epoch) & 0x7fffffu;
+    LsmrState *st = s->d_state;
+    const int *done = &st->done;
+    double *xs = s->d_rhs;
+
+    if (J->kind == LSQ_MAT_CSC) LSQ_TRY(lsq_ensure_csr(J));
+    const double *colsum = lsq_cached_colsum(J);  // computed once per Jacobian (reference: twice)
+    if (!colsum) return LSQ_EHIP;
+    *(volatile unsigned long long *)c->h_mail = 0ull;
+    const int gn = nvec_grid(c, n);
+    hipLaunchKernelGGL(k_lsmr_prep, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P,
+                       s->d_dg, s->d_ux);
+    {
+        long long gb = std::min<long long>(lsq_div_up(m > 0 ? m : 1, LSQ_NT), (long long)c->num_cus * 8);
+        hipLaunchKernelGGL(k_lsmr_begin, dim3((int)gb), dim3(LSQ_NT), 0, c->stream, m, d_y, st, c->d_mail,
+                           c->d_partials, c->d_counters + 1, atol, btol, 1.0 / conlim, maxiter, epoch);
+    }
+    LSQ_HIP(hipGetLastError());
+    // v~ = A'u (setup), then K3 in "first" mode
+    EpiV ev{done, 0, st, c->d_mail, s->d_P, damped ? s->d_dg : nullptr, nullptr, s->d_v,
+            c->d_partials, c->d_counters + 2};
+    LSQ_TRY(launch_product(J, 1, d_y, ev));
+    hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, s->d_P,
+                       s->d_v, s->d_h, s->d_hbar, xs, s->d_t, c->d_partials, c->d_counters + 3);
+    LSQ_HIP(hipGetLastError());
+
+    EpiU eu{done, damped ? lsq_div_up(n, LSQ_NT) : 0, st, d_y, s->d_u, n, s->d_dg, s->d_t, s->d_ux,
+            c->d_partials, c->d_counters + 1};
+    ev.ux = damped ? s->d_ux : nullptr;
+
+    int enq = 0, it = 0, istop = 0;
+    bool finished = false;
+    unsigned long long spins = 0;
+    while (!finished) {
+        unsigned long long w = *(volatile unsigned long long *)c->h_mail;
+        if ((unsigned)(w >> 41) == epoch) {
+            it = (int)(w & 0xffffffffu);
+            if ((w >> 40) & 1ull) {
+                istop = (int)((w >> 32) & 0xff);
+                finished = true;
+                break;
+            }
+        }
+        if (enq - it < lookahead && enq < maxiter) {
+            LSQ_TRY(launch_product(J, 0, s->d_t, eu));   // K1
+            eu.uold = s->d_u;                            // after the first iteration u~ lives in d_u
+            LSQ_TRY(launch_product(J, 1, s->d_u, ev));   // K2
+            hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
+                               s->d_P, s->d_v, s->d_h, s->d_hbar, xs, s->d_t, c->d_partials,
+                               c->d_counters + 3);
+            LSQ_HIP(hipGetLastError());
+            ++enq;
+            spins = 0;
+            continue;
+        }
+        if ((++spins & 0x3ffu) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
+            // stream drained: whatever the mailbox shows now is final for the enqueued work
+            w = *(volatile unsigned long long *)c->h_mail;
+            if ((unsigned)(w >> 41) == epoch && ((w >> 40) & 1ull)) continue;
+            if ((unsigned)(w >> 41) == epoch && (int)(w & 0xffffffffu) >= enq) continue;
+            // mailbox not visible (should not happen with coherent host memory): read the state
+            LsmrState hs;
+            LSQ_HIP(hipMemcpy(&hs, st, sizeof(hs), hipMemcpyDeviceToHost));
+            it = hs.iter;
+            if (hs.done) {
+                istop = hs.istop;
+                finished = true;
+            } else if (enq >= maxiter) {
+                lsq_set_error("lsmr: iteration budget exhausted without a stop rule");
+                return LSQ_EHIP;
+            }
+        }
+    }
+    hipLaunchKernelGGL(k_lsmr_finish, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, s->d_P, xs, d_x);
+    LSQ_HIP(hipGetLastError());
+    s->last_iter = it;
+    s->last_istop = istop;
+    if (nmul) *nmul = 2 * it;  // lsmr.jl:236 ch.mvps
+    return LSQ_OK;
+}

@@ -1,0 +1,787 @@
+// Solver plug point (ldiv!), the Levenberg-Marquardt / Dogleg trust-region loops on device
+// buffers (levenberg_marquardt.jl:39-144, dogleg.jl:41-203: host control flow, device arrays),
+// and the built-in device-side tanh model used by the synthetic benchmarks.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "lsq_solver.h"
+#include "lsq_spmv.h"
+
+// constants that shape trajectories (types.jl:107-111, dogleg.jl:38-39)
+static constexpr double MIN_DELTA = 1e-16, MAX_DELTA = 1e16, MIN_STEP_QUALITY = 1e-3;
+static constexpr double MIN_DIAGONAL = 1e-6, MAX_DIAGONAL = 1e32;
+static constexpr double DECREASE_THRESHOLD = 0.25, INCREASE_THRESHOLD = 0.75;
+
+// scalar slots used by the loops (ctx->d_slots)
+enum { SL_GRAD = 8, SL_DX = 9, SL_NONFIN = 10, SL_TRIAL = 11, SL_PRED = 12, SL_SSR = 13, SL_W0 = 14, SL_W1 = 15,
+       SL_W2 = 16, SL_SUM = 17 };
+
+// ---------------------------------------------------------------------------------------------
+// solver objects
+// ---------------------------------------------------------------------------------------------
+extern "C" int lsq_solver_create(lsq_ctx *c, lsq_mat *J, int kind, int for_lm, lsq_solver **out) {
+    if (!c || !J || !out) return LSQ_EARG;
+    if (kind == LSQ_QR && J->kind != LSQ_MAT_DENSE) {
+        lsq_set_error("solver QR() is not available for sparse Jacobians. Choose between Cholesky() and LSMR()");
+        return LSQ_EARG;  // types.jl:115-117
+    }
+    if (kind == LSQ_CHOLESKY && J->kind != LSQ_MAT_DENSE) {
+        lsq_set_error("MethodError: no AbstractAllocatedSolver for Cholesky() with a sparse Jacobian "
+                      "(dense_cholesky.jl:19 requires a StridedVecOrMat)");
+        return LSQ_EARG;
+    }
+    LSQ_HIP(hipSetDevice(c->device));
+    lsq_solver *s = new lsq_solver();
+    s->ctx = c;
+    s->kind = kind;
+    s->for_lm = for_lm ? 1 : 0;
+    s->m = J->m;
+    s->n = J->n;
+    int st = (kind == LSQ_LSMR) ? lsq_lsmr_alloc(s) : lsq_dense_solver_alloc(s);
+    if (st != LSQ_OK) {
+        delete s;
+        return st;
+    }
+    *out = s;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_solver_destroy(lsq_solver *s) {
+    if (!s) return LSQ_OK;
+    hipStreamSynchronize(s->ctx->stream);
+    if (s->kind == LSQ_LSMR) lsq_lsmr_free(s);
+    else lsq_dense_solver_free(s);
+    delete s;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_ldiv(lsq_solver *s, lsq_mat *J, const double *y, double *x, int *nmul) {
+    if (!s || !J || !y || !x) return LSQ_EARG;
+    if (s->for_lm && s->kind == LSQ_QR) {
+        lsq_set_error("ldiv!: this QR solver was allocated for LevenbergMarquardt (damped)");
+        return LSQ_EDIM;
+    }
+    switch (s->kind) {
+    case LSQ_LSMR: return lsq_lsmr_solve(s, J, y, nullptr, x, nmul);
+    case LSQ_CHOLESKY: return lsq_cholesky_solve(s, J, y, nullptr, x, nmul);
+    default: return lsq_qr_solve(s, J, y, nullptr, x, nmul);
+    }
+}
+
+extern "C" int lsq_ldiv_damped(lsq_solver *s, lsq_mat *J, const double *y, double *damp, double *x, int *nmul) {
+    if (!s || !J || !y || !x || !damp) return LSQ_EARG;
+    switch (s->kind) {
+    case LSQ_LSMR: return lsq_lsmr_solve(s, J, y, damp, x, nmul);
+    case LSQ_CHOLESKY: return lsq_cholesky_solve(s, J, y, damp, x, nmul);
+    default: return lsq_qr_solve(s, J, y, damp, x, nmul);
+    }
+}
+
+extern "C" int lsq_solver_info(const lsq_solver *s, int *iter, int *istop, int *rank) {
+    if (iter) *iter = s->last_iter;
+    if (istop) *istop = s->last_istop;
+    if (rank) {
+        *rank = -1;
+        if (s->kind == LSQ_QR && s->d_info) {
+            LSQ_HIP(hipStreamSynchronize(s->ctx->stream));
+            LSQ_HIP(hipMemcpy(rank, s->d_info, sizeof(int), hipMemcpyDeviceToHost));
+        }
+    }
+    return LSQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused outer-loop kernels
+// ---------------------------------------------------------------------------------------------
+// LM damping: dtd = clamp(colsum, 1e-6*mean, 1e32*mean) / Delta  (levenberg_marquardt.jl:82-86)
+__global__ void __launch_bounds__(1024)
+k_lm_damp(int n, const double *__restrict__ colsum, double inv_delta, double *__restrict__ dtd) {
+    __shared__ double sh[16];
+    __shared__ double s_mean;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += colsum[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        s_mean = t / n;
+    }
+    __syncthreads();
+    const double lo = MIN_DIAGONAL * s_mean, hi = MAX_DIAGONAL * s_mean;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        double v = colsum[i];
+        v = v > hi ? hi : (v < lo ? lo : v);
+        dtd[i] = v * inv_delta;  // rmul!(dtd, 1/Delta)
+    }
+}
+
+// Dogleg scaling: dtd = clamp(colsum, 1e-6, 1e32) (dogleg.jl:85-90)
+__global__ void __launch_bounds__(LSQ_NT)
+k_dl_scale(int n, const double *__restrict__ colsum, double *__restrict__ dtd) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
+        double v = colsum[i];
+        dtd[i] = v > MAX_DIAGONAL ? MAX_DIAGONAL : (v < MIN_DIAGONAL ? MIN_DIAGONAL : v);
+    }
+}
+
+// g = J'f with the projected max-norm fused (levenberg_marquardt.jl:102-104, dogleg.jl:99-101)
+struct EpiGrad {
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    double *g;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int j, double dot, double &) const { g[j] = dot; }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+
+// predicted residual: sum((J dx - f)^2) without storing fpredict (levenberg_marquardt.jl:114-117)
+struct EpiPredict {
+    static constexpr bool REDUCE = true;
+    const int *done;
+    int extra_blocks;
+    const double *f;
+    double *out;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int i, double dot, double &racc) const {
+        double r = dot - f[i];
+        racc += r * r;
+    }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double t) const { *out = t; }
+};
+
+// sum((J d)^2) for the Cauchy step length (dogleg.jl:109-111)
+struct EpiSumsq {
+    static constexpr bool REDUCE = true;
+    const int *done;
+    int extra_blocks;
+    double *out;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int, double dot, double &racc) const { racc += dot * dot; }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double t) const { *out = t; }
+};
+
+// x_trial = x - dx, max|dx| and first non-finite index of x_trial in one pass
+__global__ void __launch_bounds__(LSQ_NT)
+k_step(int n, const double *__restrict__ x, const double *__restrict__ dx, double *__restrict__ xt,
+       double *partials, unsigned *counters, double *out_dx, double *out_nonfin) {
+    __shared__ double sh[LSQ_NT / 64];
+    double mx = 0.0, code = 0.0;
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
+        double d = dx[i];
+        double v = x[i] + -1.0 * d;  // axpy!(-1, dx, x)
+        xt[i] = v;
+        double a = fabs(d);
+        if (isnan(a)) a = INFINITY;
+        mx = fmax(mx, a);
+        if (!isfinite(v) && code == 0.0) code = 1e15 - (double)(i + 1);
+    }
+    double b1 = block_max<LSQ_NT>(mx, sh);
+    grid_reduce<LSQ_NT, true>(b1, partials, counters, gridDim.x, sh, [=](double t) { *out_dx = t; });
+    double b2 = block_max<LSQ_NT>(code, sh);
+    grid_reduce<LSQ_NT, true>(b2, partials + LSQ_MAX_GRID, counters + 1, gridDim.x, sh,
+                              [=](double t) { *out_nonfin = (t == 0.0) ? -1.0 : (1e15 - t) - 1.0; });
+}
+
+__global__ void __launch_bounds__(LSQ_NT)
+k_revert(int n, const double *__restrict__ xt, const double *__restrict__ dx, double *__restrict__ x) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT)
+        x[i] = xt[i] + 1.0 * dx[i];  // axpy!(1, dx, x): (x - dx) + dx, as the reference computes it
+}
+
+// max |g_i| with the active-bound projection (utils.jl:39-55) -> slot
+__global__ void __launch_bounds__(LSQ_NT)
+k_gradnorm(int n, const double *__restrict__ g, const double *__restrict__ x, const double *__restrict__ lo,
+           const double *__restrict__ hi, double *partials, unsigned *counter, double *out) {
+    __shared__ double sh[LSQ_NT / 64];
+    double m = 0.0;
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
+        double gi = g[i];
+        if (lo && x[i] <= lo[i] && gi > 0.0) gi = 0.0;
+        else if (hi && x[i] >= hi[i] && gi < 0.0) gi = 0.0;
+        double a = fabs(gi);
+        if (isnan(a)) a = INFINITY;
+        m = fmax(m, a);
+    }
+    double b = block_max<LSQ_NT>(m, sh);
+    grid_reduce<LSQ_NT, true>(b, partials, counter, gridDim.x, sh, [=](double t) { *out = t; });
+}
+
+__global__ void __launch_bounds__(LSQ_NT)
+k_sumsq_slot(long long n, const double *__restrict__ x, double *partials, unsigned *counter, double *out) {
+    __shared__ double sh[LSQ_NT / 64];
+    double acc = 0.0;
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n; i += (long long)gridDim.x * LSQ_NT) {
+        double v = x[i];
+        acc += v * v;
+    }
+    double b = block_sum<LSQ_NT>(acc, sh);
+    grid_reduce<LSQ_NT>(b, partials, counter, gridDim.x, sh, [=](double t) { *out = t; });
+}
+
+// sum(w .* x .* y) -> slot (wdot, utils.jl:165-175)
+__global__ void __launch_bounds__(LSQ_NT)
+k_wdot_slot(int n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ w,
+            double *partials, unsigned *counter, double *out) {
+    __shared__ double sh[LSQ_NT / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) acc += w[i] * x[i] * y[i];
+    double b = block_sum<LSQ_NT>(acc, sh);
+    grid_reduce<LSQ_NT>(b, partials, counter, gridDim.x, sh, [=](double t) { *out = t; });
+}
+
+// dx = a*p + b*q  (dogleg cases 2/3: dogleg.jl:127-129, 141-143)
+__global__ void __launch_bounds__(LSQ_NT)
+k_lincomb(int n, double a, const double *__restrict__ p, double b, const double *__restrict__ q,
+          double *__restrict__ out) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
+        double v = p[i] * a;          // copyto!(dx, p); rmul!(dx, a)
+        if (q) v += b * q[i];         // axpy!(b, q, dx)
+        out[i] = v;
+    }
+}
+
+static inline int ngrid(const lsq_ctx *c, long long n) {
+    long long g = (n + LSQ_NT - 1) / LSQ_NT;
+    long long cap = (long long)c->num_cus * 8;
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : (int)g;
+}
+
+struct LoopBuffers {
+    lsq_ctx *c;
+    int m, n;
+    double *dx = nullptr, *dtd = nullptr, *xt = nullptr, *ftrial = nullptr;
+    double *dgn = nullptr, *dgr = nullptr;
+    double *lo = nullptr, *hi = nullptr;
+    ~LoopBuffers() {
+        hipFree(dx); hipFree(dtd); hipFree(xt); hipFree(ftrial); hipFree(dgn); hipFree(dgr); hipFree(lo); hipFree(hi);
+    }
+};
+
+static int alloc_loop(LoopBuffers &b, lsq_ctx *c, int m, int n, const lsq_options *o, bool dogleg) {
+    b.c = c; b.m = m; b.n = n;
+    size_t nb = (size_t)(n > 0 ? n : 1) * sizeof(double), mb = (size_t)(m > 0 ? m : 1) * sizeof(double);
+    LSQ_HIP(hipMalloc(&b.dx, nb));
+    LSQ_HIP(hipMalloc(&b.dtd, nb));
+    LSQ_HIP(hipMalloc(&b.xt, nb));
+    LSQ_HIP(hipMalloc(&b.ftrial, mb));
+    LSQ_HIP(hipMemsetAsync(b.dx, 0, nb, c->stream));
+    if (dogleg) {
+        LSQ_HIP(hipMalloc(&b.dgn, nb));
+        LSQ_HIP(hipMalloc(&b.dgr, nb));
+    }
+    if (o->h_lower) {
+        LSQ_HIP(hipMalloc(&b.lo, nb));
+        LSQ_HIP(hipMemcpyAsync(b.lo, o->h_lower, nb, hipMemcpyHostToDevice, c->stream));
+    }
+    if (o->h_upper) {
+        LSQ_HIP(hipMalloc(&b.hi, nb));
+        LSQ_HIP(hipMemcpyAsync(b.hi, o->h_upper, nb, hipMemcpyHostToDevice, c->stream));
+    }
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+// utils.jl:7-31: an if/elseif chain -- at most one flag fires
+static bool assess(double maxabs_dx, double maxabs_gr, double ssr, double trial_ssr, double xtol, double ftol,
+                   double gtol, bool accepted, int *xc, int *fc, int *gc) {
+    *xc = *fc = *gc = 0;
+    if (accepted && std::fabs(trial_ssr - ssr) <= ftol * (std::fabs(ssr) + ftol)) *fc = 1;
+    else if (maxabs_dx <= xtol) *xc = 1;
+    else if (maxabs_gr <= gtol) *gc = 1;
+    return *xc || *fc || *gc;
+}
+
+static void record(const lsq_options *o, lsq_ctx *c, int it, int n, double ssr, double g, double delta, double rho,
+                   int inner, int acc, const double *d_x) {
+    if (it > o->trace_cap) return;
+    int k = it - 1;
+    if (o->trace_ssr) o->trace_ssr[k] = ssr;
+    if (o->trace_gnorm) o->trace_gnorm[k] = g;
+    if (o->trace_delta) o->trace_delta[k] = delta;
+    if (o->trace_rho) o->trace_rho[k] = rho;
+    if (o->trace_inner) o->trace_inner[k] = inner;
+    if (o->trace_accept) o->trace_accept[k] = acc;
+    if (o->trace_x) {
+        hipMemcpyAsync(o->trace_x + (size_t)k * n, d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        hipStreamSynchronize(c->stream);
+    }
+}
+
+extern "C" void lsq_options_default(lsq_options *o) {
+    memset(o, 0, sizeof(*o));
+    o->x_tol = o->f_tol = o->g_tol = 1e-8;
+    o->iterations = 1000;
+    o->delta = -1.0;
+}
+
+static int check_start(const double *hx, int n, const lsq_options *o) {
+    // levenberg_marquardt.jl:49-51 / dogleg.jl:52-54
+    for (int i = 0; i < n; ++i) {
+        if (o->h_lower && !(hx[i] >= o->h_lower[i])) return LSQ_EBOUNDS;
+        if (o->h_upper && !(hx[i] <= o->h_upper[i])) return LSQ_EBOUNDS;
+    }
+    return LSQ_OK;
+}
+
+// One global exchange per outer iteration for sharded problems.
+static int global_exchange(const lsq_options *o, double *ssr, double *gnorm, int *all_converged) {
+    if (!o->allreduce) return LSQ_OK;
+    double v[3] = {*ssr, *gnorm, (double)*all_converged};
+    if (o->allreduce(v, 3, o->allreduce_user) != 0) {
+        lsq_set_error("allreduce callback failed");
+        return LSQ_ECALLBACK;
+    }
+    *ssr = v[0];
+    *gnorm = v[1];
+    *all_converged = v[2] > 0.5 ? 1 : 0;
+    return LSQ_OK;
+}
+
+#define CB(call)                                          \
+    do {                                                  \
+        if ((call) != 0) {                                \
+            lsq_set_error("user callback reported failure"); \
+            return LSQ_ECALLBACK;                         \
+        }                                                 \
+    } while (0)
+
+static int call_g(lsq_g_callback g, lsq_mat *J, const double *x, void *user) {
+    J->version++;
+    if (J->kind == LSQ_MAT_CSC) J->csr_fresh = false;
+    CB(g(J, x, user));
+    return lsq_ensure_csr(J);
+}
+
+// ---------------------------------------------------------------------------------------------
+// levenberg_marquardt.jl:39-144
+// ---------------------------------------------------------------------------------------------
+static int optimize_lm(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double *fcur, lsq_f_callback f,
+                       lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
+    const int m = J->m, n = J->n;
+    LoopBuffers b;
+    LSQ_TRY(alloc_loop(b, c, m, n, o, false));
+    double delta = o->delta > 0 ? o->delta : 10.0;
+    double decrease_factor = 2.0;
+    int f_calls = 0, g_calls = 0, mul_calls = 0, xc = 0, fc = 0, gc = 0;
+    bool converged = false;
+    CB(f(fcur, x, user));
+    f_calls++;
+    double ssr;
+    LSQ_TRY(lsq_sumsq(c, m, fcur, &ssr));
+    double maxabs_gr = INFINITY;
+    bool need_jac = true;
+    int iter = 0, nonfinite_at = -1;
+    LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
+    const int gn = ngrid(c, n), gm = ngrid(c, m);
+    int local_done = 0;
+    double gssr = ssr, ggr = maxabs_gr;
+    long long inner_total = 0;
+    while (iter < o->iterations) {
+        if (!o->allreduce && converged) break;
+        if (o->allreduce) {
+            // frozen ranks keep taking part in the exchange until every problem has converged
+            int all = converged ? 1 : 0;
+            gssr = ssr; ggr = maxabs_gr;
+            LSQ_TRY(global_exchange(o, &gssr, &ggr, &all));
+            if (all) break;
+            if (converged) { ++iter; local_done = 1; continue; }
+        }
+        iter++;
+        if (nonfinite_at >= 0) {  // check_isfinite(x), utils.jl:70-75
+            r->bad_index = nonfinite_at;
+            r->iterations = iter - 1;
+            lsq_set_error("IsFiniteException: non-finite x at index %d", nonfinite_at);
+            return LSQ_ENONFINITE;
+        }
+        if (need_jac) {
+            LSQ_TRY(call_g(g, J, x, user));
+            g_calls++;
+            need_jac = false;
+        }
+        const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
+        if (!cs) return LSQ_EHIP;
+        hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
+        int lmiter = 0;
+        LSQ_TRY(lsq_ldiv_damped(sv, J, fcur, b.dtd, b.dx, &lmiter));     // :87
+        LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
+        mul_calls += lmiter;
+        inner_total += lmiter / 2;
+        {   // :102-104 gradient at the pre-step x (dtd is reused as scratch, like the reference)
+            EpiGrad eg{nullptr, 0, b.dtd, nullptr, nullptr};
+            LSQ_TRY(launch_product(J, 1, fcur, eg));
+            hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dtd, x, b.lo, b.hi,
+                               c->d_partials, c->d_counters + 4, c->d_slots + SL_GRAD);
+            mul_calls++;
+        }
+        hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
+                           c->d_counters + 5, c->d_slots + SL_DX, c->d_slots + SL_NONFIN);   // :106
+        LSQ_HIP(hipGetLastError());
+        CB(f(b.ftrial, b.xt, user));                                      // :107
+        f_calls++;
+        hipLaunchKernelGGL(k_sumsq_slot, dim3(gm), dim3(LSQ_NT), 0, c->stream, (long long)m, b.ftrial,
+                           c->d_partials, c->d_counters + 7, c->d_slots + SL_TRIAL);          // :111
+        {   // :114-117
+            EpiPredict ep{nullptr, 0, fcur, c->d_slots + SL_PRED, c->d_partials, c->d_counters + 8};
+            LSQ_TRY(launch_product(J, 0, b.dx, ep));
+            mul_calls++;
+        }
+        LSQ_HIP(hipGetLastError());
+        double sl[5];
+        LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));   // the one host sync of the outer iteration
+        maxabs_gr = sl[0];
+        const double maxabs_dx = sl[1];
+        const int trial_nonfinite = (int)sl[2];
+        const double trial_ssr = sl[3], predicted_ssr = sl[4];
+        const double pred_red = std::fabs(ssr - predicted_ssr);
+        const double rho = pred_red > 0 ? (ssr - trial_ssr) / pred_red : 0.0;   // :118-119
+        const bool accepted = rho > MIN_STEP_QUALITY;                           // :122 (strict)
+        converged = assess(maxabs_dx, maxabs_gr, ssr, trial_ssr, o->x_tol, o->f_tol, o->g_tol, accepted, &xc, &fc, &gc);
+        if (accepted) {
+            LSQ_TRY(lsq_d2d(c, fcur, b.ftrial, (size_t)m * sizeof(double)));   // copyto!(fcur, ftrial)
+            LSQ_TRY(lsq_d2d(c, x, b.xt, (size_t)n * sizeof(double)));
+            ssr = trial_ssr;
+            double q = 1.0 - (2.0 * rho - 1.0) * (2.0 * rho - 1.0) * (2.0 * rho - 1.0);
+            delta = std::min(delta / std::max(1.0 / 3.0, q), MAX_DELTA);        // :130
+            decrease_factor = 2.0;
+            need_jac = true;
+            nonfinite_at = trial_nonfinite;
+        } else {
+            hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.xt, b.dx, x);  // :135
+            delta = std::max(delta / decrease_factor, MIN_DELTA);
+            decrease_factor *= 2.0;
+        }
+        record(o, c, iter, n, ssr, maxabs_gr, delta, rho, lmiter, accepted ? 1 : 0, x);
+    }
+    (void)local_done;
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    r->optimizer = LSQ_LEVENBERG_MARQUARDT;
+    r->ssr = o->allreduce ? gssr : ssr;
+    r->iterations = iter;
+    r->converged = converged; r->x_converged = xc; r->f_converged = fc; r->g_converged = gc;
+    r->f_calls = f_calls; r->g_calls = g_calls; r->mul_calls = mul_calls;
+    r->lsmr_iterations = inner_total;
+    return LSQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dogleg.jl:41-203
+// ---------------------------------------------------------------------------------------------
+static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double *fcur, lsq_f_callback f,
+                           lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
+    const int m = J->m, n = J->n;
+    LoopBuffers b;
+    LSQ_TRY(alloc_loop(b, c, m, n, o, true));
+    double delta = o->delta > 0 ? o->delta : 1.0;
+    bool reuse = false, converged = false;
+    double wnorm_dgn = 0.0, wnorm_dgr = 0.0, alpha = 0.0, wdot_gr_gn = 0.0;
+    int f_calls = 0, g_calls = 0, mul_calls = 0, xc = 0, fc = 0, gc = 0;
+    CB(f(fcur, x, user));
+    f_calls++;
+    double ssr;
+    LSQ_TRY(lsq_sumsq(c, m, fcur, &ssr));
+    double maxabs_gr = INFINITY;
+    int iter = 0, nonfinite_at = -1;
+    LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
+    const int gn = ngrid(c, n), gm = ngrid(c, m);
+    double gssr = ssr, ggr = maxabs_gr;
+    long long inner_total = 0;
+    while (iter < o->iterations) {
+        if (!o->allreduce && converged) break;
+        if (o->allreduce) {
+            int all = converged ? 1 : 0;
+            gssr = ssr; ggr = maxabs_gr;
+            LSQ_TRY(global_exchange(o, &gssr, &ggr, &all));
+            if (all) break;
+            if (converged) { ++iter; continue; }
+        }
+        iter++;
+        if (nonfinite_at >= 0) {
+            r->bad_index = nonfinite_at;
+            r->iterations = iter - 1;
+            lsq_set_error("IsFiniteException: non-finite x at index %d", nonfinite_at);
+            return LSQ_ENONFINITE;
+        }
+        int ls_iter = 0;
+        if (!reuse) {
+            LSQ_TRY(call_g(g, J, x, user));                               // :83
+            g_calls++;
+            const double *cs = lsq_cached_colsum(J);                      // :85
+            if (!cs) return LSQ_EHIP;
+            hipLaunchKernelGGL(k_dl_scale, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, cs, b.dtd);  // :90
+            if (iter == 1) {                                              // :92-97
+                double wx2;
+                LSQ_TRY(lsq_wdot(c, n, x, x, b.dtd, &wx2));
+                double wx = std::sqrt(wx2);
+                if (wx > 0) delta *= wx;
+            }
+            EpiGrad eg{nullptr, 0, b.dgr, nullptr, nullptr};              // :99
+            LSQ_TRY(launch_product(J, 1, fcur, eg));
+            mul_calls++;
+            hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, x, b.lo, b.hi,
+                               c->d_partials, c->d_counters + 4, c->d_slots + SL_GRAD);
+            LSQ_TRY(lsq_ediv(c, n, b.dgr, b.dtd, b.dgr));                 // :105
+            hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, b.dgr, b.dtd,
+                               c->d_partials, c->d_counters + 5, c->d_slots + SL_W0);          // :106
+            EpiSumsq es{nullptr, 0, c->d_slots + SL_SUM, c->d_partials, c->d_counters + 6};   // :109-111
+            LSQ_TRY(launch_product(J, 0, b.dgr, es));
+            mul_calls++;
+            LSQ_TRY(lsq_fill(c, n, 0.0, b.dgn));
+            LSQ_TRY(lsq_ldiv(sv, J, fcur, b.dgn, &ls_iter));              // :115
+            mul_calls += ls_iter;
+            inner_total += ls_iter / 2;
+            hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgn, b.dgn, b.dtd,
+                               c->d_partials, c->d_counters + 5, c->d_slots + SL_W1);          // :117
+            hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, b.dgn, b.dtd,
+                               c->d_partials, c->d_counters + 5, c->d_slots + SL_W2);          // :134 (used in case 3)
+            LSQ_HIP(hipGetLastError());
+            double s0[1];
+            LSQ_TRY(lsq_read_slots(c, SL_GRAD, 1, s0));
+            maxabs_gr = s0[0];
+            double w[4];
+            LSQ_TRY(lsq_read_slots(c, SL_W0, 4, w));
+            wnorm_dgr = std::sqrt(w[0]);
+            wnorm_dgn = std::sqrt(w[1]);
+            alpha = wnorm_dgr * wnorm_dgr / w[3];
+            wdot_gr_gn = w[2];  // wdot(dgr, dgn, dtd), needed only if case 3 is taken (:134)
+        }
+        double wnorm_dx;
+        if (wnorm_dgn <= delta) {                                         // :120 case 1
+            LSQ_TRY(lsq_d2d(c, b.dx, b.dgn, (size_t)n * sizeof(double)));
+            wnorm_dx = wnorm_dgn;
+        } else if (wnorm_dgr * alpha >= delta) {                          // :124 case 2
+            hipLaunchKernelGGL(k_lincomb, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, delta / wnorm_dgr, b.dgr, 0.0,
+                               (const double *)nullptr, b.dx);
+            wnorm_dx = delta;
+        } else {                                                          // :131 case 3
+            double b_dot_a = alpha * wdot_gr_gn;
+            double a2 = (alpha * wnorm_dgr) * (alpha * wnorm_dgr);
+            double bma2 = a2 - 2 * b_dot_a + wnorm_dgn * wnorm_dgn;
+            double cc = b_dot_a - a2;
+            double d = std::sqrt(cc * cc + bma2 * (delta * delta - a2));
+            double beta = (cc <= 0) ? (d - cc) / bma2 : (delta * delta - a2) / (d + cc);
+            hipLaunchKernelGGL(k_lincomb, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, beta, b.dgn, alpha * (1 - beta),
+                               (const double *)b.dgr, b.dx);
+            double w2;
+            LSQ_TRY(lsq_wdot(c, n, b.dx, b.dx, b.dtd, &w2));              // :144
+            wnorm_dx = std::sqrt(w2);
+        }
+        LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                 // :148-160
+        hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
+                           c->d_counters + 5, c->d_slots + SL_DX, c->d_slots + SL_NONFIN);    // :160
+        LSQ_HIP(hipGetLastError());
+        CB(f(b.ftrial, b.xt, user));                                      // :164
+        f_calls++;
+        hipLaunchKernelGGL(k_sumsq_slot, dim3(gm), dim3(LSQ_NT), 0, c->stream, (long long)m, b.ftrial,
+                           c->d_partials, c->d_counters + 7, c->d_slots + SL_TRIAL);
+        EpiPredict ep{nullptr, 0, fcur, c->d_slots + SL_PRED, c->d_partials, c->d_counters + 8};  // :171-174
+        LSQ_TRY(launch_product(J, 0, b.dx, ep));
+        mul_calls++;
+        double sl[4];
+        LSQ_TRY(lsq_read_slots(c, SL_DX, 4, sl));
+        const double maxabs_dx = sl[0];
+        const int trial_nonfinite = (int)sl[1];
+        const double trial_ssr = sl[2], predicted_ssr = sl[3];
+        const double pred_red = std::fabs(ssr - predicted_ssr);
+        const double rho = pred_red > 0 ? (ssr - trial_ssr) / pred_red : 0.0;
+        const bool accepted = rho >= MIN_STEP_QUALITY;                    // :178 (non-strict)
+        converged = assess(maxabs_dx, maxabs_gr, ssr, trial_ssr, o->x_tol, o->f_tol, o->g_tol, accepted, &xc, &fc, &gc);
+        if (accepted) {
+            reuse = false;
+            LSQ_TRY(lsq_d2d(c, fcur, b.ftrial, (size_t)m * sizeof(double)));
+            LSQ_TRY(lsq_d2d(c, x, b.xt, (size_t)n * sizeof(double)));
+            ssr = trial_ssr;
+            nonfinite_at = trial_nonfinite;
+        } else {
+            reuse = true;
+            hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.xt, b.dx, x);
+        }
+        if (rho < DECREASE_THRESHOLD) delta = std::max(MIN_DELTA, delta * 0.5);           // :193-197
+        else if (rho > INCREASE_THRESHOLD) delta = std::max(delta, 3.0 * wnorm_dx);
+        record(o, c, iter, n, ssr, maxabs_gr, delta, rho, ls_iter, accepted ? 1 : 0, x);
+    }
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    r->optimizer = LSQ_DOGLEG;
+    r->ssr = o->allreduce ? gssr : ssr;
+    r->iterations = iter;
+    r->converged = converged; r->x_converged = xc; r->f_converged = fc; r->g_converged = gc;
+    r->f_calls = f_calls; r->g_calls = g_calls; r->mul_calls = mul_calls;
+    r->lsmr_iterations = inner_total;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_optimize(lsq_ctx *c, int optimizer, int solver_kind, lsq_mat *J, double *x, double *fcur,
+                            lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *opt, lsq_result *res) {
+    if (!c || !J || !x || !fcur || !f || !g || !opt || !res) {
+        lsq_set_error("lsq_optimize: null argument");
+        return LSQ_EARG;
+    }
+    memset(res, 0, sizeof(*res));
+    res->bad_index = -1;
+    LSQ_HIP(hipSetDevice(c->device));
+    const int n = J->n;
+    if (opt->h_lower || opt->h_upper) {
+        std::vector<double> hx(n);
+        LSQ_TRY(lsq_d2h(c, hx.data(), x, (size_t)n * sizeof(double)));
+        int st = check_start(hx.data(), n, opt);
+        if (st != LSQ_OK) {
+            lsq_set_error("ArgumentError: Initial guess must be within bounds.");
+            res->status = st;
+            return st;
+        }
+    }
+    lsq_solver *sv = nullptr;
+    int st = lsq_solver_create(c, J, solver_kind, optimizer == LSQ_LEVENBERG_MARQUARDT, &sv);
+    if (st != LSQ_OK) {
+        res->status = st;
+        return st;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    st = (optimizer == LSQ_LEVENBERG_MARQUARDT) ? optimize_lm(c, sv, J, x, fcur, f, g, user, opt, res)
+                                                : optimize_dogleg(c, sv, J, x, fcur, f, g, user, opt, res);
+    hipStreamSynchronize(c->stream);
+    res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    res->status = st;
+    lsq_solver_destroy(sv);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// built-in model: r(x) = A tanh(x) - b ; J = A diag(1 - tanh(x)^2)      
+// ---------------------------------------------------------------------------------------------
+struct lsq_model {
+    lsq_ctx *ctx;
+    lsq_mat *J;
+    double *d_Acsc = nullptr;  // A values, CSC order (or dense column-major)
+    double *d_Acsr = nullptr;  // A values, CSR order
+    double *d_b = nullptr;
+    double *d_t = nullptr;     // tanh(x)
+};
+
+__global__ void __launch_bounds__(LSQ_NT) k_tanh(int n, const double *__restrict__ x, double *__restrict__ t) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) t[i] = tanh(x[i]);
+}
+
+struct EpiResidual {  // out = A t - b
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    const double *b;
+    double *out;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int i, double dot, double &) const { out[i] = dot - b[i]; }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+
+// column scaling of a column-segmented value array (CSC nzval or dense columns)
+__global__ void __launch_bounds__(LSQ_NT)
+k_scale_cols(int n, const int *__restrict__ colptr, int m_dense, const double *__restrict__ A,
+             const double *__restrict__ x, double *__restrict__ out) {
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        double t = tanh(x[j]);
+        double s = 1.0 - t * t;
+        long long k0 = colptr ? colptr[j] : (long long)j * m_dense;
+        long long k1 = colptr ? colptr[j + 1] : (long long)(j + 1) * m_dense;
+        for (long long k = k0 + threadIdx.x; k < k1; k += LSQ_NT) out[k] = A[k] * s;
+    }
+}
+// the CSR mirror: scale by the column of each entry
+__global__ void __launch_bounds__(LSQ_NT)
+k_scale_csr(long long nnz, const int *__restrict__ colidx, const double *__restrict__ A, const double *__restrict__ sfac,
+            double *__restrict__ out) {
+    for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < nnz; k += (long long)gridDim.x * LSQ_NT)
+        out[k] = A[k] * sfac[colidx[k]];
+}
+__global__ void __launch_bounds__(LSQ_NT) k_sfac(int n, const double *__restrict__ x, double *__restrict__ s) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
+        double t = tanh(x[i]);
+        s[i] = 1.0 - t * t;
+    }
+}
+
+static int model_f(double *out, const double *x, void *user) {
+    lsq_model *md = (lsq_model *)user;
+    lsq_ctx *c = md->ctx;
+    lsq_mat *J = md->J;
+    hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+    EpiResidual e{nullptr, 0, md->d_b, out, nullptr, nullptr};
+    if (J->kind == LSQ_MAT_CSC) {
+        LsqSegs A = J->csr;  // same pattern, A's values
+        A.d_val = md->d_Acsr;
+        if (launch_segs<false>(c, A, md->d_t, e) != LSQ_OK) return 1;
+    } else {
+        lsq_mat tmp = *J;
+        tmp.d_dense = md->d_Acsc;
+        if (launch_product(&tmp, 0, md->d_t, e) != LSQ_OK) return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+static int model_g(lsq_mat *J, const double *x, void *user) {
+    lsq_model *md = (lsq_model *)user;
+    lsq_ctx *c = md->ctx;
+    if (J->kind == LSQ_MAT_CSC) {
+        int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
+        hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, md->d_Acsc, x,
+                           J->csc.d_val);
+        hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+        long long g2 = std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
+        if (J->nnz > 0)
+            hipLaunchKernelGGL(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
+                               md->d_Acsr, md->d_t, J->csr.d_val);
+        J->csr_fresh = true;  // both mirrors written directly: no permutation pass needed
+    } else {
+        int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
+        hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, (const int *)nullptr, J->m,
+                           md->d_Acsc, x, J->d_dense);
+    }
+    J->version++;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+extern "C" lsq_f_callback lsq_model_f(void) { return model_f; }
+extern "C" lsq_g_callback lsq_model_g(void) { return model_g; }
+
+extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, const double *hb, lsq_model **out) {
+    if (!c || !J || !hA || !hb || !out) return LSQ_EARG;
+    LSQ_HIP(hipSetDevice(c->device));
+    lsq_model *md = new lsq_model();
+    md->ctx = c;
+    md->J = J;
+    size_t vb = (size_t)(J->nnz + 8) * sizeof(double);
+    LSQ_HIP(hipMalloc(&md->d_Acsc, vb));
+    LSQ_HIP(hipMemset(md->d_Acsc, 0, vb));
+    LSQ_HIP(hipMemcpy(md->d_Acsc, hA, (size_t)J->nnz * sizeof(double), hipMemcpyHostToDevice));
+    LSQ_HIP(hipMalloc(&md->d_b, (size_t)(J->m > 0 ? J->m : 1) * sizeof(double)));
+    LSQ_HIP(hipMemcpy(md->d_b, hb, (size_t)J->m * sizeof(double), hipMemcpyHostToDevice));
+    LSQ_HIP(hipMalloc(&md->d_t, (size_t)(J->n > 0 ? J->n : 1) * sizeof(double)));
+    if (J->kind == LSQ_MAT_CSC) {
+        LSQ_HIP(hipMalloc(&md->d_Acsr, vb));
+        LSQ_HIP(hipMemset(md->d_Acsr, 0, vb));
+        // reuse the CSC->CSR map of the pattern to permute A once
+        LSQ_TRY(lsq_permute_to_csr(J, md->d_Acsc, md->d_Acsr));
+        LSQ_HIP(hipStreamSynchronize(c->stream));
+    }
+    *out = md;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_model_destroy(lsq_model *md) {
+    if (!md) return LSQ_OK;
+    hipStreamSynchronize(md->ctx->stream);
+    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_b); hipFree(md->d_t);
+    delete md;
+    return LSQ_OK;
+}

@@ -1,0 +1,293 @@
+// Jacobian handles (dense / CSC + CSR mirror), the generic operator products mul!(y,J,x,a,b) and
+// mul!(x,J',y,a,b), and colsumabs2! for sparse Jacobians (utils.jl:146-151).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "lsq_spmv.h"
+
+// ---------------------------------------------------------------------------------------------
+// plan construction (host, once per pattern)
+// ---------------------------------------------------------------------------------------------
+static int choose_plan(const char *envname, long long nnz, int nseg) {
+    if (const char *e = getenv(envname)) {
+        if (!strcmp(e, "stream")) return LSQ_PLAN_STREAM;
+        if (!strcmp(e, "wave")) return LSQ_PLAN_WAVE;
+        if (!strcmp(e, "block")) return LSQ_PLAN_BLOCK;
+    }
+    double avg = nseg > 0 ? (double)nnz / nseg : 0.0;
+    if (avg < 48.0) return LSQ_PLAN_STREAM;
+    if (avg < 384.0) return LSQ_PLAN_WAVE;
+    return LSQ_PLAN_BLOCK;
+}
+
+static void build_tiles(const std::vector<int> &ptr, int nseg, std::vector<int> &tiles) {
+    tiles.clear();
+    int s = 0;
+    tiles.push_back(0);
+    while (s < nseg) {
+        int start = s;
+        long long base = ptr[s];
+        while (s < nseg && s - start < LSQ_TILE_SEGS && ptr[s + 1] - base <= LSQ_TILE_NNZ) ++s;
+        if (s == start) ++s;  // one segment longer than a tile: handled by the block-stride path
+        tiles.push_back(s);
+    }
+}
+
+static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, const std::vector<int> &idx,
+                       const char *envname) {
+    S.nseg = (int)ptr.size() - 1;
+    S.nnz = ptr.back();
+    S.plan = choose_plan(envname, S.nnz, S.nseg);
+    const size_t pad = 4;
+    LSQ_HIP(hipMalloc(&S.d_ptr, (S.nseg + 1) * sizeof(int)));
+    LSQ_HIP(hipMalloc(&S.d_idx, (S.nnz + pad) * sizeof(int)));
+    LSQ_HIP(hipMalloc(&S.d_val, (S.nnz + pad) * sizeof(double)));
+    LSQ_HIP(hipMemset(S.d_idx, 0, (S.nnz + pad) * sizeof(int)));
+    LSQ_HIP(hipMemset(S.d_val, 0, (S.nnz + pad) * sizeof(double)));
+    LSQ_HIP(hipMemcpy(S.d_ptr, ptr.data(), (S.nseg + 1) * sizeof(int), hipMemcpyHostToDevice));
+    if (S.nnz) LSQ_HIP(hipMemcpy(S.d_idx, idx.data(), S.nnz * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int> tiles;
+    build_tiles(ptr, S.nseg, tiles);
+    S.ntiles = (int)tiles.size() - 1;
+    LSQ_HIP(hipMalloc(&S.d_tiles, tiles.size() * sizeof(int)));
+    LSQ_HIP(hipMemcpy(S.d_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
+    (void)c;
+    return LSQ_OK;
+}
+
+static void free_segs(LsqSegs &S) {
+    hipFree(S.d_ptr);
+    hipFree(S.d_idx);
+    hipFree(S.d_val);
+    hipFree(S.d_tiles);
+    S = LsqSegs();
+}
+
+extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const int *rowval, lsq_mat **out) {
+    if (!c || !out || m < 0 || n < 0 || !colptr) {
+        lsq_set_error("lsq_csc_create: bad arguments");
+        return LSQ_EARG;
+    }
+    LSQ_HIP(hipSetDevice(c->device));
+    const long long nnz = colptr[n];
+    if (colptr[0] != 0 || nnz < 0 || nnz > 2147483000LL) {
+        lsq_set_error("lsq_csc_create: colptr must start at 0 and nnz must fit int32");
+        return LSQ_EDIM;
+    }
+    for (int j = 0; j < n; ++j)
+        if (colptr[j + 1] < colptr[j]) {
+            lsq_set_error("lsq_csc_create: colptr not monotone at column %d", j);
+            return LSQ_EDIM;
+        }
+    for (long long k = 0; k < nnz; ++k)
+        if (rowval[k] < 0 || rowval[k] >= m) {
+            lsq_set_error("lsq_csc_create: row index out of range at entry %lld", k);
+            return LSQ_EDIM;
+        }
+    lsq_mat *J = new lsq_mat();
+    J->ctx = c;
+    J->kind = LSQ_MAT_CSC;
+    J->m = m;
+    J->n = n;
+    J->nnz = nnz;
+    // CSR mirror by counting sort; column order inside a row is increasing (stable)
+    std::vector<int> cptr(colptr, colptr + n + 1), cidx(rowval, rowval + nnz);
+    std::vector<int> rptr(m + 1, 0), ridx(nnz), map(nnz);
+    for (long long k = 0; k < nnz; ++k) rptr[rowval[k] + 1]++;
+    for (int i = 0; i < m; ++i) rptr[i + 1] += rptr[i];
+    {
+        std::vector<int> fill(rptr.begin(), rptr.end() - 1);
+        for (int j = 0; j < n; ++j)
+            for (int k = colptr[j]; k < colptr[j + 1]; ++k) {
+                int p = fill[rowval[k]]++;
+                ridx[p] = j;
+                map[p] = k;
+            }
+    }
+    LSQ_TRY(upload_segs(c, J->csc, cptr, cidx, "LSQ_PLAN_CSC"));
+    LSQ_TRY(upload_segs(c, J->csr, rptr, ridx, "LSQ_PLAN_CSR"));
+    LSQ_HIP(hipMalloc(&J->d_map, (nnz + 4) * sizeof(int)));
+    if (nnz) LSQ_HIP(hipMemcpy(J->d_map, map.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+    LSQ_HIP(hipMalloc(&J->d_colsum, (n > 0 ? n : 1) * sizeof(double)));
+    J->csr_fresh = true;  // all zeros
+    *out = J;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_dense_create(lsq_ctx *c, int m, int n, lsq_mat **out) {
+    if (!c || !out || m < 0 || n < 0) return LSQ_EARG;
+    LSQ_HIP(hipSetDevice(c->device));
+    lsq_mat *J = new lsq_mat();
+    J->ctx = c;
+    J->kind = LSQ_MAT_DENSE;
+    J->m = m;
+    J->n = n;
+    J->nnz = (long long)m * n;
+    size_t bytes = (size_t)(J->nnz + 8) * sizeof(double);
+    LSQ_HIP(hipMalloc(&J->d_dense, bytes));
+    LSQ_HIP(hipMemset(J->d_dense, 0, bytes));
+    LSQ_HIP(hipMalloc(&J->d_colsum, (n > 0 ? n : 1) * sizeof(double)));
+    *out = J;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_mat_destroy(lsq_mat *J) {
+    if (!J) return LSQ_OK;
+    hipStreamSynchronize(J->ctx->stream);
+    hipFree(J->d_dense);
+    free_segs(J->csc);
+    free_segs(J->csr);
+    hipFree(J->d_map);
+    hipFree(J->d_colsum);
+    delete J;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_mat_size(const lsq_mat *J, int *m, int *n, long long *nnz) {
+    if (m) *m = J->m;
+    if (n) *n = J->n;
+    if (nnz) *nnz = J->nnz;
+    return LSQ_OK;
+}
+
+extern "C" double *lsq_mat_values(lsq_mat *J) {
+    J->version++;
+    if (J->kind == LSQ_MAT_DENSE) return J->d_dense;
+    J->csr_fresh = false;
+    return J->csc.d_val;
+}
+
+__global__ void __launch_bounds__(LSQ_NT)
+k_permute(long long nnz, const int *__restrict__ map, const double *__restrict__ src, double *__restrict__ dst) {
+    for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < nnz;
+         k += (long long)gridDim.x * LSQ_NT)
+        dst[k] = src[map[k]];
+}
+
+int lsq_permute_to_csr(lsq_mat *J, const double *d_csc_vals, double *d_csr_vals) {
+    if (J->nnz > 0) {
+        int grid = (int)std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
+        hipLaunchKernelGGL(k_permute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, J->nnz, J->d_map,
+                           d_csc_vals, d_csr_vals);
+        LSQ_HIP(hipGetLastError());
+    }
+    return LSQ_OK;
+}
+
+int lsq_ensure_csr(lsq_mat *J) {
+    if (J->kind != LSQ_MAT_CSC || J->csr_fresh) return LSQ_OK;
+    LSQ_TRY(lsq_permute_to_csr(J, J->csc.d_val, J->csr.d_val));
+    J->csr_fresh = true;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_mat_refresh(lsq_mat *J) {
+    J->version++;
+    if (J->kind == LSQ_MAT_CSC) J->csr_fresh = false;
+    return lsq_ensure_csr(J);
+}
+
+extern "C" int lsq_mat_set_values(lsq_mat *J, const double *h) {
+    double *dst = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
+    if (J->nnz)
+        LSQ_HIP(hipMemcpyAsync(dst, h, J->nnz * sizeof(double), hipMemcpyHostToDevice, J->ctx->stream));
+    LSQ_HIP(hipStreamSynchronize(J->ctx->stream));  // h is borrowed for the call only
+    return lsq_mat_refresh(J);
+}
+
+extern "C" int lsq_mat_get_values(const lsq_mat *J, double *h) {
+    const double *src = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
+    if (J->nnz)
+        LSQ_HIP(hipMemcpyAsync(h, src, J->nnz * sizeof(double), hipMemcpyDeviceToHost, J->ctx->stream));
+    LSQ_HIP(hipStreamSynchronize(J->ctx->stream));
+    return LSQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic products
+// ---------------------------------------------------------------------------------------------
+struct EpiAxpby {  // y[s] = alpha*dot + beta*y[s]   (beta == 0 overwrites: _rmul_or_fill! [stdlib])
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    double alpha, beta;
+    double *y;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int s, double dot, double &) const {
+        y[s] = (beta == 0.0) ? alpha * dot : alpha * dot + beta * y[s];
+    }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+
+int lsq_sparse_mul(lsq_mat *J, int trans, double alpha, const double *x, double beta, double *y) {
+    EpiAxpby e{nullptr, 0, alpha, beta, y, nullptr, nullptr};
+    if (!trans) {
+        LSQ_TRY(lsq_ensure_csr(J));
+        return launch_segs<false>(J->ctx, J->csr, x, e);
+    }
+    return launch_segs<false>(J->ctx, J->csc, x, e);
+}
+
+struct EpiStore {  // out[s] = dot
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    double *out;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int s, double dot, double &) const { out[s] = dot; }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+
+int lsq_sparse_colsumabs2(lsq_mat *J, double *out) {
+    EpiStore e{nullptr, 0, out, nullptr, nullptr};
+    return launch_segs<true>(J->ctx, J->csc, nullptr, e);
+}
+
+const double *lsq_cached_colsum(lsq_mat *J) {
+    if (J->colsum_version != J->version) {
+        int st = J->kind == LSQ_MAT_DENSE ? lsq_dense_colsumabs2(J, J->d_colsum)
+                                          : lsq_sparse_colsumabs2(J, J->d_colsum);
+        if (st != LSQ_OK) return nullptr;
+        J->colsum_version = J->version;
+    }
+    return J->d_colsum;
+}
+
+extern "C" int lsq_mul(lsq_mat *J, int trans, double alpha, const double *x, double beta, double *y) {
+    if (!J || !x || !y) {
+        lsq_set_error("lsq_mul: null argument");
+        return LSQ_EARG;
+    }
+    return J->kind == LSQ_MAT_DENSE ? lsq_dense_mul(J, trans, alpha, x, beta, y)
+                                    : lsq_sparse_mul(J, trans, alpha, x, beta, y);
+}
+
+extern "C" int lsq_colsumabs2(lsq_mat *J, double *out) {
+    if (!J || !out) return LSQ_EARG;
+    const double *cs = lsq_cached_colsum(J);
+    if (!cs) return LSQ_EHIP;
+    return lsq_d2d(J->ctx, out, cs, (size_t)J->n * sizeof(double));
+}
+
+extern "C" int lsq_bench_mul(lsq_mat *J, int trans, int reps, const double *x, double *y, double beta,
+                             float *ms) {
+    hipEvent_t e0, e1;
+    LSQ_HIP(hipEventCreate(&e0));
+    LSQ_HIP(hipEventCreate(&e1));
+    LSQ_TRY(lsq_mul(J, trans, 1.0, x, beta, y));  // warm-up (also refreshes the CSR mirror)
+    LSQ_HIP(hipEventRecord(e0, J->ctx->stream));
+    for (int i = 0; i < reps; ++i) LSQ_TRY(lsq_mul(J, trans, 1.0, x, beta, y));
+    LSQ_HIP(hipEventRecord(e1, J->ctx->stream));
+    LSQ_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    LSQ_HIP(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / (reps > 0 ? reps : 1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return LSQ_OK;
+}

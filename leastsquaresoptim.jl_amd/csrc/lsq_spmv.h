@@ -1,0 +1,318 @@
+// Segmented sparse product engines for gfx950 (64-wide wavefronts, HBM-bound).
+//
+// A "segment" is a CSR row (J*x, gather from an n-vector) or a CSC column (J'*y, gather from an
+// m-vector).  Both products are GATHERS: the CSC scatter of the reference's SparseArrays mul!
+// (call sites levenberg_marquardt.jl:114, iterative_lsmr.jl:91) is avoided by keeping a CSR
+// mirror of the fixed pattern.  Three launch plans, picked once per pattern:
+//   STREAM  short segments (~10 nnz, C4 rows): a 256-thread block streams a tile of <= 2045
+//           consecutive nnz with 16-byte loads (2x double2 + int4 per lane per step), parks the
+//           products in LDS, then one thread per segment sums its slice in index order.
+//   WAVE    medium segments: one 64-lane wavefront per segment, double2/int2 loads, DPP-free
+//           shuffle reduction.
+//   BLOCK   long segments (C4 columns, 1000 nnz): one 256-thread block per segment.
+// Every plan calls an epilogue functor once per segment with the finished dot product, so the
+// LSMR/LM fusions (axpy with the previous vector, damping rows, preconditioner scaling, sum of
+// squares for the next norm) cost no extra pass over an m- or n-vector.
+// Reductions are two-stage and index-ordered (grid_reduce) => run-to-run deterministic.
+#pragma once
+#include "lsq_common.h"
+
+constexpr int LSQ_TILE_WINDOW = 2048;                // LDS doubles per stream tile
+constexpr int LSQ_TILE_NNZ = LSQ_TILE_WINDOW - 3;    // aligned-down window may start 3 early
+constexpr int LSQ_TILE_SEGS = LSQ_NT;                // one thread per segment in a tile
+
+struct SegsDev {
+    const int *ptr;
+    const int *idx;
+    const double *val;
+    const int *tiles;
+    int nseg;
+    int ntiles;
+};
+
+// Epilogue concept:
+//   static constexpr bool REDUCE;           // grid-reduce a per-segment contribution?
+//   const int *done;                        // optional early-exit flag (device), may be null
+//   int extra_blocks;                       // blocks appended to the grid for side work
+//   __device__ void seg(int s, double dot, double &racc) const;
+//   __device__ void extra(int blk, double &racc) const;
+//   double *partials; unsigned *counter;    // if REDUCE
+//   __device__ void finalize(double total) const;   // thread 0 of the last block
+
+template <bool SQ>
+__device__ __forceinline__ double prod1(double v, const double *__restrict__ x, int c) {
+    return SQ ? v * v : v * x[c];
+}
+
+template <class Epi>
+__device__ __forceinline__ void finish_block(const Epi &epi, double racc, double *sh) {
+    if constexpr (Epi::REDUCE) {
+        double bv = block_sum<LSQ_NT>(racc, sh);
+        grid_reduce<LSQ_NT>(bv, epi.partials, epi.counter, gridDim.x, sh,
+                            [&](double t) { epi.finalize(t); });
+    }
+}
+
+template <class Epi, bool SQ>
+__global__ void __launch_bounds__(LSQ_NT) k_seg_stream(SegsDev S, const double *__restrict__ x, Epi epi) {
+    __shared__ __attribute__((aligned(16))) double prod[LSQ_TILE_WINDOW];
+    __shared__ double sh[LSQ_NT / 64];
+    if (epi.done && *epi.done) return;
+    const int tid = threadIdx.x;
+    const int nwork = S.ntiles + epi.extra_blocks;
+    double racc = 0.0;
+    for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
+        if (b >= S.ntiles) {
+            epi.extra(b - S.ntiles, racc);
+            continue;
+        }
+        const int s0 = S.tiles[b], s1 = S.tiles[b + 1];
+        const int k0 = S.ptr[s0], k1 = S.ptr[s1];
+        if (k1 - k0 <= LSQ_TILE_NNZ) {
+            const int ka = k0 & ~3;  // 32-byte aligned for val, 16-byte for idx
+#pragma unroll
+            for (int c = 0; c < LSQ_TILE_WINDOW / (4 * LSQ_NT); ++c) {
+                const int k = ka + c * 4 * LSQ_NT + 4 * tid;
+                if (k < k1) {
+                    // arrays are padded by 4 entries, neighbours' indices are valid gather
+                    // targets, and out-of-segment products land in LDS slots nobody reads.
+                    const double2 v0 = *reinterpret_cast<const double2 *>(S.val + k);
+                    const double2 v1 = *reinterpret_cast<const double2 *>(S.val + k + 2);
+                    int4 ci = make_int4(0, 0, 0, 0);
+                    if (!SQ) ci = *reinterpret_cast<const int4 *>(S.idx + k);
+                    double2 p0, p1;
+                    p0.x = prod1<SQ>(v0.x, x, ci.x);
+                    p0.y = prod1<SQ>(v0.y, x, ci.y);
+                    p1.x = prod1<SQ>(v1.x, x, ci.z);
+                    p1.y = prod1<SQ>(v1.y, x, ci.w);
+                    double2 *dst = reinterpret_cast<double2 *>(prod + (k - ka));
+                    dst[0] = p0;
+                    dst[1] = p1;
+                }
+            }
+            __syncthreads();
+            const int s = s0 + tid;
+            if (s < s1) {
+                const int a = S.ptr[s] - ka, e = S.ptr[s + 1] - ka;
+                double sum = 0.0;
+                for (int j = a; j < e; ++j) sum += prod[j];
+                epi.seg(s, sum, racc);
+            }
+            __syncthreads();  // prod is rewritten by the next work item
+        } else {
+            // a single segment longer than a tile: the whole block strides over it
+            double sum = 0.0;
+            for (int k = k0 + tid; k < k1; k += LSQ_NT) sum += prod1<SQ>(S.val[k], x, SQ ? 0 : S.idx[k]);
+            sum = block_sum<LSQ_NT>(sum, sh);
+            if (tid == 0) epi.seg(s0, sum, racc);
+        }
+    }
+    finish_block(epi, racc, sh);
+}
+
+// pair-wise masked partial dot over [k0,k1) for a group of G lanes (lane index g in [0,G))
+template <bool SQ, int G>
+__device__ __forceinline__ double seg_partial(const SegsDev &S, const double *__restrict__ x, int k0,
+                                              int k1, int g) {
+    const int ka = k0 & ~1;
+    double s0 = 0.0, s1 = 0.0;
+    int k = ka + 2 * g;
+    // two independent 16-byte streams in flight per lane
+    for (; k + 2 * G < k1; k += 4 * G) {
+        const double2 va = *reinterpret_cast<const double2 *>(S.val + k);
+        const double2 vb = *reinterpret_cast<const double2 *>(S.val + k + 2 * G);
+        int2 ca = make_int2(0, 0), cb = make_int2(0, 0);
+        if (!SQ) {
+            ca = *reinterpret_cast<const int2 *>(S.idx + k);
+            cb = *reinterpret_cast<const int2 *>(S.idx + k + 2 * G);
+        }
+        double a0 = (k >= k0) ? prod1<SQ>(va.x, x, ca.x) : 0.0;
+        double a1 = prod1<SQ>(va.y, x, ca.y);  // k+1 < k1 holds: k + 2G < k1
+        double b0 = prod1<SQ>(vb.x, x, cb.x);
+        double b1 = (k + 2 * G + 1 < k1) ? prod1<SQ>(vb.y, x, cb.y) : 0.0;
+        s0 += a0 + a1;
+        s1 += b0 + b1;
+    }
+    if (k < k1) {
+        const double2 va = *reinterpret_cast<const double2 *>(S.val + k);
+        int2 ca = make_int2(0, 0);
+        if (!SQ) ca = *reinterpret_cast<const int2 *>(S.idx + k);
+        double a0 = (k >= k0) ? prod1<SQ>(va.x, x, ca.x) : 0.0;
+        double a1 = (k + 1 < k1) ? prod1<SQ>(va.y, x, ca.y) : 0.0;
+        s0 += a0 + a1;
+    }
+    return s0 + s1;
+}
+
+template <class Epi, bool SQ>
+__global__ void __launch_bounds__(LSQ_NT) k_seg_wave(SegsDev S, const double *__restrict__ x, Epi epi,
+                                                      int nsegblocks) {
+    __shared__ double sh[LSQ_NT / 64];
+    if (epi.done && *epi.done) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nwork = nsegblocks + epi.extra_blocks;
+    double racc = 0.0;
+    for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
+        if (b >= nsegblocks) {
+            epi.extra(b - nsegblocks, racc);
+            continue;
+        }
+        const int s = b * (LSQ_NT / 64) + w;
+        if (s < S.nseg) {
+            const int k0 = S.ptr[s], k1 = S.ptr[s + 1];
+            double sum = wave_sum(seg_partial<SQ, 64>(S, x, k0, k1, lane));
+            if (lane == 0) epi.seg(s, sum, racc);
+        }
+    }
+    finish_block(epi, racc, sh);
+}
+
+template <class Epi, bool SQ>
+__global__ void __launch_bounds__(LSQ_NT) k_seg_block(SegsDev S, const double *__restrict__ x, Epi epi) {
+    __shared__ double sh[LSQ_NT / 64];
+    if (epi.done && *epi.done) return;
+    const int nwork = S.nseg + epi.extra_blocks;
+    double racc = 0.0;
+    for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
+        if (b >= S.nseg) {
+            epi.extra(b - S.nseg, racc);
+            continue;
+        }
+        const int k0 = S.ptr[b], k1 = S.ptr[b + 1];
+        double sum = block_sum<LSQ_NT>(seg_partial<SQ, LSQ_NT>(S, x, k0, k1, threadIdx.x), sh);
+        if (threadIdx.x == 0) epi.seg(b, sum, racc);
+    }
+    finish_block(epi, racc, sh);
+}
+
+static inline SegsDev segs_dev(const LsqSegs &s) {
+    return SegsDev{s.d_ptr, s.d_idx, s.d_val, s.d_tiles, s.nseg, s.ntiles};
+}
+
+// Launch the plan chosen for `segs`.  Work items = segment blocks + epi.extra_blocks; the grid is
+// capped (blocks loop over work items) so the partial-sum buffer always suffices.
+constexpr int LSQ_MAX_GRID = 16384;
+template <bool SQ, class Epi>
+static inline int launch_segs(lsq_ctx *ctx, const LsqSegs &segs, const double *x, const Epi &epi) {
+    SegsDev S = segs_dev(segs);
+    static_assert(LSQ_MAX_GRID <= LSQ_MAX_PARTIALS, "partials buffer too small");
+    auto cap = [](long long w) { return (int)(w > LSQ_MAX_GRID ? LSQ_MAX_GRID : w); };
+    switch (segs.plan) {
+    case LSQ_PLAN_STREAM: {
+        int grid = cap((long long)segs.ntiles + epi.extra_blocks);
+        if (grid > 0)
+            hipLaunchKernelGGL((k_seg_stream<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi);
+        break;
+    }
+    case LSQ_PLAN_WAVE: {
+        int nb = lsq_div_up(segs.nseg, LSQ_NT / 64);
+        int grid = cap((long long)nb + epi.extra_blocks);
+        if (grid > 0)
+            hipLaunchKernelGGL((k_seg_wave<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi, nb);
+        break;
+    }
+    default: {
+        int grid = cap((long long)segs.nseg + epi.extra_blocks);
+        if (grid > 0)
+            hipLaunchKernelGGL((k_seg_block<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi);
+        break;
+    }
+    }
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense column-major products with the same epilogue interface (dense Jacobian + LSMR, and the
+// GEMVs of the optimizer loops: levenberg_marquardt.jl:102,114; dogleg.jl:99,109,171)
+// ---------------------------------------------------------------------------------------------
+// y = J x: one thread per row; lanes read consecutive rows of a column => coalesced.  Columns are
+// split in 4 interleaved accumulators to keep 4 loads in flight.
+template <class Epi>
+__global__ void __launch_bounds__(LSQ_NT) k_dense_n(const double *__restrict__ A, int m, int n,
+                                                     const double *__restrict__ x, Epi epi, int nrowblocks) {
+    __shared__ double sh[LSQ_NT / 64];
+    if (epi.done && *epi.done) return;
+    const int nwork = nrowblocks + epi.extra_blocks;
+    double racc = 0.0;
+    for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
+        if (b >= nrowblocks) {
+            epi.extra(b - nrowblocks, racc);
+            continue;
+        }
+        const int i = b * LSQ_NT + threadIdx.x;
+        if (i < m) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const double *p = A + i;
+            int j = 0;
+            for (; j + 3 < n; j += 4) {
+                a0 += p[(size_t)j * m] * x[j];
+                a1 += p[(size_t)(j + 1) * m] * x[j + 1];
+                a2 += p[(size_t)(j + 2) * m] * x[j + 2];
+                a3 += p[(size_t)(j + 3) * m] * x[j + 3];
+            }
+            for (; j < n; ++j) a0 += p[(size_t)j * m] * x[j];
+            epi.seg(i, (a0 + a1) + (a2 + a3), racc);
+        }
+    }
+    finish_block(epi, racc, sh);
+}
+
+// x = J' y (SQ: column sums of squares): one block per column, contiguous reads.
+template <class Epi, bool SQ>
+__global__ void __launch_bounds__(LSQ_NT) k_dense_t(const double *__restrict__ A, int m, int n,
+                                                     const double *__restrict__ y, Epi epi) {
+    __shared__ double sh[LSQ_NT / 64];
+    if (epi.done && *epi.done) return;
+    const int nwork = n + epi.extra_blocks;
+    double racc = 0.0;
+    for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
+        if (b >= n) {
+            epi.extra(b - n, racc);
+            continue;
+        }
+        const double *col = A + (size_t)b * m;
+        double a0 = 0.0, a1 = 0.0;
+        int i = threadIdx.x;
+        for (; i + LSQ_NT < m; i += 2 * LSQ_NT) {
+            double c0 = col[i], c1 = col[i + LSQ_NT];
+            a0 += SQ ? c0 * c0 : c0 * y[i];
+            a1 += SQ ? c1 * c1 : c1 * y[i + LSQ_NT];
+        }
+        if (i < m) {
+            double c0 = col[i];
+            a0 += SQ ? c0 * c0 : c0 * y[i];
+        }
+        double sum = block_sum<LSQ_NT>(a0 + a1, sh);
+        if (threadIdx.x == 0) epi.seg(b, sum, racc);
+    }
+    finish_block(epi, racc, sh);
+}
+
+// One entry point for "dot every row (trans=0) / column (trans=1) of J with x, then epilogue".
+template <class Epi>
+static inline int launch_product(lsq_mat *J, int trans, const double *x, const Epi &epi) {
+    lsq_ctx *c = J->ctx;
+    auto cap = [](long long w) { return (int)(w > LSQ_MAX_GRID ? LSQ_MAX_GRID : w); };
+    if (J->kind == LSQ_MAT_CSC) {
+        if (!trans) {
+            LSQ_TRY(lsq_ensure_csr(J));
+            return launch_segs<false>(c, J->csr, x, epi);
+        }
+        return launch_segs<false>(c, J->csc, x, epi);
+    }
+    if (!trans) {
+        int nb = lsq_div_up(J->m, LSQ_NT);
+        int grid = cap((long long)nb + epi.extra_blocks);
+        if (grid > 0)
+            hipLaunchKernelGGL((k_dense_n<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m,
+                               J->n, x, epi, nb);
+    } else {
+        int grid = cap((long long)J->n + epi.extra_blocks);
+        if (grid > 0)
+            hipLaunchKernelGGL((k_dense_t<Epi, false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense,
+                               J->m, J->n, x, epi);
+    }
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}

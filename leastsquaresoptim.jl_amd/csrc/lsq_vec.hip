@@ -1,0 +1,305 @@
+// Context, device memory and BLAS-1 kernels on device vectors (gfx950).
+// These are what lsmr.jl:30-44 and the optimizer loops require from a vector type
+// (norm, rmul!, axpy!, copyto!, fill!, sum(abs2,.), maximum(abs,.), clamp!, map!) plus
+// wdot/wnorm (utils.jl:165-176) and maxabs_projected_gradient (utils.jl:39-55).
+#include <cmath>
+#include <cstring>
+
+#include "lsq_common.h"
+
+static thread_local char g_err[512] = "";
+
+void lsq_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *lsq_last_error(void) { return g_err; }
+extern "C" int lsq_version(void) { return 100; }
+
+extern "C" int lsq_ctx_create(int device, void *stream, lsq_ctx **out) {
+    if (!out) return LSQ_EARG;
+    int ndev = 0;
+    LSQ_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0 || device < 0 || device >= ndev) {
+        lsq_set_error("lsq_ctx_create: device %d not available (%d HIP devices); this library "
+                      "has no CPU fallback", device, ndev);
+        return LSQ_EHIP;
+    }
+    LSQ_HIP(hipSetDevice(device));
+    lsq_ctx *c = new lsq_ctx();
+    c->device = device;
+    c->mail_epoch = 0;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        LSQ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    LSQ_HIP(hipMalloc(&c->d_slots, LSQ_NSLOTS * sizeof(double)));
+    LSQ_HIP(hipMemset(c->d_slots, 0, LSQ_NSLOTS * sizeof(double)));
+    LSQ_HIP(hipHostMalloc(&c->h_slots, LSQ_NSLOTS * sizeof(double), hipHostMallocDefault));
+    LSQ_HIP(hipMalloc(&c->d_partials, LSQ_MAX_PARTIALS * sizeof(double)));
+    LSQ_HIP(hipMalloc(&c->d_counters, LSQ_NSLOTS * sizeof(unsigned)));
+    LSQ_HIP(hipMemset(c->d_counters, 0, LSQ_NSLOTS * sizeof(unsigned)));
+    LSQ_HIP(hipHostMalloc((void **)&c->h_mail, sizeof(LsqMailbox),
+                          hipHostMallocMapped | hipHostMallocCoherent));
+    memset((void *)c->h_mail, 0, sizeof(LsqMailbox));
+    LSQ_HIP(hipHostGetDevicePointer((void **)&c->d_mail, (void *)c->h_mail, 0));
+    hipDeviceProp_t prop;
+    LSQ_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    LSQ_HIP(hipDeviceSynchronize());
+    *out = c;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_ctx_destroy(lsq_ctx *c) {
+    if (!c) return LSQ_OK;
+    hipStreamSynchronize(c->stream);
+    hipFree(c->d_slots);
+    hipHostFree(c->h_slots);
+    hipFree(c->d_partials);
+    hipFree(c->d_counters);
+    hipHostFree((void *)c->h_mail);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_ctx_sync(lsq_ctx *c) {
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+extern "C" void *lsq_ctx_stream(lsq_ctx *c) { return (void *)c->stream; }
+
+extern "C" int lsq_malloc(lsq_ctx *c, size_t bytes, void **out) {
+    LSQ_HIP(hipSetDevice(c->device));
+    LSQ_HIP(hipMalloc(out, bytes ? bytes : 8));
+    return LSQ_OK;
+}
+extern "C" int lsq_free(lsq_ctx *c, void *p) {
+    if (!p) return LSQ_OK;
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    LSQ_HIP(hipFree(p));
+    return LSQ_OK;
+}
+extern "C" int lsq_h2d(lsq_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return LSQ_OK;
+    LSQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+extern "C" int lsq_d2h(lsq_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return LSQ_OK;
+    LSQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+extern "C" int lsq_d2d(lsq_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return LSQ_OK;
+    LSQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return LSQ_OK;
+}
+
+int lsq_read_slots(lsq_ctx *c, int first, int count, double *h_out) {
+    LSQ_HIP(hipMemcpyAsync(c->h_slots + first, c->d_slots + first, count * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < count; ++i) h_out[i] = c->h_slots[first + i];
+    return LSQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise kernels: grid-stride, 2 doubles (16 B) per lane per step where alignment allows
+// ---------------------------------------------------------------------------------------------
+static inline int ew_grid(const lsq_ctx *c, long long n) {
+    long long g = (n + LSQ_NT - 1) / LSQ_NT;
+    long long cap = (long long)c->num_cus * 8;
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : (int)g;
+}
+
+__global__ void __launch_bounds__(LSQ_NT) k_axpy(int n, double a, const double *__restrict__ x,
+                                                  double *__restrict__ y) {
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
+         i += (long long)gridDim.x * LSQ_NT)
+        y[i] += a * x[i];
+}
+__global__ void __launch_bounds__(LSQ_NT) k_scal(int n, double a, double *__restrict__ x) {
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
+         i += (long long)gridDim.x * LSQ_NT)
+        x[i] *= a;
+}
+__global__ void __launch_bounds__(LSQ_NT) k_fill(int n, double a, double *__restrict__ x) {
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
+         i += (long long)gridDim.x * LSQ_NT)
+        x[i] = a;
+}
+__global__ void __launch_bounds__(LSQ_NT) k_clamp(int n, double lo, double hi, double *__restrict__ x) {
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
+         i += (long long)gridDim.x * LSQ_NT) {
+        double v = x[i];
+        x[i] = v > hi ? hi : (v < lo ? lo : v);  // Base.clamp
+    }
+}
+__global__ void __launch_bounds__(LSQ_NT) k_ediv(int n, const double *__restrict__ x,
+                                                  const double *__restrict__ y, double *__restrict__ o) {
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
+         i += (long long)gridDim.x * LSQ_NT)
+        o[i] = x[i] / y[i];
+}
+__global__ void __launch_bounds__(LSQ_NT) k_box_clip(int n, double *__restrict__ dx,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ lo,
+                                                      const double *__restrict__ hi) {
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
+         i += (long long)gridDim.x * LSQ_NT) {
+        double d = dx[i];
+        if (lo) d = fmin(d, x[i] - lo[i]);
+        if (hi) d = fmax(d, x[i] - hi[i]);
+        dx[i] = d;
+    }
+}
+
+// reductions: MODE 0 sum(x), 1 sum(x^2), 2 sum(w*x*y), 3 max|x|, 4 projected-gradient max
+template <int MODE>
+__global__ void __launch_bounds__(LSQ_NT)
+k_reduce(int n, const double *__restrict__ x, const double *__restrict__ y,
+         const double *__restrict__ w, const double *__restrict__ lo, const double *__restrict__ hi,
+         double *partials, unsigned *counter, double *out) {
+    __shared__ double sh[LSQ_NT / 64];
+    double acc = 0.0;
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
+         i += (long long)gridDim.x * LSQ_NT) {
+        double v = x[i];
+        if (MODE == 0) acc += v;
+        if (MODE == 1) acc += v * v;
+        if (MODE == 2) acc += w[i] * v * y[i];
+        if (MODE == 3) {  // maximum(abs, x); a NaN is reported as +inf (both fail every "<= tol")
+            double a = fabs(v);
+            if (isnan(a)) a = INFINITY;
+            acc = fmax(acc, a);
+        }
+        if (MODE == 4) {  // utils.jl:44-53: v = g[i], y = x
+            double gi = v;
+            if (lo && y[i] <= lo[i] && gi > 0.0) gi = 0.0;
+            else if (hi && y[i] >= hi[i] && gi < 0.0) gi = 0.0;
+            double a = fabs(gi);
+            if (a > acc) acc = a;
+        }
+    }
+    constexpr bool IS_MAX = (MODE >= 3);
+    double bv = IS_MAX ? block_max<LSQ_NT>(acc, sh) : block_sum<LSQ_NT>(acc, sh);
+    grid_reduce<LSQ_NT, IS_MAX>(bv, partials, counter, gridDim.x, sh, [=](double t) { *out = t; });
+}
+
+// check_isfinite (utils.jl:70-75): smallest non-finite index, or -1.  A hit at index i is coded
+// as 1e15-(i+1) > 0 so that a max-reduction returns the smallest index; 0 codes "none".
+__global__ void __launch_bounds__(LSQ_NT)
+k_first_nonfinite(int n, const double *__restrict__ x, double *partials, unsigned *counter, double *out) {
+    __shared__ double sh[LSQ_NT / 64];
+    double code = 0.0;
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
+         i += (long long)gridDim.x * LSQ_NT) {
+        if (!isfinite(x[i]) && code == 0.0) code = 1e15 - (double)(i + 1);
+    }
+    double bv = block_max<LSQ_NT>(code, sh);
+    grid_reduce<LSQ_NT, true>(bv, partials, counter, gridDim.x, sh, [=](double t) {
+        *out = (t == 0.0) ? -1.0 : (1e15 - t) - 1.0;
+    });
+}
+
+#define LSQ_LAUNCH_EW(kernel, n, ...)                                                     \
+    do {                                                                                  \
+        if ((n) > 0)                                                                      \
+            hipLaunchKernelGGL(kernel, dim3(ew_grid(c, (n))), dim3(LSQ_NT), 0, c->stream, \
+                               __VA_ARGS__);                                              \
+        LSQ_HIP(hipGetLastError());                                                       \
+    } while (0)
+
+extern "C" int lsq_axpy(lsq_ctx *c, int n, double a, const double *x, double *y) {
+    LSQ_LAUNCH_EW(k_axpy, n, n, a, x, y);
+    return LSQ_OK;
+}
+extern "C" int lsq_scal(lsq_ctx *c, int n, double a, double *x) {
+    LSQ_LAUNCH_EW(k_scal, n, n, a, x);
+    return LSQ_OK;
+}
+extern "C" int lsq_copy(lsq_ctx *c, int n, const double *x, double *y) {
+    return lsq_d2d(c, y, x, (size_t)n * sizeof(double));
+}
+extern "C" int lsq_fill(lsq_ctx *c, int n, double a, double *x) {
+    LSQ_LAUNCH_EW(k_fill, n, n, a, x);
+    return LSQ_OK;
+}
+extern "C" int lsq_clamp(lsq_ctx *c, int n, double lo, double hi, double *x) {
+    LSQ_LAUNCH_EW(k_clamp, n, n, lo, hi, x);
+    return LSQ_OK;
+}
+extern "C" int lsq_ediv(lsq_ctx *c, int n, const double *x, const double *y, double *o) {
+    LSQ_LAUNCH_EW(k_ediv, n, n, x, y, o);
+    return LSQ_OK;
+}
+extern "C" int lsq_box_clip(lsq_ctx *c, int n, double *dx, const double *x, const double *lo,
+                            const double *hi) {
+    if (!lo && !hi) return LSQ_OK;
+    LSQ_LAUNCH_EW(k_box_clip, n, n, dx, x, lo, hi);
+    return LSQ_OK;
+}
+
+template <int MODE>
+static int reduce_to_host(lsq_ctx *c, int n, const double *x, const double *y, const double *w,
+                          const double *lo, const double *hi, double *h_out) {
+    if (n <= 0) {
+        *h_out = 0.0;
+        return LSQ_OK;
+    }
+    int grid = ew_grid(c, n);
+    hipLaunchKernelGGL(k_reduce<MODE>, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x, y, w, lo, hi,
+                       c->d_partials, c->d_counters + 0, c->d_slots + 0);
+    LSQ_HIP(hipGetLastError());
+    LSQ_TRY(lsq_read_slots(c, 0, 1, h_out));
+    return LSQ_OK;
+}
+
+extern "C" int lsq_sum(lsq_ctx *c, int n, const double *x, double *h) {
+    return reduce_to_host<0>(c, n, x, nullptr, nullptr, nullptr, nullptr, h);
+}
+extern "C" int lsq_sumsq(lsq_ctx *c, int n, const double *x, double *h) {
+    return reduce_to_host<1>(c, n, x, nullptr, nullptr, nullptr, nullptr, h);
+}
+extern "C" int lsq_nrm2(lsq_ctx *c, int n, const double *x, double *h) {
+    LSQ_TRY(reduce_to_host<1>(c, n, x, nullptr, nullptr, nullptr, nullptr, h));
+    *h = sqrt(*h);
+    return LSQ_OK;
+}
+extern "C" int lsq_wdot(lsq_ctx *c, int n, const double *x, const double *y, const double *w, double *h) {
+    return reduce_to_host<2>(c, n, x, y, w, nullptr, nullptr, h);
+}
+extern "C" int lsq_amax(lsq_ctx *c, int n, const double *x, double *h) {
+    LSQ_TRY(reduce_to_host<3>(c, n, x, nullptr, nullptr, nullptr, nullptr, h));
+    return LSQ_OK;
+}
+extern "C" int lsq_amax_projected(lsq_ctx *c, int n, const double *g, const double *x,
+                                  const double *lo, const double *hi, double *h) {
+    if (!lo && !hi) return lsq_amax(c, n, g, h);
+    return reduce_to_host<4>(c, n, g, x, nullptr, lo, hi, h);
+}
+extern "C" int lsq_first_nonfinite(lsq_ctx *c, int n, const double *x, int *h_index) {
+    if (n <= 0) {
+        *h_index = -1;
+        return LSQ_OK;
+    }
+    int grid = ew_grid(c, n);
+    hipLaunchKernelGGL(k_first_nonfinite, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x,
+                       c->d_partials, c->d_counters + 0, c->d_slots + 0);
+    LSQ_HIP(hipGetLastError());
+    double v;
+    LSQ_TRY(lsq_read_slots(c, 0, 1, &v));
+    *h_index = (int)v;
+    return LSQ_OK;
+}

@@ -1,0 +1,370 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+inputs.  Tolerances (fp64; summation order differs: tree reductions vs the serial loops of the
+reference):
+    kernels                         |err| <= 1e-12 * scale
+    one linear solve (ldiv!)        rel 1e-9 (direct), LSMR: identical iteration count, rel 1e-8
+    trust-region trajectories       identical iteration / f / g / mul counts and accept pattern,
+                                    ||x_k - x_k^ref||_inf <= 1e-7 * max(1, ||x_k||_inf) per iterate
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import problems as P
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+lsq = pytest.importorskip("lsq_amd")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return lsq.default_context()
+
+
+def rand_csc(m, n, density, seed):
+    rng = np.random.default_rng(seed)
+    S = sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    S.sort_indices()
+    return S
+
+
+# ------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("plan", ["stream", "wave", "block", None])
+@pytest.mark.parametrize("m,n,density", [(3000, 200, 0.01), (500, 40, 0.5), (64, 3000, 0.02)])
+def test_sparse_products(ctx, plan, m, n, density):
+    for k in ("LSQ_PLAN_CSC", "LSQ_PLAN_CSR"):
+        if plan:
+            os.environ[k] = plan
+        else:
+            os.environ.pop(k, None)
+    try:
+        S = rand_csc(m, n, density, m + n)
+        # ragged extremes: an empty column/row and one very long row
+        S = S.tolil()
+        S[:, 1] = 0
+        S[3, :] = 0
+        S[5, :] = np.random.default_rng(0).standard_normal(n)
+        S = S.tocsc()
+        S.sort_indices()
+        S.eliminate_zeros()
+        J = lsq.DeviceMatrix(ctx, S)
+    finally:
+        os.environ.pop("LSQ_PLAN_CSC", None)
+        os.environ.pop("LSQ_PLAN_CSR", None)
+    A = O.Mat.from_scipy(S)
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    dx, dy = lsq.DeviceVector(ctx, n, x), lsq.DeviceVector(ctx, m, y)
+    scale = 1 + np.abs(S).sum(axis=1).max()
+    out = lsq.mul_(lsq.DeviceVector(ctx, m, y), J, dx, 1.5, -0.5).get()
+    assert np.max(np.abs(out - O.mul(A, x, 1.5, -0.5, y))) <= 1e-12 * scale
+    out = lsq.mul_(lsq.DeviceVector(ctx, m, np.full(m, np.nan)), J, dx, 1.0, 0.0).get()
+    assert np.max(np.abs(out - O.mul(A, x))) <= 1e-12 * scale  # beta == 0 overwrites NaN
+    scale_t = 1 + np.abs(S).sum(axis=0).max()
+    out = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, dy, -2.0, 0.25, trans=True).get()
+    assert np.max(np.abs(out - O.mulT(A, y, -2.0, 0.25, x))) <= 1e-12 * scale_t
+    cs = lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get()
+    assert np.allclose(cs, O.colsumabs2(A), rtol=1e-13, atol=0)
+    assert cs[1] == 0.0
+
+
+def test_empty_and_tiny_sparse(ctx):
+    S = sp.csc_matrix((5, 3))
+    J = lsq.DeviceMatrix(ctx, S)
+    out = lsq.mul_(lsq.DeviceVector(ctx, 5, np.ones(5)), J, lsq.DeviceVector(ctx, 3, np.ones(3)), 1.0, 2.0).get()
+    assert np.all(out == 2.0)
+    S = sp.csc_matrix(np.array([[2.0]]))
+    J = lsq.DeviceMatrix(ctx, S)
+    assert lsq.mul_(lsq.DeviceVector(ctx, 1), J, lsq.DeviceVector(ctx, 1, [3.0])).get()[0] == 6.0
+
+
+@pytest.mark.parametrize("m,n", [(300, 17), (7, 40), (1025, 129)])
+def test_dense_products(ctx, m, n):
+    rng = np.random.default_rng(m * n)
+    D = rng.standard_normal((m, n))
+    J = lsq.DeviceMatrix(ctx, D)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    out = lsq.mul_(lsq.DeviceVector(ctx, m, y), J, lsq.DeviceVector(ctx, n, x), 0.5, 2.0).get()
+    assert np.allclose(out, 0.5 * D @ x + 2 * y, rtol=1e-12, atol=1e-12)
+    out = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, lsq.DeviceVector(ctx, m, y), 1.0, 0.0, trans=True).get()
+    assert np.allclose(out, D.T @ y, rtol=1e-12, atol=1e-12)
+    assert np.allclose(lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get(), (D * D).sum(0), rtol=1e-13)
+
+
+def test_blas1(ctx):
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 1000, 100003):
+        x, y, w = rng.standard_normal(n), rng.standard_normal(n), rng.random(n)
+        dx, dy, dw = (lsq.DeviceVector(ctx, n, v) for v in (x, y, w))
+        assert lsq.sumsq(dx) == pytest.approx(np.sum(x * x), rel=1e-13)
+        assert lsq.norm(dx) == pytest.approx(np.linalg.norm(x), rel=1e-13)
+        assert lsq.wdot(dx, dy, dw) == pytest.approx(O.wdot(x, y, w), rel=1e-12, abs=1e-12)
+        assert lsq.maxabs(dx) == np.max(np.abs(x))
+        lo, hi = x - (rng.random(n) < 0.3) * 0.0 - 1.0 * (rng.random(n) < 0.5), x + 1.0
+        lo[::2] = x[::2]  # half the coordinates sit on their lower bound
+        dlo, dhi = lsq.DeviceVector(ctx, n, lo), lsq.DeviceVector(ctx, n, hi)
+        assert lsq.maxabs_projected_gradient(dy, dx, dlo, dhi) == O.maxabs_projected_gradient(y, x, lo, hi)
+    # run-to-run determinism of the two-stage reduction
+    big = lsq.DeviceVector(ctx, 1 << 20, rng.standard_normal(1 << 20))
+    assert len({lsq.sumsq(big) for _ in range(5)}) == 1
+
+
+# ------------------------------------------------------------------------------- ldiv!
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("damped", [True, False])
+def test_ldiv_lsmr(ctx, sparse, damped):
+    m, n = 400, 60
+    S = rand_csc(m, n, 0.1, 21)
+    rng = np.random.default_rng(22)
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.05
+    Jh = S if sparse else S.toarray()
+    A = O.Mat.from_scipy(S) if sparse else O.Mat(dense=S.toarray())
+    J = lsq.DeviceMatrix(ctx, Jh)
+    sv = lsq.AllocatedSolver(J, lsq.LSMR(), for_lm=damped)
+    dy, dxo = lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n)
+    if damped:
+        dd = lsq.DeviceVector(ctx, n, damp)
+        _, nmul = sv.ldiv_(dxo, dy, dd)
+        st, xr, nmul_r, dafter = O.ldiv(O.LSMR, A, y, damp)
+        assert np.allclose(dd.get(), dafter, rtol=1e-15)  # damp <- sqrt(damp) (iterative_lsmr.jl:252)
+    else:
+        _, nmul = sv.ldiv_(dxo, dy)
+        st, xr, nmul_r = O.ldiv(O.LSMR, A, y)
+    assert nmul == nmul_r and nmul > 0
+    assert np.allclose(dxo.get(), xr, rtol=1e-8, atol=1e-10)
+    assert np.array_equal(dy.get(), y)  # y preserved
+    # zero right-hand side: ||A'b|| == 0 early exit, mvps == 0 (lsmr.jl:115)
+    dz = lsq.DeviceVector(ctx, m)
+    if damped:
+        _, nmul0 = sv.ldiv_(dxo, dz, lsq.DeviceVector(ctx, n, damp))
+    else:
+        _, nmul0 = sv.ldiv_(dxo, dz)
+    assert nmul0 == 0 and np.all(dxo.get() == 0)
+
+
+@pytest.mark.parametrize("n", [1, 9, 70, 200])
+def test_ldiv_cholesky(ctx, n):
+    rng = np.random.default_rng(30 + n)
+    m = 3 * n + 5
+    D = rng.standard_normal((m, n))
+    y = rng.standard_normal(m)
+    damp = rng.random(n)
+    J = lsq.DeviceMatrix(ctx, D)
+    dy, dxo = lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n)
+    sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+    _, nmul = sv.ldiv_(dxo, dy, lsq.DeviceVector(ctx, n, damp))
+    st, xr, _, _ = O.ldiv(O.CHOLESKY, O.Mat(dense=D), y, damp)
+    assert nmul == 1 and np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
+    sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=False)  # pivoted (Dogleg)
+    _, nmul = sv.ldiv_(dxo, dy)
+    st, xr, _ = O.ldiv(O.CHOLESKY, O.Mat(dense=D), y)
+    assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
+
+
+def test_cholesky_failures(ctx):
+    rng = np.random.default_rng(33)
+    D = rng.standard_normal((30, 6))
+    D[:, 4] = D[:, 2]
+    J = lsq.DeviceMatrix(ctx, D)
+    dy, dxo = lsq.DeviceVector(ctx, 30, rng.standard_normal(30)), lsq.DeviceVector(ctx, 6)
+    with pytest.raises(lsq.RankDeficientException):
+        lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=False).ldiv_(dxo, dy)
+    D[:, 4] = 0.0
+    J = lsq.DeviceMatrix(ctx, D)
+    with pytest.raises(lsq.PosDefException):
+        lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True).ldiv_(dxo, dy, lsq.DeviceVector(ctx, 6))
+
+
+@pytest.mark.parametrize("m,n,rank", [(40, 10, 10), (12, 12, 12), (30, 12, 7), (9, 6, 5), (20, 8, 1),
+                                      (6, 10, 6), (6, 10, 4), (300, 65, 65)])
+def test_ldiv_qr(ctx, m, n, rank):
+    rng = np.random.default_rng(100 + m + n + rank)
+    A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n))
+    y = rng.standard_normal(m)
+    J = lsq.DeviceMatrix(ctx, A)
+    sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+    dxo = lsq.DeviceVector(ctx, n)
+    _, nmul = sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+    xr, rk, *_ = O.qr_solve(A, y)
+    assert nmul == 1 and sv.info()["qr_rank"] == rk == rank
+    assert np.allclose(dxo.get(), xr, rtol=1e-8, atol=1e-10)
+    if rank == min(m, n) and m >= n:
+        damp = rng.random(n) + 0.01
+        svd = lsq.AllocatedSolver(J, lsq.QR(), for_lm=True)
+        svd.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+        st, xr, _, _ = O.ldiv(O.QR, O.Mat(dense=A), y, damp)
+        assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------- trust-region trajectories
+def gpu_run(p, optimizer, solver, sparse=False, **kw):
+    name, f, g, x0 = p[:4]
+    n = len(x0)
+    if sparse:
+        m_, n_, colptr, rowval = P.full_csc_pattern(n, n)
+        J = sp.csc_matrix((np.zeros(n * n), rowval, colptr), shape=(n, n))
+
+        def g_(Jm, x):
+            g(Jm.data.reshape((n, n), order="F"), x)
+    else:
+        J = np.zeros((n, n), order="F")
+        g_ = g
+    nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(n), f_=f, g_=g_, J=J)
+    return lsq.optimize_(nls, optimizer(solver), full_trace=True, **kw)
+
+
+def oracle_run(p, optimizer, solver, sparse=False, **kw):
+    name, f, g, x0 = p[:4]
+    n = len(x0)
+    J = (O.Mat(csc=(*P.full_csc_pattern(n, n), np.zeros(n * n))) if sparse else O.Mat(dense=np.zeros((n, n))))
+    ff, gg = P.wrap_dense(f, g, n, n)
+    return O.optimize(optimizer, solver, J, x0, ff, gg, **kw)
+
+
+OPT = {"dogleg": (lsq.Dogleg, O.DOGLEG), "lm": (lsq.LevenbergMarquardt, O.LM)} if hasattr(lsq, "Dogleg") else {}
+SOL = {"qr": (lsq.QR, O.QR), "cholesky": (lsq.Cholesky, O.CHOLESKY), "lsmr": (lsq.LSMR, O.LSMR)} if OPT else {}
+
+
+def compare(rg, ro, label, xtol=1e-7):
+    assert rg.ssr <= 1e-3, (label, rg.ssr)                       # the reference's own pin
+    assert rg.iterations == ro.iterations, (label, rg.iterations, ro.iterations)
+    assert (rg.f_calls, rg.g_calls, rg.mul_calls) == (ro.f_calls, ro.g_calls, ro.mul_calls), label
+    assert (rg.converged, rg.x_converged, rg.f_converged, rg.g_converged) == \
+           (ro.converged, ro.x_converged, ro.f_converged, ro.g_converged), label
+    assert np.array_equal(rg.trace["accept"], ro.trace["accept"]), label
+    assert np.array_equal(rg.trace["inner"], ro.trace["inner"]), label
+    for k in range(ro.iterations):
+        xr = ro.trace["x"][k]
+        assert np.max(np.abs(rg.trace["x"][k] - xr)) <= xtol * max(1.0, np.max(np.abs(xr))), (label, k)
+
+
+GRID = [("dogleg", "qr", False), ("lm", "qr", False), ("dogleg", "lsmr", False), ("lm", "lsmr", False),
+        ("dogleg", "lsmr", True), ("lm", "lsmr", True)]
+
+
+@pytest.mark.parametrize("opt,sol,sparse", GRID)
+def test_minpack_trajectories(opt, sol, sparse):
+    """test/nonlinearsolvers.jl:505-537 on the device, trajectory-checked against the oracle."""
+    for p in P.minpack_all():
+        rg = gpu_run(p, OPT[opt][0], SOL[sol][0](), sparse)
+        ro = oracle_run(p, OPT[opt][1], SOL[sol][1], sparse)
+        compare(rg, ro, (P.label(p), opt, sol, sparse))
+
+
+@pytest.mark.parametrize("opt", ["dogleg", "lm"])
+def test_minpack_cholesky_trajectories(opt):
+    """test/nonlinearsolvers.jl:573-595"""
+    for p in P.minpack_cholesky():
+        rg = gpu_run(p, OPT[opt][0], lsq.Cholesky())
+        ro = oracle_run(p, OPT[opt][1], O.CHOLESKY)
+        assert rg.converged
+        compare(rg, ro, (P.label(p), opt, "cholesky"))
+
+
+def test_kat_trajectories():
+    """SURVEY 8c KAT-DL / KAT-LM through the HIP path."""
+    r = gpu_run(P.readme_rosenbrock(), lsq.Dogleg, lsq.QR(), iterations=2)
+    assert r.trace["rho"][0] == pytest.approx(-9999.0, rel=1e-12)
+    assert r.trace["rho"][1] == pytest.approx(-624.25 / 0.75, rel=1e-12)
+    assert list(r.trace["delta"]) == [0.5, 0.25] and np.all(r.trace["x"] == 0)
+    r = gpu_run(P.readme_rosenbrock(), lsq.LevenbergMarquardt, lsq.QR(), iterations=1)
+    assert r.trace["rho"][0] == pytest.approx(-6886.0523416, rel=1e-9) and r.trace["delta"][0] == 5.0
+
+
+@pytest.mark.parametrize("opt", ["dogleg", "lm"])
+def test_factor_model(opt):
+    """test/nonlinearleastsquares.jl:96-110 (rank-deficient J'J: pins the min-norm QR solve)."""
+    name, f, g, x0 = P.factor_dense()
+    nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.ones(9), f_=f, g_=g, J=np.ones((9, 6)))
+    r = lsq.optimize_(nls, OPT[opt][0](lsq.QR()), full_trace=True)
+    ff, gg = P.wrap_dense(f, g, 9, 6)
+    ro = O.optimize(OPT[opt][1], O.QR, O.Mat(dense=np.zeros((9, 6))), x0, ff, gg)
+    assert r.converged and r.ssr <= 12
+    assert r.iterations == ro.iterations and np.allclose(r.minimizer, ro.minimizer, rtol=1e-6, atol=1e-8)
+    name, f, gs, x0, (m, n, colptr, rowval) = P.factor_sparse()
+    J = sp.csc_matrix((np.ones(18), rowval, colptr), shape=(9, 6))
+    nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.ones(9), f_=f, g_=lambda Jm, x: gs(Jm.data, x), J=J)
+    r = lsq.optimize_(nls, OPT[opt][0](lsq.LSMR()), full_trace=True)
+    ro = O.optimize(OPT[opt][1], O.LSMR, O.Mat(csc=(m, n, colptr, rowval, np.zeros(18))), x0, f, gs)
+    assert r.converged and r.ssr <= 12
+    assert r.iterations == ro.iterations and r.mul_calls == ro.mul_calls
+
+
+@pytest.mark.parametrize("opt", ["dogleg", "lm"])
+def test_bounds(opt):
+    """test/bounds.jl:7-38"""
+    mk = OPT[opt][0]
+
+    def go(p, **kw):
+        name, f, g, x0 = p
+        nls = lsq.LeastSquaresProblem(x=x0.copy(), f_=f, g_=g, output_length=2)
+        return lsq.optimize_(nls, mk(), **kw)
+
+    r = go(P.readme_rosenbrock(), lower=[0.0, 0.0])
+    assert r.converged and np.all(r.minimizer >= -1e-8) and np.linalg.norm(r.minimizer - [1, 1]) <= 1e-6
+    r = go(P.bound_lower_active(), lower=[1.0, -100.0], x_tol=1e-50, f_tol=1e-50)
+    assert r.converged and r.g_converged and np.linalg.norm(r.minimizer - [1, 3]) <= 1e-6
+    r = go(P.bound_upper_active(), upper=[2.0, 100.0], x_tol=1e-50, f_tol=1e-50)
+    assert r.converged and r.g_converged and np.linalg.norm(r.minimizer - [2, 2]) <= 1e-6
+    with pytest.raises(lsq.ArgumentError):
+        go(P.readme_rosenbrock(), lower=[1.0, 1.0])
+
+
+def test_finite_difference_and_defaults():
+    """test/runtests.jl:19-70 + test/nonlinearsolvers.jl:619-628"""
+    rosen = lambda x: np.array([1 - x[0], 100 * (x[1] - x[0] ** 2)])
+    for o in (lsq.Dogleg(), lsq.LevenbergMarquardt()):
+        r = lsq.optimize(rosen, np.zeros(2), o)
+        assert r.converged and r.ssr <= 1e-8
+    r = lsq.optimize(lambda x: np.sum(x ** 2), np.array([1.0, 1.0]), lsq.Dogleg())  # issue #41
+    assert r.converged
+    name, f, g, x0 = P.wood()
+    r = lsq.optimize_(lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(4), f_=f, g_=g, J=np.ones((4, 4))))
+    assert r.optimizer == "Dogleg"
+    Js = sp.csc_matrix(np.ones((4, 4)))
+    r = lsq.optimize_(lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(4), f_=f,
+                                              g_=lambda Jm, x: g(Jm.data.reshape((4, 4), order="F"), x), J=Js))
+    assert r.optimizer == "LevenbergMarquardt"
+    r = lsq.optimize(rosen, np.zeros(2), lsq.LevenbergMarquardt(), store_trace=True)
+    assert len(r.tr) >= 1 and isinstance(r.tr[0], lsq.OptimizationState)
+    # output_length defaults to size(J, 1) (runtests.jl:54-61)
+    over = lambda o, x: o.__setitem__(slice(None), [x[0] - 1, x[1] - 2, x[2] - 3, x[0] + x[1], x[1] + x[2]])
+    p = lsq.LeastSquaresProblem(x=np.zeros(3), f_=over, J=np.zeros((5, 3)))
+    assert len(p.y) == 5 and lsq.optimize_(p, lsq.Dogleg()).converged
+
+
+def test_nonfinite_raises():
+    name, f, g, x0 = P.readme_rosenbrock()
+    nls = lsq.LeastSquaresProblem(x=np.array([np.nan, 0.0]), f_=f, g_=g, output_length=2)
+    with pytest.raises(lsq.IsFiniteException) as e:
+        lsq.optimize_(nls, lsq.LevenbergMarquardt())
+    assert e.value.indices == [0]
+
+
+# --------------------------------------------------------------- synthetic model (bench family)
+@pytest.mark.parametrize("sparse,opt,sol", [(True, "lm", "lsmr"), (False, "lm", "cholesky"),
+                                            (False, "dogleg", "qr"), (True, "dogleg", "lsmr")])
+def test_tanh_model_matches_oracle(ctx, sparse, opt, sol):
+    """Reduced-size C4/C2/C3 family: device f!/g! + device solver vs the oracle's C model."""
+    m, n, per_col = (20000, 200, 100) if sparse else (1500, 48, None)
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=sparse, per_col=per_col, seed=7, ctx=ctx)
+    pr.reset()
+    okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
+    skind = {"lsmr": lsq._lib.LSMR, "cholesky": lsq._lib.CHOLESKY, "qr": lsq._lib.QR}[sol]
+    rg = pr.optimize(okind, skind, trace=True, iterations=50)
+    A = (O.Mat(csc=(m, n, pr.colptr, pr.rowval, pr.A)) if sparse else O.Mat(dense=pr.A.reshape((m, n), order="F")))
+    J = (O.Mat(csc=(m, n, pr.colptr, pr.rowval, np.zeros_like(pr.A))) if sparse else O.Mat(dense=np.zeros((m, n))))
+    f, g, ud, keep = O.tanh_model(A, pr.b)
+    ro = O.optimize(OPT[opt][1], SOL[sol][1], J, np.zeros(n), f, g, ud=ud, iterations=50)
+    assert rg.iterations == ro.iterations and rg.mul_calls == ro.mul_calls
+    assert rg.converged == ro.converged and rg.ssr == pytest.approx(ro.ssr, rel=1e-9)
+    assert np.array_equal(rg.trace["inner"], ro.trace["inner"])
+    for k in range(ro.iterations):
+        xr = ro.trace["x"][k]
+        assert np.max(np.abs(rg.trace["x"][k] - xr)) <= 1e-8 * max(1.0, np.max(np.abs(xr)))
+    pr.close()
