@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- LM+LSMR outer iterations / second on the C4 workload of BASELINE.json
+(sparse CSC 10^6 x 10^4, 0.1 % nnz => nnz = 10^7, LevenbergMarquardt(LSMR())), one problem per GPU.
+
+A "step" is ONE Levenberg-Marquardt outer iteration of the hot path (levenberg_marquardt.jl:72-140)
+on the synthetic tanh model: g! (when the previous step was accepted), colsumabs2, the damped
+preconditioned LSMR solve (k inner iterations of J*v / J'*u), J'f, f!, J*dx and the accept/reject
+logic -- everything resident in HBM, f!/g! on the device.  The timed region is EXACTLY K steps
+(tolerances are set to 0 so the loop cannot stop early).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, the J*v product inside LSMR
+(k_seg_stream<EpiU>): algorithmic bytes per launch (12*nnz + 4*(m+1) + 8*n + 16*m
+= 140.08 MB, plus 24*n for the fused damping rows) / average launch duration measured with HIP
+events on the library's stream inside the timed region.  `cpu_baseline` is the oracle (scalar C
+port, 1 thread) timed on this box's host on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--m", type=int, default=1_000_000)
+    ap.add_argument("--n", type=int, default=10_000)
+    ap.add_argument("--per-col", type=int, default=1000)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="outer iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch  # plumbing only: device selection, barrier, RCCL all-reduce
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    import numpy as np
+    import lsq_amd as lsq
+    L = lsq.lib()
+    ctx = lsq.Context(local_rank)
+    m, n, pc = a.m, a.n, a.per_col
+    nnz = n * pc
+    seed = lsq.synthetic.BASE_SEED + rank  # the 8 problems of C5 differ
+    t0 = time.time()
+    inputs = lsq.synthetic.sparse_inputs(m, n, pc, seed)
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=seed, ctx=ctx, inputs=inputs)
+    t_setup = time.time() - t0
+
+    # one scalar all-reduce per outer iteration for the sharded (C5) case: sum of ssr over problems,
+    # max of the gradient norms, min of the converged flags -- all in ONE RCCL all-reduce of
+    # world+2 doubles (each rank owns one slot for its max; sums elsewhere).
+    allreduce = None
+    if world > 1:
+        buf = torch.zeros(world + 2, dtype=torch.float64, device="cuda")
+
+        def _ar(vals, count, _user):
+            try:
+                buf.zero_()
+                host = torch.tensor([vals[0], vals[2]], dtype=torch.float64)
+                buf[0:2] = host.to("cuda")
+                buf[2 + rank] = vals[1]
+                dist.all_reduce(buf)
+                h = buf.cpu()
+                vals[0] = float(h[0])
+                vals[1] = float(h[2:].max())
+                vals[2] = 1.0 if float(h[1]) >= world - 0.5 else 0.0
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("allreduce failed:", e, file=sys.stderr)
+                return 1
+
+        allreduce = lsq._lib.ALLREDUCE_CALLBACK(_ar)
+
+    LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
+
+    def run(iters, prof=False):
+        pr.reset()
+        if prof:
+            L.lsq_prof_begin(ctx.h, 4096)
+        r = pr.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=iters, allreduce=allreduce)
+        return r
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    if a.warmup > 0:
+        run(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    r = run(a.steps, prof=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    avg = (C.c_double * 2)()
+    cnt = (C.c_int * 2)()
+    L.lsq_prof_end(ctx.h, avg, cnt)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        it = torch.tensor([float(r.lsmr_iterations)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(it)
+        inner_total = float(it.item())
+    else:
+        inner_total = float(r.lsmr_iterations)
+    assert r.iterations == a.steps, (r.iterations, a.steps)
+
+    # generic J*v (y <- J x + y) timed back-to-back with HIP events, for reference
+    xv = lsq.DeviceVector(ctx, n, np.random.default_rng(0).standard_normal(n))
+    yv = lsq.DeviceVector(ctx, m, np.zeros(m))
+    ms = C.c_float(0)
+    lsq._lib.check(L.lsq_bench_mul(pr.J, 0, 50, xv.ptr, yv.ptr, 1.0, C.byref(ms)))
+    ms_t = C.c_float(0)
+    lsq._lib.check(L.lsq_bench_mul(pr.J, 1, 50, yv.ptr, xv.ptr, 1.0, C.byref(ms_t)))
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    bytes_jv = 12 * nnz + 4 * (m + 1) + 8 * n + 16 * m      # SURVEY 8d (CSR mirror, beta != 0)
+    bytes_k1 = bytes_jv + 24 * n                            # + fused damping rows (t, dg, ux rw)
+    bytes_jtu = 12 * nnz + 4 * (n + 1) + 8 * m + 16 * n
+    k1_ms = avg[0] if cnt[0] > 0 else float("nan")
+    achieved = bytes_k1 / (k1_ms * 1e-3) / 1e9 if cnt[0] > 0 else None
+    roof = {"bound": "hbm", "kernel": "k_seg_stream<EpiU> (LSMR J*v: u <- J t - cu*u, + sum u^2)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "algorithmic_bytes_per_launch": bytes_k1, "avg_launch_ms": k1_ms, "launches_timed": int(cnt[0]),
+            "jtu_kernel_avg_ms": avg[1], "jtu_GBps": (bytes_jtu + 16 * n) / (avg[1] * 1e-3) / 1e9 if cnt[1] else None,
+            "generic_jv_ms": ms.value, "generic_jv_GBps": bytes_jv / (ms.value * 1e-3) / 1e9,
+            "generic_jtu_ms": ms_t.value, "generic_jtu_GBps": bytes_jtu / (ms_t.value * 1e-3) / 1e9}
+
+    cpu = None
+    if not a.no_cpu and a.cpu_steps > 0:
+        cpu = cpu_baseline(a, pr, inputs)
+
+    value = a.steps * world / dt
+    out = {"metric": "lm_lsmr_outer_iterations_per_sec", "value": value, "unit": "LM outer iterations/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": "C4: sparse CSC %dx%d, nnz=%d (%.3g%%), LevenbergMarquardt(LSMR()), tanh model, "
+                                  "1 problem per GPU" % (m, n, nnz, 100.0 * nnz / (m * n)),
+                      "m": m, "n": n, "nnz": nnz, "seed": lsq.synthetic.BASE_SEED, "problems": world,
+                      "lsmr_inner_iterations_total": inner_total,
+                      "lsmr_inner_per_outer": inner_total / (a.steps * world),
+                      "lsmr_inner_iterations_per_sec": inner_total / dt,
+                      "final_ssr": r.ssr, "setup_seconds": t_setup},
+           "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, pr, inputs):
+    """The oracle (scalar C port of the reference, 1 thread) on the SAME inputs, bounded sample."""
+    import numpy as np
+    from oracle import oracle as O
+    m, n = a.m, a.n
+    colptr, rowval, nzval = inputs
+    A = O.Mat(csc=(m, n, colptr, rowval, nzval))
+    J = O.Mat(csc=(m, n, colptr, rowval, np.zeros_like(nzval)))
+    f, g, ud, keep = O.tanh_model(A, pr.b)
+    t0 = time.perf_counter()
+    ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=a.cpu_steps, x_tol=0.0, f_tol=0.0,
+                    g_tol=0.0, trace=True, trace_x=False)
+    dt = time.perf_counter() - t0
+    inner = int(ro.trace["inner"].sum()) // 2
+    # CPU J*v bandwidth on the same matrix (algorithmic bytes, same formula)
+    x = np.random.default_rng(0).standard_normal(n)
+    t1 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        O.mul(A, x, 1.0, 1.0, np.zeros(m))
+    t_mv = (time.perf_counter() - t1) / reps
+    nnz = len(nzval)
+    return {"value": a.cpu_steps / dt, "unit": "LM outer iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d LM outer iterations (%d LSMR inner) of the same C4 problem with oracle/lsq_oracle.c, "
+                      "1 thread, %.1f s" % (a.cpu_steps, inner, dt),
+            "lsmr_inner_iterations_per_sec": inner / dt, "host_cores_available": os.cpu_count(),
+            "jv_GBps": (12 * nnz + 4 * (m + 1) + 8 * n + 16 * m) / t_mv / 1e9}
+
+
+if __name__ == "__main__":
+    main()

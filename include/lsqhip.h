@@ -184,6 +184,13 @@ int lsq_synth_normal(int n, unsigned long long seed, double *h_out);
 int lsq_bench_mul(lsq_mat *J, int trans, int reps, const double *d_x, double *d_y, double beta,
                   float *h_ms_per_launch);
 
+/* HIP-event instrumentation of the two dominant kernels inside lsq_ldiv(_damped) with LSMR:
+ * kernel 0 = K1 (u <- J t - cu u, the J*v product), kernel 1 = K2 (v <- J'u ..., the J'*u product).
+ * Events are recorded on the context stream around each launch while enabled (up to max_samples
+ * per kernel); lsq_prof_end waits for them and returns average milliseconds and sample counts. */
+int lsq_prof_begin(lsq_ctx *ctx, int max_samples);
+int lsq_prof_end(lsq_ctx *ctx, double h_avg_ms[2], int h_count[2]);
+
 #ifdef __cplusplus
 }
 #endif

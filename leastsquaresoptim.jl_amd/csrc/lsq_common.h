@@ -29,7 +29,7 @@ void lsq_set_error(const char *fmt, ...);
 
 constexpr int LSQ_NT = 256;             // threads per block for streaming kernels (4 waves)
 constexpr int LSQ_MAX_PARTIALS = 1 << 16;
-constexpr int LSQ_NSLOTS = 64;          // device scalar slots
+constexpr int LSQ_NSLOTS = 64;          // device scalar slots / reduction counter slots
 
 // Host-visible mailbox (pinned, coherent): the device publishes inner-loop progress here so the
 // host never calls hipStreamSynchronize inside LSMR.
@@ -52,7 +52,22 @@ struct lsq_ctx {
     LsqMailbox *d_mail;   // device address of h_mail
     int num_cus;
     unsigned mail_epoch;  // bumps per inner solve; tags mailbox words
+    // optional HIP-event instrumentation (lsq_prof_begin/end)
+    int prof_max = 0;
+    std::vector<hipEvent_t> prof_ev[2];  // start/stop pairs per kernel id
 };
+
+// record a start (phase 0) / stop (phase 1) event for kernel `kid` if instrumentation is on
+static inline void lsq_prof_mark(lsq_ctx *c, int kid, int phase) {
+    if (c->prof_max <= 0) return;
+    auto &v = c->prof_ev[kid];
+    if (phase == 0 && (int)v.size() >= 2 * c->prof_max) return;
+    if (phase == 1 && (v.size() & 1) == 0) return;  // start was not recorded
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    hipEventRecord(e, c->stream);
+    v.push_back(e);
+}
 
 // ---------------------------------------------------------------------------------------------
 // sparse / dense matrix handle
@@ -71,6 +86,10 @@ struct LsqSegs {
     int plan = LSQ_PLAN_STREAM;
     int ntiles = 0;        // stream plan: number of tiles
     int *d_tiles = nullptr; // ntiles+1 segment boundaries of the tiles
+    int *d_order = nullptr; // optional permutation of the work items (XCD-aware placement)
+    int nx = 0;            // length of the gathered vector (n for CSR rows, m for CSC columns)
+    int nbig = 0;          // stream plan, LDS-staged variant: number of big tiles
+    int *d_big = nullptr;  // nbig+1 segment boundaries (<= 8189 nnz, <= 1024 segments each)
 };
 
 struct lsq_mat {
@@ -85,6 +104,15 @@ struct lsq_mat {
     LsqSegs csr;           // rows; d_val refreshed from csc.d_val through d_map
     int *d_map = nullptr;  // csr position -> csc position
     bool csr_fresh = false;
+    // Row-window-blocked CSC for J'*y when the gathered m-vector outgrows an XCD's L2 (4 MiB):
+    // rows are cut into `nwin` windows; segment (w, j) holds column j's entries with rows in
+    // window w, so all gathers of a window hit a <= 1 MiB slice of y that stays L2-resident on
+    // the XCD the window is scheduled on.  Per-window column sums land in d_bpart (nwin x n)
+    // and are combined in index order by k_combine.
+    LsqSegs bcsc;
+    int nwin = 0;
+    int *d_bmap = nullptr;  // bcsc position -> csc position
+    double *d_bpart = nullptr;
     unsigned long long version = 0;  // bumps whenever values change
     // cached colsumabs2 (utils.jl:139-151 is called twice per LM iteration by the reference)
     double *d_colsum = nullptr;
@@ -141,8 +169,14 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
 // Two-stage grid reduction without a second launch: every block publishes its partial with an
 // agent-scope (write-through) store, drains it, then takes a ticket; the block that draws the
 // last ticket re-reads all partials with agent-scope loads IN INDEX ORDER (run-to-run
-// deterministic) and calls fin(total) from thread 0.  The counter is left at zero.
+// deterministic) and calls fin(total) from thread 0.  Tickets are hierarchical -- one counter per
+// XCD-sized group of blocks (own cache line each) and a top counter taken by each group's last
+// arriver -- because a single device-scope counter serialises at ~12 ns per arrival (a 2048-block
+// grid would spend 25 us in the fan-in alone).  All counters are left at zero.
 // Returns true in every thread of the last block (after fin has run).
+constexpr int LSQ_RGROUPS = 8;          // ticket groups (blocks b % 8: one per XCD)
+constexpr int LSQ_CTR_STRIDE = 32;      // unsigneds between counters (128-byte lines)
+constexpr int LSQ_CTR_SLOT = (LSQ_RGROUPS + 1) * LSQ_CTR_STRIDE;  // unsigneds per reduction slot
 template <int NT, bool IS_MAX = false, class Fin>
 __device__ __forceinline__ bool grid_reduce(double block_val, double *partials, unsigned *counter,
                                             int nblocks, double *sh, Fin fin) {
@@ -151,8 +185,20 @@ __device__ __forceinline__ bool grid_reduce(double block_val, double *partials, 
     if (threadIdx.x == 0) {
         __hip_atomic_store(&partials[b], block_val, RLX_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned t = __hip_atomic_fetch_add(counter, 1u, RLX_AGENT);
-        s_last = (t == (unsigned)(nblocks - 1));
+        const int g = b % LSQ_RGROUPS;
+        const int ngroups = nblocks < LSQ_RGROUPS ? nblocks : LSQ_RGROUPS;
+        const unsigned gsize = (unsigned)((nblocks - g + LSQ_RGROUPS - 1) / LSQ_RGROUPS);
+        unsigned t = __hip_atomic_fetch_add(counter + (1 + g) * LSQ_CTR_STRIDE, 1u, RLX_AGENT);
+        int last = 0;
+        if (t == gsize - 1) {
+            __hip_atomic_store(counter + (1 + g) * LSQ_CTR_STRIDE, 0u, RLX_AGENT);
+            unsigned t2 = __hip_atomic_fetch_add(counter, 1u, RLX_AGENT);
+            if (t2 == (unsigned)(ngroups - 1)) {
+                __hip_atomic_store(counter, 0u, RLX_AGENT);
+                last = 1;
+            }
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return false;
@@ -164,13 +210,11 @@ __device__ __forceinline__ bool grid_reduce(double block_val, double *partials, 
         acc = IS_MAX ? fmax(acc, p) : acc + p;
     }
     double tot = IS_MAX ? block_max<NT>(acc, sh) : block_sum<NT>(acc, sh);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(counter, 0u, RLX_AGENT);
-        fin(tot);
-    }
+    if (threadIdx.x == 0) fin(tot);
     return true;
 }
 
+static inline unsigned *lsq_ctr(const lsq_ctx *c, int k) { return c->d_counters + (size_t)k * LSQ_CTR_SLOT; }
 static inline int lsq_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // internal entry points shared between translation units
@@ -180,6 +224,7 @@ int lsq_dense_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_sparse_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_ensure_csr(lsq_mat *J);
 int lsq_permute_to_csr(lsq_mat *J, const double *d_csc_vals, double *d_csr_vals);
+int lsq_permute_to_bcsc(lsq_mat *J, const double *d_csc_vals, double *d_bcsc_vals);
 const double *lsq_cached_colsum(lsq_mat *J);  // nullptr on failure (error set)
 // reads slot values to host (synchronises the stream)
 int lsq_read_slots(lsq_ctx *ctx, int first, int count, double *h_out);

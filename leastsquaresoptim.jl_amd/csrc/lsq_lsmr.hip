@@ -342,19 +342,19 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     {
         long long gb = std::min<long long>(lsq_div_up(m > 0 ? m : 1, LSQ_NT), (long long)c->num_cus * 8);
         hipLaunchKernelGGL(k_lsmr_begin, dim3((int)gb), dim3(LSQ_NT), 0, c->stream, m, d_y, st, c->d_mail,
-                           c->d_partials, c->d_counters + 1, atol, btol, 1.0 / conlim, maxiter, epoch);
+                           c->d_partials, lsq_ctr(c, 1), atol, btol, 1.0 / conlim, maxiter, epoch);
     }
     LSQ_HIP(hipGetLastError());
     // v~ = A'u (setup), then K3 in "first" mode
     EpiV ev{done, 0, st, c->d_mail, s->d_P, damped ? s->d_dg : nullptr, nullptr, s->d_v,
-            c->d_partials, c->d_counters + 2};
+            c->d_partials, lsq_ctr(c, 2)};
     LSQ_TRY(launch_product(J, 1, d_y, ev));
     hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, s->d_P,
-                       s->d_v, s->d_h, s->d_hbar, xs, s->d_t, c->d_partials, c->d_counters + 3);
+                       s->d_v, s->d_h, s->d_hbar, xs, s->d_t, c->d_partials, lsq_ctr(c, 3));
     LSQ_HIP(hipGetLastError());
 
     EpiU eu{done, damped ? lsq_div_up(n, LSQ_NT) : 0, st, d_y, s->d_u, n, s->d_dg, s->d_t, s->d_ux,
-            c->d_partials, c->d_counters + 1};
+            c->d_partials, lsq_ctr(c, 1)};
     ev.ux = damped ? s->d_ux : nullptr;
 
     int enq = 0, it = 0, istop = 0;
@@ -371,12 +371,16 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             }
         }
         if (enq - it < lookahead && enq < maxiter) {
+            lsq_prof_mark(c, 0, 0);
             LSQ_TRY(launch_product(J, 0, s->d_t, eu));   // K1
+            lsq_prof_mark(c, 0, 1);
             eu.uold = s->d_u;                            // after the first iteration u~ lives in d_u
+            lsq_prof_mark(c, 1, 0);
             LSQ_TRY(launch_product(J, 1, s->d_u, ev));   // K2
+            lsq_prof_mark(c, 1, 1);
             hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
                                s->d_P, s->d_v, s->d_h, s->d_hbar, xs, s->d_t, c->d_partials,
-                               c->d_counters + 3);
+                               lsq_ctr(c, 3));
             LSQ_HIP(hipGetLastError());
             ++enq;
             spins = 0;

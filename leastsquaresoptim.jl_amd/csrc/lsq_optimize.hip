@@ -188,7 +188,7 @@ k_step(int n, const double *__restrict__ x, const double *__restrict__ dx, doubl
     double b1 = block_max<LSQ_NT>(mx, sh);
     grid_reduce<LSQ_NT, true>(b1, partials, counters, gridDim.x, sh, [=](double t) { *out_dx = t; });
     double b2 = block_max<LSQ_NT>(code, sh);
-    grid_reduce<LSQ_NT, true>(b2, partials + LSQ_MAX_GRID, counters + 1, gridDim.x, sh,
+    grid_reduce<LSQ_NT, true>(b2, partials + LSQ_MAX_GRID, counters + LSQ_CTR_SLOT, gridDim.x, sh,
                               [=](double t) { *out_nonfin = (t == 0.0) ? -1.0 : (1e15 - t) - 1.0; });
 }
 
@@ -421,18 +421,18 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double
             EpiGrad eg{nullptr, 0, b.dtd, nullptr, nullptr};
             LSQ_TRY(launch_product(J, 1, fcur, eg));
             hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dtd, x, b.lo, b.hi,
-                               c->d_partials, c->d_counters + 4, c->d_slots + SL_GRAD);
+                               c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             mul_calls++;
         }
         hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
-                           c->d_counters + 5, c->d_slots + SL_DX, c->d_slots + SL_NONFIN);   // :106
+                           lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN);   // :106
         LSQ_HIP(hipGetLastError());
         CB(f(b.ftrial, b.xt, user));                                      // :107
         f_calls++;
         hipLaunchKernelGGL(k_sumsq_slot, dim3(gm), dim3(LSQ_NT), 0, c->stream, (long long)m, b.ftrial,
-                           c->d_partials, c->d_counters + 7, c->d_slots + SL_TRIAL);          // :111
+                           c->d_partials, lsq_ctr(c, 7), c->d_slots + SL_TRIAL);          // :111
         {   // :114-117
-            EpiPredict ep{nullptr, 0, fcur, c->d_slots + SL_PRED, c->d_partials, c->d_counters + 8};
+            EpiPredict ep{nullptr, 0, fcur, c->d_slots + SL_PRED, c->d_partials, lsq_ctr(c, 8)};
             LSQ_TRY(launch_product(J, 0, b.dx, ep));
             mul_calls++;
         }
@@ -529,11 +529,11 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, do
             LSQ_TRY(launch_product(J, 1, fcur, eg));
             mul_calls++;
             hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, x, b.lo, b.hi,
-                               c->d_partials, c->d_counters + 4, c->d_slots + SL_GRAD);
+                               c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             LSQ_TRY(lsq_ediv(c, n, b.dgr, b.dtd, b.dgr));                 // :105
             hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, b.dgr, b.dtd,
-                               c->d_partials, c->d_counters + 5, c->d_slots + SL_W0);          // :106
-            EpiSumsq es{nullptr, 0, c->d_slots + SL_SUM, c->d_partials, c->d_counters + 6};   // :109-111
+                               c->d_partials, lsq_ctr(c, 5), c->d_slots + SL_W0);          // :106
+            EpiSumsq es{nullptr, 0, c->d_slots + SL_SUM, c->d_partials, lsq_ctr(c, 6)};   // :109-111
             LSQ_TRY(launch_product(J, 0, b.dgr, es));
             mul_calls++;
             LSQ_TRY(lsq_fill(c, n, 0.0, b.dgn));
@@ -541,9 +541,9 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, do
             mul_calls += ls_iter;
             inner_total += ls_iter / 2;
             hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgn, b.dgn, b.dtd,
-                               c->d_partials, c->d_counters + 5, c->d_slots + SL_W1);          // :117
+                               c->d_partials, lsq_ctr(c, 5), c->d_slots + SL_W1);          // :117
             hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, b.dgn, b.dtd,
-                               c->d_partials, c->d_counters + 5, c->d_slots + SL_W2);          // :134 (used in case 3)
+                               c->d_partials, lsq_ctr(c, 5), c->d_slots + SL_W2);          // :134 (used in case 3)
             LSQ_HIP(hipGetLastError());
             double s0[1];
             LSQ_TRY(lsq_read_slots(c, SL_GRAD, 1, s0));
@@ -578,13 +578,13 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, do
         }
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                 // :148-160
         hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
-                           c->d_counters + 5, c->d_slots + SL_DX, c->d_slots + SL_NONFIN);    // :160
+                           lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN);    // :160
         LSQ_HIP(hipGetLastError());
         CB(f(b.ftrial, b.xt, user));                                      // :164
         f_calls++;
         hipLaunchKernelGGL(k_sumsq_slot, dim3(gm), dim3(LSQ_NT), 0, c->stream, (long long)m, b.ftrial,
-                           c->d_partials, c->d_counters + 7, c->d_slots + SL_TRIAL);
-        EpiPredict ep{nullptr, 0, fcur, c->d_slots + SL_PRED, c->d_partials, c->d_counters + 8};  // :171-174
+                           c->d_partials, lsq_ctr(c, 7), c->d_slots + SL_TRIAL);
+        EpiPredict ep{nullptr, 0, fcur, c->d_slots + SL_PRED, c->d_partials, lsq_ctr(c, 8)};  // :171-174
         LSQ_TRY(launch_product(J, 0, b.dx, ep));
         mul_calls++;
         double sl[4];
@@ -664,6 +664,7 @@ struct lsq_model {
     lsq_mat *J;
     double *d_Acsc = nullptr;  // A values, CSC order (or dense column-major)
     double *d_Acsr = nullptr;  // A values, CSR order
+    double *d_Ab = nullptr;    // A values, window-blocked CSC order
     double *d_b = nullptr;
     double *d_t = nullptr;     // tanh(x)
 };
@@ -711,6 +712,18 @@ __global__ void __launch_bounds__(LSQ_NT) k_sfac(int n, const double *__restrict
     }
 }
 
+// window-blocked CSC: segment s belongs to column s % n; one wave per segment
+__global__ void __launch_bounds__(LSQ_NT)
+k_scale_bcsc(int nseg, int n, const int *__restrict__ ptr, const double *__restrict__ A, const double *__restrict__ sfac,
+             double *__restrict__ out) {
+    const int lane = threadIdx.x & 63, per = LSQ_NT / 64;
+    for (int s = blockIdx.x * per + (threadIdx.x >> 6); s < nseg; s += gridDim.x * per) {
+        const double f = sfac[s % n];
+        const int k1 = ptr[s + 1];
+        for (int k = ptr[s] + lane; k < k1; k += 64) out[k] = A[k] * f;
+    }
+}
+
 static int model_f(double *out, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
@@ -741,7 +754,13 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         if (J->nnz > 0)
             hipLaunchKernelGGL(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
                                md->d_Acsr, md->d_t, J->csr.d_val);
-        J->csr_fresh = true;  // both mirrors written directly: no permutation pass needed
+        if (J->nwin > 1) {
+            int nsegs = J->bcsc.nseg;
+            int g3 = std::min(lsq_div_up(nsegs, LSQ_NT / 64), c->num_cus * 16);
+            hipLaunchKernelGGL(k_scale_bcsc, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n, J->bcsc.d_ptr,
+                               md->d_Ab, md->d_t, J->bcsc.d_val);
+        }
+        J->csr_fresh = true;  // every mirror written directly: no permutation pass needed
     } else {
         int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
         hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, (const int *)nullptr, J->m,
@@ -772,6 +791,11 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
         LSQ_HIP(hipMemset(md->d_Acsr, 0, vb));
         // reuse the CSC->CSR map of the pattern to permute A once
         LSQ_TRY(lsq_permute_to_csr(J, md->d_Acsc, md->d_Acsr));
+        if (J->nwin > 1) {
+            LSQ_HIP(hipMalloc(&md->d_Ab, vb));
+            LSQ_HIP(hipMemset(md->d_Ab, 0, vb));
+            LSQ_TRY(lsq_permute_to_bcsc(J, md->d_Acsc, md->d_Ab));
+        }
         LSQ_HIP(hipStreamSynchronize(c->stream));
     }
     *out = md;
@@ -781,7 +805,7 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
 extern "C" int lsq_model_destroy(lsq_model *md) {
     if (!md) return LSQ_OK;
     hipStreamSynchronize(md->ctx->stream);
-    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_b); hipFree(md->d_t);
+    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_Ab); hipFree(md->d_b); hipFree(md->d_t);
     delete md;
     return LSQ_OK;
 }

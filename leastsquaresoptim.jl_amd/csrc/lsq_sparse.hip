@@ -21,21 +21,45 @@ static int choose_plan(const char *envname, long long nnz, int nseg) {
     return LSQ_PLAN_BLOCK;
 }
 
-static void build_tiles(const std::vector<int> &ptr, int nseg, std::vector<int> &tiles) {
+// `group` > 0: tiles never straddle a multiple of `group` segments (window boundaries)
+static void build_tiles(const std::vector<int> &ptr, int nseg, std::vector<int> &tiles, int group = 0,
+                        int max_segs = LSQ_TILE_SEGS, int max_nnz = LSQ_TILE_NNZ) {
     tiles.clear();
     int s = 0;
     tiles.push_back(0);
     while (s < nseg) {
         int start = s;
         long long base = ptr[s];
-        while (s < nseg && s - start < LSQ_TILE_SEGS && ptr[s + 1] - base <= LSQ_TILE_NNZ) ++s;
+        int limit = group > 0 ? std::min(nseg, (start / group + 1) * group) : nseg;
+        while (s < limit && s - start < max_segs && ptr[s + 1] - base <= max_nnz) ++s;
         if (s == start) ++s;  // one segment longer than a tile: handled by the block-stride path
         tiles.push_back(s);
     }
 }
 
+// XCD-aware placement: work item k (a tile, or a block of 4 segments) of window w should run on
+// XCD w % 8, and the dispatcher places block b on XCD b % 8 (observed, used for speed only): deal
+// the work items of each residue class out to the grid positions of that residue.
+static void build_order(const std::vector<int> &item_window, std::vector<int> &order) {
+    const int nw = (int)item_window.size();
+    std::vector<std::vector<int>> byx(8);
+    for (int k = 0; k < nw; ++k) byx[item_window[k] % 8].push_back(k);
+    order.assign(nw, -1);
+    std::vector<size_t> next(8, 0);
+    std::vector<int> leftover;
+    for (int p = 0; p < nw; ++p) {
+        int x = p % 8;
+        if (next[x] < byx[x].size()) order[p] = byx[x][next[x]++];
+    }
+    for (int x = 0; x < 8; ++x)
+        for (size_t k = next[x]; k < byx[x].size(); ++k) leftover.push_back(byx[x][k]);
+    size_t q = 0;
+    for (int p = 0; p < nw; ++p)
+        if (order[p] < 0) order[p] = leftover[q++];
+}
+
 static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, const std::vector<int> &idx,
-                       const char *envname) {
+                       const char *envname, int group = 0) {
     S.nseg = (int)ptr.size() - 1;
     S.nnz = ptr.back();
     S.plan = choose_plan(envname, S.nnz, S.nseg);
@@ -48,10 +72,30 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
     LSQ_HIP(hipMemcpy(S.d_ptr, ptr.data(), (S.nseg + 1) * sizeof(int), hipMemcpyHostToDevice));
     if (S.nnz) LSQ_HIP(hipMemcpy(S.d_idx, idx.data(), S.nnz * sizeof(int), hipMemcpyHostToDevice));
     std::vector<int> tiles;
-    build_tiles(ptr, S.nseg, tiles);
+    build_tiles(ptr, S.nseg, tiles, group);
     S.ntiles = (int)tiles.size() - 1;
     LSQ_HIP(hipMalloc(&S.d_tiles, tiles.size() * sizeof(int)));
     LSQ_HIP(hipMemcpy(S.d_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
+    // big tiles for the LDS-staged stream kernel (only worth it on large patterns)
+    if (S.plan == LSQ_PLAN_STREAM && group == 0 && S.nnz >= (1 << 20) && !getenv("LSQ_NO_LDS_X")) {
+        std::vector<int> big;
+        build_tiles(ptr, S.nseg, big, 0, LSQ_BIG_SEGS, LSQ_BIG_NNZ);
+        S.nbig = (int)big.size() - 1;
+        LSQ_HIP(hipMalloc(&S.d_big, big.size() * sizeof(int)));
+        LSQ_HIP(hipMemcpy(S.d_big, big.data(), big.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (group > 0 && S.plan != LSQ_PLAN_BLOCK) {
+        std::vector<int> win, order;
+        if (S.plan == LSQ_PLAN_STREAM) {
+            for (int t = 0; t < S.ntiles; ++t) win.push_back(tiles[t] / group);
+        } else {
+            const int per = LSQ_NT / 64;
+            for (int b = 0; b * per < S.nseg; ++b) win.push_back((b * per) / group);
+        }
+        build_order(win, order);
+        LSQ_HIP(hipMalloc(&S.d_order, (order.size() + 1) * sizeof(int)));
+        LSQ_HIP(hipMemcpy(S.d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     (void)c;
     return LSQ_OK;
 }
@@ -61,6 +105,8 @@ static void free_segs(LsqSegs &S) {
     hipFree(S.d_idx);
     hipFree(S.d_val);
     hipFree(S.d_tiles);
+    hipFree(S.d_order);
+    hipFree(S.d_big);
     S = LsqSegs();
 }
 
@@ -105,11 +151,39 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
                 map[p] = k;
             }
     }
+    J->csc.nx = m;
+    J->csr.nx = n;
+    J->bcsc.nx = m;
     LSQ_TRY(upload_segs(c, J->csc, cptr, cidx, "LSQ_PLAN_CSC"));
     LSQ_TRY(upload_segs(c, J->csr, rptr, ridx, "LSQ_PLAN_CSR"));
     LSQ_HIP(hipMalloc(&J->d_map, (nnz + 4) * sizeof(int)));
     if (nnz) LSQ_HIP(hipMemcpy(J->d_map, map.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&J->d_colsum, (n > 0 ? n : 1) * sizeof(double)));
+    // window-blocked CSC when the gathered m-vector is larger than ~1 MiB
+    {
+        int rows_per_win = 131072;
+        if (const char *e = getenv("LSQ_WINDOW_ROWS")) rows_per_win = std::max(1024, atoi(e));
+        int nwin = (m + rows_per_win - 1) / rows_per_win;
+        if (nwin > 1 && nnz > 0 && (long long)nwin * n < 100000000LL) {
+            const int rw = (m + nwin - 1) / nwin;
+            std::vector<int> bptr((size_t)nwin * n + 1, 0), bidx(nnz), bmap(nnz);
+            for (int j = 0; j < n; ++j)
+                for (int k = colptr[j]; k < colptr[j + 1]; ++k) bptr[(size_t)(rowval[k] / rw) * n + j + 1]++;
+            for (size_t s2 = 0; s2 < (size_t)nwin * n; ++s2) bptr[s2 + 1] += bptr[s2];
+            std::vector<int> fill(bptr.begin(), bptr.end() - 1);
+            for (int j = 0; j < n; ++j)
+                for (int k = colptr[j]; k < colptr[j + 1]; ++k) {
+                    int p = fill[(size_t)(rowval[k] / rw) * n + j]++;
+                    bidx[p] = rowval[k];
+                    bmap[p] = k;
+                }
+            LSQ_TRY(upload_segs(c, J->bcsc, bptr, bidx, "LSQ_PLAN_BCSC", n));
+            LSQ_HIP(hipMalloc(&J->d_bmap, (nnz + 4) * sizeof(int)));
+            LSQ_HIP(hipMemcpy(J->d_bmap, bmap.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+            LSQ_HIP(hipMalloc(&J->d_bpart, (size_t)nwin * n * sizeof(double)));
+            J->nwin = nwin;
+        }
+    }
     J->csr_fresh = true;  // all zeros
     *out = J;
     return LSQ_OK;
@@ -139,6 +213,9 @@ extern "C" int lsq_mat_destroy(lsq_mat *J) {
     free_segs(J->csc);
     free_segs(J->csr);
     hipFree(J->d_map);
+    free_segs(J->bcsc);
+    hipFree(J->d_bmap);
+    hipFree(J->d_bpart);
     hipFree(J->d_colsum);
     delete J;
     return LSQ_OK;
@@ -175,9 +252,21 @@ int lsq_permute_to_csr(lsq_mat *J, const double *d_csc_vals, double *d_csr_vals)
     return LSQ_OK;
 }
 
+int lsq_permute_to_bcsc(lsq_mat *J, const double *d_csc_vals, double *d_bcsc_vals) {
+    if (J->nnz > 0 && J->nwin > 1) {
+        int grid = (int)std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
+        hipLaunchKernelGGL(k_permute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, J->nnz, J->d_bmap,
+                           d_csc_vals, d_bcsc_vals);
+        LSQ_HIP(hipGetLastError());
+    }
+    return LSQ_OK;
+}
+
+// refreshes every mirror (CSR, window-blocked CSC) of the user-visible CSC values
 int lsq_ensure_csr(lsq_mat *J) {
     if (J->kind != LSQ_MAT_CSC || J->csr_fresh) return LSQ_OK;
     LSQ_TRY(lsq_permute_to_csr(J, J->csc.d_val, J->csr.d_val));
+    LSQ_TRY(lsq_permute_to_bcsc(J, J->csc.d_val, J->bcsc.d_val));
     J->csr_fresh = true;
     return LSQ_OK;
 }
@@ -224,11 +313,7 @@ struct EpiAxpby {  // y[s] = alpha*dot + beta*y[s]   (beta == 0 overwrites: _rmu
 
 int lsq_sparse_mul(lsq_mat *J, int trans, double alpha, const double *x, double beta, double *y) {
     EpiAxpby e{nullptr, 0, alpha, beta, y, nullptr, nullptr};
-    if (!trans) {
-        LSQ_TRY(lsq_ensure_csr(J));
-        return launch_segs<false>(J->ctx, J->csr, x, e);
-    }
-    return launch_segs<false>(J->ctx, J->csc, x, e);
+    return launch_product(J, trans, x, e);
 }
 
 struct EpiStore {  // out[s] = dot

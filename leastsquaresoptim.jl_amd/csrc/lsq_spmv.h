@@ -15,6 +15,8 @@
 // squares for the next norm) cost no extra pass over an m- or n-vector.
 // Reductions are two-stage and index-ordered (grid_reduce) => run-to-run deterministic.
 #pragma once
+#include <algorithm>
+
 #include "lsq_common.h"
 
 constexpr int LSQ_TILE_WINDOW = 2048;                // LDS doubles per stream tile
@@ -26,6 +28,7 @@ struct SegsDev {
     const int *idx;
     const double *val;
     const int *tiles;
+    const int *order;  // optional work-item permutation
     int nseg;
     int ntiles;
 };
@@ -61,11 +64,12 @@ __global__ void __launch_bounds__(LSQ_NT) k_seg_stream(SegsDev S, const double *
     const int tid = threadIdx.x;
     const int nwork = S.ntiles + epi.extra_blocks;
     double racc = 0.0;
-    for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
-        if (b >= S.ntiles) {
-            epi.extra(b - S.ntiles, racc);
+    for (int bb = blockIdx.x; bb < nwork; bb += gridDim.x) {
+        if (bb >= S.ntiles) {
+            epi.extra(bb - S.ntiles, racc);
             continue;
         }
+        const int b = S.order ? S.order[bb] : bb;
         const int s0 = S.tiles[b], s1 = S.tiles[b + 1];
         const int k0 = S.ptr[s0], k1 = S.ptr[s1];
         if (k1 - k0 <= LSQ_TILE_NNZ) {
@@ -110,6 +114,101 @@ __global__ void __launch_bounds__(LSQ_NT) k_seg_stream(SegsDev S, const double *
     finish_block(epi, racc, sh);
 }
 
+// STREAM plan with the gathered vector staged in LDS ("column tiles in LDS"): when x is small
+// enough (n*8 <= 96 KiB, e.g. the 80 KB n-vector of C4) every gather x[idx[k]] otherwise costs a
+// 128-byte L1 line fill from L2 for 8 useful bytes, and that fill traffic -- not HBM -- bounds the
+// kernel.  One persistent 1024-thread workgroup per CU copies x into LDS once (coalesced), then
+// streams big tiles of <= 8189 nnz: 16-byte loads of val/idx, products against the LDS copy into
+// an LDS product buffer, one thread per segment sums its slice in index order.  The next tile's
+// val/idx are prefetched into registers before the current tile is reduced.
+constexpr int LSQ_BIG_NT = 1024;
+constexpr int LSQ_BIG_WINDOW = 8 * LSQ_BIG_NT;          // product doubles in LDS
+constexpr int LSQ_BIG_NNZ = LSQ_BIG_WINDOW - 3;
+constexpr int LSQ_BIG_SEGS = LSQ_BIG_NT;
+constexpr int LSQ_LDS_X_MAX = 12160;                     // doubles of x staged (95 KiB; 160 KiB LDS total)
+
+template <class Epi>
+__global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const int *__restrict__ big, int nbig,
+                                                               const double *__restrict__ x, int nx, int nxpad,
+                                                               Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double sh[LSQ_BIG_NT / 64];
+    if (epi.done && *epi.done) return;
+    double *xl = smem;
+    double *prod = smem + nxpad;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nx; i += LSQ_BIG_NT) xl[i] = x[i];
+    __syncthreads();
+    const int nwork = nbig + epi.extra_blocks;
+    double racc = 0.0;
+    // register prefetch of the first tile owned by this block
+    double2 v0[2], v1[2];
+    int4 ci[2];
+    int b = blockIdx.x;
+    auto load_tile = [&](int tb) {
+        const int s0 = big[tb], s1 = big[tb + 1];
+        const int k0 = S.ptr[s0], k1 = S.ptr[s1];
+        const int ka = k0 & ~3;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = ka + c * 4 * LSQ_BIG_NT + 4 * tid;
+            if (k < k1 && k1 - k0 <= LSQ_BIG_NNZ) {
+                v0[c] = *reinterpret_cast<const double2 *>(S.val + k);
+                v1[c] = *reinterpret_cast<const double2 *>(S.val + k + 2);
+                ci[c] = *reinterpret_cast<const int4 *>(S.idx + k);
+            }
+        }
+    };
+    if (b < nbig) load_tile(b);
+    for (; b < nwork; b += gridDim.x) {
+        if (b >= nbig) {
+            if (tid < LSQ_NT) epi.extra(b - nbig, racc);  // side work is laid out for LSQ_NT-thread blocks
+            continue;
+        }
+        const int s0 = big[b], s1 = big[b + 1];
+        const int k0 = S.ptr[s0], k1 = S.ptr[s1];
+        if (k1 - k0 <= LSQ_BIG_NNZ) {
+            const int ka = k0 & ~3;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int k = ka + c * 4 * LSQ_BIG_NT + 4 * tid;
+                if (k < k1) {
+                    double2 p0, p1;
+                    p0.x = v0[c].x * xl[ci[c].x];
+                    p0.y = v0[c].y * xl[ci[c].y];
+                    p1.x = v1[c].x * xl[ci[c].z];
+                    p1.y = v1[c].y * xl[ci[c].w];
+                    double2 *dst = reinterpret_cast<double2 *>(prod + (k - ka));
+                    dst[0] = p0;
+                    dst[1] = p1;
+                }
+            }
+            const int nb = b + gridDim.x;
+            if (nb < nbig) load_tile(nb);  // in flight while this tile is reduced
+            __syncthreads();
+            const int s = s0 + tid;
+            if (s < s1) {
+                const int a = S.ptr[s] - ka, e = S.ptr[s + 1] - ka;
+                double sum = 0.0;
+                for (int j = a; j < e; ++j) sum += prod[j];
+                epi.seg(s, sum, racc);
+            }
+            __syncthreads();
+        } else {
+            double sum = 0.0;  // one segment longer than a big tile
+            for (int k = k0 + tid; k < k1; k += LSQ_BIG_NT) sum += S.val[k] * xl[S.idx[k]];
+            sum = block_sum<LSQ_BIG_NT>(sum, sh);
+            if (tid == 0) epi.seg(s0, sum, racc);
+            const int nb = b + gridDim.x;
+            if (nb < nbig) load_tile(nb);
+        }
+    }
+    if constexpr (Epi::REDUCE) {
+        double bv = block_sum<LSQ_BIG_NT>(racc, sh);
+        grid_reduce<LSQ_BIG_NT>(bv, epi.partials, epi.counter, gridDim.x, sh, [&](double t) { epi.finalize(t); });
+    }
+}
+
 // pair-wise masked partial dot over [k0,k1) for a group of G lanes (lane index g in [0,G))
 template <bool SQ, int G>
 __device__ __forceinline__ double seg_partial(const SegsDev &S, const double *__restrict__ x, int k0,
@@ -152,11 +251,12 @@ __global__ void __launch_bounds__(LSQ_NT) k_seg_wave(SegsDev S, const double *__
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nwork = nsegblocks + epi.extra_blocks;
     double racc = 0.0;
-    for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
-        if (b >= nsegblocks) {
-            epi.extra(b - nsegblocks, racc);
+    for (int bb = blockIdx.x; bb < nwork; bb += gridDim.x) {
+        if (bb >= nsegblocks) {
+            epi.extra(bb - nsegblocks, racc);
             continue;
         }
+        const int b = S.order ? S.order[bb] : bb;
         const int s = b * (LSQ_NT / 64) + w;
         if (s < S.nseg) {
             const int k0 = S.ptr[s], k1 = S.ptr[s + 1];
@@ -186,7 +286,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_seg_block(SegsDev S, const double *_
 }
 
 static inline SegsDev segs_dev(const LsqSegs &s) {
-    return SegsDev{s.d_ptr, s.d_idx, s.d_val, s.d_tiles, s.nseg, s.ntiles};
+    return SegsDev{s.d_ptr, s.d_idx, s.d_val, s.d_tiles, s.d_order, s.nseg, s.ntiles};
 }
 
 // Launch the plan chosen for `segs`.  Work items = segment blocks + epi.extra_blocks; the grid is
@@ -196,9 +296,28 @@ template <bool SQ, class Epi>
 static inline int launch_segs(lsq_ctx *ctx, const LsqSegs &segs, const double *x, const Epi &epi) {
     SegsDev S = segs_dev(segs);
     static_assert(LSQ_MAX_GRID <= LSQ_MAX_PARTIALS, "partials buffer too small");
-    auto cap = [](long long w) { return (int)(w > LSQ_MAX_GRID ? LSQ_MAX_GRID : w); };
+    // reducing kernels keep the grid at <= 2048 blocks (8 per CU): fewer arrival tickets
+    constexpr int maxg = Epi::REDUCE ? 2048 : LSQ_MAX_GRID;
+    auto cap = [](long long w) { return (int)(w > maxg ? maxg : w); };
     switch (segs.plan) {
     case LSQ_PLAN_STREAM: {
+        if (!SQ && segs.nbig > 0 && segs.nx <= LSQ_LDS_X_MAX) {
+            // LDS-staged gather vector: one persistent 1024-thread workgroup per CU
+            const int nxpad = (segs.nx + 1) & ~1;
+            const size_t lds = (size_t)(nxpad + LSQ_BIG_WINDOW) * sizeof(double);
+            auto kern = k_seg_stream_lds<Epi>;
+            static thread_local const void *configured = nullptr;
+            if (configured != (const void *)kern) {
+                LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)((LSQ_LDS_X_MAX + LSQ_BIG_WINDOW) * sizeof(double))));
+                configured = (const void *)kern;
+            }
+            long long work = (long long)segs.nbig + epi.extra_blocks;
+            int grid = (int)std::min<long long>(work, ctx->num_cus);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, segs.d_big, segs.nbig, x,
+                               segs.nx, nxpad, epi);
+            break;
+        }
         int grid = cap((long long)segs.ntiles + epi.extra_blocks);
         if (grid > 0)
             hipLaunchKernelGGL((k_seg_stream<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi);
@@ -289,15 +408,63 @@ __global__ void __launch_bounds__(LSQ_NT) k_dense_t(const double *__restrict__ A
     finish_block(epi, racc, sh);
 }
 
+// Per-window column sums -> d_bpart[w*n + j] (first pass of the window-blocked J'*y)
+struct EpiPart {
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    double *part;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int s, double dot, double &) const { part[s] = dot; }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+
+// second pass: column j = sum over windows in index order, then the caller's epilogue
+template <class Epi>
+__global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ part, int n, int nwin, Epi epi,
+                                                     int ncolblocks) {
+    __shared__ double sh[LSQ_NT / 64];
+    if (epi.done && *epi.done) return;
+    const int nwork = ncolblocks + epi.extra_blocks;
+    double racc = 0.0;
+    for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
+        if (b >= ncolblocks) {
+            epi.extra(b - ncolblocks, racc);
+            continue;
+        }
+        const int j = b * LSQ_NT + threadIdx.x;
+        if (j < n) {
+            double dot = 0.0;
+            for (int w = 0; w < nwin; ++w) dot += part[(size_t)w * n + j];
+            epi.seg(j, dot, racc);
+        }
+    }
+    finish_block(epi, racc, sh);
+}
+
 // One entry point for "dot every row (trans=0) / column (trans=1) of J with x, then epilogue".
 template <class Epi>
 static inline int launch_product(lsq_mat *J, int trans, const double *x, const Epi &epi) {
     lsq_ctx *c = J->ctx;
-    auto cap = [](long long w) { return (int)(w > LSQ_MAX_GRID ? LSQ_MAX_GRID : w); };
+    constexpr int maxg = Epi::REDUCE ? 2048 : LSQ_MAX_GRID;
+    auto cap = [](long long w) { return (int)(w > maxg ? maxg : w); };
     if (J->kind == LSQ_MAT_CSC) {
         if (!trans) {
             LSQ_TRY(lsq_ensure_csr(J));
             return launch_segs<false>(c, J->csr, x, epi);
+        }
+        if (J->nwin > 1) {
+            LSQ_TRY(lsq_ensure_csr(J));
+            EpiPart ep{epi.done, 0, J->d_bpart, nullptr, nullptr};
+            LSQ_TRY(launch_segs<false>(c, J->bcsc, x, ep));
+            int nb = lsq_div_up(J->n, LSQ_NT);
+            int grid = cap((long long)nb + epi.extra_blocks);
+            hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_bpart, J->n,
+                               J->nwin, epi, nb);
+            LSQ_HIP(hipGetLastError());
+            return LSQ_OK;
         }
         return launch_segs<false>(c, J->csc, x, epi);
     }

@@ -43,8 +43,8 @@ extern "C" int lsq_ctx_create(int device, void *stream, lsq_ctx **out) {
     LSQ_HIP(hipMemset(c->d_slots, 0, LSQ_NSLOTS * sizeof(double)));
     LSQ_HIP(hipHostMalloc(&c->h_slots, LSQ_NSLOTS * sizeof(double), hipHostMallocDefault));
     LSQ_HIP(hipMalloc(&c->d_partials, LSQ_MAX_PARTIALS * sizeof(double)));
-    LSQ_HIP(hipMalloc(&c->d_counters, LSQ_NSLOTS * sizeof(unsigned)));
-    LSQ_HIP(hipMemset(c->d_counters, 0, LSQ_NSLOTS * sizeof(unsigned)));
+    LSQ_HIP(hipMalloc(&c->d_counters, (size_t)LSQ_NSLOTS * LSQ_CTR_SLOT * sizeof(unsigned)));
+    LSQ_HIP(hipMemset(c->d_counters, 0, (size_t)LSQ_NSLOTS * LSQ_CTR_SLOT * sizeof(unsigned)));
     LSQ_HIP(hipHostMalloc((void **)&c->h_mail, sizeof(LsqMailbox),
                           hipHostMallocMapped | hipHostMallocCoherent));
     memset((void *)c->h_mail, 0, sizeof(LsqMailbox));
@@ -67,6 +67,37 @@ extern "C" int lsq_ctx_destroy(lsq_ctx *c) {
     hipHostFree((void *)c->h_mail);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_prof_begin(lsq_ctx *c, int max_samples) {
+    for (int k = 0; k < 2; ++k) {
+        for (hipEvent_t e : c->prof_ev[k]) hipEventDestroy(e);
+        c->prof_ev[k].clear();
+    }
+    c->prof_max = max_samples;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_prof_end(lsq_ctx *c, double avg_ms[2], int count[2]) {
+    c->prof_max = 0;
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k) {
+        auto &v = c->prof_ev[k];
+        double tot = 0.0;
+        int n = 0;
+        for (size_t i = 0; i + 1 < v.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess) {
+                tot += ms;
+                ++n;
+            }
+        }
+        avg_ms[k] = n ? tot / n : 0.0;
+        count[k] = n;
+        for (hipEvent_t e : v) hipEventDestroy(e);
+        v.clear();
+    }
     return LSQ_OK;
 }
 
@@ -260,7 +291,7 @@ static int reduce_to_host(lsq_ctx *c, int n, const double *x, const double *y, c
     }
     int grid = ew_grid(c, n);
     hipLaunchKernelGGL(k_reduce<MODE>, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x, y, w, lo, hi,
-                       c->d_partials, c->d_counters + 0, c->d_slots + 0);
+                       c->d_partials, lsq_ctr(c, 0), c->d_slots + 0);
     LSQ_HIP(hipGetLastError());
     LSQ_TRY(lsq_read_slots(c, 0, 1, h_out));
     return LSQ_OK;
@@ -296,7 +327,7 @@ extern "C" int lsq_first_nonfinite(lsq_ctx *c, int n, const double *x, int *h_in
     }
     int grid = ew_grid(c, n);
     hipLaunchKernelGGL(k_first_nonfinite, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x,
-                       c->d_partials, c->d_counters + 0, c->d_slots + 0);
+                       c->d_partials, lsq_ctr(c, 0), c->d_slots + 0);
     LSQ_HIP(hipGetLastError());
     double v;
     LSQ_TRY(lsq_read_slots(c, 0, 1, &v));

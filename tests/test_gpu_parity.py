@@ -33,28 +33,33 @@ def rand_csc(m, n, density, seed):
 
 
 # ------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("window_rows", [None, 1024])
 @pytest.mark.parametrize("plan", ["stream", "wave", "block", None])
 @pytest.mark.parametrize("m,n,density", [(3000, 200, 0.01), (500, 40, 0.5), (64, 3000, 0.02)])
-def test_sparse_products(ctx, plan, m, n, density):
-    for k in ("LSQ_PLAN_CSC", "LSQ_PLAN_CSR"):
+def test_sparse_products(ctx, plan, m, n, density, window_rows):
+    """All three launch plans, for the CSR rows, the CSC columns and (window_rows: forced small so
+    that small test matrices are cut into several windows) the row-window-blocked CSC of J'*y."""
+    for k in ("LSQ_PLAN_CSC", "LSQ_PLAN_CSR", "LSQ_PLAN_BCSC"):
         if plan:
             os.environ[k] = plan
         else:
             os.environ.pop(k, None)
+    if window_rows:
+        os.environ["LSQ_WINDOW_ROWS"] = str(window_rows)
     try:
         S = rand_csc(m, n, density, m + n)
         # ragged extremes: an empty column/row and one very long row
         S = S.tolil()
+        S[5, :] = np.random.default_rng(0).standard_normal(n)
         S[:, 1] = 0
         S[3, :] = 0
-        S[5, :] = np.random.default_rng(0).standard_normal(n)
         S = S.tocsc()
         S.sort_indices()
         S.eliminate_zeros()
         J = lsq.DeviceMatrix(ctx, S)
     finally:
-        os.environ.pop("LSQ_PLAN_CSC", None)
-        os.environ.pop("LSQ_PLAN_CSR", None)
+        for k in ("LSQ_PLAN_CSC", "LSQ_PLAN_CSR", "LSQ_PLAN_BCSC", "LSQ_WINDOW_ROWS"):
+            os.environ.pop(k, None)
     A = O.Mat.from_scipy(S)
     rng = np.random.default_rng(1)
     x, y = rng.standard_normal(n), rng.standard_normal(m)
@@ -347,11 +352,16 @@ def test_nonfinite_raises():
 
 
 # --------------------------------------------------------------- synthetic model (bench family)
-@pytest.mark.parametrize("sparse,opt,sol", [(True, "lm", "lsmr"), (False, "lm", "cholesky"),
-                                            (False, "dogleg", "qr"), (True, "dogleg", "lsmr")])
-def test_tanh_model_matches_oracle(ctx, sparse, opt, sol):
-    """Reduced-size C4/C2/C3 family: device f!/g! + device solver vs the oracle's C model."""
+@pytest.mark.parametrize("sparse,opt,sol,big", [(True, "lm", "lsmr", False), (False, "lm", "cholesky", False),
+                                                (False, "dogleg", "qr", False), (True, "dogleg", "lsmr", False),
+                                                (True, "lm", "lsmr", True), (True, "dogleg", "lsmr", True)])
+def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big):
+    """Reduced-size C4/C2/C3 family: device f!/g! + device solver vs the oracle's C model.
+    `big` is large enough (m > 131072 rows, nnz >= 2^20) to take the paths C4 takes: the
+    LDS-staged J*v kernel and the row-window-blocked J'*u."""
     m, n, per_col = (20000, 200, 100) if sparse else (1500, 48, None)
+    if big:
+        m, n, per_col = 300000, 2000, 600
     pr = lsq.synthetic.TanhProblem(m, n, sparse=sparse, per_col=per_col, seed=7, ctx=ctx)
     pr.reset()
     okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
