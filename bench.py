@@ -33,12 +33,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--m", type=int, default=1_000_000)
     ap.add_argument("--n", type=int, default=10_000)
     ap.add_argument("--per-col", type=int, default=1000)
-    ap.add_argument("--cpu-steps", type=int, default=3, help="outer iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=200, help="outer iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 

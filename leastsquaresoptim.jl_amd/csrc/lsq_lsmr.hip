@@ -93,8 +93,11 @@ struct EpiU {
     double *ux;
     double *partials;
     unsigned *counter;
-    __device__ void seg(int s, double dot, double &racc) const {
-        double un = dot - st->cu * uold[s];
+    __device__ void seg(int s, double dot, double &racc) const { seg_pre(s, dot, uold[s], racc); }
+    using has_pre = void;
+    __device__ double pre(int s) const { return uold[s]; }
+    __device__ void seg_pre(int s, double dot, double uo, double &racc) const {
+        double un = dot - st->cu * uo;
         unew[s] = un;
         racc += un * un;
     }

@@ -149,8 +149,11 @@ struct EpiPredict {
     double *out;
     double *partials;
     unsigned *counter;
-    __device__ void seg(int i, double dot, double &racc) const {
-        double r = dot - f[i];
+    __device__ void seg(int i, double dot, double &racc) const { seg_pre(i, dot, f[i], racc); }
+    using has_pre = void;
+    __device__ double pre(int i) const { return f[i]; }
+    __device__ void seg_pre(int, double dot, double fi, double &racc) const {
+        double r = dot - fi;
         racc += r * r;
     }
     __device__ void extra(int, double &) const {}
@@ -682,6 +685,9 @@ struct EpiResidual {  // out = A t - b
     double *partials;
     unsigned *counter;
     __device__ void seg(int i, double dot, double &) const { out[i] = dot - b[i]; }
+    using has_pre = void;
+    __device__ double pre(int i) const { return b[i]; }
+    __device__ void seg_pre(int i, double dot, double bi, double &) const { out[i] = dot - bi; }
     __device__ void extra(int, double &) const {}
     __device__ void finalize(double) const {}
 };

@@ -78,8 +78,12 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
     LSQ_HIP(hipMemcpy(S.d_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
     // big tiles for the LDS-staged stream kernel (only worth it on large patterns)
     if (S.plan == LSQ_PLAN_STREAM && group == 0 && S.nnz >= (1 << 20) && !getenv("LSQ_NO_LDS_X")) {
+        // size the big tiles so that every persistent workgroup (one per CU) gets the same count
         std::vector<int> big;
-        build_tiles(ptr, S.nseg, big, 0, LSQ_BIG_SEGS, LSQ_BIG_NNZ);
+        long long per_round = (long long)LSQ_BIG_NNZ * c->num_cus;
+        long long rounds = (S.nnz + per_round - 1) / per_round;
+        int target = (int)std::min<long long>(LSQ_BIG_NNZ, S.nnz / (rounds * c->num_cus) + 16);
+        build_tiles(ptr, S.nseg, big, 0, LSQ_BIG_SEGS, std::max(target, 1024));
         S.nbig = (int)big.size() - 1;
         LSQ_HIP(hipMalloc(&S.d_big, big.size() * sizeof(int)));
         LSQ_HIP(hipMemcpy(S.d_big, big.data(), big.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -306,6 +310,11 @@ struct EpiAxpby {  // y[s] = alpha*dot + beta*y[s]   (beta == 0 overwrites: _rmu
     unsigned *counter;
     __device__ void seg(int s, double dot, double &) const {
         y[s] = (beta == 0.0) ? alpha * dot : alpha * dot + beta * y[s];
+    }
+    using has_pre = void;
+    __device__ double pre(int s) const { return beta == 0.0 ? 0.0 : y[s]; }
+    __device__ void seg_pre(int s, double dot, double yo, double &) const {
+        y[s] = (beta == 0.0) ? alpha * dot : alpha * dot + beta * yo;
     }
     __device__ void extra(int, double &) const {}
     __device__ void finalize(double) const {}

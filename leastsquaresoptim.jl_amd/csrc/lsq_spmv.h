@@ -16,6 +16,8 @@
 // Reductions are two-stage and index-ordered (grid_reduce) => run-to-run deterministic.
 #pragma once
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 
 #include "lsq_common.h"
 
@@ -127,6 +129,23 @@ constexpr int LSQ_BIG_NNZ = LSQ_BIG_WINDOW - 3;
 constexpr int LSQ_BIG_SEGS = LSQ_BIG_NT;
 constexpr int LSQ_LDS_X_MAX = 12160;                     // doubles of x staged (95 KiB; 160 KiB LDS total)
 
+struct BigTileRegs {  // one big tile's worth of val/idx per thread (8 nnz) + its epilogue inputs
+    double2 v0[2], v1[2];
+    int4 ci[2];
+    int s0, s1, k0, k1;   // tile extent (wave-uniform)
+    int pa, pe;           // this thread's segment slice [pa, pe) in absolute nnz positions
+    double pre;           // value the epilogue wants from memory for this thread's segment
+};
+
+// optional epilogue hook: `double pre(int s)` is loaded together with the tile (so the global
+// read of e.g. the previous u[s] is not a serialized latency in the reduce phase) and handed to
+// `seg_pre(s, dot, pre, racc)`.
+// An epilogue opts in with a member typedef `using has_pre = void;`.
+template <class E, class = void>
+struct EpiHasPre : std::false_type {};
+template <class E>
+struct EpiHasPre<E, std::void_t<typename E::has_pre>> : std::true_type {};
+
 template <class Epi>
 __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const int *__restrict__ big, int nbig,
                                                                const double *__restrict__ x, int nx, int nxpad,
@@ -137,36 +156,37 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const 
     double *xl = smem;
     double *prod = smem + nxpad;
     const int tid = threadIdx.x;
-    for (int i = tid; i < nx; i += LSQ_BIG_NT) xl[i] = x[i];
-    __syncthreads();
-    const int nwork = nbig + epi.extra_blocks;
-    double racc = 0.0;
-    // register prefetch of the first tile owned by this block
-    double2 v0[2], v1[2];
-    int4 ci[2];
-    int b = blockIdx.x;
-    auto load_tile = [&](int tb) {
-        const int s0 = big[tb], s1 = big[tb + 1];
-        const int k0 = S.ptr[s0], k1 = S.ptr[s1];
-        const int ka = k0 & ~3;
+    const int G = gridDim.x;
+    constexpr bool HAS_PRE = EpiHasPre<Epi>::value;
+    auto load_tile = [&](BigTileRegs &r, int tb) {
+        r.s0 = r.s1 = r.k0 = r.k1 = 0;
+        if (tb >= nbig) return;
+        r.s0 = big[tb];
+        r.s1 = big[tb + 1];
+        r.k0 = S.ptr[r.s0];
+        r.k1 = S.ptr[r.s1];
+        if (r.k1 - r.k0 > LSQ_BIG_NNZ) return;
+        const int ka = r.k0 & ~3;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int k = ka + c * 4 * LSQ_BIG_NT + 4 * tid;
-            if (k < k1 && k1 - k0 <= LSQ_BIG_NNZ) {
-                v0[c] = *reinterpret_cast<const double2 *>(S.val + k);
-                v1[c] = *reinterpret_cast<const double2 *>(S.val + k + 2);
-                ci[c] = *reinterpret_cast<const int4 *>(S.idx + k);
+            if (k < r.k1) {
+                r.v0[c] = *reinterpret_cast<const double2 *>(S.val + k);
+                r.v1[c] = *reinterpret_cast<const double2 *>(S.val + k + 2);
+                r.ci[c] = *reinterpret_cast<const int4 *>(S.idx + k);
             }
         }
-    };
-    if (b < nbig) load_tile(b);
-    for (; b < nwork; b += gridDim.x) {
-        if (b >= nbig) {
-            if (tid < LSQ_NT) epi.extra(b - nbig, racc);  // side work is laid out for LSQ_NT-thread blocks
-            continue;
+        const int s = r.s0 + tid;
+        if (s < r.s1) {
+            r.pa = S.ptr[s];
+            r.pe = S.ptr[s + 1];
+            if constexpr (HAS_PRE) r.pre = epi.pre(s);
         }
-        const int s0 = big[b], s1 = big[b + 1];
-        const int k0 = S.ptr[s0], k1 = S.ptr[s1];
+    };
+    double racc = 0.0;
+    // products of the tile held in r -> LDS; re-arm r with tile `tb + 2G`; reduce; epilogue
+    auto step = [&](BigTileRegs &r, int tb) {
+        const int s0 = r.s0, s1 = r.s1, k0 = r.k0, k1 = r.k1;
         if (k1 - k0 <= LSQ_BIG_NNZ) {
             const int ka = k0 & ~3;
 #pragma unroll
@@ -174,24 +194,25 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const 
                 const int k = ka + c * 4 * LSQ_BIG_NT + 4 * tid;
                 if (k < k1) {
                     double2 p0, p1;
-                    p0.x = v0[c].x * xl[ci[c].x];
-                    p0.y = v0[c].y * xl[ci[c].y];
-                    p1.x = v1[c].x * xl[ci[c].z];
-                    p1.y = v1[c].y * xl[ci[c].w];
+                    p0.x = r.v0[c].x * xl[r.ci[c].x];
+                    p0.y = r.v0[c].y * xl[r.ci[c].y];
+                    p1.x = r.v1[c].x * xl[r.ci[c].z];
+                    p1.y = r.v1[c].y * xl[r.ci[c].w];
                     double2 *dst = reinterpret_cast<double2 *>(prod + (k - ka));
                     dst[0] = p0;
                     dst[1] = p1;
                 }
             }
-            const int nb = b + gridDim.x;
-            if (nb < nbig) load_tile(nb);  // in flight while this tile is reduced
-            __syncthreads();
+            const int a = r.pa - ka, e = r.pe - ka;
+            const double pre = r.pre;
             const int s = s0 + tid;
+            load_tile(r, tb + 2 * G);  // two tiles stay in flight per workgroup
+            __syncthreads();
             if (s < s1) {
-                const int a = S.ptr[s] - ka, e = S.ptr[s + 1] - ka;
                 double sum = 0.0;
                 for (int j = a; j < e; ++j) sum += prod[j];
-                epi.seg(s, sum, racc);
+                if constexpr (HAS_PRE) epi.seg_pre(s, sum, pre, racc);
+                else epi.seg(s, sum, racc);
             }
             __syncthreads();
         } else {
@@ -199,10 +220,24 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const 
             for (int k = k0 + tid; k < k1; k += LSQ_BIG_NT) sum += S.val[k] * xl[S.idx[k]];
             sum = block_sum<LSQ_BIG_NT>(sum, sh);
             if (tid == 0) epi.seg(s0, sum, racc);
-            const int nb = b + gridDim.x;
-            if (nb < nbig) load_tile(nb);
+            load_tile(r, tb + 2 * G);
         }
+    };
+    BigTileRegs ra, rb;
+    const int b0 = blockIdx.x;
+    load_tile(ra, b0);       // HBM loads are in flight while x is copied into LDS
+    load_tile(rb, b0 + G);
+    for (int i = tid; i < nx; i += LSQ_BIG_NT) xl[i] = x[i];
+    __syncthreads();
+    int b = b0;
+    for (; b + G < nbig; b += 2 * G) {
+        step(ra, b);
+        step(rb, b + G);
     }
+    if (b < nbig) step(ra, b);
+    // side work (e.g. the damped rows of LSMR) is laid out for LSQ_NT-thread blocks
+    for (int e = blockIdx.x; e < epi.extra_blocks; e += G)
+        if (tid < LSQ_NT) epi.extra(e, racc);
     if constexpr (Epi::REDUCE) {
         double bv = block_sum<LSQ_BIG_NT>(racc, sh);
         grid_reduce<LSQ_BIG_NT>(bv, epi.partials, epi.counter, gridDim.x, sh, [&](double t) { epi.finalize(t); });
@@ -312,8 +347,7 @@ static inline int launch_segs(lsq_ctx *ctx, const LsqSegs &segs, const double *x
                                             (int)((LSQ_LDS_X_MAX + LSQ_BIG_WINDOW) * sizeof(double))));
                 configured = (const void *)kern;
             }
-            long long work = (long long)segs.nbig + epi.extra_blocks;
-            int grid = (int)std::min<long long>(work, ctx->num_cus);
+            int grid = std::max(1, std::min(segs.nbig, ctx->num_cus));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, segs.d_big, segs.nbig, x,
                                segs.nx, nxpad, epi);
             break;
