@@ -73,7 +73,7 @@ static inline void lsq_prof_mark(lsq_ctx *c, int kid, int phase) {
 // sparse / dense matrix handle
 // ---------------------------------------------------------------------------------------------
 enum { LSQ_MAT_DENSE = 0, LSQ_MAT_CSC = 1 };
-enum { LSQ_PLAN_STREAM = 0, LSQ_PLAN_WAVE = 1, LSQ_PLAN_BLOCK = 2 };
+enum { LSQ_PLAN_STREAM = 0, LSQ_PLAN_WAVE = 1, LSQ_PLAN_BLOCK = 2, LSQ_PLAN_LDSWIN = 3 };
 
 // One direction of a sparse product: segments (rows for J*x via the CSR mirror, columns for
 // J'*y via CSC) with the launch plan chosen once per pattern from the segment-length profile.
@@ -88,8 +88,11 @@ struct LsqSegs {
     int *d_tiles = nullptr; // ntiles+1 segment boundaries of the tiles
     int *d_order = nullptr; // optional permutation of the work items (XCD-aware placement)
     int nx = 0;            // length of the gathered vector (n for CSR rows, m for CSC columns)
+    int rw = 0;            // window-blocked CSC: rows per window
+    int nwin = 0;          // window-blocked CSC: number of windows (segments = nwin * n)
+    int *d_wtile = nullptr; // LDS-window plan: nwin+1 big-tile ranges of the windows
     int nbig = 0;          // stream plan, LDS-staged variant: number of big tiles
-    int *d_big = nullptr;  // nbig+1 segment boundaries (<= 8189 nnz, <= 1024 segments each)
+    int *d_big = nullptr;  // nbig x int4 {s0, s1, k0, k1} (<= 8189 nnz, <= 1024 segments each)
 };
 
 struct lsq_mat {

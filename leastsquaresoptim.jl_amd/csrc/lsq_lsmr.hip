@@ -93,11 +93,18 @@ struct EpiU {
     double *ux;
     double *partials;
     unsigned *counter;
-    __device__ void seg(int s, double dot, double &racc) const { seg_pre(s, dot, uold[s], racc); }
+    double cu;  // cached st->cu (prepare)
+    using has_prepare = void;
+    __device__ void prepare() { cu = st->cu; }
+    __device__ void seg(int s, double dot, double &racc) const {
+        double un = dot - st->cu * uold[s];
+        unew[s] = un;
+        racc += un * un;
+    }
     using has_pre = void;
     __device__ double pre(int s) const { return uold[s]; }
     __device__ void seg_pre(int s, double dot, double uo, double &racc) const {
-        double un = dot - st->cu * uo;
+        double un = dot - cu * uo;
         unew[s] = un;
         racc += un * un;
     }
@@ -357,11 +364,12 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     LSQ_HIP(hipGetLastError());
 
     EpiU eu{done, damped ? lsq_div_up(n, LSQ_NT) : 0, st, d_y, s->d_u, n, s->d_dg, s->d_t, s->d_ux,
-            c->d_partials, lsq_ctr(c, 1)};
+            c->d_partials, lsq_ctr(c, 1), 0.0};
     ev.ux = damped ? s->d_ux : nullptr;
 
     int enq = 0, it = 0, istop = 0;
     bool finished = false;
+    const size_t prof_base[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
     unsigned long long spins = 0;
     while (!finished) {
         unsigned long long w = *(volatile unsigned long long *)c->h_mail;
@@ -405,6 +413,16 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                 lsq_set_error("lsmr: iteration budget exhausted without a stop rule");
                 return LSQ_EHIP;
             }
+        }
+    }
+    // instrumentation: launches queued beyond the stopping iteration returned on their first
+    // instruction -- drop their samples so the reported average is over working launches only
+    for (int k = 0; k < 2; ++k) {
+        auto &v = c->prof_ev[k];
+        const size_t keep = prof_base[k] + 2 * (size_t)it;
+        while (v.size() > keep && v.size() > prof_base[k]) {
+            hipEventDestroy(v.back());
+            v.pop_back();
         }
     }
     hipLaunchKernelGGL(k_lsmr_finish, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, s->d_P, xs, d_x);

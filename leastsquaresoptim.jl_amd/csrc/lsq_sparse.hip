@@ -9,12 +9,13 @@
 // ---------------------------------------------------------------------------------------------
 // plan construction (host, once per pattern)
 // ---------------------------------------------------------------------------------------------
-static int choose_plan(const char *envname, long long nnz, int nseg) {
+static int choose_plan(const char *envname, long long nnz, int nseg, int group_hint = 0) {
     if (const char *e = getenv(envname)) {
         if (!strcmp(e, "stream")) return LSQ_PLAN_STREAM;
         if (!strcmp(e, "wave")) return LSQ_PLAN_WAVE;
         if (!strcmp(e, "block")) return LSQ_PLAN_BLOCK;
     }
+    if (group_hint > 0 && nseg > 0 && (double)nnz / nseg < 48.0) return LSQ_PLAN_STREAM;
     double avg = nseg > 0 ? (double)nnz / nseg : 0.0;
     if (avg < 48.0) return LSQ_PLAN_STREAM;
     if (avg < 384.0) return LSQ_PLAN_WAVE;
@@ -63,7 +64,7 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
     S.nseg = (int)ptr.size() - 1;
     S.nnz = ptr.back();
     S.plan = choose_plan(envname, S.nnz, S.nseg);
-    const size_t pad = 4;
+    const size_t pad = 8;
     LSQ_HIP(hipMalloc(&S.d_ptr, (S.nseg + 1) * sizeof(int)));
     LSQ_HIP(hipMalloc(&S.d_idx, (S.nnz + pad) * sizeof(int)));
     LSQ_HIP(hipMalloc(&S.d_val, (S.nnz + pad) * sizeof(double)));
@@ -85,8 +86,17 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
         int target = (int)std::min<long long>(LSQ_BIG_NNZ, S.nnz / (rounds * c->num_cus) + 16);
         build_tiles(ptr, S.nseg, big, 0, LSQ_BIG_SEGS, std::max(target, 1024));
         S.nbig = (int)big.size() - 1;
-        LSQ_HIP(hipMalloc(&S.d_big, big.size() * sizeof(int)));
-        LSQ_HIP(hipMemcpy(S.d_big, big.data(), big.size() * sizeof(int), hipMemcpyHostToDevice));
+        for (int t = 0; t < S.nbig && S.nbig > 0; ++t)
+            if (ptr[big[t + 1]] - ptr[big[t]] > LSQ_BIG_NNZ) S.nbig = 0;  // a segment too long for LDS tiles
+        std::vector<int> bm((size_t)4 * S.nbig + 4);
+        for (int t = 0; t < S.nbig; ++t) {
+            bm[4 * t + 0] = big[t];
+            bm[4 * t + 1] = big[t + 1];
+            bm[4 * t + 2] = ptr[big[t]];
+            bm[4 * t + 3] = ptr[big[t + 1]];
+        }
+        LSQ_HIP(hipMalloc(&S.d_big, (bm.size() + 4) * sizeof(int)));
+        LSQ_HIP(hipMemcpy(S.d_big, bm.data(), bm.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     if (group > 0 && S.plan != LSQ_PLAN_BLOCK) {
         std::vector<int> win, order;
@@ -111,6 +121,7 @@ static void free_segs(LsqSegs &S) {
     hipFree(S.d_tiles);
     hipFree(S.d_order);
     hipFree(S.d_big);
+    hipFree(S.d_wtile);
     S = LsqSegs();
 }
 
@@ -163,13 +174,27 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
     LSQ_HIP(hipMalloc(&J->d_map, (nnz + 4) * sizeof(int)));
     if (nnz) LSQ_HIP(hipMemcpy(J->d_map, map.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&J->d_colsum, (n > 0 ? n : 1) * sizeof(double)));
-    // window-blocked CSC when the gathered m-vector is larger than ~1 MiB
+    // window-blocked CSC when the gathered m-vector is larger than ~1 MiB.  Default plan: windows
+    // of <= 4096 rows staged in LDS (k_bcsc_lds), sized so that every CU gets a whole number of
+    // windows; LSQ_WINDOW_ROWS / LSQ_PLAN_BCSC select the L2-resident variants instead.
     {
+        const char *eplan = getenv("LSQ_PLAN_BCSC");
+        const char *erows = getenv("LSQ_WINDOW_ROWS");
+        bool ldswin = !eplan || !strcmp(eplan, "ldswin");
         int rows_per_win = 131072;
-        if (const char *e = getenv("LSQ_WINDOW_ROWS")) rows_per_win = std::max(1024, atoi(e));
+        if (erows) rows_per_win = std::max(64, atoi(erows));
+        const bool wanted = erows ? m > rows_per_win : m > 131072;
+        if (ldswin && wanted) {
+            int per_cu = (m + c->num_cus - 1) / c->num_cus;
+            int rounds = (per_cu + LSQ_WIN_ROWS_MAX - 1) / LSQ_WIN_ROWS_MAX;
+            rows_per_win = (m + rounds * c->num_cus - 1) / (rounds * c->num_cus);
+            rows_per_win = std::min(LSQ_WIN_ROWS_MAX, (rows_per_win + 7) & ~7);
+            if (erows) rows_per_win = std::min(LSQ_WIN_ROWS_MAX, std::max(64, atoi(erows)));
+        }
         int nwin = (m + rows_per_win - 1) / rows_per_win;
-        if (nwin > 1 && nnz > 0 && (long long)nwin * n < 100000000LL) {
-            const int rw = (m + nwin - 1) / nwin;
+        if (wanted && nwin > 1 && nnz > 0 && (long long)nwin * n < 200000000LL) {
+            const int rw = ldswin ? rows_per_win : (m + nwin - 1) / nwin;
+            nwin = (m + rw - 1) / rw;
             std::vector<int> bptr((size_t)nwin * n + 1, 0), bidx(nnz), bmap(nnz);
             for (int j = 0; j < n; ++j)
                 for (int k = colptr[j]; k < colptr[j + 1]; ++k) bptr[(size_t)(rowval[k] / rw) * n + j + 1]++;
@@ -182,7 +207,36 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
                     bmap[p] = k;
                 }
             LSQ_TRY(upload_segs(c, J->bcsc, bptr, bidx, "LSQ_PLAN_BCSC", n));
-            LSQ_HIP(hipMalloc(&J->d_bmap, (nnz + 4) * sizeof(int)));
+            J->bcsc.rw = rw;
+            J->bcsc.nwin = nwin;
+            if (ldswin) {
+                // big tiles that never straddle a window; segments longer than a tile disable the plan
+                std::vector<int> big;
+                build_tiles(bptr, J->bcsc.nseg, big, n, LSQ_WIN_SEGS, LSQ_BIG_NNZ);
+                int nb = (int)big.size() - 1;
+                bool ok = true;
+                for (int t = 0; t < nb; ++t)
+                    if (bptr[big[t + 1]] - bptr[big[t]] > LSQ_BIG_NNZ) ok = false;
+                if (ok) {
+                    std::vector<int> bm((size_t)4 * nb + 4), wt(nwin + 1, 0);
+                    for (int t = 0; t < nb; ++t) {
+                        bm[4 * t + 0] = big[t];
+                        bm[4 * t + 1] = big[t + 1];
+                        bm[4 * t + 2] = bptr[big[t]];
+                        bm[4 * t + 3] = bptr[big[t + 1]];
+                        wt[big[t] / n + 1]++;
+                    }
+                    for (int w = 0; w < nwin; ++w) wt[w + 1] += wt[w];
+                    hipFree(J->bcsc.d_big);
+                    LSQ_HIP(hipMalloc(&J->bcsc.d_big, bm.size() * sizeof(int)));
+                    LSQ_HIP(hipMemcpy(J->bcsc.d_big, bm.data(), bm.size() * sizeof(int), hipMemcpyHostToDevice));
+                    LSQ_HIP(hipMalloc(&J->bcsc.d_wtile, wt.size() * sizeof(int)));
+                    LSQ_HIP(hipMemcpy(J->bcsc.d_wtile, wt.data(), wt.size() * sizeof(int), hipMemcpyHostToDevice));
+                    J->bcsc.nbig = nb;
+                    J->bcsc.plan = LSQ_PLAN_LDSWIN;
+                }
+            }
+            LSQ_HIP(hipMalloc(&J->d_bmap, (nnz + 8) * sizeof(int)));
             LSQ_HIP(hipMemcpy(J->d_bmap, bmap.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
             LSQ_HIP(hipMalloc(&J->d_bpart, (size_t)nwin * n * sizeof(double)));
             J->nwin = nwin;

@@ -132,22 +132,33 @@ constexpr int LSQ_LDS_X_MAX = 12160;                     // doubles of x staged 
 struct BigTileRegs {  // one big tile's worth of val/idx per thread (8 nnz) + its epilogue inputs
     double2 v0[2], v1[2];
     int4 ci[2];
-    int s0, s1, k0, k1;   // tile extent (wave-uniform)
+    int4 meta;            // {s0, s1, k0, k1}: tile extent (wave-uniform)
     int pa, pe;           // this thread's segment slice [pa, pe) in absolute nnz positions
     double pre;           // value the epilogue wants from memory for this thread's segment
 };
 
 // optional epilogue hook: `double pre(int s)` is loaded together with the tile (so the global
 // read of e.g. the previous u[s] is not a serialized latency in the reduce phase) and handed to
-// `seg_pre(s, dot, pre, racc)`.
-// An epilogue opts in with a member typedef `using has_pre = void;`.
+// `seg_pre(s, dot, pre, racc)`.  An epilogue opts in with a member typedef `using has_pre = void;`.
+// `prepare()` (opt in with `using has_prepare = void;`) runs once per thread at kernel start, to
+// cache device-resident scalars the epilogue needs: a scalar read inside the tile loop would be
+// the newest entry of the in-order vmcnt queue and force a full drain of the prefetches.
+template <class E, class = void>
+struct EpiHasPrepare : std::false_type {};
+template <class E>
+struct EpiHasPrepare<E, std::void_t<typename E::has_prepare>> : std::true_type {};
 template <class E, class = void>
 struct EpiHasPre : std::false_type {};
 template <class E>
 struct EpiHasPre<E, std::void_t<typename E::has_pre>> : std::true_type {};
 
+// `meta[t]` = {first segment, end segment, first nnz, end nnz} of big tile t (one 16-byte load).
+// The loads of a tile need its extent, and vmcnt retires in order: fetching the extent right
+// before the tile would make every prefetch wait for all older loads.  So extents are fetched two
+// tiles ahead of the data, data two tiles ahead of use, and every step issues the same number of
+// (clamped, never predicated) loads so that the compiler waits with counted vmcnt.
 template <class Epi>
-__global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const int *__restrict__ big, int nbig,
+__global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const int4 *__restrict__ meta, int nbig,
                                                                const double *__restrict__ x, int nx, int nxpad,
                                                                Epi epi) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -158,89 +169,207 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const 
     const int tid = threadIdx.x;
     const int G = gridDim.x;
     constexpr bool HAS_PRE = EpiHasPre<Epi>::value;
-    auto load_tile = [&](BigTileRegs &r, int tb) {
-        r.s0 = r.s1 = r.k0 = r.k1 = 0;
-        if (tb >= nbig) return;
-        r.s0 = big[tb];
-        r.s1 = big[tb + 1];
-        r.k0 = S.ptr[r.s0];
-        r.k1 = S.ptr[r.s1];
-        if (r.k1 - r.k0 > LSQ_BIG_NNZ) return;
-        const int ka = r.k0 & ~3;
+    if constexpr (EpiHasPrepare<Epi>::value) epi.prepare();
+    const int kmax = (S.ptr[S.nseg] + 3) & ~3;   // arrays are padded by 8 entries
+    auto load_meta = [&](int tb) {
+        int4 mt = meta[tb < nbig ? tb : nbig - 1];
+        if (tb >= nbig) mt.y = mt.x;  // dummy tile: no segments
+        return mt;
+    };
+    auto load_data = [&](BigTileRegs &r, int4 mt) {
+        r.meta = mt;
+        const int ka = mt.z & ~3;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int k = ka + c * 4 * LSQ_BIG_NT + 4 * tid;
-            if (k < r.k1) {
-                r.v0[c] = *reinterpret_cast<const double2 *>(S.val + k);
-                r.v1[c] = *reinterpret_cast<const double2 *>(S.val + k + 2);
-                r.ci[c] = *reinterpret_cast<const int4 *>(S.idx + k);
-            }
+            const int k = min(ka + c * 4 * LSQ_BIG_NT + 4 * tid, kmax);
+            r.v0[c] = *reinterpret_cast<const double2 *>(S.val + k);
+            r.v1[c] = *reinterpret_cast<const double2 *>(S.val + k + 2);
+            r.ci[c] = *reinterpret_cast<const int4 *>(S.idx + k);
         }
-        const int s = r.s0 + tid;
-        if (s < r.s1) {
-            r.pa = S.ptr[s];
-            r.pe = S.ptr[s + 1];
-            if constexpr (HAS_PRE) r.pre = epi.pre(s);
-        }
+        const int s = min(mt.x + tid, S.nseg - 1);
+        r.pa = S.ptr[s];
+        r.pe = S.ptr[s + 1];
+        if constexpr (HAS_PRE) r.pre = epi.pre(s);
     };
     double racc = 0.0;
-    // products of the tile held in r -> LDS; re-arm r with tile `tb + 2G`; reduce; epilogue
-    auto step = [&](BigTileRegs &r, int tb) {
-        const int s0 = r.s0, s1 = r.s1, k0 = r.k0, k1 = r.k1;
-        if (k1 - k0 <= LSQ_BIG_NNZ) {
-            const int ka = k0 & ~3;
+    // products of the tile held in r -> LDS; re-arm r with the tile described by `nm`; fetch the
+    // extent of the tile after that into `nm`; reduce; epilogue
+    auto step = [&](BigTileRegs &r, int4 &nm, int tb_after_next) {
+        // (the plan builder only enables this kernel when every segment fits a big tile, so there
+        //  is exactly one code path here and the outstanding-load counts are static)
+        const int s0 = r.meta.x, s1 = r.meta.y, k0 = r.meta.z;
+        const int ka = k0 & ~3;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int k = ka + c * 4 * LSQ_BIG_NT + 4 * tid;
-                if (k < k1) {
-                    double2 p0, p1;
-                    p0.x = r.v0[c].x * xl[r.ci[c].x];
-                    p0.y = r.v0[c].y * xl[r.ci[c].y];
-                    p1.x = r.v1[c].x * xl[r.ci[c].z];
-                    p1.y = r.v1[c].y * xl[r.ci[c].w];
-                    double2 *dst = reinterpret_cast<double2 *>(prod + (k - ka));
-                    dst[0] = p0;
-                    dst[1] = p1;
-                }
-            }
-            const int a = r.pa - ka, e = r.pe - ka;
-            const double pre = r.pre;
-            const int s = s0 + tid;
-            load_tile(r, tb + 2 * G);  // two tiles stay in flight per workgroup
-            __syncthreads();
-            if (s < s1) {
-                double sum = 0.0;
-                for (int j = a; j < e; ++j) sum += prod[j];
-                if constexpr (HAS_PRE) epi.seg_pre(s, sum, pre, racc);
-                else epi.seg(s, sum, racc);
-            }
-            __syncthreads();
-        } else {
-            double sum = 0.0;  // one segment longer than a big tile
-            for (int k = k0 + tid; k < k1; k += LSQ_BIG_NT) sum += S.val[k] * xl[S.idx[k]];
-            sum = block_sum<LSQ_BIG_NT>(sum, sh);
-            if (tid == 0) epi.seg(s0, sum, racc);
-            load_tile(r, tb + 2 * G);
+        for (int c = 0; c < 2; ++c) {
+            // unconditional: slots past the tile hold products of (valid, clamped) neighbour
+            // entries that nobody reads -- a branch here would cost a full vmcnt(0) drain
+            double2 p0, p1;
+            p0.x = r.v0[c].x * xl[r.ci[c].x];
+            p0.y = r.v0[c].y * xl[r.ci[c].y];
+            p1.x = r.v1[c].x * xl[r.ci[c].z];
+            p1.y = r.v1[c].y * xl[r.ci[c].w];
+            double2 *dst = reinterpret_cast<double2 *>(prod + c * 4 * LSQ_BIG_NT + 4 * tid);
+            dst[0] = p0;
+            dst[1] = p1;
         }
+        const int a = r.pa - ka, e = r.pe - ka;
+        const double pre = r.pre;
+        const int s = s0 + tid;
+        load_data(r, nm);
+        nm = load_meta(tb_after_next);
+        __syncthreads();
+        if (s < s1) {
+            double sum = 0.0;
+            for (int j = a; j < e; ++j) sum += prod[j];
+            if constexpr (HAS_PRE) epi.seg_pre(s, sum, pre, racc);
+            else epi.seg(s, sum, racc);
+        }
+        __syncthreads();
     };
     BigTileRegs ra, rb;
     const int b0 = blockIdx.x;
-    load_tile(ra, b0);       // HBM loads are in flight while x is copied into LDS
-    load_tile(rb, b0 + G);
-    for (int i = tid; i < nx; i += LSQ_BIG_NT) xl[i] = x[i];
+    int4 ma = load_meta(b0), mb = load_meta(b0 + G);
+    load_data(ra, ma);       // HBM loads are in flight while x is copied into LDS
+    load_data(rb, mb);
+    ma = load_meta(b0 + 2 * G);
+    mb = load_meta(b0 + 3 * G);
+    {   // copy x into LDS: all (<= 12) loads of a thread are issued before the first is used
+        constexpr int XR = (LSQ_LDS_X_MAX + LSQ_BIG_NT - 1) / LSQ_BIG_NT;
+        double xr[XR];
+#pragma unroll
+        for (int j = 0; j < XR; ++j) xr[j] = x[min(tid + j * LSQ_BIG_NT, nx - 1)];
+#pragma unroll
+        for (int j = 0; j < XR; ++j)
+            if (tid + j * LSQ_BIG_NT < nx) xl[tid + j * LSQ_BIG_NT] = xr[j];
+    }
     __syncthreads();
     int b = b0;
     for (; b + G < nbig; b += 2 * G) {
-        step(ra, b);
-        step(rb, b + G);
+        step(ra, ma, b + 4 * G);
+        step(rb, mb, b + 5 * G);
     }
-    if (b < nbig) step(ra, b);
+    if (b < nbig) step(ra, ma, b + 4 * G);
     // side work (e.g. the damped rows of LSMR) is laid out for LSQ_NT-thread blocks
     for (int e = blockIdx.x; e < epi.extra_blocks; e += G)
         if (tid < LSQ_NT) epi.extra(e, racc);
     if constexpr (Epi::REDUCE) {
         double bv = block_sum<LSQ_BIG_NT>(racc, sh);
         grid_reduce<LSQ_BIG_NT>(bv, epi.partials, epi.counter, gridDim.x, sh, [&](double t) { epi.finalize(t); });
+    }
+}
+
+// J'*y with the gathered m-vector staged window by window in LDS.  A gather y[row] from global
+// memory costs a 128-byte L1 line fill for 8 useful bytes, and for an 8 MB y that fill traffic
+// (not HBM) bounds the product.  Rows are cut into windows of `rw` rows (<= 4096: 32 KiB of y);
+// one persistent 1024-thread workgroup owns a window at a time: it copies y[window] into LDS with
+// coalesced loads, then streams the window's entries (column-sorted, big tiles of <= 8189 nnz and
+// <= 2048 (window, column) segments) exactly like k_seg_stream_lds: 16-byte val/idx loads two
+// tiles ahead, products against the LDS copy, per-segment sums in index order.  Segment sums go
+// to part[w*n + j]; k_combine adds the windows of a column in index order (deterministic).
+constexpr int LSQ_WIN_ROWS_MAX = 4096;
+constexpr int LSQ_WIN_SEGS = 2 * LSQ_BIG_NT;
+struct WinTileRegs {
+    double2 v0[2], v1[2];
+    int4 ci[2];
+    int4 meta;
+    int pa[2], pe[2];
+};
+
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(LSQ_BIG_NT)
+k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wtile, int nwin, int rw, int m,
+           const double *__restrict__ y, double *__restrict__ part, const int *done) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (done && *done) return;
+    double *yl = smem;                       // rw doubles
+    double *prod = smem + LSQ_WIN_ROWS_MAX;  // LSQ_BIG_WINDOW doubles
+    const int tid = threadIdx.x;
+    const int kmax = (S.ptr[S.nseg] + 3) & ~3;
+    const int nbig = wtile[nwin];
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int t0 = wtile[w], t1 = wtile[w + 1];
+        const int base = w * rw;
+        auto load_meta = [&](int tb) {
+            int4 mt = meta[tb < t1 ? tb : (nbig > 0 ? nbig - 1 : 0)];
+            if (tb >= t1) mt.y = mt.x;
+            return mt;
+        };
+        auto load_data = [&](WinTileRegs &r, int4 mt) {
+            r.meta = mt;
+            const int ka = mt.z & ~3;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int k = min(ka + c * 4 * LSQ_BIG_NT + 4 * tid, kmax);
+                r.v0[c] = *reinterpret_cast<const double2 *>(S.val + k);
+                r.v1[c] = *reinterpret_cast<const double2 *>(S.val + k + 2);
+                r.ci[c] = *reinterpret_cast<const int4 *>(S.idx + k);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int s = min(mt.x + tid + q * LSQ_BIG_NT, S.nseg - 1);
+                r.pa[q] = S.ptr[s];
+                r.pe[q] = S.ptr[s + 1];
+            }
+        };
+        auto step = [&](WinTileRegs &r, int4 &nm, int tb_after_next) {
+            const int s0 = r.meta.x, s1 = r.meta.y, ka = r.meta.z & ~3;
+            const int hi = rw - 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                // clamped offsets: entries of neighbouring windows (tile slack) stay inside LDS
+                double2 p0, p1;
+                p0.x = r.v0[c].x * yl[min(max(r.ci[c].x - base, 0), hi)];
+                p0.y = r.v0[c].y * yl[min(max(r.ci[c].y - base, 0), hi)];
+                p1.x = r.v1[c].x * yl[min(max(r.ci[c].z - base, 0), hi)];
+                p1.y = r.v1[c].y * yl[min(max(r.ci[c].w - base, 0), hi)];
+                double2 *dst = reinterpret_cast<double2 *>(prod + c * 4 * LSQ_BIG_NT + 4 * tid);
+                dst[0] = p0;
+                dst[1] = p1;
+            }
+            int a[2], e[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a[q] = r.pa[q] - ka;
+                e[q] = r.pe[q] - ka;
+            }
+            load_data(r, nm);
+            nm = load_meta(tb_after_next);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int s = s0 + tid + q * LSQ_BIG_NT;
+                if (s < s1) {
+                    double sum = 0.0;
+                    for (int j = a[q]; j < e[q]; ++j) sum += prod[j];
+                    part[s] = sum;
+                }
+            }
+            __syncthreads();
+        };
+        WinTileRegs ra, rb;
+        int4 ma = load_meta(t0), mb = load_meta(t0 + 1);
+        load_data(ra, ma);
+        load_data(rb, mb);
+        ma = load_meta(t0 + 2);
+        mb = load_meta(t0 + 3);
+        {   // window of y -> LDS (all loads issued before the first use)
+            constexpr int YR = LSQ_WIN_ROWS_MAX / LSQ_BIG_NT;
+            const int rows = min(rw, m - base);
+            double yr[YR];
+#pragma unroll
+            for (int j = 0; j < YR; ++j) yr[j] = y[base + min(tid + j * LSQ_BIG_NT, rows - 1)];
+#pragma unroll
+            for (int j = 0; j < YR; ++j)
+                if (tid + j * LSQ_BIG_NT < rw) yl[tid + j * LSQ_BIG_NT] = (tid + j * LSQ_BIG_NT < rows) ? yr[j] : 0.0;
+        }
+        __syncthreads();
+        int b = t0;
+        for (; b + 1 < t1; b += 2) {
+            step(ra, ma, b + 4);
+            step(rb, mb, b + 5);
+        }
+        if (b < t1) step(ra, ma, b + 4);
+        __syncthreads();  // the next window overwrites yl
     }
 }
 
@@ -348,7 +477,7 @@ static inline int launch_segs(lsq_ctx *ctx, const LsqSegs &segs, const double *x
                 configured = (const void *)kern;
             }
             int grid = std::max(1, std::min(segs.nbig, ctx->num_cus));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, segs.d_big, segs.nbig, x,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, (const int4 *)segs.d_big, segs.nbig, x,
                                segs.nx, nxpad, epi);
             break;
         }
@@ -455,25 +584,47 @@ struct EpiPart {
     __device__ void finalize(double) const {}
 };
 
-// second pass: column j = sum over windows in index order, then the caller's epilogue
+// second pass: column j = sum over windows, then the caller's epilogue.  A block owns 32 columns;
+// 8 thread groups each add every 8th window in index order (8 loads in flight per thread), and
+// the 8 group sums are added in index order -- a fixed association, hence deterministic.
+constexpr int LSQ_CMB_COLS = 32;
+constexpr int LSQ_CMB_GROUPS = LSQ_NT / LSQ_CMB_COLS;
 template <class Epi>
 __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ part, int n, int nwin, Epi epi,
                                                      int ncolblocks) {
     __shared__ double sh[LSQ_NT / 64];
+    __shared__ double grp[LSQ_CMB_GROUPS][LSQ_CMB_COLS + 1];
     if (epi.done && *epi.done) return;
     const int nwork = ncolblocks + epi.extra_blocks;
+    const int cidx = threadIdx.x % LSQ_CMB_COLS, g = threadIdx.x / LSQ_CMB_COLS;
     double racc = 0.0;
     for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
         if (b >= ncolblocks) {
             epi.extra(b - ncolblocks, racc);
             continue;
         }
-        const int j = b * LSQ_NT + threadIdx.x;
+        const int j = b * LSQ_CMB_COLS + cidx;
+        double acc = 0.0;
         if (j < n) {
+            int w = g;
+            for (; w + 7 * LSQ_CMB_GROUPS < nwin; w += 8 * LSQ_CMB_GROUPS) {
+                double t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = part[(size_t)(w + q * LSQ_CMB_GROUPS) * n + j];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += t[q];
+            }
+            for (; w < nwin; w += LSQ_CMB_GROUPS) acc += part[(size_t)w * n + j];
+        }
+        grp[g][cidx] = acc;
+        __syncthreads();
+        if (g == 0 && j < n) {
             double dot = 0.0;
-            for (int w = 0; w < nwin; ++w) dot += part[(size_t)w * n + j];
+#pragma unroll
+            for (int q = 0; q < LSQ_CMB_GROUPS; ++q) dot += grp[q][cidx];
             epi.seg(j, dot, racc);
         }
+        __syncthreads();
     }
     finish_block(epi, racc, sh);
 }
@@ -491,9 +642,23 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
         }
         if (J->nwin > 1) {
             LSQ_TRY(lsq_ensure_csr(J));
-            EpiPart ep{epi.done, 0, J->d_bpart, nullptr, nullptr};
-            LSQ_TRY(launch_segs<false>(c, J->bcsc, x, ep));
-            int nb = lsq_div_up(J->n, LSQ_NT);
+            if (J->bcsc.plan == LSQ_PLAN_LDSWIN) {
+                static thread_local bool configured = false;
+                const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + LSQ_BIG_WINDOW) * sizeof(double);
+                if (!configured) {
+                    LSQ_HIP(hipFuncSetAttribute((const void *)k_bcsc_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)lds));
+                    configured = true;
+                }
+                int g2 = std::max(1, std::min(J->bcsc.nwin, c->num_cus));
+                hipLaunchKernelGGL(k_bcsc_lds<0>, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc),
+                                   (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m, x,
+                                   J->d_bpart, epi.done);
+            } else {
+                EpiPart ep{epi.done, 0, J->d_bpart, nullptr, nullptr};
+                LSQ_TRY(launch_segs<false>(c, J->bcsc, x, ep));
+            }
+            int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
             int grid = cap((long long)nb + epi.extra_blocks);
             hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_bpart, J->n,
                                J->nwin, epi, nb);

@@ -33,14 +33,14 @@ def rand_csc(m, n, density, seed):
 
 
 # ------------------------------------------------------------------------------- kernels
-@pytest.mark.parametrize("window_rows", [None, 1024])
-@pytest.mark.parametrize("plan", ["stream", "wave", "block", None])
+@pytest.mark.parametrize("window_rows", [None, 1024, 96])
+@pytest.mark.parametrize("plan", ["stream", "wave", "block", "ldswin", None])
 @pytest.mark.parametrize("m,n,density", [(3000, 200, 0.01), (500, 40, 0.5), (64, 3000, 0.02)])
 def test_sparse_products(ctx, plan, m, n, density, window_rows):
     """All three launch plans, for the CSR rows, the CSC columns and (window_rows: forced small so
     that small test matrices are cut into several windows) the row-window-blocked CSC of J'*y."""
     for k in ("LSQ_PLAN_CSC", "LSQ_PLAN_CSR", "LSQ_PLAN_BCSC"):
-        if plan:
+        if plan and not (plan == "ldswin" and k != "LSQ_PLAN_BCSC"):
             os.environ[k] = plan
         else:
             os.environ.pop(k, None)
