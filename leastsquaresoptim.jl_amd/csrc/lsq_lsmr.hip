@@ -321,7 +321,8 @@ static inline int nvec_grid(const lsq_ctx *c, int n) {
 }
 
 // d_damp == nullptr: undamped (Dogleg, atol = btol = 1e-6); else LM (btol = 0.5).
-int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul) {
+int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
+                   const double *d_Jty) {
     lsq_ctx *c = s->ctx;
     const int m = J->m, n = J->n;
     if (m != s->m || n != s->n) {
@@ -358,7 +359,13 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     // v~ = A'u (setup), then K3 in "first" mode
     EpiV ev{done, 0, st, c->d_mail, s->d_P, damped ? s->d_dg : nullptr, nullptr, s->d_v,
             c->d_partials, lsq_ctr(c, 2)};
-    LSQ_TRY(launch_product(J, 1, d_y, ev));
+    if (d_Jty) {
+        // A'b from the caller's J'y: only the n-length epilogue runs (k_combine with one "window")
+        int nb = lsq_div_up(n, LSQ_CMB_COLS);
+        hipLaunchKernelGGL((k_combine<EpiV>), dim3(nb), dim3(LSQ_NT), 0, c->stream, d_Jty, n, 1, ev, nb);
+    } else {
+        LSQ_TRY(launch_product(J, 1, d_y, ev));
+    }
     hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, s->d_P,
                        s->d_v, s->d_h, s->d_hbar, xs, s->d_t, c->d_partials, lsq_ctr(c, 3));
     LSQ_HIP(hipGetLastError());

@@ -264,10 +264,11 @@ struct LoopBuffers {
     lsq_ctx *c;
     int m, n;
     double *dx = nullptr, *dtd = nullptr, *xt = nullptr, *ftrial = nullptr;
-    double *dgn = nullptr, *dgr = nullptr;
+    double *dgn = nullptr, *dgr = nullptr, *grad = nullptr;
     double *lo = nullptr, *hi = nullptr;
     ~LoopBuffers() {
-        hipFree(dx); hipFree(dtd); hipFree(xt); hipFree(ftrial); hipFree(dgn); hipFree(dgr); hipFree(lo); hipFree(hi);
+        hipFree(dx); hipFree(dtd); hipFree(xt); hipFree(ftrial); hipFree(dgn); hipFree(dgr); hipFree(grad); hipFree(lo);
+        hipFree(hi);
     }
 };
 
@@ -278,6 +279,7 @@ static int alloc_loop(LoopBuffers &b, lsq_ctx *c, int m, int n, const lsq_option
     LSQ_HIP(hipMalloc(&b.dtd, nb));
     LSQ_HIP(hipMalloc(&b.xt, nb));
     LSQ_HIP(hipMalloc(&b.ftrial, mb));
+    LSQ_HIP(hipMalloc(&b.grad, nb));
     LSQ_HIP(hipMemsetAsync(b.dx, 0, nb, c->stream));
     if (dogleg) {
         LSQ_HIP(hipMalloc(&b.dgn, nb));
@@ -415,18 +417,21 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double
         const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
         if (!cs) return LSQ_EHIP;
         hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
-        int lmiter = 0;
-        LSQ_TRY(lsq_ldiv_damped(sv, J, fcur, b.dtd, b.dx, &lmiter));     // :87
-        LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
-        mul_calls += lmiter;
-        inner_total += lmiter / 2;
-        {   // :102-104 gradient at the pre-step x (dtd is reused as scratch, like the reference)
-            EpiGrad eg{nullptr, 0, b.dtd, nullptr, nullptr};
+        {   // :102-104 gradient g = J'f at the pre-step x.  The reference forms it AFTER the solve
+            // (into dtd); J and fcur do not change in between, so it is formed once, before the
+            // solve, and LSMR's setup product A'b = P.*(J'f)/beta reuses it (saves one pass over J).
+            EpiGrad eg{nullptr, 0, b.grad, nullptr, nullptr};
             LSQ_TRY(launch_product(J, 1, fcur, eg));
-            hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dtd, x, b.lo, b.hi,
+            hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.grad, x, b.lo, b.hi,
                                c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             mul_calls++;
         }
+        int lmiter = 0;
+        if (sv->kind == LSQ_LSMR) LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad));  // :87
+        else LSQ_TRY(lsq_ldiv_damped(sv, J, fcur, b.dtd, b.dx, &lmiter));
+        LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
+        mul_calls += lmiter;
+        inner_total += lmiter / 2;
         hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
                            lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN);   // :106
         LSQ_HIP(hipGetLastError());
@@ -730,6 +735,17 @@ k_scale_bcsc(int nseg, int n, const int *__restrict__ ptr, const double *__restr
     }
 }
 
+// short segments (LDS-window plan: ~4 entries): one thread per segment
+__global__ void __launch_bounds__(LSQ_NT)
+k_scale_bcsc_thread(int nseg, int n, const int *__restrict__ ptr, const double *__restrict__ A,
+                    const double *__restrict__ sfac, double *__restrict__ out) {
+    for (int s = blockIdx.x * LSQ_NT + threadIdx.x; s < nseg; s += gridDim.x * LSQ_NT) {
+        const double f = sfac[s % n];
+        const int k1 = ptr[s + 1];
+        for (int k = ptr[s]; k < k1; ++k) out[k] = A[k] * f;
+    }
+}
+
 static int model_f(double *out, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
@@ -762,9 +778,15 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
                                md->d_Acsr, md->d_t, J->csr.d_val);
         if (J->nwin > 1) {
             int nsegs = J->bcsc.nseg;
-            int g3 = std::min(lsq_div_up(nsegs, LSQ_NT / 64), c->num_cus * 16);
-            hipLaunchKernelGGL(k_scale_bcsc, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n, J->bcsc.d_ptr,
-                               md->d_Ab, md->d_t, J->bcsc.d_val);
+            if (J->nnz < 16LL * nsegs) {
+                int g3 = std::min(lsq_div_up(nsegs, LSQ_NT), c->num_cus * 16);
+                hipLaunchKernelGGL(k_scale_bcsc_thread, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n,
+                                   J->bcsc.d_ptr, md->d_Ab, md->d_t, J->bcsc.d_val);
+            } else {
+                int g3 = std::min(lsq_div_up(nsegs, LSQ_NT / 64), c->num_cus * 16);
+                hipLaunchKernelGGL(k_scale_bcsc, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n, J->bcsc.d_ptr,
+                                   md->d_Ab, md->d_t, J->bcsc.d_val);
+            }
         }
         J->csr_fresh = true;  // every mirror written directly: no permutation pass needed
     } else {

@@ -52,7 +52,9 @@ struct lsq_solver {
 // implemented in lsq_lsmr.hip
 int lsq_lsmr_alloc(lsq_solver *s);
 void lsq_lsmr_free(lsq_solver *s);
-int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul);
+// d_Jty (optional): J'*y already formed by the caller (the LM gradient) -- skips the setup product
+int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
+                   const double *d_Jty = nullptr);
 // implemented in lsq_dense.hip
 int lsq_dense_solver_alloc(lsq_solver *s);
 void lsq_dense_solver_free(lsq_solver *s);
