@@ -82,6 +82,7 @@ struct LsqSegs {
     long long nnz = 0;
     int *d_ptr = nullptr;  // nseg+1
     int *d_idx = nullptr;  // nnz (gather index)
+    unsigned short *d_idx16 = nullptr;  // same indices in 16 bits when they fit (LDS-staged kernels: 10 B/nnz)
     double *d_val = nullptr;
     int plan = LSQ_PLAN_STREAM;
     int ntiles = 0;        // stream plan: number of tiles

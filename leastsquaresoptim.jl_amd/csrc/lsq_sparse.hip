@@ -97,6 +97,12 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
         }
         LSQ_HIP(hipMalloc(&S.d_big, (bm.size() + 4) * sizeof(int)));
         LSQ_HIP(hipMemcpy(S.d_big, bm.data(), bm.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (S.nbig > 0 && S.nx <= 65535 && !getenv("LSQ_NO_IDX16")) {  // 10 B/nnz instead of 12
+            std::vector<unsigned short> i16(S.nnz + pad, 0);
+            for (long long k = 0; k < S.nnz; ++k) i16[k] = (unsigned short)idx[k];
+            LSQ_HIP(hipMalloc(&S.d_idx16, i16.size() * sizeof(unsigned short)));
+            LSQ_HIP(hipMemcpy(S.d_idx16, i16.data(), i16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
     }
     if (group > 0 && S.plan != LSQ_PLAN_BLOCK) {
         std::vector<int> win, order;
@@ -117,6 +123,7 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
 static void free_segs(LsqSegs &S) {
     hipFree(S.d_ptr);
     hipFree(S.d_idx);
+    hipFree(S.d_idx16);
     hipFree(S.d_val);
     hipFree(S.d_tiles);
     hipFree(S.d_order);
@@ -234,6 +241,13 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
                     LSQ_HIP(hipMemcpy(J->bcsc.d_wtile, wt.data(), wt.size() * sizeof(int), hipMemcpyHostToDevice));
                     J->bcsc.nbig = nb;
                     J->bcsc.plan = LSQ_PLAN_LDSWIN;
+                    if (!getenv("LSQ_NO_IDX16")) {  // in-window row offsets (< 4096) in 16 bits
+                        std::vector<unsigned short> i16(nnz + 8, 0);
+                        for (long long k = 0; k < nnz; ++k) i16[k] = (unsigned short)(bidx[k] % rw);
+                        LSQ_HIP(hipMalloc(&J->bcsc.d_idx16, i16.size() * sizeof(unsigned short)));
+                        LSQ_HIP(hipMemcpy(J->bcsc.d_idx16, i16.data(), i16.size() * sizeof(unsigned short),
+                                          hipMemcpyHostToDevice));
+                    }
                 }
             }
             LSQ_HIP(hipMalloc(&J->d_bmap, (nnz + 8) * sizeof(int)));

@@ -30,6 +30,7 @@ struct SegsDev {
     const int *idx;
     const double *val;
     const int *tiles;
+    const unsigned short *idx16;
     const int *order;  // optional work-item permutation
     int nseg;
     int ntiles;
@@ -129,6 +130,17 @@ constexpr int LSQ_BIG_NNZ = LSQ_BIG_WINDOW - 3;
 constexpr int LSQ_BIG_SEGS = LSQ_BIG_NT;
 constexpr int LSQ_LDS_X_MAX = 12160;                     // doubles of x staged (95 KiB; 160 KiB LDS total)
 
+// four gather indices of entries k..k+3 (k a multiple of 4): 16-byte int4 or 8-byte ushort4
+template <bool IDX16>
+__device__ __forceinline__ int4 load_idx4(const SegsDev &S, int k) {
+    if constexpr (IDX16) {
+        const uint2 p = *reinterpret_cast<const uint2 *>(S.idx16 + k);
+        return make_int4((int)(p.x & 0xffffu), (int)(p.x >> 16), (int)(p.y & 0xffffu), (int)(p.y >> 16));
+    } else {
+        return *reinterpret_cast<const int4 *>(S.idx + k);
+    }
+}
+
 struct BigTileRegs {  // one big tile's worth of val/idx per thread (8 nnz) + its epilogue inputs
     double2 v0[2], v1[2];
     int4 ci[2];
@@ -157,7 +169,7 @@ struct EpiHasPre<E, std::void_t<typename E::has_pre>> : std::true_type {};
 // before the tile would make every prefetch wait for all older loads.  So extents are fetched two
 // tiles ahead of the data, data two tiles ahead of use, and every step issues the same number of
 // (clamped, never predicated) loads so that the compiler waits with counted vmcnt.
-template <class Epi>
+template <class Epi, bool IDX16>
 __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const int4 *__restrict__ meta, int nbig,
                                                                const double *__restrict__ x, int nx, int nxpad,
                                                                Epi epi) {
@@ -184,7 +196,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const 
             const int k = min(ka + c * 4 * LSQ_BIG_NT + 4 * tid, kmax);
             r.v0[c] = *reinterpret_cast<const double2 *>(S.val + k);
             r.v1[c] = *reinterpret_cast<const double2 *>(S.val + k + 2);
-            r.ci[c] = *reinterpret_cast<const int4 *>(S.idx + k);
+            r.ci[c] = load_idx4<IDX16>(S, k);
         }
         const int s = min(mt.x + tid, S.nseg - 1);
         r.pa = S.ptr[s];
@@ -275,7 +287,7 @@ struct WinTileRegs {
     int pa[2], pe[2];
 };
 
-template <int UNUSED = 0>
+template <bool IDX16>
 __global__ void __launch_bounds__(LSQ_BIG_NT)
 k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wtile, int nwin, int rw, int m,
            const double *__restrict__ y, double *__restrict__ part, const int *done) {
@@ -302,7 +314,7 @@ k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wti
                 const int k = min(ka + c * 4 * LSQ_BIG_NT + 4 * tid, kmax);
                 r.v0[c] = *reinterpret_cast<const double2 *>(S.val + k);
                 r.v1[c] = *reinterpret_cast<const double2 *>(S.val + k + 2);
-                r.ci[c] = *reinterpret_cast<const int4 *>(S.idx + k);
+                r.ci[c] = load_idx4<IDX16>(S, k);
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -316,12 +328,20 @@ k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wti
             const int hi = rw - 1;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                // clamped offsets: entries of neighbouring windows (tile slack) stay inside LDS
+                // 16-bit indices are offsets inside the window; 32-bit ones are global rows, clamped
+                // so that tile-slack entries of neighbouring windows stay inside the LDS copy
                 double2 p0, p1;
-                p0.x = r.v0[c].x * yl[min(max(r.ci[c].x - base, 0), hi)];
-                p0.y = r.v0[c].y * yl[min(max(r.ci[c].y - base, 0), hi)];
-                p1.x = r.v1[c].x * yl[min(max(r.ci[c].z - base, 0), hi)];
-                p1.y = r.v1[c].y * yl[min(max(r.ci[c].w - base, 0), hi)];
+                if constexpr (IDX16) {
+                    p0.x = r.v0[c].x * yl[r.ci[c].x];
+                    p0.y = r.v0[c].y * yl[r.ci[c].y];
+                    p1.x = r.v1[c].x * yl[r.ci[c].z];
+                    p1.y = r.v1[c].y * yl[r.ci[c].w];
+                } else {
+                    p0.x = r.v0[c].x * yl[min(max(r.ci[c].x - base, 0), hi)];
+                    p0.y = r.v0[c].y * yl[min(max(r.ci[c].y - base, 0), hi)];
+                    p1.x = r.v1[c].x * yl[min(max(r.ci[c].z - base, 0), hi)];
+                    p1.y = r.v1[c].y * yl[min(max(r.ci[c].w - base, 0), hi)];
+                }
                 double2 *dst = reinterpret_cast<double2 *>(prod + c * 4 * LSQ_BIG_NT + 4 * tid);
                 dst[0] = p0;
                 dst[1] = p1;
@@ -450,7 +470,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_seg_block(SegsDev S, const double *_
 }
 
 static inline SegsDev segs_dev(const LsqSegs &s) {
-    return SegsDev{s.d_ptr, s.d_idx, s.d_val, s.d_tiles, s.d_order, s.nseg, s.ntiles};
+    return SegsDev{s.d_ptr, s.d_idx, s.d_val, s.d_tiles, s.d_idx16, s.d_order, s.nseg, s.ntiles};
 }
 
 // Launch the plan chosen for `segs`.  Work items = segment blocks + epi.extra_blocks; the grid is
@@ -469,12 +489,13 @@ static inline int launch_segs(lsq_ctx *ctx, const LsqSegs &segs, const double *x
             // LDS-staged gather vector: one persistent 1024-thread workgroup per CU
             const int nxpad = (segs.nx + 1) & ~1;
             const size_t lds = (size_t)(nxpad + LSQ_BIG_WINDOW) * sizeof(double);
-            auto kern = k_seg_stream_lds<Epi>;
-            static thread_local const void *configured = nullptr;
-            if (configured != (const void *)kern) {
+            const bool i16 = segs.d_idx16 != nullptr;
+            auto kern = i16 ? k_seg_stream_lds<Epi, true> : k_seg_stream_lds<Epi, false>;
+            static thread_local const void *configured[2] = {nullptr, nullptr};
+            if (configured[i16] != (const void *)kern) {
                 LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)((LSQ_LDS_X_MAX + LSQ_BIG_WINDOW) * sizeof(double))));
-                configured = (const void *)kern;
+                configured[i16] = (const void *)kern;
             }
             int grid = std::max(1, std::min(segs.nbig, ctx->num_cus));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, (const int4 *)segs.d_big, segs.nbig, x,
@@ -643,15 +664,16 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
         if (J->nwin > 1) {
             LSQ_TRY(lsq_ensure_csr(J));
             if (J->bcsc.plan == LSQ_PLAN_LDSWIN) {
-                static thread_local bool configured = false;
+                static thread_local bool configured[2] = {false, false};
                 const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + LSQ_BIG_WINDOW) * sizeof(double);
-                if (!configured) {
-                    LSQ_HIP(hipFuncSetAttribute((const void *)k_bcsc_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)lds));
-                    configured = true;
+                const bool i16 = J->bcsc.d_idx16 != nullptr;
+                auto kern = i16 ? k_bcsc_lds<true> : k_bcsc_lds<false>;
+                if (!configured[i16]) {
+                    LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    configured[i16] = true;
                 }
                 int g2 = std::max(1, std::min(J->bcsc.nwin, c->num_cus));
-                hipLaunchKernelGGL(k_bcsc_lds<0>, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc),
+                hipLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc),
                                    (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m, x,
                                    J->d_bpart, epi.done);
             } else {
