@@ -49,22 +49,12 @@ k_lsmr_prep(int n, const double *__restrict__ colsum, double *__restrict__ damp,
     }
 }
 
-// ---- beta_1 = ||b|| and state reset (lsmr.jl:73-75 with x == 0) ------------------------------
+// ---- beta_1^2 = sum(b^2) as block partials, and state reset (lsmr.jl:73-75 with x == 0) --------
 __global__ void __launch_bounds__(LSQ_NT)
-k_lsmr_begin(int m, const double *__restrict__ y, LsmrState *st, LsqMailbox *mail, double *partials,
-             unsigned *counter, double atol, double btol, double ctol, int maxiter, unsigned epoch) {
+k_lsmr_begin(int m, const double *__restrict__ y, LsmrState *st, double *pu, int *npu, double atol, double btol,
+             double ctol, int maxiter, unsigned epoch) {
     __shared__ double sh[LSQ_NT / 64];
-    double acc = 0.0;
-    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < m; i += (long long)gridDim.x * LSQ_NT) {
-        double v = y[i];
-        acc += v * v;
-    }
-    double bv = block_sum<LSQ_NT>(acc, sh);
-    grid_reduce<LSQ_NT>(bv, partials, counter, gridDim.x, sh, [=](double t) {
-        double beta = sqrt(t);
-        st->beta = beta;
-        st->beta_zero = !(beta > 0.0);
-        st->inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // no other kernel touches the state concurrently
         st->iter = 0;
         st->istop = 0;
         st->done = 0;
@@ -74,13 +64,22 @@ k_lsmr_begin(int m, const double *__restrict__ y, LsmrState *st, LsqMailbox *mai
         st->ctol = ctol;
         st->maxiter = maxiter;
         st->epoch = epoch;
-    });
-    (void)mail;
+        st->cu = 0.0;
+        *npu = (int)gridDim.x;
+    }
+    double acc = 0.0;
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < m; i += (long long)gridDim.x * LSQ_NT) {
+        double v = y[i];
+        acc += v * v;
+    }
+    double bv = block_sum<LSQ_NT>(acc, sh);
+    if (threadIdx.x == 0) pu[blockIdx.x] = bv;
 }
 
-// ---- K1: u~ <- J t - cu u~ --------------------------------------------------------------------
+// ---- K1: u~ <- J t - cu u~ ; publishes the block partials of sum(u~^2) --------------------------
 struct EpiU {
     static constexpr bool REDUCE = true;
+    using defer = void;
     const int *done;
     int extra_blocks;
     LsmrState *st;
@@ -91,9 +90,10 @@ struct EpiU {
     const double *dg;
     const double *t;
     double *ux;
-    double *partials;
-    unsigned *counter;
-    double cu;  // cached st->cu (prepare)
+    double *partials;   // pu
+    int *npartials;
+    unsigned *counter;  // unused (deferred)
+    double cu;          // cached st->cu
     using has_prepare = void;
     __device__ void prepare() { cu = st->cu; }
     __device__ void seg(int s, double dot, double &racc) const {
@@ -108,76 +108,56 @@ struct EpiU {
         unew[s] = un;
         racc += un * un;
     }
-    __device__ void extra(int blk, double &racc) const {  // DampenedMatrix rows, iterative_lsmr.jl:92
-        int j = blk * LSQ_NT + threadIdx.x;
-        if (j < n) {
-            double un = t[j] * dg[j] - st->cu * ux[j];
-            ux[j] = un;
-            racc += un * un;
-        }
-    }
-    __device__ void finalize(double total) const {  // lsmr.jl:119-121, DampenedVector norm il:72
-        double beta = sqrt(total);
-        st->beta = beta;
-        st->beta_zero = !(beta > 0.0);
-        st->inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
-    }
+    __device__ void extra(int, double &) const {}   // (the damped rows are updated by K3)
+    __device__ void finalize(double) const {}
 };
 
-// ---- K2: v~ <- P (J'u~ + d ux~)/beta - beta v, alpha, rotations -------------------------------
+// ---- K2: v~ <- P (J'u~ + d ux~)/beta - beta v ; publishes the block partials of sum(v~^2) -------
+// beta = sqrt(sum u~^2) is formed by every block from K1's partials (lsmr.jl:119, il:72).
 struct EpiV {
     static constexpr bool REDUCE = true;
+    using defer = void;
     const int *done;
     int extra_blocks;
     LsmrState *st;
-    LsqMailbox *mail;
+    const double *pu;   // K1's (or k_lsmr_begin's) partials of sum(u~_y^2)
+    const int *npu;
+    const double *px;   // K3's partials of sum(u~_x^2) (damped rows), or null
+    const int *npx;
     const double *P;
     const double *dg;
     const double *ux;   // null during setup (zerosvector)
     double *v;
-    double *partials;
-    unsigned *counter;
+    double *partials;   // pv
+    int *npartials;
+    unsigned *counter;  // unused (deferred)
+    double beta, inv_beta;
+    int beta_zero, first;
+    using has_block_prepare = void;
+    __device__ void block_prepare() {
+        double b2 = ordered_sum256(pu, *npu);
+        if (px) b2 += ordered_sum256(px, *npx);     // DampenedVector norm, iterative_lsmr.jl:72
+        beta = sqrt(b2);
+        beta_zero = !(beta > 0.0);
+        inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;   // lsmr.jl:120-121 rmul!(u, inv(beta))
+        first = st->first;
+    }
     __device__ void seg(int j, double dot, double &racc) const {
-        if (st->beta_zero) return;  // lsmr.jl:120
+        if (beta_zero) return;                      // lsmr.jl:120
         double w = dot;
         if (dg && ux) w += ux[j] * dg[j];           // iterative_lsmr.jl:107
-        w *= st->inv_beta;                          // u = u~/beta
+        w *= inv_beta;                              // u = u~/beta
         if (P) w *= P[j];                           // :41
-        double vn = st->first ? w : w - st->beta * v[j];  // :42-49 (beta == 0 => fill!)
+        double vn = first ? w : w - beta * v[j];    // :42-49 (beta == 0 => fill!)
         v[j] = vn;
         racc += vn * vn;
     }
     __device__ void extra(int, double &) const {}
-    __device__ void finalize(double total) const;
+    __device__ void finalize(double) const {}
 };
 
-__device__ void EpiV::finalize(double total) const {
-    LsmrState &s = *st;
-    if (!s.beta_zero) {
-        s.alpha = sqrt(total);                       // lsmr.jl:77,123
-        s.vscale = s.alpha > 0.0 ? 1.0 / s.alpha : 1.0;
-    } else {
-        if (s.first) s.alpha = 0.0;
-        s.vscale = 1.0;
-    }
-    const double alpha = s.alpha, beta = s.beta;
-    if (s.first) {                                   // lsmr.jl:82-113
-        s.zetabar = alpha * beta;
-        s.alphabar = alpha;
-        s.rho = 1.0; s.rhobar = 1.0; s.cbar = 1.0; s.sbar = 0.0;
-        s.betadd = beta; s.betad = 0.0; s.rhodold = 1.0; s.tautildeold = 0.0;
-        s.thetatilde = 0.0; s.zeta = 0.0; s.d = 0.0;
-        s.normA = -1.0; s.condA = -1.0; s.normx = -1.0;
-        s.normA2 = alpha * alpha;
-        s.maxrbar = 0.0; s.minrbar = 1e100;
-        s.normb = beta; s.normr = beta; s.normAr = alpha * beta;
-        s.cu = beta > 0.0 ? alpha / beta : alpha;
-        if (!(s.normAr != 0.0)) {                    // lsmr.jl:115: exit if b = 0 or A'b = 0
-            s.done = 1;
-            publish(mail, st);
-        }
-        return;
-    }
+// the scalar recurrence of one iteration (lsmr.jl:127-196, :205), on a private copy of the state
+__device__ void lsmr_rotate(LsmrState &s, double alpha, double beta) {
     const double lambda = 0.0;
     // lsmr.jl:127-130
     double alphahat = sqrt(s.alphabar * s.alphabar + lambda * lambda);
@@ -197,7 +177,8 @@ __device__ void EpiV::finalize(double total) const {
     s.sbar = thetanew / rhobar;
     s.zeta = s.cbar * s.zetabar;
     s.zetabar = -s.sbar * s.zetabar;
-    s.rho = rho; s.rhobar = rhobar;
+    s.rho = rho;
+    s.rhobar = rhobar;
     // :152-156 coefficients of the vector updates
     s.c1 = -thetabar * rho / (rhoold * rhobarold);
     s.c2 = s.zeta / (rho * rhobar);
@@ -225,19 +206,55 @@ __device__ void EpiV::finalize(double total) const {
     if (s.iter + 1 > 1) s.minrbar = fmin(s.minrbar, rhobarold);
     s.condA = fmax(s.maxrbar, rhotemp) / fmin(s.minrbar, rhotemp);
     s.normAr = fabs(s.zetabar);                      // :205
-    s.cu = beta > 0.0 ? alpha / beta : alpha;        // next K1: u~_new = A v - (alpha/beta) u~
 }
 
-// ---- K3: n-vector updates, ||x||, stopping rules ----------------------------------------------
+// ---- K3: alpha, rotations (every block, redundantly and identically), n-vector updates, ||x||,
+//          stopping rules and the commit of the new state (last block) --------------------------
 __global__ void __launch_bounds__(LSQ_NT)
-k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *__restrict__ P, double *__restrict__ v,
-              double *__restrict__ h, double *__restrict__ hbar, double *__restrict__ x,
-              double *__restrict__ t, double *partials, unsigned *counter) {
+k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const int *npu, const double *pv,
+              const int *npv, const double *px_in, const int *npx_in, double *px, int *npx,
+              const double *__restrict__ dg, double *__restrict__ ux,
+              const double *__restrict__ P, double *__restrict__ v, double *__restrict__ h,
+              double *__restrict__ hbar, double *__restrict__ x, double *__restrict__ t, double *partials,
+              unsigned *counter) {
     __shared__ double sh[LSQ_NT / 64];
+    __shared__ LsmrState ns;   // this iteration's state, computed from the committed one
     if (st->done) return;
-    const bool first = st->first;
-    const double vs = st->vscale, c1 = st->c1, c2 = st->c2, c3 = st->c3;
-    double acc = 0.0;
+    double beta2 = ordered_sum256(pu, *npu);
+    if (px_in) beta2 += ordered_sum256(px_in, *npx_in);   // (null in the setup pass: u~x == 0)
+    const double alpha2 = ordered_sum256(pv, *npv);
+    if (threadIdx.x == 0) {
+        ns = *st;
+        const double beta = sqrt(beta2);
+        ns.beta = beta;
+        ns.beta_zero = !(beta > 0.0);
+        if (!ns.beta_zero) {
+            ns.alpha = sqrt(alpha2);                       // lsmr.jl:77,123
+            ns.vscale = ns.alpha > 0.0 ? 1.0 / ns.alpha : 1.0;
+        } else {
+            if (ns.first) ns.alpha = 0.0;
+            ns.vscale = 1.0;                               // v was left untouched (lsmr.jl:120)
+        }
+        const double alpha = ns.alpha;
+        if (ns.first) {                                    // lsmr.jl:82-113
+            ns.zetabar = alpha * beta;
+            ns.alphabar = alpha;
+            ns.rho = 1.0; ns.rhobar = 1.0; ns.cbar = 1.0; ns.sbar = 0.0;
+            ns.betadd = beta; ns.betad = 0.0; ns.rhodold = 1.0; ns.tautildeold = 0.0;
+            ns.thetatilde = 0.0; ns.zeta = 0.0; ns.d = 0.0;
+            ns.normA = -1.0; ns.condA = -1.0; ns.normx = -1.0;
+            ns.normA2 = alpha * alpha;
+            ns.maxrbar = 0.0; ns.minrbar = 1e100;
+            ns.normb = beta; ns.normr = beta; ns.normAr = alpha * beta;
+        } else {
+            lsmr_rotate(ns, alpha, beta);
+        }
+        ns.cu = beta > 0.0 ? alpha / beta : alpha;         // next K1: u~_new = A v - (alpha/beta) u~
+    }
+    __syncthreads();
+    const bool first = ns.first;
+    const double vs = ns.vscale, c1 = ns.c1, c2 = ns.c2, c3 = ns.c3, cu = ns.cu;
+    double acc = 0.0, accx = 0.0;
     for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT) {
         double vj = v[j] * vs;                       // lsmr.jl:78,124 rmul!(v, inv(alpha))
         v[j] = vj;
@@ -253,13 +270,29 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *__restrict__
             h[j] = h[j] * c3 + vj;                   // :155-156
             acc += xj * xj;
         }
-        t[j] = P ? vj * P[j] : vj;                   // iterative_lsmr.jl:31 ldiv!(tmp, P, a)
+        const double tj = P ? vj * P[j] : vj;        // iterative_lsmr.jl:31 ldiv!(tmp, P, a)
+        t[j] = tj;
+        if (dg) {   // damped rows of the NEXT u (iterative_lsmr.jl:92): u~x <- d.*t - cu*u~x
+            double un = tj * dg[j] - cu * ux[j];
+            ux[j] = un;
+            accx += un * un;
+        }
+    }
+    if (dg) {       // deferred partials of sum(u~x^2): read by the next K2 / K3
+        double bx = block_sum<LSQ_NT>(accx, sh);
+        if (threadIdx.x == 0) {
+            px[blockIdx.x] = bx;
+            if (blockIdx.x == 0) *npx = (int)gridDim.x;
+        }
     }
     double bv = block_sum<LSQ_NT>(acc, sh);
-    grid_reduce<LSQ_NT>(bv, partials, counter, gridDim.x, sh, [=](double total) {
-        LsmrState &s = *st;
+    grid_reduce<LSQ_NT>(bv, partials, counter, gridDim.x, sh, [&](double total) {
+        // last block: every other block is past its prologue, so the state can be committed
+        LsmrState &s = ns;
         if (s.first) {
             s.first = 0;
+            if (!(s.normAr != 0.0)) s.done = 1;      // lsmr.jl:115: exit if b = 0 or A'b = 0
+            *st = s;
             publish(mail, st);
             return;
         }
@@ -280,6 +313,7 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *__restrict__
         else if (test1 <= rtol) istop = 1;
         s.istop = istop;
         if (istop) s.done = 1;
+        *st = s;
         publish(mail, st);
     });
 }
@@ -306,12 +340,14 @@ int lsq_lsmr_alloc(lsq_solver *s) {
     LSQ_HIP(hipMalloc(&s->d_P, nb));
     LSQ_HIP(hipMalloc(&s->d_dg, nb));
     LSQ_HIP(hipMalloc(&s->d_rhs, nb));  // LSMR iterate (un-preconditioned space)
+    LSQ_HIP(hipMalloc(&s->d_red, 4 * 4096 * sizeof(double) + 64));  // pu, pv, px[2] (4096 each), counts
+    LSQ_HIP(hipMemset(s->d_red, 0, 4 * 4096 * sizeof(double) + 64));
     return LSQ_OK;
 }
 
 void lsq_lsmr_free(lsq_solver *s) {
     hipFree(s->d_state); hipFree(s->d_u); hipFree(s->d_ux); hipFree(s->d_v); hipFree(s->d_h);
-    hipFree(s->d_hbar); hipFree(s->d_t); hipFree(s->d_P); hipFree(s->d_dg); hipFree(s->d_rhs);
+    hipFree(s->d_hbar); hipFree(s->d_t); hipFree(s->d_P); hipFree(s->d_dg); hipFree(s->d_rhs); hipFree(s->d_red);
 }
 
 static inline int nvec_grid(const lsq_ctx *c, int n) {
@@ -342,6 +378,11 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     LsmrState *st = s->d_state;
     const int *done = &st->done;
     double *xs = s->d_rhs;
+    double *pu = s->d_red, *pv = s->d_red + 4096;   // deferred-reduction partials (sum u~^2 / sum v~^2)
+    // sum(u~x^2) partials are double-buffered: K3 reads iteration k's while writing k+1's
+    double *pxb[2] = {s->d_red + 2 * 4096, s->d_red + 3 * 4096};
+    int *npu = (int *)(s->d_red + 4 * 4096), *npv = npu + 1;
+    int *npxb[2] = {npu + 2, npu + 3};
 
     if (J->kind == LSQ_MAT_CSC) LSQ_TRY(lsq_ensure_csr(J));
     const double *colsum = lsq_cached_colsum(J);  // computed once per Jacobian (reference: twice)
@@ -352,26 +393,30 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                        s->d_dg, s->d_ux);
     {
         long long gb = std::min<long long>(lsq_div_up(m > 0 ? m : 1, LSQ_NT), (long long)c->num_cus * 8);
-        hipLaunchKernelGGL(k_lsmr_begin, dim3((int)gb), dim3(LSQ_NT), 0, c->stream, m, d_y, st, c->d_mail,
-                           c->d_partials, lsq_ctr(c, 1), atol, btol, 1.0 / conlim, maxiter, epoch);
+        if (gb > 4096) gb = 4096;
+        hipLaunchKernelGGL(k_lsmr_begin, dim3((int)gb), dim3(LSQ_NT), 0, c->stream, m, d_y, st, pu, npu, atol,
+                           btol, 1.0 / conlim, maxiter, epoch);
     }
     LSQ_HIP(hipGetLastError());
     // v~ = A'u (setup), then K3 in "first" mode
-    EpiV ev{done, 0, st, c->d_mail, s->d_P, damped ? s->d_dg : nullptr, nullptr, s->d_v,
-            c->d_partials, lsq_ctr(c, 2)};
+    EpiV ev{done, 0, st, pu, npu, nullptr, nullptr, s->d_P, damped ? s->d_dg : nullptr, nullptr, s->d_v, pv, npv,
+            nullptr, 0.0, 0.0, 0, 0};
     if (d_Jty) {
         // A'b from the caller's J'y: only the n-length epilogue runs (k_combine with one "window")
         int nb = lsq_div_up(n, LSQ_CMB_COLS);
-        hipLaunchKernelGGL((k_combine<EpiV>), dim3(nb), dim3(LSQ_NT), 0, c->stream, d_Jty, n, 1, ev, nb);
+        hipLaunchKernelGGL((k_combine<EpiV>), dim3(std::min(nb, 2048)), dim3(LSQ_NT), 0, c->stream, d_Jty, n, 1,
+                           ev, nb);
     } else {
         LSQ_TRY(launch_product(J, 1, d_y, ev));
     }
-    hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, s->d_P,
-                       s->d_v, s->d_h, s->d_hbar, xs, s->d_t, c->d_partials, lsq_ctr(c, 3));
+    // setup K3: u~x is still zero, so only sum(u~_y^2) enters beta_1; it already forms iteration 1's u~x
+    const double *dgk = damped ? s->d_dg : nullptr;
+    hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
+                       (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P, s->d_v,
+                       s->d_h, s->d_hbar, xs, s->d_t, c->d_partials, lsq_ctr(c, 3));
     LSQ_HIP(hipGetLastError());
 
-    EpiU eu{done, damped ? lsq_div_up(n, LSQ_NT) : 0, st, d_y, s->d_u, n, s->d_dg, s->d_t, s->d_ux,
-            c->d_partials, lsq_ctr(c, 1), 0.0};
+    EpiU eu{done, 0, st, d_y, s->d_u, n, s->d_dg, s->d_t, s->d_ux, pu, npu, nullptr, 0.0};
     ev.ux = damped ? s->d_ux : nullptr;
 
     int enq = 0, it = 0, istop = 0;
@@ -393,12 +438,16 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             LSQ_TRY(launch_product(J, 0, s->d_t, eu));   // K1
             lsq_prof_mark(c, 0, 1);
             eu.uold = s->d_u;                            // after the first iteration u~ lives in d_u
+            const int cur = enq & 1;                     // px buffer holding this iteration's sum(u~x^2)
+            ev.px = damped ? pxb[cur] : nullptr;
+            ev.npx = npxb[cur];
             lsq_prof_mark(c, 1, 0);
             LSQ_TRY(launch_product(J, 1, s->d_u, ev));   // K2
             lsq_prof_mark(c, 1, 1);
-            hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
-                               s->d_P, s->d_v, s->d_h, s->d_hbar, xs, s->d_t, c->d_partials,
-                               lsq_ctr(c, 3));
+            hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu,
+                               pv, npv, (const double *)(damped ? pxb[cur] : nullptr), (const int *)npxb[cur],
+                               pxb[cur ^ 1], npxb[cur ^ 1], dgk, s->d_ux, s->d_P, s->d_v, s->d_h, s->d_hbar, xs,
+                               s->d_t, c->d_partials, lsq_ctr(c, 3));
             LSQ_HIP(hipGetLastError());
             ++enq;
             spins = 0;

@@ -32,6 +32,7 @@ struct lsq_solver {
     double *d_v = nullptr, *d_h = nullptr, *d_hbar = nullptr, *d_t = nullptr;  // n
     double *d_P = nullptr;     // n   InverseDiagonal._
     double *d_dg = nullptr;    // n   sqrt(damp)
+    double *d_red = nullptr;   // deferred-reduction partials: pu[4096] | pv[4096] | int counts[2]
     unsigned epoch = 0;
     int last_iter = 0, last_istop = 0;
     // --- dense Cholesky (dense_cholesky.jl:7-21) ---

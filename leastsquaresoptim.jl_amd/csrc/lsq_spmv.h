@@ -34,6 +34,7 @@ struct SegsDev {
     const int *order;  // optional work-item permutation
     int nseg;
     int ntiles;
+    int nnz;
 };
 
 // Epilogue concept:
@@ -50,13 +51,59 @@ __device__ __forceinline__ double prod1(double v, const double *__restrict__ x, 
     return SQ ? v * v : v * x[c];
 }
 
+// Deferred ("consumer-side") finalisation: an epilogue with `using defer = void;` only publishes
+// its block partial (plain store) and the number of partials; the NEXT kernel's blocks each add
+// the partials in a fixed order (ordered_sum256) -- no arrival tickets, no acquire fence and no
+// serial last-block tail in the producing kernel, and still run-to-run deterministic.
+template <class E, class = void>
+struct EpiDefers : std::false_type {};
+template <class E>
+struct EpiDefers<E, std::void_t<typename E::defer>> : std::true_type {};
+// `block_prepare()` (opt in with `using has_block_prepare = void;`) is executed by every thread
+// of every block at kernel start (it may use __syncthreads): the place for consumer-side sums.
+template <class E, class = void>
+struct EpiHasBlockPrepare : std::false_type {};
+template <class E>
+struct EpiHasBlockPrepare<E, std::void_t<typename E::has_block_prepare>> : std::true_type {};
+
+// Sum of partials[0..count) identical in every block of every kernel: thread t < 256 adds
+// partials[t], partials[t+256], ... in order, waves 0-3 are combined in order, then broadcast.
+__device__ __forceinline__ double ordered_sum256(const double *partials, int count) {
+    __shared__ double s_w[4];
+    __shared__ double s_tot;
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    if (tid < 256)
+        for (int i = tid; i < count; i += 256) acc += partials[i];
+    if (tid < 256) {
+        acc = wave_sum(acc);
+        if ((tid & 63) == 0) s_w[tid >> 6] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) s_tot = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+    __syncthreads();
+    const double r = s_tot;
+    __syncthreads();
+    return r;
+}
+
+template <int NT, class Epi>
+__device__ __forceinline__ void finish_block_nt(const Epi &epi, double racc, double *sh) {
+    if constexpr (Epi::REDUCE) {
+        double bv = block_sum<NT>(racc, sh);
+        if constexpr (EpiDefers<Epi>::value) {
+            if (threadIdx.x == 0) {
+                epi.partials[blockIdx.x] = bv;
+                if (blockIdx.x == 0) *epi.npartials = (int)gridDim.x;
+            }
+        } else {
+            grid_reduce<NT>(bv, epi.partials, epi.counter, gridDim.x, sh, [&](double t) { epi.finalize(t); });
+        }
+    }
+}
 template <class Epi>
 __device__ __forceinline__ void finish_block(const Epi &epi, double racc, double *sh) {
-    if constexpr (Epi::REDUCE) {
-        double bv = block_sum<LSQ_NT>(racc, sh);
-        grid_reduce<LSQ_NT>(bv, epi.partials, epi.counter, gridDim.x, sh,
-                            [&](double t) { epi.finalize(t); });
-    }
+    finish_block_nt<LSQ_NT>(epi, racc, sh);
 }
 
 template <class Epi, bool SQ>
@@ -64,6 +111,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_seg_stream(SegsDev S, const double *
     __shared__ __attribute__((aligned(16))) double prod[LSQ_TILE_WINDOW];
     __shared__ double sh[LSQ_NT / 64];
     if (epi.done && *epi.done) return;
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     const int tid = threadIdx.x;
     const int nwork = S.ntiles + epi.extra_blocks;
     double racc = 0.0;
@@ -175,14 +223,12 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const 
                                                                Epi epi) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sh[LSQ_BIG_NT / 64];
-    if (epi.done && *epi.done) return;
     double *xl = smem;
     double *prod = smem + nxpad;
     const int tid = threadIdx.x;
     const int G = gridDim.x;
     constexpr bool HAS_PRE = EpiHasPre<Epi>::value;
-    if constexpr (EpiHasPrepare<Epi>::value) epi.prepare();
-    const int kmax = (S.ptr[S.nseg] + 3) & ~3;   // arrays are padded by 8 entries
+    const int kmax = (S.nnz + 3) & ~3;   // arrays are padded by 8 entries
     auto load_meta = [&](int tb) {
         int4 mt = meta[tb < nbig ? tb : nbig - 1];
         if (tb >= nbig) mt.y = mt.x;  // dummy tile: no segments
@@ -238,6 +284,9 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const 
         }
         __syncthreads();
     };
+    if (epi.done && *epi.done) return;   // launches queued behind a finished solve stop here
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
+    if constexpr (EpiHasPrepare<Epi>::value) epi.prepare();
     BigTileRegs ra, rb;
     const int b0 = blockIdx.x;
     int4 ma = load_meta(b0), mb = load_meta(b0 + G);
@@ -264,10 +313,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_seg_stream_lds(SegsDev S, const 
     // side work (e.g. the damped rows of LSMR) is laid out for LSQ_NT-thread blocks
     for (int e = blockIdx.x; e < epi.extra_blocks; e += G)
         if (tid < LSQ_NT) epi.extra(e, racc);
-    if constexpr (Epi::REDUCE) {
-        double bv = block_sum<LSQ_BIG_NT>(racc, sh);
-        grid_reduce<LSQ_BIG_NT>(bv, epi.partials, epi.counter, gridDim.x, sh, [&](double t) { epi.finalize(t); });
-    }
+    finish_block_nt<LSQ_BIG_NT>(epi, racc, sh);
 }
 
 // J'*y with the gathered m-vector staged window by window in LDS.  A gather y[row] from global
@@ -296,7 +342,7 @@ k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wti
     double *yl = smem;                       // rw doubles
     double *prod = smem + LSQ_WIN_ROWS_MAX;  // LSQ_BIG_WINDOW doubles
     const int tid = threadIdx.x;
-    const int kmax = (S.ptr[S.nseg] + 3) & ~3;
+    const int kmax = (S.nnz + 3) & ~3;
     const int nbig = wtile[nwin];
     for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
         const int t0 = wtile[w], t1 = wtile[w + 1];
@@ -432,6 +478,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_seg_wave(SegsDev S, const double *__
                                                       int nsegblocks) {
     __shared__ double sh[LSQ_NT / 64];
     if (epi.done && *epi.done) return;
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nwork = nsegblocks + epi.extra_blocks;
     double racc = 0.0;
@@ -455,6 +502,7 @@ template <class Epi, bool SQ>
 __global__ void __launch_bounds__(LSQ_NT) k_seg_block(SegsDev S, const double *__restrict__ x, Epi epi) {
     __shared__ double sh[LSQ_NT / 64];
     if (epi.done && *epi.done) return;
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     const int nwork = S.nseg + epi.extra_blocks;
     double racc = 0.0;
     for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
@@ -470,7 +518,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_seg_block(SegsDev S, const double *_
 }
 
 static inline SegsDev segs_dev(const LsqSegs &s) {
-    return SegsDev{s.d_ptr, s.d_idx, s.d_val, s.d_tiles, s.d_idx16, s.d_order, s.nseg, s.ntiles};
+    return SegsDev{s.d_ptr, s.d_idx, s.d_val, s.d_tiles, s.d_idx16, s.d_order, s.nseg, s.ntiles, (int)s.nnz};
 }
 
 // Launch the plan chosen for `segs`.  Work items = segment blocks + epi.extra_blocks; the grid is
@@ -536,6 +584,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_dense_n(const double *__restrict__ A
                                                      const double *__restrict__ x, Epi epi, int nrowblocks) {
     __shared__ double sh[LSQ_NT / 64];
     if (epi.done && *epi.done) return;
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     const int nwork = nrowblocks + epi.extra_blocks;
     double racc = 0.0;
     for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
@@ -567,6 +616,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_dense_t(const double *__restrict__ A
                                                      const double *__restrict__ y, Epi epi) {
     __shared__ double sh[LSQ_NT / 64];
     if (epi.done && *epi.done) return;
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     const int nwork = n + epi.extra_blocks;
     double racc = 0.0;
     for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
@@ -616,6 +666,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ p
     __shared__ double sh[LSQ_NT / 64];
     __shared__ double grp[LSQ_CMB_GROUPS][LSQ_CMB_COLS + 1];
     if (epi.done && *epi.done) return;
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     const int nwork = ncolblocks + epi.extra_blocks;
     const int cidx = threadIdx.x % LSQ_CMB_COLS, g = threadIdx.x / LSQ_CMB_COLS;
     double racc = 0.0;
