@@ -74,30 +74,12 @@ def main():
     pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=seed, ctx=ctx, inputs=inputs)
     t_setup = time.time() - t0
 
-    # one scalar all-reduce per outer iteration for the sharded (C5) case: sum of ssr over problems,
-    # max of the gradient norms, min of the converged flags -- all in ONE RCCL all-reduce of
-    # world+2 doubles (each rank owns one slot for its max; sums elsewhere).
+    # one scalar all-reduce per outer iteration for the sharded (C5) case (sharding.py): sum of ssr,
+    # max of the gradient norms, all-converged -- ONE RCCL all-reduce of world+2 doubles.
     allreduce = None
     if world > 1:
-        buf = torch.zeros(world + 2, dtype=torch.float64, device="cuda")
-
-        def _ar(vals, count, _user):
-            try:
-                buf.zero_()
-                host = torch.tensor([vals[0], vals[2]], dtype=torch.float64)
-                buf[0:2] = host.to("cuda")
-                buf[2 + rank] = vals[1]
-                dist.all_reduce(buf)
-                h = buf.cpu()
-                vals[0] = float(h[0])
-                vals[1] = float(h[2:].max())
-                vals[2] = 1.0 if float(h[1]) >= world - 0.5 else 0.0
-                return 0
-            except Exception as e:  # pragma: no cover
-                print("allreduce failed:", e, file=sys.stderr)
-                return 1
-
-        allreduce = lsq._lib.ALLREDUCE_CALLBACK(_ar)
+        from lsq_amd import sharding
+        allreduce = sharding.make_allreduce_callback(dist, rank, world, "cuda")
 
     LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
 
@@ -170,6 +152,16 @@ def main():
             "jtu_kernel_avg_ms": avg[1], "jtu_GBps": (bytes_jtu + 16 * n) / (avg[1] * 1e-3) / 1e9 if cnt[1] else None,
             "generic_jv_ms": ms.value, "generic_jv_GBps": bytes_jv / (ms.value * 1e-3) / 1e9,
             "generic_jtu_ms": ms_t.value, "generic_jtu_GBps": bytes_jtu / (ms_t.value * 1e-3) / 1e9}
+
+    # HBM traffic of that kernel comes from rocprofv3 PMC passes (it cannot be read inside this
+    # process): the committed measurement for exactly this workload, if present
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        if tr["config"] == {"m": m, "n": n, "nnz": nnz}:
+            roof["traffic"] = tr["hbm_bytes_per_launch"]
+            roof["traffic_source"] = tr["source"]
+    except Exception:
+        pass
 
     cpu = None
     if not a.no_cpu and a.cpu_steps > 0:

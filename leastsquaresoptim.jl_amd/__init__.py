@@ -8,6 +8,6 @@ from .api import (AllocatedSolver, Cholesky, Context, DeviceMatrix, DeviceVector
                   colsumabs2_, converged, default_context, default_optimizer, default_solver,
                   maxabs, maxabs_projected_gradient, mul_, norm, optimize, optimize_, sumsq, wdot,
                   wnorm)
-from . import synthetic
+from . import sharding, synthetic
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -83,6 +83,7 @@ struct LsqSegs {
     int *d_ptr = nullptr;  // nseg+1
     int *d_idx = nullptr;  // nnz (gather index)
     unsigned short *d_idx16 = nullptr;  // same indices in 16 bits when they fit (LDS-staged kernels: 10 B/nnz)
+    unsigned short *d_col16 = nullptr;  // window-blocked CSC: column of every entry (device-side g! scaling)
     double *d_val = nullptr;
     int plan = LSQ_PLAN_STREAM;
     int ntiles = 0;        // stream plan: number of tiles

@@ -735,6 +735,32 @@ k_scale_bcsc(int nseg, int n, const int *__restrict__ ptr, const double *__restr
     }
 }
 
+// out[k] = A[k] * sfac[col16[k]] with the n scale factors staged in LDS: pure streaming
+// (16-byte value loads/stores, 8-byte index loads), one persistent 1024-thread workgroup per CU.
+__global__ void __launch_bounds__(1024)
+k_scale_lds(long long nnz4, const unsigned short *__restrict__ col16, const double *__restrict__ A,
+            const double *__restrict__ x, int n, double *__restrict__ out) {
+    extern __shared__ double sf[];
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        double t = tanh(x[i]);
+        sf[i] = 1.0 - t * t;
+    }
+    __syncthreads();
+    for (long long q = blockIdx.x * 1024LL + threadIdx.x; q < nnz4; q += (long long)gridDim.x * 1024) {
+        const long long k = 4 * q;  // arrays are padded to a multiple of 4 (+8)
+        const double2 a0 = *reinterpret_cast<const double2 *>(A + k);
+        const double2 a1 = *reinterpret_cast<const double2 *>(A + k + 2);
+        const uint2 c = *reinterpret_cast<const uint2 *>(col16 + k);
+        double2 o0, o1;
+        o0.x = a0.x * sf[c.x & 0xffffu];
+        o0.y = a0.y * sf[c.x >> 16];
+        o1.x = a1.x * sf[c.y & 0xffffu];
+        o1.y = a1.y * sf[c.y >> 16];
+        *reinterpret_cast<double2 *>(out + k) = o0;
+        *reinterpret_cast<double2 *>(out + k + 2) = o1;
+    }
+}
+
 // short segments (LDS-window plan: ~4 entries): one thread per segment
 __global__ void __launch_bounds__(LSQ_NT)
 k_scale_bcsc_thread(int nseg, int n, const int *__restrict__ ptr, const double *__restrict__ A,
@@ -771,14 +797,31 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
         hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, md->d_Acsc, x,
                            J->csc.d_val);
-        hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+        const bool lds_ok = J->n <= 12000 && J->nnz >= (1 << 20);
+        const size_t lds = (size_t)J->n * sizeof(double);
+        static thread_local bool attr = false;
+        if (lds_ok && !attr) {
+            hipFuncSetAttribute((const void *)k_scale_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 12000 * 8);
+            attr = true;
+        }
+        const long long nnz4 = (J->nnz + 3) / 4;
+        if (!(lds_ok && J->csr.d_idx16 && (J->nwin <= 1 || J->bcsc.d_col16)))
+            hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
         long long g2 = std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
-        if (J->nnz > 0)
-            hipLaunchKernelGGL(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
-                               md->d_Acsr, md->d_t, J->csr.d_val);
+        if (J->nnz > 0) {
+            if (lds_ok && J->csr.d_idx16)
+                hipLaunchKernelGGL(k_scale_lds, dim3(c->num_cus), dim3(1024), lds, c->stream, nnz4, J->csr.d_idx16,
+                                   md->d_Acsr, x, J->n, J->csr.d_val);
+            else
+                hipLaunchKernelGGL(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
+                                   md->d_Acsr, md->d_t, J->csr.d_val);
+        }
         if (J->nwin > 1) {
             int nsegs = J->bcsc.nseg;
-            if (J->nnz < 16LL * nsegs) {
+            if (lds_ok && J->bcsc.d_col16) {
+                hipLaunchKernelGGL(k_scale_lds, dim3(c->num_cus), dim3(1024), lds, c->stream, nnz4, J->bcsc.d_col16,
+                                   md->d_Ab, x, J->n, J->bcsc.d_val);
+            } else if (J->nnz < 16LL * nsegs) {
                 int g3 = std::min(lsq_div_up(nsegs, LSQ_NT), c->num_cus * 16);
                 hipLaunchKernelGGL(k_scale_bcsc_thread, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n,
                                    J->bcsc.d_ptr, md->d_Ab, md->d_t, J->bcsc.d_val);

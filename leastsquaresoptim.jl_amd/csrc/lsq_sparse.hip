@@ -124,6 +124,7 @@ static void free_segs(LsqSegs &S) {
     hipFree(S.d_ptr);
     hipFree(S.d_idx);
     hipFree(S.d_idx16);
+    hipFree(S.d_col16);
     hipFree(S.d_val);
     hipFree(S.d_tiles);
     hipFree(S.d_order);
@@ -247,6 +248,13 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
                         LSQ_HIP(hipMalloc(&J->bcsc.d_idx16, i16.size() * sizeof(unsigned short)));
                         LSQ_HIP(hipMemcpy(J->bcsc.d_idx16, i16.data(), i16.size() * sizeof(unsigned short),
                                           hipMemcpyHostToDevice));
+                        if (n <= 65535) {  // column of each entry, for column-scaling g! kernels
+                            for (size_t sg = 0; sg < (size_t)nwin * n; ++sg)
+                                for (int k = bptr[sg]; k < bptr[sg + 1]; ++k) i16[k] = (unsigned short)(sg % n);
+                            LSQ_HIP(hipMalloc(&J->bcsc.d_col16, i16.size() * sizeof(unsigned short)));
+                            LSQ_HIP(hipMemcpy(J->bcsc.d_col16, i16.data(), i16.size() * sizeof(unsigned short),
+                                              hipMemcpyHostToDevice));
+                        }
                     }
                 }
             }
