@@ -184,6 +184,12 @@ int lsq_synth_normal(int n, unsigned long long seed, double *h_out);
 int lsq_bench_mul(lsq_mat *J, int trans, int reps, const double *d_x, double *d_y, double beta,
                   float *h_ms_per_launch);
 
+/* Reference-order arithmetic for small problems (m, n <= 2048, nnz <= 2^18): every sum is taken in
+ * the order of the reference's serial loops, so iteration / mul counts reproduce the CPU
+ * restatement exactly even where LSMR's stop iteration depends on the last bit.
+ * on = 1 / 0 forces it on / off, -1 restores the default (on; env LSQ_EXACT=0 turns it off). */
+int lsq_set_exact(int on);
+
 /* HIP-event instrumentation of the two dominant kernels inside lsq_ldiv(_damped) with LSMR:
  * kernel 0 = K1 (u <- J t - cu u, the J*v product), kernel 1 = K2 (v <- J'u ..., the J'*u product).
  * Events are recorded on the context stream around each launch while enabled (up to max_samples

@@ -6,7 +6,7 @@ from ._lib import (ArgumentError, DimensionMismatch, HipError, IsFiniteException
 from .api import (AllocatedSolver, Cholesky, Context, DeviceMatrix, DeviceVector, Dogleg, LSMR,
                   LeastSquaresProblem, LeastSquaresResult, LevenbergMarquardt, OptimizationState, QR,
                   colsumabs2_, converged, default_context, default_optimizer, default_solver,
-                  maxabs, maxabs_projected_gradient, mul_, norm, optimize, optimize_, sumsq, wdot,
+                  maxabs, maxabs_projected_gradient, mul_, norm, optimize, optimize_, set_exact, sumsq, wdot,
                   wnorm)
 from . import sharding, synthetic
 

@@ -255,6 +255,12 @@ def maxabs_projected_gradient(g, x, lower=None, upper=None):
     return _scalar(lib().lsq_amax_projected, g.ctx, g.n, g.ptr, x.ptr, _ptr(lower), _ptr(upper))
 
 
+def set_exact(on=None):
+    """Reference-order arithmetic for small problems (include/lsqhip.h: lsq_set_exact).
+    True / False force it on / off; None restores the default (on unless LSQ_EXACT=0)."""
+    check(lib().lsq_set_exact(-1 if on is None else (1 if on else 0)))
+
+
 class AllocatedSolver:
     """AbstractAllocatedSolver(nls, optimizer) + ldiv! (the L2 plug point)."""
 

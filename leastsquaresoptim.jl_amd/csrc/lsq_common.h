@@ -222,6 +222,16 @@ __device__ __forceinline__ bool grid_reduce(double block_val, double *partials, 
 static inline unsigned *lsq_ctr(const lsq_ctx *c, int k) { return c->d_counters + (size_t)k * LSQ_CTR_SLOT; }
 static inline int lsq_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// reference-order ("exact") small-problem path, lsq_exact.hip
+constexpr int LSQ_EXACT_MAX_DIM = 2048;
+constexpr long long LSQ_EXACT_MAX_NNZ = 1 << 18;
+bool lsq_small_vec(long long n);
+bool lsq_small_mat(const lsq_mat *J);
+int lsq_exact_product(lsq_mat *J, int trans, const double *x, double *y);   // y = J x / J'x, alpha=1, beta=0
+int lsq_exact_colsumabs2(lsq_mat *J, double *out);
+int lsq_seq_reduce(lsq_ctx *c, int mode, int n, const double *x, const double *y, const double *w, double *d_out);
+int lsq_exact_lm_damp(lsq_ctx *c, int n, const double *colsum, double inv_delta, double *dtd);
+
 // internal entry points shared between translation units
 int lsq_sparse_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);
 int lsq_dense_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);

@@ -156,58 +156,6 @@ struct EpiV {
     __device__ void finalize(double) const {}
 };
 
-// the scalar recurrence of one iteration (lsmr.jl:127-196, :205), on a private copy of the state
-__device__ void lsmr_rotate(LsmrState &s, double alpha, double beta) {
-    const double lambda = 0.0;
-    // lsmr.jl:127-130
-    double alphahat = sqrt(s.alphabar * s.alphabar + lambda * lambda);
-    double chat = s.alphabar / alphahat, shat = lambda / alphahat;
-    // :132-138
-    double rhoold = s.rho;
-    double rho = sqrt(alphahat * alphahat + beta * beta);
-    double c = alphahat / rho, sn = beta / rho;
-    double thetanew = sn * alpha;
-    s.alphabar = c * alpha;
-    // :140-149
-    double rhobarold = s.rhobar, zetaold = s.zeta;
-    double thetabar = s.sbar * rho;
-    double rhotemp = s.cbar * rho;
-    double rhobar = sqrt((s.cbar * rho) * (s.cbar * rho) + thetanew * thetanew);
-    s.cbar = s.cbar * rho / rhobar;
-    s.sbar = thetanew / rhobar;
-    s.zeta = s.cbar * s.zetabar;
-    s.zetabar = -s.sbar * s.zetabar;
-    s.rho = rho;
-    s.rhobar = rhobar;
-    // :152-156 coefficients of the vector updates
-    s.c1 = -thetabar * rho / (rhoold * rhobarold);
-    s.c2 = s.zeta / (rho * rhobar);
-    s.c3 = -thetanew / rho;
-    // :164-184 estimate of ||r||
-    double betaacute = chat * s.betadd, betacheck = -shat * s.betadd;
-    double betahat = c * betaacute;
-    s.betadd = -sn * betaacute;
-    double thetatildeold = s.thetatilde;
-    double rhotildeold = sqrt(s.rhodold * s.rhodold + thetabar * thetabar);
-    double ctildeold = s.rhodold / rhotildeold, stildeold = thetabar / rhotildeold;
-    s.thetatilde = stildeold * rhobar;
-    s.rhodold = ctildeold * rhobar;
-    s.betad = -stildeold * s.betad + ctildeold * betahat;
-    s.tautildeold = (zetaold - thetatildeold * s.tautildeold) / rhotildeold;
-    double taud = (s.zeta - s.thetatilde * s.tautildeold) / s.rhodold;
-    s.d = s.d + betacheck * betacheck;
-    s.normr = sqrt(s.d + (s.betad - taud) * (s.betad - taud) + s.betadd * s.betadd);
-    // :187-189 ||A||
-    s.normA2 = s.normA2 + beta * beta;
-    s.normA = sqrt(s.normA2);
-    s.normA2 = s.normA2 + alpha * alpha;
-    // :192-196 cond(A)
-    s.maxrbar = fmax(s.maxrbar, rhobarold);
-    if (s.iter + 1 > 1) s.minrbar = fmin(s.minrbar, rhobarold);
-    s.condA = fmax(s.maxrbar, rhotemp) / fmin(s.minrbar, rhotemp);
-    s.normAr = fabs(s.zetabar);                      // :205
-}
-
 // ---- K3: alpha, rotations (every block, redundantly and identically), n-vector updates, ||x||,
 //          stopping rules and the commit of the new state (last block) --------------------------
 __global__ void __launch_bounds__(LSQ_NT)
@@ -247,7 +195,7 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
             ns.maxrbar = 0.0; ns.minrbar = 1e100;
             ns.normb = beta; ns.normr = beta; ns.normAr = alpha * beta;
         } else {
-            lsmr_rotate(ns, alpha, beta);
+            lsmr_rotate_inline(ns, alpha, beta);
         }
         ns.cu = beta > 0.0 ? alpha / beta : alpha;         // next K1: u~_new = A v - (alpha/beta) u~
     }
@@ -365,6 +313,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         lsq_set_error("lsmr: solver allocated for %dx%d, Jacobian is %dx%d", s->m, s->n, m, n);
         return LSQ_EDIM;
     }
+    if (lsq_small_mat(J)) return lsq_lsmr_exact_solve(s, J, d_y, d_damp, d_x, nmul);  // reference-order kernel
     static const int lookahead = [] {
         const char *e = getenv("LSQ_LOOKAHEAD");
         int v = e ? atoi(e) : LSQ_LOOKAHEAD_DEFAULT;

@@ -260,14 +260,31 @@ static inline int ngrid(const lsq_ctx *c, long long n) {
     return g < 1 ? 1 : (int)g;
 }
 
+// sum(x^2) -> slot: tree reduction, or the reference's left-to-right order for small problems
+static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, int ctr, double *d_out) {
+    if (exact) return lsq_seq_reduce(c, 1, (int)n, x, nullptr, nullptr, d_out);
+    long long g = (n + LSQ_NT - 1) / LSQ_NT, cap = (long long)c->num_cus * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_sumsq_slot, dim3((int)g), dim3(LSQ_NT), 0, c->stream, n, x, c->d_partials, lsq_ctr(c, ctr), d_out);
+    return LSQ_OK;
+}
+// sum((J d - f)^2) -> slot (f may be null: sum((J d)^2))
+static int predicted_to_slot(lsq_ctx *c, bool exact, lsq_mat *J, const double *d, const double *f, double *scratch,
+                             int ctr, double *d_out);
+static int wdot_to_slot(lsq_ctx *c, bool exact, int n, const double *x, const double *y, const double *w, int ctr,
+                        double *d_out);
+// g = J'f
+static int gradient_into(lsq_ctx *c, bool exact, lsq_mat *J, const double *f, double *g);
+
 struct LoopBuffers {
     lsq_ctx *c;
     int m, n;
     double *dx = nullptr, *dtd = nullptr, *xt = nullptr, *ftrial = nullptr;
-    double *dgn = nullptr, *dgr = nullptr, *grad = nullptr;
+    double *dgn = nullptr, *dgr = nullptr, *grad = nullptr, *fpred = nullptr;
     double *lo = nullptr, *hi = nullptr;
     ~LoopBuffers() {
-        hipFree(dx); hipFree(dtd); hipFree(xt); hipFree(ftrial); hipFree(dgn); hipFree(dgr); hipFree(grad); hipFree(lo);
+        hipFree(dx); hipFree(dtd); hipFree(xt); hipFree(ftrial); hipFree(dgn); hipFree(dgr); hipFree(grad); hipFree(fpred); hipFree(lo);
         hipFree(hi);
     }
 };
@@ -280,6 +297,7 @@ static int alloc_loop(LoopBuffers &b, lsq_ctx *c, int m, int n, const lsq_option
     LSQ_HIP(hipMalloc(&b.xt, nb));
     LSQ_HIP(hipMalloc(&b.ftrial, mb));
     LSQ_HIP(hipMalloc(&b.grad, nb));
+    LSQ_HIP(hipMalloc(&b.fpred, mb));
     LSQ_HIP(hipMemsetAsync(b.dx, 0, nb, c->stream));
     if (dogleg) {
         LSQ_HIP(hipMalloc(&b.dgn, nb));
@@ -295,6 +313,34 @@ static int alloc_loop(LoopBuffers &b, lsq_ctx *c, int m, int n, const lsq_option
     }
     LSQ_HIP(hipStreamSynchronize(c->stream));
     return LSQ_OK;
+}
+
+static int predicted_to_slot(lsq_ctx *c, bool exact, lsq_mat *J, const double *d, const double *f, double *scratch,
+                             int ctr, double *d_out) {
+    if (exact) {
+        LSQ_TRY(lsq_exact_product(J, 0, d, scratch));
+        return lsq_seq_reduce(c, f ? 3 : 1, J->m, scratch, f, nullptr, d_out);
+    }
+    if (f) {
+        EpiPredict ep{nullptr, 0, f, d_out, c->d_partials, lsq_ctr(c, ctr)};
+        return launch_product(J, 0, d, ep);
+    }
+    EpiSumsq es{nullptr, 0, d_out, c->d_partials, lsq_ctr(c, ctr)};
+    return launch_product(J, 0, d, es);
+}
+static int wdot_to_slot(lsq_ctx *c, bool exact, int n, const double *x, const double *y, const double *w, int ctr,
+                        double *d_out) {
+    if (exact) return lsq_seq_reduce(c, 2, n, x, y, w, d_out);
+    int g = lsq_div_up(n > 0 ? n : 1, LSQ_NT), cap = c->num_cus * 8;
+    hipLaunchKernelGGL(k_wdot_slot, dim3(g > cap ? cap : g), dim3(LSQ_NT), 0, c->stream, n, x, y, w, c->d_partials,
+                       lsq_ctr(c, ctr), d_out);
+    return LSQ_OK;
+}
+static int gradient_into(lsq_ctx *c, bool exact, lsq_mat *J, const double *f, double *g) {
+    (void)c;
+    if (exact) return lsq_exact_product(J, 1, f, g);
+    EpiGrad eg{nullptr, 0, g, nullptr, nullptr};
+    return launch_product(J, 1, f, eg);
 }
 
 // utils.jl:7-31: an if/elseif chain -- at most one flag fires
@@ -388,7 +434,8 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double
     bool need_jac = true;
     int iter = 0, nonfinite_at = -1;
     LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
-    const int gn = ngrid(c, n), gm = ngrid(c, m);
+    const int gn = ngrid(c, n);
+    const bool exact = lsq_small_mat(J);  // reference summation order for small problems (lsq_exact.hip)
     int local_done = 0;
     double gssr = ssr, ggr = maxabs_gr;
     long long inner_total = 0;
@@ -416,12 +463,12 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double
         }
         const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
         if (!cs) return LSQ_EHIP;
-        hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
+        if (exact) LSQ_TRY(lsq_exact_lm_damp(c, n, cs, 1.0 / delta, b.dtd));
+        else hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
         {   // :102-104 gradient g = J'f at the pre-step x.  The reference forms it AFTER the solve
             // (into dtd); J and fcur do not change in between, so it is formed once, before the
             // solve, and LSMR's setup product A'b = P.*(J'f)/beta reuses it (saves one pass over J).
-            EpiGrad eg{nullptr, 0, b.grad, nullptr, nullptr};
-            LSQ_TRY(launch_product(J, 1, fcur, eg));
+            LSQ_TRY(gradient_into(c, exact, J, fcur, b.grad));
             hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.grad, x, b.lo, b.hi,
                                c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             mul_calls++;
@@ -437,13 +484,9 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double
         LSQ_HIP(hipGetLastError());
         CB(f(b.ftrial, b.xt, user));                                      // :107
         f_calls++;
-        hipLaunchKernelGGL(k_sumsq_slot, dim3(gm), dim3(LSQ_NT), 0, c->stream, (long long)m, b.ftrial,
-                           c->d_partials, lsq_ctr(c, 7), c->d_slots + SL_TRIAL);          // :111
-        {   // :114-117
-            EpiPredict ep{nullptr, 0, fcur, c->d_slots + SL_PRED, c->d_partials, lsq_ctr(c, 8)};
-            LSQ_TRY(launch_product(J, 0, b.dx, ep));
-            mul_calls++;
-        }
+        LSQ_TRY(sumsq_to_slot(c, exact, m, b.ftrial, 7, c->d_slots + SL_TRIAL));                 // :111
+        LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));   // :114-117
+        mul_calls++;
         LSQ_HIP(hipGetLastError());
         double sl[5];
         LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));   // the one host sync of the outer iteration
@@ -501,7 +544,8 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, do
     double maxabs_gr = INFINITY;
     int iter = 0, nonfinite_at = -1;
     LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
-    const int gn = ngrid(c, n), gm = ngrid(c, m);
+    const int gn = ngrid(c, n);
+    const bool exact = lsq_small_mat(J);
     double gssr = ssr, ggr = maxabs_gr;
     long long inner_total = 0;
     while (iter < o->iterations) {
@@ -533,25 +577,20 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, do
                 double wx = std::sqrt(wx2);
                 if (wx > 0) delta *= wx;
             }
-            EpiGrad eg{nullptr, 0, b.dgr, nullptr, nullptr};              // :99
-            LSQ_TRY(launch_product(J, 1, fcur, eg));
+            LSQ_TRY(gradient_into(c, exact, J, fcur, b.dgr));              // :99
             mul_calls++;
             hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, x, b.lo, b.hi,
                                c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             LSQ_TRY(lsq_ediv(c, n, b.dgr, b.dtd, b.dgr));                 // :105
-            hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, b.dgr, b.dtd,
-                               c->d_partials, lsq_ctr(c, 5), c->d_slots + SL_W0);          // :106
-            EpiSumsq es{nullptr, 0, c->d_slots + SL_SUM, c->d_partials, lsq_ctr(c, 6)};   // :109-111
-            LSQ_TRY(launch_product(J, 0, b.dgr, es));
+            LSQ_TRY(wdot_to_slot(c, exact, n, b.dgr, b.dgr, b.dtd, 5, c->d_slots + SL_W0));     // :106
+            LSQ_TRY(predicted_to_slot(c, exact, J, b.dgr, nullptr, b.fpred, 6, c->d_slots + SL_SUM));  // :109-111
             mul_calls++;
             LSQ_TRY(lsq_fill(c, n, 0.0, b.dgn));
             LSQ_TRY(lsq_ldiv(sv, J, fcur, b.dgn, &ls_iter));              // :115
             mul_calls += ls_iter;
             inner_total += ls_iter / 2;
-            hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgn, b.dgn, b.dtd,
-                               c->d_partials, lsq_ctr(c, 5), c->d_slots + SL_W1);          // :117
-            hipLaunchKernelGGL(k_wdot_slot, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, b.dgn, b.dtd,
-                               c->d_partials, lsq_ctr(c, 5), c->d_slots + SL_W2);          // :134 (used in case 3)
+            LSQ_TRY(wdot_to_slot(c, exact, n, b.dgn, b.dgn, b.dtd, 5, c->d_slots + SL_W1));     // :117
+            LSQ_TRY(wdot_to_slot(c, exact, n, b.dgr, b.dgn, b.dtd, 5, c->d_slots + SL_W2));     // :134 (case 3)
             LSQ_HIP(hipGetLastError());
             double s0[1];
             LSQ_TRY(lsq_read_slots(c, SL_GRAD, 1, s0));
@@ -590,10 +629,8 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, do
         LSQ_HIP(hipGetLastError());
         CB(f(b.ftrial, b.xt, user));                                      // :164
         f_calls++;
-        hipLaunchKernelGGL(k_sumsq_slot, dim3(gm), dim3(LSQ_NT), 0, c->stream, (long long)m, b.ftrial,
-                           c->d_partials, lsq_ctr(c, 7), c->d_slots + SL_TRIAL);
-        EpiPredict ep{nullptr, 0, fcur, c->d_slots + SL_PRED, c->d_partials, lsq_ctr(c, 8)};  // :171-174
-        LSQ_TRY(launch_product(J, 0, b.dx, ep));
+        LSQ_TRY(sumsq_to_slot(c, exact, m, b.ftrial, 7, c->d_slots + SL_TRIAL));
+        LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));  // :171-174
         mul_calls++;
         double sl[4];
         LSQ_TRY(lsq_read_slots(c, SL_DX, 4, sl));

@@ -50,12 +50,69 @@ struct lsq_solver {
     int last_rank = -1;
 };
 
+#ifdef __HIPCC__
+// the scalar recurrence of one iteration (lsmr.jl:127-196, :205), on a private copy of the state
+__device__ inline void lsmr_rotate_inline(LsmrState &s, double alpha, double beta) {
+    const double lambda = 0.0;
+    // lsmr.jl:127-130
+    double alphahat = sqrt(s.alphabar * s.alphabar + lambda * lambda);
+    double chat = s.alphabar / alphahat, shat = lambda / alphahat;
+    // :132-138
+    double rhoold = s.rho;
+    double rho = sqrt(alphahat * alphahat + beta * beta);
+    double c = alphahat / rho, sn = beta / rho;
+    double thetanew = sn * alpha;
+    s.alphabar = c * alpha;
+    // :140-149
+    double rhobarold = s.rhobar, zetaold = s.zeta;
+    double thetabar = s.sbar * rho;
+    double rhotemp = s.cbar * rho;
+    double rhobar = sqrt((s.cbar * rho) * (s.cbar * rho) + thetanew * thetanew);
+    s.cbar = s.cbar * rho / rhobar;
+    s.sbar = thetanew / rhobar;
+    s.zeta = s.cbar * s.zetabar;
+    s.zetabar = -s.sbar * s.zetabar;
+    s.rho = rho;
+    s.rhobar = rhobar;
+    // :152-156 coefficients of the vector updates
+    s.c1 = -thetabar * rho / (rhoold * rhobarold);
+    s.c2 = s.zeta / (rho * rhobar);
+    s.c3 = -thetanew / rho;
+    // :164-184 estimate of ||r||
+    double betaacute = chat * s.betadd, betacheck = -shat * s.betadd;
+    double betahat = c * betaacute;
+    s.betadd = -sn * betaacute;
+    double thetatildeold = s.thetatilde;
+    double rhotildeold = sqrt(s.rhodold * s.rhodold + thetabar * thetabar);
+    double ctildeold = s.rhodold / rhotildeold, stildeold = thetabar / rhotildeold;
+    s.thetatilde = stildeold * rhobar;
+    s.rhodold = ctildeold * rhobar;
+    s.betad = -stildeold * s.betad + ctildeold * betahat;
+    s.tautildeold = (zetaold - thetatildeold * s.tautildeold) / rhotildeold;
+    double taud = (s.zeta - s.thetatilde * s.tautildeold) / s.rhodold;
+    s.d = s.d + betacheck * betacheck;
+    s.normr = sqrt(s.d + (s.betad - taud) * (s.betad - taud) + s.betadd * s.betadd);
+    // :187-189 ||A||
+    s.normA2 = s.normA2 + beta * beta;
+    s.normA = sqrt(s.normA2);
+    s.normA2 = s.normA2 + alpha * alpha;
+    // :192-196 cond(A)
+    s.maxrbar = fmax(s.maxrbar, rhobarold);
+    if (s.iter + 1 > 1) s.minrbar = fmin(s.minrbar, rhobarold);
+    s.condA = fmax(s.maxrbar, rhotemp) / fmin(s.minrbar, rhotemp);
+    s.normAr = fabs(s.zetabar);                      // :205
+}
+
+#endif
+
 // implemented in lsq_lsmr.hip
 int lsq_lsmr_alloc(lsq_solver *s);
 void lsq_lsmr_free(lsq_solver *s);
 // d_Jty (optional): J'*y already formed by the caller (the LM gradient) -- skips the setup product
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
                    const double *d_Jty = nullptr);
+// implemented in lsq_exact.hip (reference-order kernels for small problems)
+int lsq_lsmr_exact_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul);
 // implemented in lsq_dense.hip
 int lsq_dense_solver_alloc(lsq_solver *s);
 void lsq_dense_solver_free(lsq_solver *s);

@@ -420,8 +420,9 @@ int lsq_sparse_colsumabs2(lsq_mat *J, double *out) {
 
 const double *lsq_cached_colsum(lsq_mat *J) {
     if (J->colsum_version != J->version) {
-        int st = J->kind == LSQ_MAT_DENSE ? lsq_dense_colsumabs2(J, J->d_colsum)
-                                          : lsq_sparse_colsumabs2(J, J->d_colsum);
+        int st = lsq_small_mat(J) ? lsq_exact_colsumabs2(J, J->d_colsum)
+                 : J->kind == LSQ_MAT_DENSE ? lsq_dense_colsumabs2(J, J->d_colsum)
+                                            : lsq_sparse_colsumabs2(J, J->d_colsum);
         if (st != LSQ_OK) return nullptr;
         J->colsum_version = J->version;
     }

@@ -289,6 +289,10 @@ static int reduce_to_host(lsq_ctx *c, int n, const double *x, const double *y, c
         *h_out = 0.0;
         return LSQ_OK;
     }
+    if (MODE <= 2 && lsq_small_vec(n)) {  // reference summation order for small vectors (lsq_exact.hip)
+        LSQ_TRY(lsq_seq_reduce(c, MODE, n, x, y, w, c->d_slots + 0));
+        return lsq_read_slots(c, 0, 1, h_out);
+    }
     int grid = ew_grid(c, n);
     hipLaunchKernelGGL(k_reduce<MODE>, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x, y, w, lo, hi,
                        c->d_partials, lsq_ctr(c, 0), c->d_slots + 0);
