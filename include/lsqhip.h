@@ -196,6 +196,9 @@ int lsq_set_exact(int on);
  * per kernel); lsq_prof_end waits for them and returns average milliseconds and sample counts. */
 int lsq_prof_begin(lsq_ctx *ctx, int max_samples);
 int lsq_prof_end(lsq_ctx *ctx, double h_avg_ms[2], int h_count[2]);
+/* average milliseconds between two HIP events recorded back to back with NOTHING in between: the
+ * marker overhead contained in every bracketed interval above (for calibration). */
+int lsq_prof_overhead(lsq_ctx *ctx, int pairs, double *h_ms);
 
 #ifdef __cplusplus
 }

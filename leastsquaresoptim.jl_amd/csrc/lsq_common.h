@@ -54,19 +54,36 @@ struct lsq_ctx {
     unsigned mail_epoch;  // bumps per inner solve; tags mailbox words
     // optional HIP-event instrumentation (lsq_prof_begin/end)
     int prof_max = 0;
+    int prof_pending = -1;               // kernel id whose NEXT launch should carry dispatch timestamps
     std::vector<hipEvent_t> prof_ev[2];  // start/stop pairs per kernel id
 };
 
 // record a start (phase 0) / stop (phase 1) event for kernel `kid` if instrumentation is on
+// phase 0 arms the instrumentation for kernel `kid`: a launch site that supports it (the LDS-staged
+// kernels) then launches with hipExtLaunchKernelGGL(start, stop), whose events carry the DISPATCH's
+// own begin/end timestamps (what rocprofv3 reports) -- no marker packets between kernels.  Launch
+// sites that do not support it are bracketed with ordinary event records instead (phase 1).
 static inline void lsq_prof_mark(lsq_ctx *c, int kid, int phase) {
     if (c->prof_max <= 0) return;
     auto &v = c->prof_ev[kid];
-    if (phase == 0 && (int)v.size() >= 2 * c->prof_max) return;
-    if (phase == 1 && (v.size() & 1) == 0) return;  // start was not recorded
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return;
-    hipEventRecord(e, c->stream);
-    v.push_back(e);
+    if (phase == 0) {
+        if ((int)v.size() >= 2 * c->prof_max) return;
+        c->prof_pending = kid;
+        return;
+    }
+    if (c->prof_pending != kid) return;   // consumed by an ext launch (or never armed)
+    c->prof_pending = -1;                 // not consumed: nothing was timed for this launch
+}
+// used by launch sites: returns true and fills start/stop when the launch should be timed
+static inline bool lsq_prof_take(lsq_ctx *c, hipEvent_t *start, hipEvent_t *stop) {
+    if (c->prof_max <= 0 || c->prof_pending < 0) return false;
+    if (hipEventCreate(start) != hipSuccess) return false;
+    if (hipEventCreate(stop) != hipSuccess) { hipEventDestroy(*start); return false; }
+    auto &v = c->prof_ev[c->prof_pending];
+    v.push_back(*start);
+    v.push_back(*stop);
+    c->prof_pending = -1;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------

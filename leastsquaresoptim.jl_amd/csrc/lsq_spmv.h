@@ -15,6 +15,8 @@
 // squares for the next norm) cost no extra pass over an m- or n-vector.
 // Reductions are two-stage and index-ordered (grid_reduce) => run-to-run deterministic.
 #pragma once
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -546,8 +548,13 @@ static inline int launch_segs(lsq_ctx *ctx, const LsqSegs &segs, const double *x
                 configured[i16] = (const void *)kern;
             }
             int grid = std::max(1, std::min(segs.nbig, ctx->num_cus));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, (const int4 *)segs.d_big, segs.nbig, x,
-                               segs.nx, nxpad, epi);
+            hipEvent_t e0, e1;
+            if (lsq_prof_take(ctx, &e0, &e1))
+                hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, e0, e1, 0, S,
+                                      (const int4 *)segs.d_big, segs.nbig, x, segs.nx, nxpad, epi);
+            else
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, (const int4 *)segs.d_big,
+                                   segs.nbig, x, segs.nx, nxpad, epi);
             break;
         }
         int grid = cap((long long)segs.ntiles + epi.extra_blocks);
@@ -724,9 +731,15 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
                     configured[i16] = true;
                 }
                 int g2 = std::max(1, std::min(J->bcsc.nwin, c->num_cus));
-                hipLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc),
-                                   (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m, x,
-                                   J->d_bpart, epi.done);
+                hipEvent_t e0, e1;
+                if (lsq_prof_take(c, &e0, &e1))
+                    hipExtLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, segs_dev(J->bcsc),
+                                          (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m,
+                                          x, J->d_bpart, epi.done);
+                else
+                    hipLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc),
+                                       (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m, x,
+                                       J->d_bpart, epi.done);
             } else {
                 EpiPart ep{epi.done, 0, J->d_bpart, nullptr, nullptr};
                 LSQ_TRY(launch_segs<false>(c, J->bcsc, x, ep));

@@ -101,6 +101,30 @@ extern "C" int lsq_prof_end(lsq_ctx *c, double avg_ms[2], int count[2]) {
     return LSQ_OK;
 }
 
+__global__ void k_fill(int n, double a, double *__restrict__ x);
+
+extern "C" int lsq_prof_overhead(lsq_ctx *c, int pairs, double *h_ms) {
+    if (pairs < 1) pairs = 1;
+    std::vector<hipEvent_t> ev(2 * pairs);
+    for (auto &e : ev) LSQ_HIP(hipEventCreate(&e));
+    // a small kernel before each pair so the first marker waits for real work, like in the solve
+    for (int i = 0; i < pairs; ++i) {
+        hipLaunchKernelGGL(k_fill, dim3(1), dim3(LSQ_NT), 0, c->stream, 1, 0.0, c->d_slots + LSQ_NSLOTS - 1);
+        LSQ_HIP(hipEventRecord(ev[2 * i], c->stream));
+        LSQ_HIP(hipEventRecord(ev[2 * i + 1], c->stream));
+    }
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (int i = 0; i < pairs; ++i) {
+        float ms = 0.f;
+        LSQ_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms;
+    }
+    for (auto &e : ev) hipEventDestroy(e);
+    *h_ms = tot / pairs;
+    return LSQ_OK;
+}
+
 extern "C" int lsq_ctx_sync(lsq_ctx *c) {
     LSQ_HIP(hipStreamSynchronize(c->stream));
     return LSQ_OK;
