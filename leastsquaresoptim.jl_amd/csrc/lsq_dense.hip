@@ -6,8 +6,12 @@
 #include <cfloat>
 #include <cmath>
 
+#include <cstdlib>
+
 #include "lsq_solver.h"
 #include "lsq_spmv.h"
+
+int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x);  // lsq_dense_mfma.hip
 
 // ---------------------------------------------------------------------------------------------
 // generic dense products
@@ -576,7 +580,18 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
         return LSQ_EARG;
     }
     if (n != s->n || m != s->m) { lsq_set_error("cholesky: size mismatch"); return LSQ_EDIM; }
-    if (n > 0) {
+    if (n >= 128 && d_damp && !getenv("LSQ_NO_MFMA")) {
+        // C2 scale: MFMA SYRK + blocked Cholesky + blocked solves (lsq_dense_mfma.hip)
+        LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
+        LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x));
+        int info = 0;
+        LSQ_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        LSQ_HIP(hipStreamSynchronize(c->stream));
+        if (info != 0) {
+            lsq_set_error("PosDefException: matrix is not positive definite; Cholesky failed at %d", info);
+            return LSQ_ENOTPD;
+        }
+    } else if (n > 0) {
         const int nt = (n + SY_T - 1) / SY_T;
         hipLaunchKernelGGL(k_syrk_upper, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, J->d_dense, m, n,
                            s->d_chol, d_damp);

@@ -1,0 +1,310 @@
+// Dense normal-equation path at C2 scale (dense_cholesky.jl:43-59): fp64-MFMA SYRK for J'J,
+// blocked right-looking Cholesky (64-wide panels: diagonal block factored in LDS, row panel by
+// forward substitution, trailing update on the MFMA kernel again) and blocked triangular solves.
+//
+// v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16), one f64 of A and of B per lane
+//   A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+//   D: 4 f64 per lane, col = lane&15, row = (lane>>4) + 4*reg            (cdna_hip_programming.md §3)
+// Here A = (tile of J)' and B = tile of J, both read from an LDS image [column][k] of J's columns
+// (J is column-major, so a column's k-run is contiguous in global memory and in LDS).
+#include <cfloat>
+#include <cmath>
+
+#include "lsq_solver.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int MT = 64;        // output tile (MT x MT) per 256-thread workgroup; each wave 32 x 32
+constexpr int KC = 32;        // k-rows staged per step
+constexpr int KS = KC + 2;    // LDS row stride in doubles: 68 dwords = 4 banks apart => conflict-free b64 reads
+
+// C(tile bi,bj) (+)= A(:, i-range)' * A(:, j-range) over rows [k_begin, k_end) of A (lda).
+// MODE 0: write the partial tile to W[slice][tile] (split-K, reduced by k_syrk_reduce)
+// MODE 1: C_tile -= product (trailing update of the blocked Cholesky; upper tiles only)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_syrk_mfma(const double *__restrict__ A, int lda, int krows, int ncols, int col0, int kslices, double *__restrict__ W,
+            double *__restrict__ C, int ldc) {
+    __shared__ double sA[MT * KS];
+    __shared__ double sB[MT * KS];
+    const int nt = (ncols + MT - 1) / MT;
+    const int ntiles = nt * (nt + 1) / 2;
+    const int tile = blockIdx.x % ntiles, slice = blockIdx.x / ntiles;
+    int t = tile, bi = 0;
+    while (t >= nt - bi) { t -= nt - bi; ++bi; }
+    const int bj = bi + t;
+    const int i0 = bi * MT, j0 = bj * MT;
+    const int kper = ((krows + kslices - 1) / kslices + KC - 1) / KC * KC;
+    const int kb = slice * kper, ke = min(krows, kb + kper);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;   // this wave's 32x32 quadrant of the tile
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int lc = tid >> 2, lk = (tid & 3) * 8;        // loader: column lc (0..63), 8 consecutive k
+    for (int k0 = kb; k0 < ke; k0 += KC) {
+        {
+            const int ci = i0 + lc, cj = j0 + lc;
+            const double *pa = A + (size_t)(col0 + ci) * lda + k0 + lk;
+            const double *pb = A + (size_t)(col0 + cj) * lda + k0 + lk;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool kin = (k0 + lk + q) < ke;
+                sA[lc * KS + lk + q] = (kin && ci < ncols) ? pa[q] : 0.0;
+                sB[lc * KS + lk + q] = (kin && cj < ncols) ? pb[q] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const int ko = kk + (lane >> 4);
+            const double a0 = sA[(wr + (lane & 15)) * KS + ko];
+            const double a1 = sA[(wr + 16 + (lane & 15)) * KS + ko];
+            const double b0 = sB[(wc + (lane & 15)) * KS + ko];
+            const double b1 = sB[(wc + 16 + (lane & 15)) * KS + ko];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + a * 16 + (lane >> 4) + 4 * r;   // f64 C/D map
+                const int col = wc + b * 16 + (lane & 15);
+                if (MODE == 0) {
+                    W[((size_t)slice * ntiles + tile) * (MT * MT) + (size_t)col * MT + row] = acc[a][b][r];
+                } else {
+                    const int gi = i0 + row, gj = j0 + col;
+                    if (gi < ncols && gj < ncols && gi <= gj)
+                        C[(size_t)(col0 + gj) * ldc + col0 + gi] -= acc[a][b][r];
+                }
+            }
+}
+
+// C(upper) = sum over slices of W, + damp on the diagonal (dense_cholesky.jl:51-53)
+__global__ void __launch_bounds__(256)
+k_syrk_reduce(const double *__restrict__ W, int n, int kslices, const double *__restrict__ damp, double *__restrict__ C) {
+    const int nt = (n + MT - 1) / MT;
+    const int ntiles = nt * (nt + 1) / 2;
+    const int tile = blockIdx.x / 16, part = blockIdx.x % 16;   // 16 workgroups per tile, 256 entries each
+    int t = tile, bi = 0;
+    while (t >= nt - bi) { t -= nt - bi; ++bi; }
+    const int bj = bi + t;
+    {
+        const int e = part * 256 + threadIdx.x;
+        const int row = e % MT, col = e / MT;
+        const int gi = bi * MT + row, gj = bj * MT + col;
+        if (gi < n && gj < n && gi <= gj) {
+            double s = 0.0;
+            for (int sl = 0; sl < kslices; ++sl) s += W[((size_t)sl * ntiles + tile) * (MT * MT) + e];  // fixed order
+            if (gi == gj && damp) s += damp[gi];
+            C[(size_t)gj * n + gi] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// blocked Cholesky, step j0: every workgroup factors the NB x NB diagonal block in LDS (cheap and
+// saves a launch); workgroup 0 writes it back; each workgroup then turns 256 columns of the row
+// panel A(j0:j0+NB, j0+NB:n) into U12 = U11^{-T} A12 by forward substitution (one column per
+// thread, the 64 unknowns in registers, U11 broadcast from LDS).
+// ---------------------------------------------------------------------------------------------
+constexpr int NB = 64;
+// (a) diagonal block: one workgroup, right-looking potf2 on the upper triangle held in LDS
+__global__ void __launch_bounds__(256)
+k_chol_diag(double *__restrict__ C, int n, int j0, int *__restrict__ info) {
+    __shared__ double U[NB][NB + 1];
+    __shared__ double R[NB][NB + 1];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int nb = min(NB, n - j0);
+    if (*info != 0) return;  // an earlier panel failed
+    if (tid == 0) s_fail = 0;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    // One barrier per column: every thread reads the pivot a_jj itself; the trailing update uses
+    // the UNSCALED pivot row, U[i][k] -= U[j][i]*U[j][k]/a_jj, while the scaled row U[j][k]/sqrt(a_jj)
+    // is written to a separate image R (so nobody reads a value that is being rewritten).
+    for (int j = 0; j < nb; ++j) {
+        const double ajj = U[j][j];
+        if (ajj <= 0.0 || isnan(ajj)) {   // uniform: every thread sees the same pivot
+            if (tid == 0) s_fail = j + 1;
+            break;
+        }
+        const double inv = 1.0 / ajj;
+        const double root = sqrt(ajj);
+        if (tid < nb - j) R[j][j + tid] = (tid == 0) ? root : U[j][j + tid] / root;
+        {   // 16 x 16 thread grid over the trailing block, 4 x 4 entries per thread: all LDS reads
+            // are issued before the first use (one latency per column instead of sixteen)
+            const int ti = j + 1 + (tid >> 4), tk = j + 1 + (tid & 15);
+            double ui[4], uk[4], v[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                ui[a] = (ti + 16 * a < nb) ? U[j][ti + 16 * a] * inv : 0.0;
+                uk[a] = (tk + 16 * a < nb) ? U[j][tk + 16 * a] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = ti + 16 * a, k = tk + 16 * b;
+                    v[a][b] = (i < nb && k < nb && i <= k) ? U[i][k] : 0.0;
+                }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = ti + 16 * a, k = tk + 16 * b;
+                    if (i < nb && k < nb && i <= k) U[i][k] = v[a][b] - ui[a] * uk[b];
+                }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) *info = j0 + s_fail;   // PosDefException position (1-based)
+        return;
+    }
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int r = e % nb, cidx = e / nb;
+        if (r <= cidx) C[(size_t)(j0 + cidx) * n + j0 + r] = R[r][cidx];
+    }
+}
+
+// (b) row panel: U12 = U11^{-T} A12.  A workgroup owns 64 columns of A12; the 64 x 64 chunk X and
+// U11 live in LDS; row r of X is finished and its multiples subtracted from the rows below, one
+// barrier per row (thread = (column, row group)).
+__global__ void __launch_bounds__(256)
+k_chol_trsm(double *__restrict__ C, int n, int j0, const int *__restrict__ info) {
+    __shared__ double U[NB][NB + 1];
+    __shared__ double X[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const int nb = min(NB, n - j0);
+    if (*info != 0) return;
+    const int c0 = j0 + nb + blockIdx.x * NB;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
+        X[r][cidx] = (r < nb && c0 + cidx < n) ? C[(size_t)(c0 + cidx) * n + j0 + r] : 0.0;
+    }
+    __syncthreads();
+    const int cc = tid & 63, qg = tid >> 6;
+    for (int r = 0; r < nb; ++r) {
+        const double xr = X[r][cc] / U[r][r];
+        __syncthreads();                       // everyone has read row r before it is overwritten
+        if (qg == 0) X[r][cc] = xr;
+        for (int q = r + 1 + qg; q < nb; q += 4) X[q][cc] -= U[r][q] * xr;
+        __syncthreads();
+    }
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        if (r < nb && c0 + cidx < n) C[(size_t)(c0 + cidx) * n + j0 + r] = X[r][cidx];
+    }
+}
+
+// blocked solves U'z = b then U x = z in ONE workgroup: per 64-block, one wavefront does the
+// triangular part (lane r holds unknown r; shuffles broadcast each solved value), then all
+// threads subtract the block's contribution from the rest of the right-hand side.
+__global__ void __launch_bounds__(1024)
+k_chol_trsv(const double *__restrict__ U, int n, double *__restrict__ b) {
+    __shared__ double zb[NB];
+    __shared__ double D[NB][NB + 1];   // the current diagonal block, D[r][c] = U[j0+r, j0+c]
+    __shared__ double Dinv[NB];        // reciprocals of its diagonal (one division per row, off the serial chain)
+    const int tid = threadIdx.x, lane = tid & 63;
+    auto load_diag = [&](int j0, int nb) {
+        for (int e = tid; e < NB * NB; e += 1024) {
+            const int r = e % NB, cidx = e / NB;
+            D[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? U[(size_t)(j0 + cidx) * n + j0 + r] : 0.0;
+        }
+        if (tid < NB) Dinv[tid] = tid < nb ? 1.0 / U[(size_t)(j0 + tid) * n + j0 + tid] : 0.0;
+        __syncthreads();
+    };
+    // forward: U' z = b   (row r of U' = column r of U: contiguous)
+    for (int j0 = 0; j0 < n; j0 += NB) {
+        const int nb = min(NB, n - j0);
+        load_diag(j0, nb);
+        if (tid < 64) {
+            double v = lane < nb ? b[j0 + lane] : 0.0;
+            for (int r = 0; r < nb; ++r) {
+                const double zr = __shfl(v, r, 64) * Dinv[r];
+                if (lane == r) v = zr;
+                else if (lane > r && lane < nb) v -= D[r][lane] * zr;
+            }
+            if (lane < nb) { b[j0 + lane] = v; zb[lane] = v; }
+        }
+        __syncthreads();
+        for (int i = j0 + nb + tid; i < n; i += 1024) {   // b_i -= sum_r U[j0+r, i] z_r  (column i, rows j0..)
+            const double *ci = U + (size_t)i * n + j0;
+            double s = 0.0;
+            for (int r = 0; r < nb; ++r) s += ci[r] * zb[r];
+            b[i] -= s;
+        }
+        __syncthreads();
+    }
+    // backward: U x = z
+    for (int jb = (n - 1) / NB; jb >= 0; --jb) {
+        const int j0 = jb * NB, nb = min(NB, n - j0);
+        load_diag(j0, nb);
+        if (tid < 64) {
+            double v = lane < nb ? b[j0 + lane] : 0.0;
+            for (int r = nb - 1; r >= 0; --r) {
+                const double xr = __shfl(v, r, 64) * Dinv[r];
+                if (lane == r) v = xr;
+                else if (lane < r) v -= D[lane][r] * xr;
+            }
+            if (lane < nb) { b[j0 + lane] = v; zb[lane] = v; }
+        }
+        __syncthreads();
+        for (int i = tid; i < j0; i += 1024) {            // b_i -= sum_r U[i, j0+r] x_r
+            double s = 0.0;
+            for (int r = 0; r < nb; ++r) s += U[(size_t)(j0 + r) * n + i] * zb[r];
+            b[i] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+// dense_cholesky.jl:43-59 for n >= 128: returns LSQ_ENOTPD through *info like the small kernel
+int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x) {
+    lsq_ctx *c = s->ctx;
+    const int m = J->m, n = J->n;
+    const int nt = (n + MT - 1) / MT, ntiles = nt * (nt + 1) / 2;
+    int kslices = std::max(1, std::min(64, (2 * c->num_cus + ntiles - 1) / ntiles));
+    kslices = std::min(kslices, std::max(1, m / (4 * KC)));
+    const size_t need = (size_t)kslices * ntiles * MT * MT;
+    if (s->work_elems < need) {
+        hipFree(s->d_T);
+        LSQ_HIP(hipMalloc(&s->d_T, need * sizeof(double)));
+        s->work_elems = need;
+    }
+    LSQ_HIP(hipMemsetAsync(s->d_info, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices), dim3(256), 0, c->stream, J->d_dense, m, m, n, 0, kslices,
+                       s->d_T, (double *)nullptr, 0);
+    hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
+    for (int j0 = 0; j0 < n; j0 += NB) {
+        const int nb = std::min(NB, n - j0), rest = n - j0 - nb;
+        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, j0, s->d_info);
+        if (rest > 0) {
+            hipLaunchKernelGGL(k_chol_trsm, dim3((rest + NB - 1) / NB), dim3(256), 0, c->stream, s->d_chol, n, j0,
+                               (const int *)s->d_info);
+            const int nt2 = (rest + MT - 1) / MT;
+            // A22 -= U12' U12 : "A" = rows j0..j0+nb of chol (lda n), columns from j0+nb
+            hipLaunchKernelGGL((k_syrk_mfma<1>), dim3(nt2 * (nt2 + 1) / 2), dim3(256), 0, c->stream, s->d_chol + j0, n, nb,
+                               rest, j0 + nb, 1, (double *)nullptr, s->d_chol, n);
+        }
+    }
+    hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}

@@ -434,3 +434,78 @@ def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big):
         xr = ro.trace["x"][k]
         assert np.max(np.abs(rg.trace["x"][k] - xr)) <= 1e-8 * max(1.0, np.max(np.abs(xr)))
     pr.close()
+
+
+# ----------------------------------------------------------- full BASELINE sizes (C2, C4): properties
+def test_c2_dense_lm_cholesky_full_size(ctx):
+    """C2: dense 4096 x 512, LevenbergMarquardt(Cholesky()) -- MFMA SYRK + blocked Cholesky path.
+    Oracle comparison on the first iterations, then size-independent properties of one ldiv!:
+    the normal equations hold, and the solve is run-to-run bit-identical."""
+    m, n = 4096, 512
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=False, seed=lsq.synthetic.BASE_SEED + 2, ctx=ctx)
+    pr.reset()
+    rg = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.CHOLESKY, trace=True, iterations=3)
+    A = O.Mat(dense=pr.A.reshape((m, n), order="F"))
+    J = O.Mat(dense=np.zeros((m, n)))
+    f, g, ud, keep = O.tanh_model(A, pr.b)
+    ro = O.optimize(O.LM, O.CHOLESKY, J, np.zeros(n), f, g, ud=ud, iterations=3)
+    assert rg.iterations == ro.iterations == 3 and rg.mul_calls == ro.mul_calls
+    assert np.array_equal(rg.trace["accept"], ro.trace["accept"])
+    for k in range(3):
+        assert np.max(np.abs(rg.trace["x"][k] - ro.trace["x"][k])) <= 1e-9 * max(1.0, np.max(np.abs(ro.trace["x"][k])))
+    # one damped solve: (J'J + D) x = J'y to round-off, deterministic
+    Jm = pr.A.reshape((m, n), order="F")
+    Jd = lsq.DeviceMatrix(ctx, Jm)
+    rng = np.random.default_rng(5)
+    y, damp = rng.standard_normal(m), rng.random(n) + 0.1
+    sv = lsq.AllocatedSolver(Jd, lsq.Cholesky(), for_lm=True)
+    xs = []
+    for _ in range(2):
+        xo = lsq.DeviceVector(ctx, n)
+        sv.ldiv_(xo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+        xs.append(xo.get())
+    assert np.array_equal(xs[0], xs[1])
+    res = Jm.T @ (Jm @ xs[0] - y) + damp * xs[0]
+    assert np.max(np.abs(res)) <= 1e-11 * np.max(np.abs(Jm.T @ y))
+    pr.close()
+
+
+def test_c4_sparse_full_size_properties(ctx):
+    """C4: sparse 10^6 x 10^4, nnz = 10^7 -- the kernels the bench times, checked through
+    size-independent properties: linearity and adjointness of the two products
+    (<J x, y> == <x, J'y>), colsumabs2 against the product with unit vectors' squares, run-to-run
+    determinism of a full LM+LSMR solve, and the reference's convergence on the tanh model."""
+    m, n, pc = 1_000_000, 10_000, 1000
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=lsq.synthetic.BASE_SEED, ctx=ctx)
+    L = lsq.lib()
+    rng = np.random.default_rng(1)
+    x1, x2, y1 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(m)
+    # J currently holds zeros: load A's values into it through the model's g! at x = 0 (J = A)
+    pr.reset()
+    r = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, iterations=1, x_tol=0, f_tol=0, g_tol=0)
+    class _J:  # handle wrapper for mul_
+        h = pr.J
+    dx1, dx2, dy1 = (lsq.DeviceVector(ctx, len(v), v) for v in (x1, x2, y1))
+    out = lambda k: lsq.DeviceVector(ctx, k)
+    jx1 = lsq.mul_(out(m), _J, dx1).get()
+    jx2 = lsq.mul_(out(m), _J, dx2).get()
+    jsum = lsq.mul_(out(m), _J, lsq.DeviceVector(ctx, n, 2.0 * x1 - 3.0 * x2)).get()
+    assert np.max(np.abs(jsum - (2 * jx1 - 3 * jx2))) <= 1e-12 * (1 + np.max(np.abs(jsum)))      # linearity
+    jty = lsq.mul_(out(n), _J, dy1, trans=True).get()
+    assert abs(np.dot(jx1, y1) - np.dot(x1, jty)) <= 1e-10 * np.linalg.norm(jx1) * np.linalg.norm(y1)  # adjoint
+    # against the host CSC arrays (J = A .* (1 - tanh(0)^2) = A at the first iteration's x = 0)
+    ref = lsq.synthetic.csc_matvec(m, pr.colptr, pr.rowval, pr.A, x1)
+    assert np.max(np.abs(jx1 - ref)) <= 1e-12 * (1 + np.max(np.abs(ref)))
+    cs = lsq.colsumabs2_(out(n), _J).get()
+    assert np.allclose(cs, np.add.reduceat(pr.A * pr.A, pr.colptr[:-1]), rtol=1e-12)
+    # determinism + convergence of the whole loop
+    runs = []
+    for _ in range(2):
+        pr.reset()
+        rr = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, iterations=30)
+        runs.append((rr.iterations, rr.mul_calls, rr.ssr, rr.minimizer.copy()))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    assert np.array_equal(runs[0][3], runs[1][3])
+    assert rr.converged and rr.iterations <= 10
+    assert np.max(np.abs(rr.minimizer - pr.x_true)) < 0.05      # recovers the planted parameters
+    pr.close()
