@@ -320,7 +320,7 @@ __device__ void laic1_dev(int job, double alpha, double sest, double gamma, doub
 __global__ void __launch_bounds__(QR_NT)
 k_qrcp_solve(double *__restrict__ A, int M, int n, double *__restrict__ b, int lenb, double *__restrict__ x,
              double *__restrict__ ws, int *__restrict__ jp, double *__restrict__ Cz /* n*n scratch */,
-             double rcond, int *__restrict__ rank_out) {
+             double rcond, int *__restrict__ rank_out, int phase /* 1: factor, 2: apply Q' to b; solve always */) {
     __shared__ double sh[QR_NT / 64];
     __shared__ double s_val;
     __shared__ double s_val2;
@@ -330,6 +330,7 @@ k_qrcp_solve(double *__restrict__ A, int M, int n, double *__restrict__ b, int l
     double *vn1 = ws, *vn2 = ws + n, *tau = ws + 2 * n, *wmin = tau + mn, *wmax = wmin + mn;
     double *tz = wmax + mn, *perm = tz + n;
     const double tol3z = sqrt(DBL_EPSILON / 2);
+    if (phase & 1) {
     // column norms
     for (int j = wv; j < n; j += NW) {
         const double *c = A + (size_t)j * M;
@@ -411,6 +412,7 @@ k_qrcp_solve(double *__restrict__ A, int M, int n, double *__restrict__ b, int l
         }
         __syncthreads();
     }
+    }  // phase & 1
     // ---- rank detection (dlaic1), LinearAlgebra.ldiv!(::QRPivoted, B, rcond) [stdlib] ----
     int rnk = 0;
     {
@@ -443,7 +445,7 @@ k_qrcp_solve(double *__restrict__ A, int M, int n, double *__restrict__ b, int l
         __syncthreads();
     }
     // ---- Q'b (dorm2r 'L','T'): H(0), H(1), ... in order ----
-    for (int i = 0; i < mn; ++i) {
+    for (int i = 0; (phase & 2) && i < mn; ++i) {
         const double *ci = A + (size_t)i * M;
         double acc = 0.0;
         for (int k = i + 1 + tid; k < M; k += QR_NT) acc += ci[k] * b[k];
@@ -523,6 +525,127 @@ k_qrcp_solve(double *__restrict__ A, int M, int n, double *__restrict__ b, int l
     for (int k = tid; k < n; k += QR_NT) x[k] = perm[k];
     if (tid == 0) *rank_out = rnk;
     (void)lenb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-CU column-pivoted Householder QR for larger matrices: the dlaqp2 recurrence, one column per
+// step, two launches per step -- (a) pivot choice, column swap and reflector in one workgroup,
+// (b) reflector applied to all trailing columns AND the right-hand side (column index n) with the
+// partial-norm downdate, one wavefront per column.  Same arithmetic as k_qrcp_solve's factor phase.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_qr_norms(const double *__restrict__ A, int M, int n, double *__restrict__ vn1, double *__restrict__ vn2,
+           int *__restrict__ jp) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double *c = A + (size_t)j * M;
+    double acc = 0.0;
+    for (int k = lane; k < M; k += 64) acc += c[k] * c[k];
+    acc = wave_sum(acc);
+    if (lane == 0) { double v = sqrt(acc); vn1[j] = v; vn2[j] = v; jp[j] = j; }
+}
+
+__global__ void __launch_bounds__(QR_NT)
+k_qr_pivot(double *__restrict__ A, int M, int n, int i, double *__restrict__ vn1, double *__restrict__ vn2,
+           int *__restrict__ jp, double *__restrict__ tau) {
+    __shared__ double sh[QR_NT / 64];
+    __shared__ double s_best[QR_NT / 64];
+    __shared__ int s_bidx[QR_NT / 64];
+    __shared__ int s_p;
+    __shared__ double s_tau, s_scale;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // idamax over vn1[i:n): the FIRST maximum
+    double best = -1.0;
+    int bidx = n;
+    for (int j = i + tid; j < n; j += QR_NT) {
+        const double v = vn1[j];
+        if (v > best) { best = v; bidx = j; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) { s_best[wv] = best; s_bidx[wv] = bidx; }
+    __syncthreads();
+    if (tid == 0) {
+        double b = s_best[0];
+        int p = s_bidx[0];
+        for (int w = 1; w < QR_NT / 64; ++w)
+            if (s_best[w] > b || (s_best[w] == b && s_bidx[w] < p)) { b = s_best[w]; p = s_bidx[w]; }
+        s_p = p < n ? p : i;
+    }
+    __syncthreads();
+    const int p = s_p;
+    double *ci = A + (size_t)i * M;
+    if (p != i) {
+        double *cp = A + (size_t)p * M;
+        for (int k = tid; k < M; k += QR_NT) { double t = cp[k]; cp[k] = ci[k]; ci[k] = t; }
+        if (tid == 0) { int t = jp[p]; jp[p] = jp[i]; jp[i] = t; vn1[p] = vn1[i]; vn2[p] = vn2[i]; }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int k = i + 1 + tid; k < M; k += QR_NT) acc += ci[k] * ci[k];
+    const double xn = sqrt(blk_sum_qr(acc, sh));
+    if (tid == 0) {
+        const double alpha = ci[i];
+        if (xn == 0.0) { s_tau = 0.0; s_scale = 0.0; }
+        else {
+            const double beta = -copysign(hypot(alpha, xn), alpha);
+            s_tau = (beta - alpha) / beta;
+            s_scale = 1.0 / (alpha - beta);
+            ci[i] = beta;
+        }
+        tau[i] = s_tau;
+    }
+    __syncthreads();
+    if (s_tau != 0.0) {
+        const double sc = s_scale;
+        for (int k = i + 1 + tid; k < M; k += QR_NT) ci[k] *= sc;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_qr_apply(double *__restrict__ A, int M, int n, int i, double *__restrict__ rhs, const double *__restrict__ tau,
+           double *__restrict__ vn1, double *__restrict__ vn2) {
+    const int lane = threadIdx.x & 63;
+    const int j = i + 1 + blockIdx.x * 4 + (threadIdx.x >> 6);   // j == n: the right-hand side
+    if (j > n) return;
+    const double ti = tau[i];
+    const double *ci = A + (size_t)i * M;
+    double *cj = j < n ? A + (size_t)j * M : rhs;
+    const double tol3z = sqrt(DBL_EPSILON / 2);
+    double cji = cj[i];
+    if (ti != 0.0) {
+        double w = 0.0;
+        for (int k = i + 1 + lane; k < M; k += 64) w += ci[k] * cj[k];
+        w = wave_sum(w);
+        w = __shfl(w, 0, 64) + cji;          // v_i = 1
+        const double tw = ti * w;
+        for (int k = i + 1 + lane; k < M; k += 64) cj[k] -= ci[k] * tw;
+        cji -= tw;
+        if (lane == 0) cj[i] = cji;
+    }
+    if (j >= n) return;
+    const double v1 = vn1[j];
+    if (v1 != 0.0) {
+        const double r = fabs(cji) / v1;
+        const double temp = fmax(1.0 - r * r, 0.0);
+        const double q = v1 / vn2[j];
+        const double temp2 = temp * q * q;
+        if (temp2 <= tol3z) {
+            double nv = 0.0;
+            if (i < M - 1) {
+                double a2 = 0.0;
+                for (int k = i + 1 + lane; k < M; k += 64) a2 += cj[k] * cj[k];
+                a2 = wave_sum(a2);
+                nv = sqrt(__shfl(a2, 0, 64));
+            }
+            if (lane == 0) { vn1[j] = nv; vn2[j] = nv; }
+        } else if (lane == 0) {
+            vn1[j] = v1 * sqrt(temp);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -640,8 +763,23 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
         hipLaunchKernelGGL(k_stack, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, m, n, d_damp, s->d_qr);
         hipLaunchKernelGGL(k_rhs, dim3(lsq_div_up(lu, LSQ_NT)), dim3(LSQ_NT), 0, c->stream, d_y, m, lu, s->d_qu);
         const int mn = std::min(M, n);
-        hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
-                           s->d_work, (int *)s->d_tau, s->d_T, (double)mn * DBL_EPSILON, s->d_info);
+        if (n >= 64 && (long long)M * n >= 65536 && !getenv("LSQ_QR_SMALL")) {
+            // multi-CU column-pivoted Householder (BLAS-2 per column, the rhs rides along as column n)
+            double *ws = s->d_work;
+            double *vn1 = ws, *vn2 = ws + n, *tau = ws + 2 * n;
+            int *jp = (int *)s->d_tau;
+            hipLaunchKernelGGL(k_qr_norms, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, s->d_qr, M, n, vn1, vn2, jp);
+            for (int i = 0; i < mn; ++i) {
+                hipLaunchKernelGGL(k_qr_pivot, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, i, vn1, vn2, jp, tau);
+                hipLaunchKernelGGL(k_qr_apply, dim3(lsq_div_up(n - i, 4)), dim3(256), 0, c->stream, s->d_qr, M, n, i,
+                                   s->d_qu, tau, vn1, vn2);
+            }
+            hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
+                               s->d_work, jp, s->d_T, (double)mn * DBL_EPSILON, s->d_info, 0);
+        } else {
+            hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
+                               s->d_work, (int *)s->d_tau, s->d_T, (double)mn * DBL_EPSILON, s->d_info, 3);
+        }
         LSQ_HIP(hipGetLastError());
     }
     s->last_rank = -1;  // fetched lazily by lsq_solver_info

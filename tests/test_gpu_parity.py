@@ -193,7 +193,8 @@ def test_cholesky_failures(ctx):
 
 
 @pytest.mark.parametrize("m,n,rank", [(40, 10, 10), (12, 12, 12), (30, 12, 7), (9, 6, 5), (20, 8, 1),
-                                      (6, 10, 6), (6, 10, 4), (300, 65, 65)])
+                                      (6, 10, 6), (6, 10, 4), (300, 65, 65), (1100, 130, 130), (900, 100, 37),
+                                      (80, 900, 80)])
 def test_ldiv_qr(ctx, m, n, rank):
     rng = np.random.default_rng(100 + m + n + rank)
     A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n))
@@ -508,4 +509,28 @@ def test_c4_sparse_full_size_properties(ctx):
     assert np.array_equal(runs[0][3], runs[1][3])
     assert rr.converged and rr.iterations <= 10
     assert np.max(np.abs(rr.minimizer - pr.x_true)) < 0.05      # recovers the planted parameters
+    pr.close()
+
+
+def test_c3_dense_dogleg_qr_full_size(ctx):
+    """C3: dense 16384 x 2048, Dogleg(QR()).  The CPU oracle's plain-C pivoted QR needs minutes at
+    this size, so the full-size checks are properties: the QR least-squares solve agrees with
+    LAPACK (numpy lstsq) and satisfies the normal equations, the detected rank is n, and three
+    Dogleg iterations on the tanh model decrease the objective with rho near 1."""
+    m, n = 16384, 2048
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=False, seed=lsq.synthetic.BASE_SEED + 3, ctx=ctx)
+    Jm = pr.A.reshape((m, n), order="F")
+    Jd = lsq.DeviceMatrix(ctx, Jm)
+    y = np.random.default_rng(9).standard_normal(m)
+    sv = lsq.AllocatedSolver(Jd, lsq.QR(), for_lm=False)
+    xo = lsq.DeviceVector(ctx, n)
+    _, nmul = sv.ldiv_(xo, lsq.DeviceVector(ctx, m, y))
+    x = xo.get()
+    assert nmul == 1 and sv.info()["qr_rank"] == n
+    xl = np.linalg.lstsq(Jm, y, rcond=None)[0]
+    assert np.linalg.norm(x - xl) <= 1e-11 * np.linalg.norm(xl)
+    assert np.max(np.abs(Jm.T @ (Jm @ x - y))) <= 1e-11 * np.max(np.abs(Jm.T @ y))
+    pr.reset()
+    r = pr.optimize(lsq._lib.DOGLEG, lsq._lib.QR, iterations=3, trace=True)
+    assert r.iterations == 3 and np.all(np.diff(r.trace["ssr"]) < 0) and np.all(r.trace["accept"] == 1)
     pr.close()
