@@ -38,7 +38,7 @@ bool lsq_small_mat(const lsq_mat *J) {
 
 // ---------------------------------------------------------------------------------------------
 // products: one thread per segment, products accumulated left to right starting from 0.0
-// (== orc_mul / orc_mulT with alpha = 1, beta = 0; SQ: utils.jl:139-151)
+// (== SparseArrays mul! with alpha = 1, beta = 0 [stdlib]; SQ: utils.jl:139-151)
 // ---------------------------------------------------------------------------------------------
 template <bool SQ>
 __global__ void __launch_bounds__(LSQ_NT)
@@ -149,7 +149,7 @@ int lsq_exact_lm_damp(lsq_ctx *c, int n, const double *colsum, double inv_delta,
 
 // ---------------------------------------------------------------------------------------------
 // whole LSMR solve in one workgroup, reference order (lsmr.jl:53-238 through the wrappers of
-// iterative_lsmr.jl:12-122; see oracle/lsq_oracle.c:orc_lsmr for the same sequence on the CPU)
+// iterative_lsmr.jl:12-122; the CPU restatement used by the tests performs the same sequence)
 // ---------------------------------------------------------------------------------------------
 struct ExactMat {
     int dense, m, n;
@@ -199,7 +199,7 @@ k_lsmr_exact(ExactMat M, const double *__restrict__ y, const double *__restrict_
             } else {
                 for (int k = M.cptr[j]; k < M.cptr[j + 1]; ++k) t += M.cval[k] * u[M.ridx[k]];
             }
-            // orc_mulT: x[j] += t * alpha with alpha = 1, after fill (x = 0) or beta = 1 on a zeroed tmp
+            // adjoint mul!: x[j] += t * alpha with alpha = 1, after fill (x = 0) or beta = 1 on a zeroed tmp
             t = 0.0 + t * 1.0;
             if (damped) t = t + 1.0 * ux[j] * dg[j];          // iterative_lsmr.jl:107
             double t2 = t * P[j];                             // :41

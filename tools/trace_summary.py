@@ -17,7 +17,7 @@ print("|---|---|---|---|---|---|---|---|")
 for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
     mn = min(v)
     early = any(t in name for t in ("k_seg_", "k_combine", "k_lsmr_update"))
-    work = [d for d in v if (d > 3 * mn and d > 8.0)] if early and mn < 6.0 else v
+    work = [d for d in v if (d > 3 * mn and d > 8.0)] if early and mn < 8.0 else v
     work = work or v
     print("| `%s` | %d | %.2f | %d | %.2f | %.2f | %.2f | %.1f |" % (
         name[:100], len(v), sum(v) / len(v), len(work), sum(work) / len(work), mn, max(v), 100 * sum(v) / tot))
