@@ -225,6 +225,60 @@ def colsumabs2_(out, J):
     return out
 
 
+# BLAS-1 on device vectors -- exactly what lsmr.jl:30-44 and the optimizer loops ask of a vector type
+def axpy_(a, x, y):
+    """axpy!(a, x, y): y += a*x"""
+    check(lib().lsq_axpy(x.ctx.h, x.n, float(a), x.ptr, y.ptr))
+    return y
+
+
+def rmul_(x, a):
+    """rmul!(x, a)"""
+    check(lib().lsq_scal(x.ctx.h, x.n, float(a), x.ptr))
+    return x
+
+
+def copyto_(dst, src):
+    """copyto!(dst, src)"""
+    check(lib().lsq_copy(src.ctx.h, src.n, src.ptr, dst.ptr))
+    return dst
+
+
+def fill_(x, a):
+    """fill!(x, a)"""
+    check(lib().lsq_fill(x.ctx.h, x.n, float(a), x.ptr))
+    return x
+
+
+def clamp_(x, lo, hi):
+    """clamp!(x, lo, hi)"""
+    check(lib().lsq_clamp(x.ctx.h, x.n, float(lo), float(hi), x.ptr))
+    return x
+
+
+def ediv_(out, x, y):
+    """map!(/, out, x, y)"""
+    check(lib().lsq_ediv(x.ctx.h, x.n, x.ptr, y.ptr, out.ptr))
+    return out
+
+
+def box_clip_(dx, x, lower=None, upper=None):
+    """the step clipping of levenberg_marquardt.jl:89-98 / dogleg.jl:148-160"""
+    check(lib().lsq_box_clip(x.ctx.h, x.n, dx.ptr, x.ptr, _ptr(lower), _ptr(upper)))
+    return dx
+
+
+def vsum(x):
+    return _scalar(lib().lsq_sum, x.ctx, x.n, x.ptr)
+
+
+def first_nonfinite(x):
+    """check_isfinite (utils.jl:70-75): first non-finite index or -1"""
+    r = C.c_int(0)
+    check(lib().lsq_first_nonfinite(x.ctx.h, x.n, x.ptr, C.byref(r)))
+    return r.value
+
+
 def _scalar(fn, ctx, n, *ptrs):
     r = C.c_double(0.0)
     check(fn(ctx.h, n, *ptrs, C.byref(r)))

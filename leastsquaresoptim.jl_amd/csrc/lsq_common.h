@@ -246,6 +246,7 @@ bool lsq_small_vec(long long n);
 bool lsq_small_mat(const lsq_mat *J);
 int lsq_exact_product(lsq_mat *J, int trans, const double *x, double *y);   // y = J x / J'x, alpha=1, beta=0
 int lsq_exact_colsumabs2(lsq_mat *J, double *out);
+int lsq_exact_mul(lsq_mat *J, int trans, double alpha, const double *x, double beta, double *y);
 int lsq_seq_reduce(lsq_ctx *c, int mode, int n, const double *x, const double *y, const double *w, double *d_out);
 int lsq_exact_lm_damp(lsq_ctx *c, int n, const double *colsum, double inv_delta, double *dtd);
 

@@ -70,6 +70,70 @@ k_dense_seq_t(const double *__restrict__ A, int m, int n, const double *__restri
     }
 }
 
+// general mul!(y, J, x, alpha, beta) / mul!(x, J', y, alpha, beta) in the reference's order:
+// SparseArrays scales y by beta (fill for beta == 0), then accumulates nz * (x[col] * alpha) column by
+// column; the adjoint forms the column dot from 0 and adds dot * alpha.
+template <bool TRANS>
+__global__ void __launch_bounds__(LSQ_NT)
+k_seg_seq_ab(int nseg, const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
+             const double *__restrict__ x, double alpha, double beta, double *__restrict__ y) {
+    for (int s = blockIdx.x * LSQ_NT + threadIdx.x; s < nseg; s += gridDim.x * LSQ_NT) {
+        const double y0 = (beta == 0.0) ? 0.0 : (beta == 1.0 ? y[s] : y[s] * beta);
+        if (TRANS) {
+            double t = 0.0;
+            for (int k = ptr[s]; k < ptr[s + 1]; ++k) t += val[k] * x[idx[k]];
+            y[s] = y0 + t * alpha;
+        } else {
+            double acc = y0;
+            for (int k = ptr[s]; k < ptr[s + 1]; ++k) acc += val[k] * (x[idx[k]] * alpha);
+            y[s] = acc;
+        }
+    }
+}
+template <bool TRANS>
+__global__ void __launch_bounds__(LSQ_NT)
+k_dense_seq_ab(const double *__restrict__ A, int m, int n, const double *__restrict__ x, double alpha, double beta,
+               double *__restrict__ y) {
+    const int nseg = TRANS ? n : m;
+    for (int s = blockIdx.x * LSQ_NT + threadIdx.x; s < nseg; s += gridDim.x * LSQ_NT) {
+        const double y0 = (beta == 0.0) ? 0.0 : (beta == 1.0 ? y[s] : y[s] * beta);
+        if (TRANS) {
+            const double *col = A + (size_t)s * m;
+            double t = 0.0;
+            for (int i = 0; i < m; ++i) t += col[i] * x[i];
+            y[s] = y0 + t * alpha;
+        } else {
+            double acc = y0;
+            for (int j = 0; j < n; ++j) acc += A[(size_t)j * m + s] * (x[j] * alpha);
+            y[s] = acc;
+        }
+    }
+}
+int lsq_exact_mul(lsq_mat *J, int trans, double alpha, const double *x, double beta, double *y) {
+    lsq_ctx *c = J->ctx;
+    const int nseg = trans ? J->n : J->m;
+    if (nseg <= 0) return LSQ_OK;
+    const int grid = lsq_div_up(nseg, LSQ_NT);
+    if (J->kind == LSQ_MAT_CSC) {
+        if (!trans) {
+            LSQ_TRY(lsq_ensure_csr(J));
+            hipLaunchKernelGGL((k_seg_seq_ab<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, nseg, J->csr.d_ptr,
+                               J->csr.d_idx, J->csr.d_val, x, alpha, beta, y);
+        } else {
+            hipLaunchKernelGGL((k_seg_seq_ab<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, nseg, J->csc.d_ptr,
+                               J->csc.d_idx, J->csc.d_val, x, alpha, beta, y);
+        }
+    } else if (!trans) {
+        hipLaunchKernelGGL((k_dense_seq_ab<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
+                           alpha, beta, y);
+    } else {
+        hipLaunchKernelGGL((k_dense_seq_ab<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
+                           alpha, beta, y);
+    }
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
 int lsq_exact_product(lsq_mat *J, int trans, const double *x, double *y) {
     lsq_ctx *c = J->ctx;
     const int nseg = trans ? J->n : J->m;

@@ -434,6 +434,7 @@ extern "C" int lsq_mul(lsq_mat *J, int trans, double alpha, const double *x, dou
         lsq_set_error("lsq_mul: null argument");
         return LSQ_EARG;
     }
+    if (lsq_small_mat(J) && x != y) return lsq_exact_mul(J, trans, alpha, x, beta, y);  // reference order
     return J->kind == LSQ_MAT_DENSE ? lsq_dense_mul(J, trans, alpha, x, beta, y)
                                     : lsq_sparse_mul(J, trans, alpha, x, beta, y);
 }

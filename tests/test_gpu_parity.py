@@ -328,6 +328,32 @@ def test_golden_fixtures():
     lsq.set_exact(None)
 
 
+@pytest.mark.parametrize("opt,sol,sparse", GRID)
+def test_operator_level_loops(opt, sol, sparse):
+    """The reference's loops restated over the OPERATOR-level ABI only (loops.py: what the Julia shim
+    runs) against the fused loop-level entry point: identical counts, equal minimisers."""
+    lsq.set_exact(True)
+    for p in P.minpack_all()[:12] + P.minpack_all()[14:]:
+        name, f, g, x0 = p
+        n = len(x0)
+        def mk():
+            if sparse:
+                m_, n_, colptr, rowval = P.full_csc_pattern(n, n)
+                J = sp.csc_matrix((np.zeros(n * n), rowval, colptr), shape=(n, n))
+                g_ = lambda Jm, x: g(Jm.data.reshape((n, n), order="F"), x)
+            else:
+                J, g_ = np.zeros((n, n), order="F"), g
+            return lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(n), f_=f, g_=g_, J=J)
+        r1 = lsq.optimize_(mk(), OPT[opt][0](SOL[sol][0]()))
+        r2 = lsq.optimize_operator_level(mk(), OPT[opt][0](SOL[sol][0]()))
+        key = (P.label(p), opt, sol, sparse)
+        assert (r1.iterations, r1.f_calls, r1.g_calls, r1.mul_calls) == (r2.iterations, r2.f_calls, r2.g_calls, r2.mul_calls), key
+        assert (r1.converged, r1.x_converged, r1.f_converged, r1.g_converged) == \
+               (r2.converged, r2.x_converged, r2.f_converged, r2.g_converged), key
+        assert np.allclose(r1.minimizer, r2.minimizer, rtol=1e-10, atol=1e-12), key
+    lsq.set_exact(None)
+
+
 def test_kat_trajectories():
     """SURVEY 8c KAT-DL / KAT-LM through the HIP path."""
     r = gpu_run(P.readme_rosenbrock(), lsq.Dogleg, lsq.QR(), iterations=2)
