@@ -195,6 +195,9 @@ int lsq_set_exact(int on);
  * Events are recorded on the context stream around each launch while enabled (up to max_samples
  * per kernel); lsq_prof_end waits for them and returns average milliseconds and sample counts. */
 int lsq_prof_begin(lsq_ctx *ctx, int max_samples);
+/* bit k of kernel_mask: instrument kernel k (default 3 = both).  A timed launch costs a few
+ * microseconds of pipeline gaps, so bench.py times only kernel 0 inside the timed region. */
+int lsq_prof_select(lsq_ctx *ctx, int kernel_mask);
 int lsq_prof_end(lsq_ctx *ctx, double h_avg_ms[2], int h_count[2]);
 /* average milliseconds between two HIP events recorded back to back with NOTHING in between: the
  * marker overhead contained in every bracketed interval above (for calibration). */

@@ -128,6 +128,7 @@ def lib():
         "lsq_synth_normal": (i, [i, C.c_ulonglong, c_dp]),
         "lsq_set_exact": (i, [i]),
         "lsq_prof_begin": (i, [vp, i]),
+        "lsq_prof_select": (i, [vp, i]),
         "lsq_prof_end": (i, [vp, c_dp, c_ip]),
         "lsq_prof_overhead": (i, [vp, i, c_dp]),
         "lsq_bench_mul": (i, [vp, i, i, vp, vp, d, C.POINTER(C.c_float)]),

@@ -45,16 +45,21 @@ struct lsq_ctx {
     hipStream_t stream;
     bool own_stream;
     double *d_slots;      // LSQ_NSLOTS device scalars (results of reductions)
-    double *h_slots;      // pinned host mirror
+    double *h_slots;      // pinned + mapped host mirror: [0..NSLOTS) values, [NSLOTS] = sequence word
+    double *d_hslots;     // device address of h_slots
+    unsigned long long slot_seq = 0;
     double *d_partials;   // LSQ_MAX_PARTIALS block partials
     unsigned *d_counters; // LSQ_NSLOTS arrival counters (zero between kernels)
     LsqMailbox *h_mail;   // pinned + mapped
     LsqMailbox *d_mail;   // device address of h_mail
     int num_cus;
     unsigned mail_epoch;  // bumps per inner solve; tags mailbox words
+    void *workspace = nullptr;  // cached LsqWorkspace of lsq_optimize (lsq_optimize.hip)
     // optional HIP-event instrumentation (lsq_prof_begin/end)
     int prof_max = 0;
     int prof_pending = -1;               // kernel id whose NEXT launch should carry dispatch timestamps
+    int prof_kernels = 3;                // bit k: instrument kernel k (a timed launch costs ~9 us of gaps)
+    int prof_stride = 1, prof_tick = 0;  // time every prof_stride-th armed launch
     std::vector<hipEvent_t> prof_ev[2];  // start/stop pairs per kernel id
 };
 
@@ -68,6 +73,7 @@ static inline void lsq_prof_mark(lsq_ctx *c, int kid, int phase) {
     auto &v = c->prof_ev[kid];
     if (phase == 0) {
         if ((int)v.size() >= 2 * c->prof_max) return;
+        if ((c->prof_tick++ % c->prof_stride) != 0) return;
         c->prof_pending = kid;
         return;
     }
@@ -249,6 +255,8 @@ int lsq_exact_colsumabs2(lsq_mat *J, double *out);
 int lsq_exact_mul(lsq_mat *J, int trans, double alpha, const double *x, double beta, double *y);
 int lsq_seq_reduce(lsq_ctx *c, int mode, int n, const double *x, const double *y, const double *w, double *d_out);
 int lsq_exact_lm_damp(lsq_ctx *c, int n, const double *colsum, double inv_delta, double *dtd);
+
+void lsq_workspace_free(void *workspace);
 
 // internal entry points shared between translation units
 int lsq_sparse_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);

@@ -371,6 +371,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     int enq = 0, it = 0, istop = 0;
     bool finished = false;
     const size_t prof_base[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
+    std::vector<int> prof_iter[2];   // iteration number of every timed launch of this solve
     unsigned long long spins = 0;
     while (!finished) {
         unsigned long long w = *(volatile unsigned long long *)c->h_mail;
@@ -383,16 +384,24 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             }
         }
         if (enq - it < lookahead && enq < maxiter) {
-            lsq_prof_mark(c, 0, 0);
-            LSQ_TRY(launch_product(J, 0, s->d_t, eu));   // K1
-            lsq_prof_mark(c, 0, 1);
+            if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 0);
+            {
+                const size_t before = c->prof_ev[0].size();
+                LSQ_TRY(launch_product(J, 0, s->d_t, eu));   // K1
+                if (c->prof_ev[0].size() > before) prof_iter[0].push_back(enq + 1);
+            }
+            if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 1);
             eu.uold = s->d_u;                            // after the first iteration u~ lives in d_u
             const int cur = enq & 1;                     // px buffer holding this iteration's sum(u~x^2)
             ev.px = damped ? pxb[cur] : nullptr;
             ev.npx = npxb[cur];
-            lsq_prof_mark(c, 1, 0);
-            LSQ_TRY(launch_product(J, 1, s->d_u, ev));   // K2
-            lsq_prof_mark(c, 1, 1);
+            if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 0);
+            {
+                const size_t before = c->prof_ev[1].size();
+                LSQ_TRY(launch_product(J, 1, s->d_u, ev));   // K2
+                if (c->prof_ev[1].size() > before) prof_iter[1].push_back(enq + 1);
+            }
+            if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 1);
             hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu,
                                pv, npv, (const double *)(damped ? pxb[cur] : nullptr), (const int *)npxb[cur],
                                pxb[cur ^ 1], npxb[cur ^ 1], dgk, s->d_ux, s->d_P, s->d_v, s->d_h, s->d_hbar, xs,
@@ -424,10 +433,13 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     // instruction -- drop their samples so the reported average is over working launches only
     for (int k = 0; k < 2; ++k) {
         auto &v = c->prof_ev[k];
-        const size_t keep = prof_base[k] + 2 * (size_t)it;
-        while (v.size() > keep && v.size() > prof_base[k]) {
+        // sample j of this solve (j = 0, 1, ...) belongs to iteration prof_iter[k][j] (1-based)
+        while (v.size() > prof_base[k] && !prof_iter[k].empty() && prof_iter[k].back() > it) {
             hipEventDestroy(v.back());
             v.pop_back();
+            hipEventDestroy(v.back());
+            v.pop_back();
+            prof_iter[k].pop_back();
         }
     }
     hipLaunchKernelGGL(k_lsmr_finish, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, s->d_P, xs, d_x);

@@ -289,6 +289,23 @@ struct LoopBuffers {
     }
 };
 
+// LeastSquaresProblemAllocated (types.jl:141-160): optimizer and solver buffers are allocated once
+// and reused by later optimize! calls on the same problem -- cached in the context.
+struct LsqWorkspace {
+    lsq_mat *J = nullptr;
+    int m = 0, n = 0, optimizer = -1, solver_kind = -1;
+    bool has_lo = false, has_hi = false;
+    LoopBuffers *buf = nullptr;
+    lsq_solver *solver = nullptr;
+};
+void lsq_workspace_free(void *p) {
+    LsqWorkspace *w = (LsqWorkspace *)p;
+    if (!w) return;
+    delete w->buf;
+    if (w->solver) lsq_solver_destroy(w->solver);
+    delete w;
+}
+
 static int alloc_loop(LoopBuffers &b, lsq_ctx *c, int m, int n, const lsq_options *o, bool dogleg) {
     b.c = c; b.m = m; b.n = n;
     size_t nb = (size_t)(n > 0 ? n : 1) * sizeof(double), mb = (size_t)(m > 0 ? m : 1) * sizeof(double);
@@ -417,11 +434,9 @@ static int call_g(lsq_g_callback g, lsq_mat *J, const double *x, void *user) {
 // ---------------------------------------------------------------------------------------------
 // levenberg_marquardt.jl:39-144
 // ---------------------------------------------------------------------------------------------
-static int optimize_lm(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double *fcur, lsq_f_callback f,
+static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x, double *fcur, lsq_f_callback f,
                        lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
     const int m = J->m, n = J->n;
-    LoopBuffers b;
-    LSQ_TRY(alloc_loop(b, c, m, n, o, false));
     double delta = o->delta > 0 ? o->delta : 10.0;
     double decrease_factor = 2.0;
     int f_calls = 0, g_calls = 0, mul_calls = 0, xc = 0, fc = 0, gc = 0;
@@ -528,11 +543,9 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double
 // ---------------------------------------------------------------------------------------------
 // dogleg.jl:41-203
 // ---------------------------------------------------------------------------------------------
-static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, lsq_mat *J, double *x, double *fcur, lsq_f_callback f,
-                           lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
+static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x, double *fcur,
+                           lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
     const int m = J->m, n = J->n;
-    LoopBuffers b;
-    LSQ_TRY(alloc_loop(b, c, m, n, o, true));
     double delta = o->delta > 0 ? o->delta : 1.0;
     bool reuse = false, converged = false;
     double wnorm_dgn = 0.0, wnorm_dgr = 0.0, alpha = 0.0, wdot_gr_gn = 0.0;
@@ -685,19 +698,43 @@ extern "C" int lsq_optimize(lsq_ctx *c, int optimizer, int solver_kind, lsq_mat 
             return st;
         }
     }
-    lsq_solver *sv = nullptr;
-    int st = lsq_solver_create(c, J, solver_kind, optimizer == LSQ_LEVENBERG_MARQUARDT, &sv);
-    if (st != LSQ_OK) {
-        res->status = st;
-        return st;
+    // allocated-problem cache: same Jacobian handle, shape, optimizer and solver => reuse everything
+    LsqWorkspace *w = (LsqWorkspace *)c->workspace;
+    const bool lm = optimizer == LSQ_LEVENBERG_MARQUARDT;
+    if (!(w && w->J == J && w->m == J->m && w->n == J->n && w->optimizer == optimizer && w->solver_kind == solver_kind &&
+          w->has_lo == (opt->h_lower != nullptr) && w->has_hi == (opt->h_upper != nullptr))) {
+        lsq_workspace_free(w);
+        c->workspace = nullptr;
+        w = new LsqWorkspace();
+        int st0 = lsq_solver_create(c, J, solver_kind, lm, &w->solver);
+        if (st0 != LSQ_OK) {
+            delete w;
+            res->status = st0;
+            return st0;
+        }
+        w->buf = new LoopBuffers();
+        st0 = alloc_loop(*w->buf, c, J->m, J->n, opt, !lm);
+        if (st0 != LSQ_OK) {
+            lsq_workspace_free(w);
+            res->status = st0;
+            return st0;
+        }
+        w->J = J; w->m = J->m; w->n = J->n; w->optimizer = optimizer; w->solver_kind = solver_kind;
+        w->has_lo = opt->h_lower != nullptr; w->has_hi = opt->h_upper != nullptr;
+        c->workspace = w;
+    } else {
+        const size_t nb = (size_t)(J->n > 0 ? J->n : 1) * sizeof(double);
+        LSQ_HIP(hipMemsetAsync(w->buf->dx, 0, nb, c->stream));
+        if (opt->h_lower) LSQ_HIP(hipMemcpyAsync(w->buf->lo, opt->h_lower, nb, hipMemcpyHostToDevice, c->stream));
+        if (opt->h_upper) LSQ_HIP(hipMemcpyAsync(w->buf->hi, opt->h_upper, nb, hipMemcpyHostToDevice, c->stream));
+        if (opt->h_lower || opt->h_upper) LSQ_HIP(hipStreamSynchronize(c->stream));
     }
     auto t0 = std::chrono::steady_clock::now();
-    st = (optimizer == LSQ_LEVENBERG_MARQUARDT) ? optimize_lm(c, sv, J, x, fcur, f, g, user, opt, res)
-                                                : optimize_dogleg(c, sv, J, x, fcur, f, g, user, opt, res);
+    int st = lm ? optimize_lm(c, w->solver, *w->buf, J, x, fcur, f, g, user, opt, res)
+                : optimize_dogleg(c, w->solver, *w->buf, J, x, fcur, f, g, user, opt, res);
     hipStreamSynchronize(c->stream);
     res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     res->status = st;
-    lsq_solver_destroy(sv);
     return st;
 }
 

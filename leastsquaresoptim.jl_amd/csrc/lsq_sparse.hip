@@ -289,6 +289,10 @@ extern "C" int lsq_dense_create(lsq_ctx *c, int m, int n, lsq_mat **out) {
 extern "C" int lsq_mat_destroy(lsq_mat *J) {
     if (!J) return LSQ_OK;
     hipStreamSynchronize(J->ctx->stream);
+    if (J->ctx->workspace && *(lsq_mat **)J->ctx->workspace == J) {  // LsqWorkspace::J is its first member
+        lsq_workspace_free(J->ctx->workspace);
+        J->ctx->workspace = nullptr;
+    }
     hipFree(J->d_dense);
     free_segs(J->csc);
     free_segs(J->csr);

@@ -41,7 +41,10 @@ extern "C" int lsq_ctx_create(int device, void *stream, lsq_ctx **out) {
     }
     LSQ_HIP(hipMalloc(&c->d_slots, LSQ_NSLOTS * sizeof(double)));
     LSQ_HIP(hipMemset(c->d_slots, 0, LSQ_NSLOTS * sizeof(double)));
-    LSQ_HIP(hipHostMalloc(&c->h_slots, LSQ_NSLOTS * sizeof(double), hipHostMallocDefault));
+    LSQ_HIP(hipHostMalloc((void **)&c->h_slots, (LSQ_NSLOTS + 1) * sizeof(double),
+                          hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_slots, 0, (LSQ_NSLOTS + 1) * sizeof(double));
+    LSQ_HIP(hipHostGetDevicePointer((void **)&c->d_hslots, c->h_slots, 0));
     LSQ_HIP(hipMalloc(&c->d_partials, LSQ_MAX_PARTIALS * sizeof(double)));
     LSQ_HIP(hipMalloc(&c->d_counters, (size_t)LSQ_NSLOTS * LSQ_CTR_SLOT * sizeof(unsigned)));
     LSQ_HIP(hipMemset(c->d_counters, 0, (size_t)LSQ_NSLOTS * LSQ_CTR_SLOT * sizeof(unsigned)));
@@ -60,6 +63,8 @@ extern "C" int lsq_ctx_create(int device, void *stream, lsq_ctx **out) {
 extern "C" int lsq_ctx_destroy(lsq_ctx *c) {
     if (!c) return LSQ_OK;
     hipStreamSynchronize(c->stream);
+    lsq_workspace_free(c->workspace);
+    c->workspace = nullptr;
     hipFree(c->d_slots);
     hipHostFree(c->h_slots);
     hipFree(c->d_partials);
@@ -76,6 +81,13 @@ extern "C" int lsq_prof_begin(lsq_ctx *c, int max_samples) {
         c->prof_ev[k].clear();
     }
     c->prof_max = max_samples;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_prof_select(lsq_ctx *c, int kernel_mask) {
+    c->prof_kernels = kernel_mask & 0xff;
+    c->prof_stride = (kernel_mask >> 8) > 0 ? (kernel_mask >> 8) : 1;   // bits 8..: time every k-th launch
+    c->prof_tick = 0;
     return LSQ_OK;
 }
 
@@ -154,17 +166,65 @@ extern "C" int lsq_d2h(lsq_ctx *c, void *dst, const void *src, size_t bytes) {
     LSQ_HIP(hipStreamSynchronize(c->stream));
     return LSQ_OK;
 }
+// device-to-device copies run as an ordinary kernel: two back-to-back hipMemcpyAsync D2D calls were
+// measured to leave a ~60 us hole in the stream between them (runtime-side staging), which cost the
+// LM loop ~75 us per accepted step.
+__global__ void __launch_bounds__(LSQ_NT) k_copy16(size_t n16, const double2 *__restrict__ src, double2 *__restrict__ dst) {
+    for (size_t i = blockIdx.x * (size_t)LSQ_NT + threadIdx.x; i < n16; i += (size_t)gridDim.x * LSQ_NT) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(LSQ_NT) k_copy8(size_t n8, const double *__restrict__ src, double *__restrict__ dst) {
+    for (size_t i = blockIdx.x * (size_t)LSQ_NT + threadIdx.x; i < n8; i += (size_t)gridDim.x * LSQ_NT) dst[i] = src[i];
+}
+
 extern "C" int lsq_d2d(lsq_ctx *c, void *dst, const void *src, size_t bytes) {
-    if (!bytes) return LSQ_OK;
-    LSQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (!bytes || dst == src) return LSQ_OK;
+    const bool a16 = (((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0;
+    const bool a8 = (((uintptr_t)dst | (uintptr_t)src | bytes) & 7) == 0;
+    if (a16) {
+        size_t n = bytes / 16;
+        size_t g = (n + LSQ_NT - 1) / LSQ_NT, cap = (size_t)c->num_cus * 8;
+        hipLaunchKernelGGL(k_copy16, dim3((unsigned)(g > cap ? cap : g)), dim3(LSQ_NT), 0, c->stream, n,
+                           (const double2 *)src, (double2 *)dst);
+    } else if (a8) {
+        size_t n = bytes / 8;
+        size_t g = (n + LSQ_NT - 1) / LSQ_NT, cap = (size_t)c->num_cus * 8;
+        hipLaunchKernelGGL(k_copy8, dim3((unsigned)(g > cap ? cap : g)), dim3(LSQ_NT), 0, c->stream, n,
+                           (const double *)src, (double *)dst);
+    } else {
+        LSQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 
+// Device scalars -> host without hipStreamSynchronize (whose interrupt-driven wake-up costs ~50 us
+// per outer iteration): a one-thread kernel stores the values into pinned, mapped host memory and
+// then a sequence word (system-scope release); the host spins on the sequence word.
+__global__ void k_publish_slots(const double *__restrict__ src, int count, double *dst, unsigned long long *seq_word,
+                                unsigned long long seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < count; ++i)
+            __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 int lsq_read_slots(lsq_ctx *c, int first, int count, double *h_out) {
-    LSQ_HIP(hipMemcpyAsync(c->h_slots + first, c->d_slots + first, count * sizeof(double),
-                           hipMemcpyDeviceToHost, c->stream));
-    LSQ_HIP(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < count; ++i) h_out[i] = c->h_slots[first + i];
+    const unsigned long long seq = ++c->slot_seq;
+    volatile unsigned long long *hw = (volatile unsigned long long *)(c->h_slots + LSQ_NSLOTS);
+    hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(64), 0, c->stream, c->d_slots + first, count,
+                       c->d_hslots + first, (unsigned long long *)(c->d_hslots + LSQ_NSLOTS), seq);
+    LSQ_HIP(hipGetLastError());
+    unsigned long long spins = 0;
+    while (*hw != seq) {
+        if ((++spins & 0xfffffu) == 0 && hipStreamQuery(c->stream) == hipSuccess && *hw != seq) {
+            // stream drained but the word is not visible (should not happen with coherent host memory)
+            LSQ_HIP(hipMemcpy(c->h_slots + first, c->d_slots + first, count * sizeof(double), hipMemcpyDeviceToHost));
+            break;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < count; ++i) h_out[i] = ((volatile double *)c->h_slots)[first + i];
     return LSQ_OK;
 }
 

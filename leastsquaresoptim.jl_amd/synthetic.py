@@ -96,7 +96,7 @@ class TanhProblem:
         self.x.set(np.zeros(self.n) if x0 is None else x0)
 
     def optimize(self, optimizer_kind, solver_kind, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iterations=1000,
-                 delta=None, trace=False, allreduce=None):
+                 delta=None, trace=False, allreduce=None, fetch_x=True):
         L = lib()
 
         class _H:  # minimal handle wrappers for _run_native
@@ -117,7 +117,7 @@ class TanhProblem:
         r.f_calls, r.g_calls, r.mul_calls = res.f_calls, res.g_calls, res.mul_calls
         r.seconds, r.lsmr_iterations = res.seconds, int(res.lsmr_iterations)
         r.trace = tr
-        r.minimizer = self.x.get()
+        r.minimizer = self.x.get() if fetch_x else None
         return r
 
     def close(self):

@@ -463,6 +463,35 @@ def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big):
     pr.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt,sol,sparse", [("lm", "lsmr", True), ("dogleg", "lsmr", True), ("lm", "cholesky", False),
+                                            ("dogleg", "qr", False)])
+def test_allocated_workspace_reuse_is_stateless(ctx, opt, sol, sparse):
+    """types.jl:141-160: an allocated problem may be optimised repeatedly.  The library keeps the
+    optimizer/solver buffers of the last (J, optimizer, solver) in the context; a second solve from
+    the same start must be bit-identical to the first, and a different problem in between must
+    invalidate the cache."""
+    m, n, per_col = (20000, 200, 100) if sparse else (1500, 48, None)
+    okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
+    skind = {"lsmr": lsq._lib.LSMR, "cholesky": lsq._lib.CHOLESKY, "qr": lsq._lib.QR}[sol]
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=sparse, per_col=per_col, seed=11, ctx=ctx)
+    other = lsq.synthetic.TanhProblem(m // 2, n, sparse=sparse, per_col=(per_col // 2 if sparse else None), seed=12, ctx=ctx)
+    runs = []
+    for k in range(3):
+        pr.reset()
+        r = pr.optimize(okind, skind, trace=True, iterations=30)
+        runs.append(r)
+        if k == 1:                      # evict the cached workspace
+            other.reset()
+            other.optimize(okind, skind, iterations=3)
+    for r in runs[1:]:
+        assert r.iterations == runs[0].iterations and r.mul_calls == runs[0].mul_calls
+        assert r.ssr == runs[0].ssr and np.array_equal(r.minimizer, runs[0].minimizer)
+        assert np.array_equal(r.trace["inner"], runs[0].trace["inner"])
+    other.close()
+    pr.close()
+
+
 # ----------------------------------------------------------- full BASELINE sizes (C2, C4): properties
 def test_c2_dense_lm_cholesky_full_size(ctx):
     """C2: dense 4096 x 512, LevenbergMarquardt(Cholesky()) -- MFMA SYRK + blocked Cholesky path.
