@@ -132,6 +132,7 @@ struct lsq_mat {
     LsqSegs csr;           // rows; d_val refreshed from csc.d_val through d_map
     int *d_map = nullptr;  // csr position -> csc position
     bool csr_fresh = false;
+    bool csc_fresh = true;  // false: a device g! wrote the mirrors only (see lsq_ensure_csc)
     // Row-window-blocked CSC for J'*y when the gathered m-vector outgrows an XCD's L2 (4 MiB):
     // rows are cut into `nwin` windows; segment (w, j) holds column j's entries with rows in
     // window w, so all gathers of a window hit a <= 1 MiB slice of y that stays L2-resident on
@@ -264,6 +265,9 @@ int lsq_dense_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double
 int lsq_dense_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_sparse_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_ensure_csr(lsq_mat *J);
+int lsq_ensure_csc(lsq_mat *J);
+bool lsq_can_fuse_grad_colsum(const lsq_mat *J);
+int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g);  // g = J'f, fills the colsum cache
 int lsq_permute_to_csr(lsq_mat *J, const double *d_csc_vals, double *d_csr_vals);
 int lsq_permute_to_bcsc(lsq_mat *J, const double *d_csc_vals, double *d_bcsc_vals);
 const double *lsq_cached_colsum(lsq_mat *J);  // nullptr on failure (error set)

@@ -476,6 +476,12 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
             g_calls++;
             need_jac = false;
         }
+        // a fresh Jacobian needs colsumabs2 (:82) and J'f (:102): one pass over J gives both
+        bool have_grad = false;
+        if (!exact && J->colsum_version != J->version && lsq_can_fuse_grad_colsum(J)) {
+            LSQ_TRY(lsq_sparse_grad_colsum(J, fcur, b.grad));
+            have_grad = true;
+        }
         const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
         if (!cs) return LSQ_EHIP;
         if (exact) LSQ_TRY(lsq_exact_lm_damp(c, n, cs, 1.0 / delta, b.dtd));
@@ -483,7 +489,7 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
         {   // :102-104 gradient g = J'f at the pre-step x.  The reference forms it AFTER the solve
             // (into dtd); J and fcur do not change in between, so it is formed once, before the
             // solve, and LSMR's setup product A'b = P.*(J'f)/beta reuses it (saves one pass over J).
-            LSQ_TRY(gradient_into(c, exact, J, fcur, b.grad));
+            if (!have_grad) LSQ_TRY(gradient_into(c, exact, J, fcur, b.grad));
             hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.grad, x, b.lo, b.hi,
                                c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             mul_calls++;
@@ -581,6 +587,11 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
         if (!reuse) {
             LSQ_TRY(call_g(g, J, x, user));                               // :83
             g_calls++;
+            bool have_grad = false;   // colsumabs2 (:85) and J'f (:99) from one pass over J
+            if (!exact && J->colsum_version != J->version && lsq_can_fuse_grad_colsum(J)) {
+                LSQ_TRY(lsq_sparse_grad_colsum(J, fcur, b.dgr));
+                have_grad = true;
+            }
             const double *cs = lsq_cached_colsum(J);                      // :85
             if (!cs) return LSQ_EHIP;
             hipLaunchKernelGGL(k_dl_scale, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, cs, b.dtd);  // :90
@@ -590,7 +601,7 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
                 double wx = std::sqrt(wx2);
                 if (wx > 0) delta *= wx;
             }
-            LSQ_TRY(gradient_into(c, exact, J, fcur, b.dgr));              // :99
+            if (!have_grad) LSQ_TRY(gradient_into(c, exact, J, fcur, b.dgr));  // :99
             mul_calls++;
             hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, x, b.lo, b.hi,
                                c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
@@ -868,10 +879,16 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
     if (J->kind == LSQ_MAT_CSC) {
-        int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
-        hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, md->d_Acsc, x,
-                           J->csc.d_val);
         const bool lds_ok = J->n <= 12000 && J->nnz >= (1 << 20);
+        // big problems: every product (and colsumabs2) reads the CSR / window-blocked mirrors, so
+        // only those are written; the CSC-ordered copy is rebuilt on demand (lsq_ensure_csc)
+        const bool lazy_csc = lds_ok && J->csr.d_idx16 && J->nwin > 1 && J->bcsc.d_col16 && lsq_can_fuse_grad_colsum(J);
+        if (!lazy_csc) {
+            int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
+            hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, md->d_Acsc,
+                               x, J->csc.d_val);
+        }
+        J->csc_fresh = !lazy_csc;
         const size_t lds = (size_t)J->n * sizeof(double);
         static thread_local bool attr = false;
         if (lds_ok && !attr) {

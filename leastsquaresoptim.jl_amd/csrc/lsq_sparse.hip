@@ -260,7 +260,7 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
             }
             LSQ_HIP(hipMalloc(&J->d_bmap, (nnz + 8) * sizeof(int)));
             LSQ_HIP(hipMemcpy(J->d_bmap, bmap.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
-            LSQ_HIP(hipMalloc(&J->d_bpart, (size_t)nwin * n * sizeof(double)));
+            LSQ_HIP(hipMalloc(&J->d_bpart, (size_t)nwin * n * 2 * sizeof(double)));  // [w][dots | squares]
             J->nwin = nwin;
         }
     }
@@ -315,6 +315,7 @@ extern "C" int lsq_mat_size(const lsq_mat *J, int *m, int *n, long long *nnz) {
 extern "C" double *lsq_mat_values(lsq_mat *J) {
     J->version++;
     if (J->kind == LSQ_MAT_DENSE) return J->d_dense;
+    if (lsq_ensure_csc(J) != LSQ_OK) return nullptr;
     J->csr_fresh = false;
     return J->csc.d_val;
 }
@@ -346,6 +347,27 @@ int lsq_permute_to_bcsc(lsq_mat *J, const double *d_csc_vals, double *d_bcsc_val
     return LSQ_OK;
 }
 
+__global__ void __launch_bounds__(LSQ_NT)
+k_unpermute(long long nnz, const int *__restrict__ map, const double *__restrict__ src, double *__restrict__ dst) {
+    for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < nnz;
+         k += (long long)gridDim.x * LSQ_NT)
+        dst[map[k]] = src[k];
+}
+
+// A device g! may write the mirrors the products read and leave the CSC-ordered copy stale
+// (csc_fresh = false); it is rebuilt from the CSR mirror the first time someone asks for it.
+int lsq_ensure_csc(lsq_mat *J) {
+    if (J->kind != LSQ_MAT_CSC || J->csc_fresh) return LSQ_OK;
+    if (J->nnz > 0) {
+        int grid = (int)std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
+        hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, J->nnz, J->d_map,
+                           J->csr.d_val, J->csc.d_val);
+        LSQ_HIP(hipGetLastError());
+    }
+    J->csc_fresh = true;
+    return LSQ_OK;
+}
+
 // refreshes every mirror (CSR, window-blocked CSC) of the user-visible CSC values
 int lsq_ensure_csr(lsq_mat *J) {
     if (J->kind != LSQ_MAT_CSC || J->csr_fresh) return LSQ_OK;
@@ -357,7 +379,10 @@ int lsq_ensure_csr(lsq_mat *J) {
 
 extern "C" int lsq_mat_refresh(lsq_mat *J) {
     J->version++;
-    if (J->kind == LSQ_MAT_CSC) J->csr_fresh = false;
+    if (J->kind == LSQ_MAT_CSC) {
+        J->csr_fresh = false;
+        J->csc_fresh = true;  // the CSC copy is the authority here
+    }
     return lsq_ensure_csr(J);
 }
 
@@ -370,6 +395,7 @@ extern "C" int lsq_mat_set_values(lsq_mat *J, const double *h) {
 }
 
 extern "C" int lsq_mat_get_values(const lsq_mat *J, double *h) {
+    LSQ_TRY(lsq_ensure_csc(const_cast<lsq_mat *>(J)));
     const double *src = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
     if (J->nnz)
         LSQ_HIP(hipMemcpyAsync(h, src, J->nnz * sizeof(double), hipMemcpyDeviceToHost, J->ctx->stream));
@@ -418,8 +444,60 @@ struct EpiStore {  // out[s] = dot
 };
 
 int lsq_sparse_colsumabs2(lsq_mat *J, double *out) {
+    LSQ_TRY(lsq_ensure_csc(J));
     EpiStore e{nullptr, 0, out, nullptr, nullptr};
     return launch_segs<true>(J->ctx, J->csc, nullptr, e);
+}
+
+// g = J'f and colsumabs2(J) from ONE pass over the window-blocked values (LM/Dogleg need both
+// right after g!: levenberg_marquardt.jl:82 + :102, dogleg.jl:85 + :99).
+struct EpiGradSq {
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    int n;
+    double *g, *cs;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int j, double dot, double &) const {
+        if (j < n) g[j] = dot;
+        else cs[j - n] = dot;
+    }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+
+bool lsq_can_fuse_grad_colsum(const lsq_mat *J) {
+    static thread_local int ok = -1;  // 160 KiB of dynamic LDS: yl + products + squares
+    if (J->kind != LSQ_MAT_CSC || J->nwin <= 1 || J->bcsc.plan != LSQ_PLAN_LDSWIN || lsq_small_mat(J)) return false;
+    if (ok < 0) {
+        const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + 2 * LSQ_BIG_WINDOW) * sizeof(double);
+        bool a = hipFuncSetAttribute((const void *)k_bcsc_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds) == hipSuccess;
+        bool b = hipFuncSetAttribute((const void *)k_bcsc_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds) == hipSuccess;
+        (void)hipGetLastError();
+        ok = a && b;
+    }
+    return ok == 1;
+}
+
+int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {
+    lsq_ctx *c = J->ctx;
+    LSQ_TRY(lsq_ensure_csr(J));
+    const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + 2 * LSQ_BIG_WINDOW) * sizeof(double);
+    auto kern = J->bcsc.d_idx16 ? k_bcsc_lds<true, true> : k_bcsc_lds<false, true>;
+    int g2 = std::max(1, std::min(J->bcsc.nwin, c->num_cus));
+    hipLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc), (const int4 *)J->bcsc.d_big,
+                       J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m, J->n, f, J->d_bpart, (const int *)nullptr);
+    EpiGradSq e{nullptr, 0, J->n, g, J->d_colsum, nullptr, nullptr};
+    int nb = lsq_div_up(2 * J->n, LSQ_CMB_COLS);
+    int grid = std::min(nb, c->num_cus * 8);
+    hipLaunchKernelGGL((k_combine<EpiGradSq>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_bpart, 2 * J->n, J->nwin,
+                       e, nb);
+    LSQ_HIP(hipGetLastError());
+    J->colsum_version = J->version;
+    return LSQ_OK;
 }
 
 const double *lsq_cached_colsum(lsq_mat *J) {

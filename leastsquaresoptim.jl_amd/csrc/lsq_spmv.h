@@ -335,14 +335,18 @@ struct WinTileRegs {
     int pa[2], pe[2];
 };
 
-template <bool IDX16>
+// SQ: the same pass also forms the per-window column sums of squares (colsumabs2, utils.jl:146-151)
+// from the values it already holds in registers; the partials are then laid out [w][2n]
+// (dots | squares) and one k_combine over 2n "columns" finishes both.
+template <bool IDX16, bool SQ>
 __global__ void __launch_bounds__(LSQ_BIG_NT)
-k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wtile, int nwin, int rw, int m,
+k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wtile, int nwin, int rw, int m, int n,
            const double *__restrict__ y, double *__restrict__ part, const int *done) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (done && *done) return;
     double *yl = smem;                       // rw doubles
     double *prod = smem + LSQ_WIN_ROWS_MAX;  // LSQ_BIG_WINDOW doubles
+    double *prod2 = prod + LSQ_BIG_WINDOW;   // SQ only
     const int tid = threadIdx.x;
     const int kmax = (S.nnz + 3) & ~3;
     const int nbig = wtile[nwin];
@@ -393,6 +397,11 @@ k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wti
                 double2 *dst = reinterpret_cast<double2 *>(prod + c * 4 * LSQ_BIG_NT + 4 * tid);
                 dst[0] = p0;
                 dst[1] = p1;
+                if constexpr (SQ) {
+                    double2 *dq = reinterpret_cast<double2 *>(prod2 + c * 4 * LSQ_BIG_NT + 4 * tid);
+                    dq[0] = make_double2(r.v0[c].x * r.v0[c].x, r.v0[c].y * r.v0[c].y);
+                    dq[1] = make_double2(r.v1[c].x * r.v1[c].x, r.v1[c].y * r.v1[c].y);
+                }
             }
             int a[2], e[2];
 #pragma unroll
@@ -408,8 +417,19 @@ k_bcsc_lds(SegsDev S, const int4 *__restrict__ meta, const int *__restrict__ wti
                 const int s = s0 + tid + q * LSQ_BIG_NT;
                 if (s < s1) {
                     double sum = 0.0;
-                    for (int j = a[q]; j < e[q]; ++j) sum += prod[j];
-                    part[s] = sum;
+                    if constexpr (SQ) {
+                        double sq = 0.0;
+                        for (int j = a[q]; j < e[q]; ++j) {
+                            sum += prod[j];
+                            sq += prod2[j];
+                        }
+                        const size_t o = (size_t)w * 2 * n + (s - w * n);
+                        part[o] = sum;
+                        part[o + n] = sq;
+                    } else {
+                        for (int j = a[q]; j < e[q]; ++j) sum += prod[j];
+                        part[s] = sum;
+                    }
                 }
             }
             __syncthreads();
@@ -725,7 +745,7 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
                 static thread_local bool configured[2] = {false, false};
                 const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + LSQ_BIG_WINDOW) * sizeof(double);
                 const bool i16 = J->bcsc.d_idx16 != nullptr;
-                auto kern = i16 ? k_bcsc_lds<true> : k_bcsc_lds<false>;
+                auto kern = i16 ? k_bcsc_lds<true, false> : k_bcsc_lds<false, false>;
                 if (!configured[i16]) {
                     LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     configured[i16] = true;
@@ -735,11 +755,11 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
                 if (lsq_prof_take(c, &e0, &e1))
                     hipExtLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, segs_dev(J->bcsc),
                                           (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m,
-                                          x, J->d_bpart, epi.done);
+                                          J->n, x, J->d_bpart, epi.done);
                 else
                     hipLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc),
-                                       (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m, x,
-                                       J->d_bpart, epi.done);
+                                       (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m,
+                                       J->n, x, J->d_bpart, epi.done);
             } else {
                 EpiPart ep{epi.done, 0, J->d_bpart, nullptr, nullptr};
                 LSQ_TRY(launch_segs<false>(c, J->bcsc, x, ep));
@@ -751,6 +771,7 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
             LSQ_HIP(hipGetLastError());
             return LSQ_OK;
         }
+        LSQ_TRY(lsq_ensure_csc(J));
         return launch_segs<false>(c, J->csc, x, epi);
     }
     if (!trans) {

@@ -464,6 +464,34 @@ def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big):
 
 
 @pytest.mark.gpu
+def test_device_g_leaves_csc_copy_lazy_but_consistent(ctx):
+    """On big sparse problems the built-in device g! writes only the mirrors the products read;
+    the CSC-ordered nzval must still read back correctly (rebuilt on demand), and colsumabs2 /
+    J'u taken afterwards must agree with the values."""
+    m, n, per_col = 300000, 2000, 600
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=5, ctx=ctx)
+    x0 = lsq.synthetic.uniform(n, 3)
+    pr.reset(x0)
+    L = lsq.lib()
+    assert L.lsq_model_g()(pr.J, pr.x.ptr, pr.model) == 0
+    sfac = 1.0 - np.tanh(x0) ** 2
+    cols = np.repeat(np.arange(n), np.diff(pr.colptr))
+    want = pr.A * sfac[cols]
+    got = np.empty_like(pr.A)
+    lsq._lib.check(L.lsq_mat_get_values(pr.J, got.ctypes.data_as(lsq._lib.c_dp)))
+    np.testing.assert_allclose(got, want, rtol=4e-16 * 8, atol=0)
+    cs = lsq.DeviceVector(ctx, n)
+    lsq._lib.check(L.lsq_colsumabs2(pr.J, cs.ptr))
+    np.testing.assert_allclose(cs.get(), np.add.reduceat(want * want, pr.colptr[:-1]), rtol=1e-12)
+    u = lsq.DeviceVector(ctx, m, lsq.synthetic.normal(m, 9))
+    g = lsq.DeviceVector(ctx, n)
+    lsq._lib.check(L.lsq_mul(pr.J, 1, 1.0, u.ptr, 0.0, g.ptr))
+    ref = np.add.reduceat(want * u.get()[pr.rowval], pr.colptr[:-1])
+    np.testing.assert_allclose(g.get(), ref, rtol=1e-10, atol=1e-10 * np.max(np.abs(ref)))
+    pr.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("opt,sol,sparse", [("lm", "lsmr", True), ("dogleg", "lsmr", True), ("lm", "cholesky", False),
                                             ("dogleg", "qr", False)])
 def test_allocated_workspace_reuse_is_stateless(ctx, opt, sol, sparse):
