@@ -243,6 +243,19 @@ __device__ __forceinline__ bool grid_reduce(double block_val, double *partials, 
     return true;
 }
 
+// device scalars -> host through the pinned, mapped slot mirror (lsq_vec.hip): either the
+// one-thread k_publish_slots launch (lsq_read_slots) or the finalize step of the kernel that
+// produces the last scalar (LsqSlotPublish handed to its epilogue), then lsq_wait_slots.
+struct LsqSlotPublish {
+    const double *src = nullptr;
+    int count = 0;
+    double *dst = nullptr;
+    unsigned long long *seq_word = nullptr;
+    unsigned long long seq = 0;
+};
+LsqSlotPublish lsq_slots_ticket(lsq_ctx *c, int first, int count);
+int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, double *h_out);
+
 static inline unsigned *lsq_ctr(const lsq_ctx *c, int k) { return c->d_counters + (size_t)k * LSQ_CTR_SLOT; }
 static inline int lsq_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 

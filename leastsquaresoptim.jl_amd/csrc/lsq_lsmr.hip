@@ -135,8 +135,9 @@ struct EpiV {
     int beta_zero, first;
     using has_block_prepare = void;
     __device__ void block_prepare() {
-        double b2 = ordered_sum256(pu, *npu);
-        if (px) b2 += ordered_sum256(px, *npx);     // DampenedVector norm, iterative_lsmr.jl:72
+        double b2, bx, unused;
+        ordered_sum256x3(pu, npu, px, npx, nullptr, nullptr, b2, bx, unused);
+        if (px) b2 += bx;                           // DampenedVector norm, iterative_lsmr.jl:72
         beta = sqrt(b2);
         beta_zero = !(beta > 0.0);
         inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;   // lsmr.jl:120-121 rmul!(u, inv(beta))
@@ -163,14 +164,14 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
               const int *npv, const double *px_in, const int *npx_in, double *px, int *npx,
               const double *__restrict__ dg, double *__restrict__ ux,
               const double *__restrict__ P, double *__restrict__ v, double *__restrict__ h,
-              double *__restrict__ hbar, double *__restrict__ x, double *__restrict__ t, double *partials,
-              unsigned *counter) {
+              double *__restrict__ hbar, double *__restrict__ x, double *__restrict__ xout,
+              double *__restrict__ t, double *partials, unsigned *counter) {
     __shared__ double sh[LSQ_NT / 64];
     __shared__ LsmrState ns;   // this iteration's state, computed from the committed one
     if (st->done) return;
-    double beta2 = ordered_sum256(pu, *npu);
-    if (px_in) beta2 += ordered_sum256(px_in, *npx_in);   // (null in the setup pass: u~x == 0)
-    const double alpha2 = ordered_sum256(pv, *npv);
+    double beta2, betax2, alpha2;
+    ordered_sum256x3(pu, npu, px_in, npx_in, pv, npv, beta2, betax2, alpha2);
+    if (px_in) beta2 += betax2;                           // (null in the setup pass: u~x == 0)
     if (threadIdx.x == 0) {
         ns = *st;
         const double beta = sqrt(beta2);
@@ -210,6 +211,7 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
             h[j] = vj;
             hbar[j] = 0.0;
             x[j] = 0.0;
+            xout[j] = 0.0;
         } else {
             double hb = hbar[j] * c1 + h[j];         // :152-153
             hbar[j] = hb;
@@ -217,6 +219,9 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
             x[j] = xj;
             h[j] = h[j] * c3 + vj;                   // :155-156
             acc += xj * xj;
+            // the caller's x always holds P.*x of the newest iterate (iterative_lsmr.jl:195-196,
+            // 256-257), so no launch is needed once the stopping rule fires
+            xout[j] = P ? xj * P[j] : xj;
         }
         const double tj = P ? vj * P[j] : vj;        // iterative_lsmr.jl:31 ldiv!(tmp, P, a)
         t[j] = tj;
@@ -266,13 +271,54 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
     });
 }
 
-// ---- x <- P .* x (iterative_lsmr.jl:195-196, 256-257) ----------------------------------------
+// ---- setup from the caller's J'y in one launch: P, sqrt(damp), state reset and
+// v~ = P.*(J'y)/beta_1 with the block partials of sum(v~^2)  (k_lsmr_prep + k_lsmr_begin +
+// k_combine<EpiV> of the general path; k_lsmr_update in "first" mode follows).
+// beta_1^2 = sum(y^2) comes from the caller when it already holds it (the LM loop's ssr), else
+// from k_lsmr_begin's partials.
 __global__ void __launch_bounds__(LSQ_NT)
-k_lsmr_finish(int n, const LsmrState *st, const double *__restrict__ P, const double *__restrict__ xs,
-              double *__restrict__ x) {
-    const bool zero = (st->iter == 0);  // A'b == 0: x stays the zero start
-    for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT)
-        x[j] = zero ? 0.0 : xs[j] * P[j];
+k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp, double *__restrict__ P,
+             double *__restrict__ dg, double *__restrict__ ux, const double *__restrict__ Jty,
+             double *__restrict__ v, LsmrState *st, double *pu, int *npu, double ysumsq, double *pv, int *npv,
+             double atol, double btol, double ctol, int maxiter, unsigned epoch) {
+    __shared__ double sh[LSQ_NT / 64];
+    const double beta2 = ysumsq >= 0.0 ? ysumsq : ordered_sum256(pu, *npu);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->iter = 0; st->istop = 0; st->done = 0; st->first = 1;
+        st->atol = atol; st->btol = btol; st->ctol = ctol;
+        st->maxiter = maxiter; st->epoch = epoch; st->cu = 0.0;
+        if (ysumsq >= 0.0) {
+            pu[0] = ysumsq;
+            *npu = 1;
+        }
+    }
+    const double beta = sqrt(beta2);
+    const bool beta_zero = !(beta > 0.0);
+    const double inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
+    double acc = 0.0;
+    for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT) {
+        double s = colsum[j];
+        if (damp) {
+            double d = damp[j];
+            s += d;                  // iterative_lsmr.jl:251
+            double r = sqrt(d);      // :252
+            dg[j] = r;
+            damp[j] = r;
+            ux[j] = 0.0;             // zerosvector (:246)
+        }
+        const double Pj = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+        P[j] = Pj;
+        if (!beta_zero) {            // lsmr.jl:76 (beta == 0: v is left untouched, :120)
+            const double w = Jty[j] * inv_beta * Pj;
+            v[j] = w;
+            acc += w * w;
+        }
+    }
+    double bv = block_sum<LSQ_NT>(acc, sh);
+    if (threadIdx.x == 0) {
+        pv[blockIdx.x] = bv;
+        if (blockIdx.x == 0) *npv = (int)gridDim.x;
+    }
 }
 
 int lsq_lsmr_alloc(lsq_solver *s) {
@@ -306,7 +352,7 @@ static inline int nvec_grid(const lsq_ctx *c, int n) {
 
 // d_damp == nullptr: undamped (Dogleg, atol = btol = 1e-6); else LM (btol = 0.5).
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
-                   const double *d_Jty) {
+                   const double *d_Jty, double y_sumsq) {
     lsq_ctx *c = s->ctx;
     const int m = J->m, n = J->n;
     if (m != s->m || n != s->n) {
@@ -338,32 +384,37 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     if (!colsum) return LSQ_EHIP;
     *(volatile unsigned long long *)c->h_mail = 0ull;
     const int gn = nvec_grid(c, n);
-    hipLaunchKernelGGL(k_lsmr_prep, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P,
-                       s->d_dg, s->d_ux);
-    {
+    const double *dgk = damped ? s->d_dg : nullptr;
+    EpiV ev{done, 0, st, pu, npu, nullptr, nullptr, s->d_P, damped ? s->d_dg : nullptr, nullptr, s->d_v, pv, npv,
+            nullptr, 0.0, 0.0, 0, 0};
+    auto launch_begin = [&]() {
         long long gb = std::min<long long>(lsq_div_up(m > 0 ? m : 1, LSQ_NT), (long long)c->num_cus * 8);
         if (gb > 4096) gb = 4096;
         hipLaunchKernelGGL(k_lsmr_begin, dim3((int)gb), dim3(LSQ_NT), 0, c->stream, m, d_y, st, pu, npu, atol,
                            btol, 1.0 / conlim, maxiter, epoch);
-    }
-    LSQ_HIP(hipGetLastError());
-    // v~ = A'u (setup), then K3 in "first" mode
-    EpiV ev{done, 0, st, pu, npu, nullptr, nullptr, s->d_P, damped ? s->d_dg : nullptr, nullptr, s->d_v, pv, npv,
-            nullptr, 0.0, 0.0, 0, 0};
+    };
     if (d_Jty) {
-        // A'b from the caller's J'y: only the n-length epilogue runs (k_combine with one "window")
-        int nb = lsq_div_up(n, LSQ_CMB_COLS);
-        hipLaunchKernelGGL((k_combine<EpiV>), dim3(std::min(nb, 2048)), dim3(LSQ_NT), 0, c->stream, d_Jty, n, 1,
-                           ev, nb);
+        if (!(y_sumsq >= 0.0)) launch_begin();
+        hipLaunchKernelGGL(k_lsmr_setup, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P, s->d_dg,
+                           s->d_ux, d_Jty, s->d_v, st, pu, npu, y_sumsq >= 0.0 ? y_sumsq : -1.0, pv, npv, atol, btol,
+                           1.0 / conlim, maxiter, epoch);
+        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
+                           (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
+                           s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
+        LSQ_HIP(hipGetLastError());
     } else {
+        hipLaunchKernelGGL(k_lsmr_prep, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P,
+                           s->d_dg, s->d_ux);
+        launch_begin();
+        LSQ_HIP(hipGetLastError());
+        // v~ = A'u (setup), then K3 in "first" mode
         LSQ_TRY(launch_product(J, 1, d_y, ev));
+        // setup K3: u~x is still zero, so only sum(u~_y^2) enters beta_1; it already forms iteration 1's u~x
+        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
+                           (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
+                           s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
+        LSQ_HIP(hipGetLastError());
     }
-    // setup K3: u~x is still zero, so only sum(u~_y^2) enters beta_1; it already forms iteration 1's u~x
-    const double *dgk = damped ? s->d_dg : nullptr;
-    hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
-                       (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P, s->d_v,
-                       s->d_h, s->d_hbar, xs, s->d_t, c->d_partials, lsq_ctr(c, 3));
-    LSQ_HIP(hipGetLastError());
 
     EpiU eu{done, 0, st, d_y, s->d_u, n, s->d_dg, s->d_t, s->d_ux, pu, npu, nullptr, 0.0};
     ev.ux = damped ? s->d_ux : nullptr;
@@ -405,7 +456,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu,
                                pv, npv, (const double *)(damped ? pxb[cur] : nullptr), (const int *)npxb[cur],
                                pxb[cur ^ 1], npxb[cur ^ 1], dgk, s->d_ux, s->d_P, s->d_v, s->d_h, s->d_hbar, xs,
-                               s->d_t, c->d_partials, lsq_ctr(c, 3));
+                               d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
             LSQ_HIP(hipGetLastError());
             ++enq;
             spins = 0;
@@ -442,8 +493,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             prof_iter[k].pop_back();
         }
     }
-    hipLaunchKernelGGL(k_lsmr_finish, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, s->d_P, xs, d_x);
-    LSQ_HIP(hipGetLastError());
     s->last_iter = it;
     s->last_istop = istop;
     if (nmul) *nmul = 2 * it;  // lsmr.jl:236 ch.mvps

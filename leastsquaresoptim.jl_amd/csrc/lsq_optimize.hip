@@ -118,6 +118,67 @@ k_lm_damp(int n, const double *__restrict__ colsum, double inv_delta, double *__
     }
 }
 
+// One-workgroup variants for n <= LSQ_ONE_WG_N: a launch costs ~4 us whatever it does, so the
+// n-length bookkeeping of an outer iteration is packed into as few launches as possible.
+constexpr int LSQ_ONE_WG_N = 16384;
+
+// k_lm_damp + k_gradnorm (levenberg_marquardt.jl:82-86 and :102-104's norm)
+__global__ void __launch_bounds__(1024)
+k_lm_damp_grad(int n, const double *__restrict__ colsum, double inv_delta, double *__restrict__ dtd,
+               const double *__restrict__ g, const double *__restrict__ x, const double *__restrict__ lo,
+               const double *__restrict__ hi, double *out_grad) {
+    constexpr int R = LSQ_ONE_WG_N / 1024;
+    __shared__ double sh[16];
+    __shared__ double s_mean;
+    double cs[R], gv[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {   // every load is issued before the first use
+        const int i = threadIdx.x + k * 1024;
+        cs[k] = i < n ? colsum[i] : 0.0;
+        gv[k] = i < n ? g[i] : 0.0;
+    }
+    double acc = 0.0, mg = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int i = threadIdx.x + k * 1024;
+        if (i < n) {
+            acc += cs[k];
+            double gi = gv[k];
+            if (lo && x[i] <= lo[i] && gi > 0.0) gi = 0.0;
+            else if (hi && x[i] >= hi[i] && gi < 0.0) gi = 0.0;
+            double a = fabs(gi);
+            if (isnan(a)) a = INFINITY;
+            mg = fmax(mg, a);
+        }
+    }
+    acc = wave_sum(acc);
+    mg = wave_max(mg);
+    __shared__ double shm[16];
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = acc;
+        shm[threadIdx.x >> 6] = mg;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0, tm = shm[0];
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        for (int w = 1; w < 16; ++w) tm = fmax(tm, shm[w]);
+        s_mean = t / n;
+        *out_grad = tm;
+    }
+    __syncthreads();
+    const double lo_d = MIN_DIAGONAL * s_mean, hi_d = MAX_DIAGONAL * s_mean;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int i = threadIdx.x + k * 1024;
+        if (i < n) {
+            double v = cs[k];
+            v = v > hi_d ? hi_d : (v < lo_d ? lo_d : v);
+            dtd[i] = v * inv_delta;  // rmul!(dtd, 1/Delta)
+        }
+    }
+}
+
 // Dogleg scaling: dtd = clamp(colsum, 1e-6, 1e32) (dogleg.jl:85-90)
 __global__ void __launch_bounds__(LSQ_NT)
 k_dl_scale(int n, const double *__restrict__ colsum, double *__restrict__ dtd) {
@@ -157,7 +218,18 @@ struct EpiPredict {
         racc += r * r;
     }
     __device__ void extra(int, double &) const {}
-    __device__ void finalize(double t) const { *out = t; }
+    // the last kernel of an outer iteration also hands the iteration's scalars to the host
+    // (what k_publish_slots would do in a launch of its own)
+    LsqSlotPublish pub;
+    __device__ void finalize(double t) const {
+        *out = t;
+        if (pub.count > 0) {
+            for (int i = 0; i < pub.count; ++i)
+                __hip_atomic_store(pub.dst + i, pub.src + i == out ? t : pub.src[i], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub.seq_word, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 };
 
 // sum((J d)^2) for the Cauchy step length (dogleg.jl:109-111)
@@ -188,11 +260,17 @@ k_step(int n, const double *__restrict__ x, const double *__restrict__ dx, doubl
         mx = fmax(mx, a);
         if (!isfinite(v) && code == 0.0) code = 1e15 - (double)(i + 1);
     }
-    double b1 = block_max<LSQ_NT>(mx, sh);
-    grid_reduce<LSQ_NT, true>(b1, partials, counters, gridDim.x, sh, [=](double t) { *out_dx = t; });
+    // both maxima ride one ticket round: partials[b] and partials[LSQ_MAX_GRID + b]
     double b2 = block_max<LSQ_NT>(code, sh);
-    grid_reduce<LSQ_NT, true>(b2, partials + LSQ_MAX_GRID, counters + LSQ_CTR_SLOT, gridDim.x, sh,
-                              [=](double t) { *out_nonfin = (t == 0.0) ? -1.0 : (1e15 - t) - 1.0; });
+    if (threadIdx.x == 0) __hip_atomic_store(&partials[LSQ_MAX_GRID + blockIdx.x], b2, RLX_AGENT);
+    double b1 = block_max<LSQ_NT>(mx, sh);
+    const int nb = gridDim.x;
+    if (grid_reduce<LSQ_NT, true>(b1, partials, counters, nb, sh, [=](double t) { *out_dx = t; })) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nb; i += LSQ_NT) acc = fmax(acc, __hip_atomic_load(&partials[LSQ_MAX_GRID + i], RLX_AGENT));
+        double t = block_max<LSQ_NT>(acc, sh);
+        if (threadIdx.x == 0) *out_nonfin = (t == 0.0) ? -1.0 : (1e15 - t) - 1.0;
+    }
 }
 
 __global__ void __launch_bounds__(LSQ_NT)
@@ -223,7 +301,16 @@ __global__ void __launch_bounds__(LSQ_NT)
 k_sumsq_slot(long long n, const double *__restrict__ x, double *partials, unsigned *counter, double *out) {
     __shared__ double sh[LSQ_NT / 64];
     double acc = 0.0;
-    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n; i += (long long)gridDim.x * LSQ_NT) {
+    const long long stride = (long long)gridDim.x * LSQ_NT;
+    long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {   // four loads in flight per lane
+        const double v0 = x[i], v1 = x[i + stride], v2 = x[i + 2 * stride], v3 = x[i + 3 * stride];
+        acc += v0 * v0;
+        acc += v1 * v1;
+        acc += v2 * v2;
+        acc += v3 * v3;
+    }
+    for (; i < n; i += stride) {
         double v = x[i];
         acc += v * v;
     }
@@ -263,7 +350,8 @@ static inline int ngrid(const lsq_ctx *c, long long n) {
 // sum(x^2) -> slot: tree reduction, or the reference's left-to-right order for small problems
 static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, int ctr, double *d_out) {
     if (exact) return lsq_seq_reduce(c, 1, (int)n, x, nullptr, nullptr, d_out);
-    long long g = (n + LSQ_NT - 1) / LSQ_NT, cap = (long long)c->num_cus * 8;
+    // few blocks: the ticket fan-in of the grid reduction (~12 ns per arrival) outweighs the loads
+    long long g = (n + LSQ_NT - 1) / LSQ_NT, cap = (long long)c->num_cus * 2;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(k_sumsq_slot, dim3((int)g), dim3(LSQ_NT), 0, c->stream, n, x, c->d_partials, lsq_ctr(c, ctr), d_out);
@@ -271,7 +359,7 @@ static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, i
 }
 // sum((J d - f)^2) -> slot (f may be null: sum((J d)^2))
 static int predicted_to_slot(lsq_ctx *c, bool exact, lsq_mat *J, const double *d, const double *f, double *scratch,
-                             int ctr, double *d_out);
+                             int ctr, double *d_out, LsqSlotPublish pub = LsqSlotPublish());
 static int wdot_to_slot(lsq_ctx *c, bool exact, int n, const double *x, const double *y, const double *w, int ctr,
                         double *d_out);
 // g = J'f
@@ -333,13 +421,13 @@ static int alloc_loop(LoopBuffers &b, lsq_ctx *c, int m, int n, const lsq_option
 }
 
 static int predicted_to_slot(lsq_ctx *c, bool exact, lsq_mat *J, const double *d, const double *f, double *scratch,
-                             int ctr, double *d_out) {
+                             int ctr, double *d_out, LsqSlotPublish pub) {
     if (exact) {
         LSQ_TRY(lsq_exact_product(J, 0, d, scratch));
         return lsq_seq_reduce(c, f ? 3 : 1, J->m, scratch, f, nullptr, d_out);
     }
     if (f) {
-        EpiPredict ep{nullptr, 0, f, d_out, c->d_partials, lsq_ctr(c, ctr)};
+        EpiPredict ep{nullptr, 0, f, d_out, c->d_partials, lsq_ctr(c, ctr), pub};
         return launch_product(J, 0, d, ep);
     }
     EpiSumsq es{nullptr, 0, d_out, c->d_partials, lsq_ctr(c, ctr)};
@@ -434,9 +522,24 @@ static int call_g(lsq_g_callback g, lsq_mat *J, const double *x, void *user) {
 // ---------------------------------------------------------------------------------------------
 // levenberg_marquardt.jl:39-144
 // ---------------------------------------------------------------------------------------------
-static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x, double *fcur, lsq_f_callback f,
-                       lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
+// The accepted trial point becomes the iterate by swapping buffers (no copyto!); whatever buffer
+// holds the iterate when the loop is left is copied back into the caller's x / fcur.
+struct IterateGuard {
+    lsq_ctx *c;
+    double *&x, *&fcur;
+    double *x_user, *fcur_user;
+    int m, n;
+    ~IterateGuard() {
+        if (x != x_user) lsq_d2d(c, x_user, x, (size_t)n * sizeof(double));
+        if (fcur != fcur_user) lsq_d2d(c, fcur_user, fcur, (size_t)m * sizeof(double));
+    }
+};
+
+static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x_user, double *fcur_user,
+                       lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
     const int m = J->m, n = J->n;
+    double *x = x_user, *fcur = fcur_user, *xt = b.xt, *ftrial = b.ftrial;
+    IterateGuard guard{c, x, fcur, x_user, fcur_user, m, n};
     double delta = o->delta > 0 ? o->delta : 10.0;
     double decrease_factor = 2.0;
     int f_calls = 0, g_calls = 0, mul_calls = 0, xc = 0, fc = 0, gc = 0;
@@ -484,33 +587,45 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
         }
         const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
         if (!cs) return LSQ_EHIP;
+        const bool one_wg = !exact && n <= LSQ_ONE_WG_N;
         if (exact) LSQ_TRY(lsq_exact_lm_damp(c, n, cs, 1.0 / delta, b.dtd));
-        else hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
+        else if (!one_wg) hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
         {   // :102-104 gradient g = J'f at the pre-step x.  The reference forms it AFTER the solve
             // (into dtd); J and fcur do not change in between, so it is formed once, before the
             // solve, and LSMR's setup product A'b = P.*(J'f)/beta reuses it (saves one pass over J).
             if (!have_grad) LSQ_TRY(gradient_into(c, exact, J, fcur, b.grad));
-            hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.grad, x, b.lo, b.hi,
-                               c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
+            if (one_wg)
+                hipLaunchKernelGGL(k_lm_damp_grad, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd, b.grad,
+                                   x, b.lo, b.hi, c->d_slots + SL_GRAD);
+            else
+                hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.grad, x, b.lo, b.hi,
+                                   c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             mul_calls++;
         }
         int lmiter = 0;
-        if (sv->kind == LSQ_LSMR) LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad));  // :87
+        if (sv->kind == LSQ_LSMR) LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr));  // :87
         else LSQ_TRY(lsq_ldiv_damped(sv, J, fcur, b.dtd, b.dx, &lmiter));
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
         mul_calls += lmiter;
         inner_total += lmiter / 2;
-        hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
+        hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
                            lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN);   // :106
         LSQ_HIP(hipGetLastError());
-        CB(f(b.ftrial, b.xt, user));                                      // :107
+        CB(f(ftrial, xt, user));                                      // :107
         f_calls++;
-        LSQ_TRY(sumsq_to_slot(c, exact, m, b.ftrial, 7, c->d_slots + SL_TRIAL));                 // :111
-        LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));   // :114-117
-        mul_calls++;
-        LSQ_HIP(hipGetLastError());
+        LSQ_TRY(sumsq_to_slot(c, exact, m, ftrial, 7, c->d_slots + SL_TRIAL));                 // :111
         double sl[5];
-        LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));   // the one host sync of the outer iteration
+        if (exact) {
+            LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));   // :114-117
+            LSQ_HIP(hipGetLastError());
+            LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));   // the one host sync of the outer iteration
+        } else {
+            LsqSlotPublish pub = lsq_slots_ticket(c, SL_GRAD, 5);
+            LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED, pub));
+            LSQ_HIP(hipGetLastError());
+            LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, pub.seq, sl));
+        }
+        mul_calls++;
         maxabs_gr = sl[0];
         const double maxabs_dx = sl[1];
         const int trial_nonfinite = (int)sl[2];
@@ -520,8 +635,8 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
         const bool accepted = rho > MIN_STEP_QUALITY;                           // :122 (strict)
         converged = assess(maxabs_dx, maxabs_gr, ssr, trial_ssr, o->x_tol, o->f_tol, o->g_tol, accepted, &xc, &fc, &gc);
         if (accepted) {
-            LSQ_TRY(lsq_d2d(c, fcur, b.ftrial, (size_t)m * sizeof(double)));   // copyto!(fcur, ftrial)
-            LSQ_TRY(lsq_d2d(c, x, b.xt, (size_t)n * sizeof(double)));
+            std::swap(fcur, ftrial);                                            // copyto!(fcur, ftrial)
+            std::swap(x, xt);
             ssr = trial_ssr;
             double q = 1.0 - (2.0 * rho - 1.0) * (2.0 * rho - 1.0) * (2.0 * rho - 1.0);
             delta = std::min(delta / std::max(1.0 / 3.0, q), MAX_DELTA);        // :130
@@ -529,7 +644,7 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
             need_jac = true;
             nonfinite_at = trial_nonfinite;
         } else {
-            hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.xt, b.dx, x);  // :135
+            hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, xt, b.dx, x);  // :135
             delta = std::max(delta / decrease_factor, MIN_DELTA);
             decrease_factor *= 2.0;
         }

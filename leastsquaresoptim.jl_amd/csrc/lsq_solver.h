@@ -108,9 +108,10 @@ __device__ inline void lsmr_rotate_inline(LsmrState &s, double alpha, double bet
 // implemented in lsq_lsmr.hip
 int lsq_lsmr_alloc(lsq_solver *s);
 void lsq_lsmr_free(lsq_solver *s);
-// d_Jty (optional): J'*y already formed by the caller (the LM gradient) -- skips the setup product
+// d_Jty (optional): J'*y already formed by the caller (the LM gradient) -- skips the setup product;
+// y_sumsq (optional, < 0 = unknown): sum(y.^2) when the caller already holds it (the LM loop's ssr)
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
-                   const double *d_Jty = nullptr);
+                   const double *d_Jty = nullptr, double y_sumsq = -1.0);
 // implemented in lsq_exact.hip (reference-order kernels for small problems)
 int lsq_lsmr_exact_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul);
 // implemented in lsq_dense.hip

@@ -89,6 +89,37 @@ __device__ __forceinline__ double ordered_sum256(const double *partials, int cou
     return r;
 }
 
+// Up to three such sums with ONE pair of barriers (the loads of all three are in flight together);
+// each result is bit-identical to ordered_sum256 of the same array.  Null arrays give 0.
+__device__ __forceinline__ void ordered_sum256x3(const double *pa, const int *na, const double *pb, const int *nb,
+                                                 const double *pc, const int *nc, double &ra, double &rb, double &rc) {
+    __shared__ double s_w3[3][4];
+    __shared__ double s_tot3[3];
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        const int ca = pa ? *na : 0, cb = pb ? *nb : 0, cc = pc ? *nc : 0;
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int i = tid; i < ca; i += 256) a += pa[i];
+        for (int i = tid; i < cb; i += 256) b += pb[i];
+        for (int i = tid; i < cc; i += 256) c += pc[i];
+        a = wave_sum(a);
+        b = wave_sum(b);
+        c = wave_sum(c);
+        if ((tid & 63) == 0) {
+            s_w3[0][tid >> 6] = a;
+            s_w3[1][tid >> 6] = b;
+            s_w3[2][tid >> 6] = c;
+        }
+    }
+    __syncthreads();
+    if (tid < 3) s_tot3[tid] = ((s_w3[tid][0] + s_w3[tid][1]) + s_w3[tid][2]) + s_w3[tid][3];
+    __syncthreads();
+    ra = s_tot3[0];
+    rb = s_tot3[1];
+    rc = s_tot3[2];
+    __syncthreads();
+}
+
 template <int NT, class Epi>
 __device__ __forceinline__ void finish_block_nt(const Epi &epi, double racc, double *sh) {
     if constexpr (Epi::REDUCE) {

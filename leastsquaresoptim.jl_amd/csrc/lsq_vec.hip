@@ -209,12 +209,18 @@ __global__ void k_publish_slots(const double *__restrict__ src, int count, doubl
     }
 }
 
-int lsq_read_slots(lsq_ctx *c, int first, int count, double *h_out) {
-    const unsigned long long seq = ++c->slot_seq;
+LsqSlotPublish lsq_slots_ticket(lsq_ctx *c, int first, int count) {
+    LsqSlotPublish p;
+    p.src = c->d_slots + first;
+    p.count = count;
+    p.dst = c->d_hslots + first;
+    p.seq_word = (unsigned long long *)(c->d_hslots + LSQ_NSLOTS);
+    p.seq = ++c->slot_seq;
+    return p;
+}
+
+int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, double *h_out) {
     volatile unsigned long long *hw = (volatile unsigned long long *)(c->h_slots + LSQ_NSLOTS);
-    hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(64), 0, c->stream, c->d_slots + first, count,
-                       c->d_hslots + first, (unsigned long long *)(c->d_hslots + LSQ_NSLOTS), seq);
-    LSQ_HIP(hipGetLastError());
     unsigned long long spins = 0;
     while (*hw != seq) {
         if ((++spins & 0xfffffu) == 0 && hipStreamQuery(c->stream) == hipSuccess && *hw != seq) {
@@ -226,6 +232,13 @@ int lsq_read_slots(lsq_ctx *c, int first, int count, double *h_out) {
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     for (int i = 0; i < count; ++i) h_out[i] = ((volatile double *)c->h_slots)[first + i];
     return LSQ_OK;
+}
+
+int lsq_read_slots(lsq_ctx *c, int first, int count, double *h_out) {
+    LsqSlotPublish p = lsq_slots_ticket(c, first, count);
+    hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(64), 0, c->stream, p.src, p.count, p.dst, p.seq_word, p.seq);
+    LSQ_HIP(hipGetLastError());
+    return lsq_wait_slots(c, first, count, p.seq, h_out);
 }
 
 // ---------------------------------------------------------------------------------------------
