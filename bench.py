@@ -110,7 +110,8 @@ def main():
         run(a.warmup)
     barrier()
     t0 = time.perf_counter()
-    steps_done, inner_local, r = run(a.steps, prof=1 | (3 << 8))   # timed region: every 3rd J*v launch carries events
+    stride = int(os.environ.get("LSQ_BENCH_PROF_STRIDE", "3"))
+    steps_done, inner_local, r = run(a.steps, prof=1 | (stride << 8))   # timed region: every 3rd J*v launch carries events
     barrier()
     dt = time.perf_counter() - t0
     avg = (C.c_double * 2)()

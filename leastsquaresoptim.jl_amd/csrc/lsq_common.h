@@ -120,6 +120,25 @@ struct LsqSegs {
     int *d_big = nullptr;  // nbig x int4 {s0, s1, k0, k1} (<= 8189 nnz, <= 1024 segments each)
 };
 
+// Sliced layout of one product direction (lsq_sell.h): replaces the CSR mirror (J*x) and the
+// window-blocked CSC (J'*y) on big patterns.
+struct LsqSell {
+    bool active = false;
+    int nblocks = 0, nslices = 0;
+    long long nstore = 0;          // stored entries incl. padding
+    int wrows = 0;                 // J*x: output rows per block
+    int ncb = 0, ccols = 0;        // J'*y: column blocks per gather window, columns per block
+    int ngw = 0, grows = 0;        // J'*y: gather windows, rows per gather window
+    int *d_wslice = nullptr;       // nblocks+1
+    int2 *d_smeta = nullptr;       // nslices x {entry offset, padded count}
+    unsigned *d_info = nullptr;    // nslices*64: output position in the block | entry count << 13
+    unsigned short *d_idx16 = nullptr;  // gather index per stored entry
+    unsigned short *d_col16 = nullptr;  // J'*y: column of every stored entry (device-side g! scaling)
+    double *d_val = nullptr;
+    int *d_map = nullptr;          // stored entry -> CSC position (-1: padding)
+    double *d_part = nullptr;      // J'*y: [gather window][2n] partials (dots | squares)
+};
+
 struct lsq_mat {
     lsq_ctx *ctx;
     int kind;
@@ -142,6 +161,7 @@ struct lsq_mat {
     int nwin = 0;
     int *d_bmap = nullptr;  // bcsc position -> csc position
     double *d_bpart = nullptr;
+    LsqSell srows, scols;   // when active they carry the values instead of csr / bcsc (whose d_val is freed)
     unsigned long long version = 0;  // bumps whenever values change
     // cached colsumabs2 (utils.jl:139-151 is called twice per LM iteration by the reference)
     double *d_colsum = nullptr;
@@ -279,10 +299,14 @@ int lsq_dense_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_sparse_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_ensure_csr(lsq_mat *J);
 int lsq_ensure_csc(lsq_mat *J);
+// mirrors of an arbitrary CSC-ordered value array (e.g. a model's constant matrix) in the layouts
+// the products of J read: rows = CSR mirror or sliced rows, cols = window-blocked CSC or sliced cols
+int lsq_mirror_rows(lsq_mat *J, const double *d_csc_vals, double *d_out);
+int lsq_mirror_cols(lsq_mat *J, const double *d_csc_vals, double *d_out);
+long long lsq_mirror_rows_len(const lsq_mat *J);
+long long lsq_mirror_cols_len(const lsq_mat *J);
 bool lsq_can_fuse_grad_colsum(const lsq_mat *J);
 int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g);  // g = J'f, fills the colsum cache
-int lsq_permute_to_csr(lsq_mat *J, const double *d_csc_vals, double *d_csr_vals);
-int lsq_permute_to_bcsc(lsq_mat *J, const double *d_csc_vals, double *d_bcsc_vals);
 const double *lsq_cached_colsum(lsq_mat *J);  // nullptr on failure (error set)
 // reads slot values to host (synchronises the stream)
 int lsq_read_slots(lsq_ctx *ctx, int first, int count, double *h_out);

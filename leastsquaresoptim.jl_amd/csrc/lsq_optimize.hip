@@ -298,7 +298,8 @@ k_gradnorm(int n, const double *__restrict__ g, const double *__restrict__ x, co
 }
 
 __global__ void __launch_bounds__(LSQ_NT)
-k_sumsq_slot(long long n, const double *__restrict__ x, double *partials, unsigned *counter, double *out) {
+k_sumsq_slot(long long n, const double *__restrict__ x, double *partials, unsigned *counter, double *out,
+             LsqSlotPublish pub) {
     __shared__ double sh[LSQ_NT / 64];
     double acc = 0.0;
     const long long stride = (long long)gridDim.x * LSQ_NT;
@@ -315,7 +316,15 @@ k_sumsq_slot(long long n, const double *__restrict__ x, double *partials, unsign
         acc += v * v;
     }
     double b = block_sum<LSQ_NT>(acc, sh);
-    grid_reduce<LSQ_NT>(b, partials, counter, gridDim.x, sh, [=](double t) { *out = t; });
+    grid_reduce<LSQ_NT>(b, partials, counter, gridDim.x, sh, [=](double t) {
+        *out = t;
+        if (pub.count > 0) {   // last kernel of an outer iteration: hand its scalars to the host
+            for (int i = 0; i < pub.count; ++i)
+                __hip_atomic_store(pub.dst + i, pub.src + i == out ? t : pub.src[i], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub.seq_word, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    });
 }
 
 // sum(w .* x .* y) -> slot (wdot, utils.jl:165-175)
@@ -348,13 +357,15 @@ static inline int ngrid(const lsq_ctx *c, long long n) {
 }
 
 // sum(x^2) -> slot: tree reduction, or the reference's left-to-right order for small problems
-static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, int ctr, double *d_out) {
+static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, int ctr, double *d_out,
+                         LsqSlotPublish pub = LsqSlotPublish()) {
     if (exact) return lsq_seq_reduce(c, 1, (int)n, x, nullptr, nullptr, d_out);
     // few blocks: the ticket fan-in of the grid reduction (~12 ns per arrival) outweighs the loads
     long long g = (n + LSQ_NT - 1) / LSQ_NT, cap = (long long)c->num_cus * 2;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_sumsq_slot, dim3((int)g), dim3(LSQ_NT), 0, c->stream, n, x, c->d_partials, lsq_ctr(c, ctr), d_out);
+    hipLaunchKernelGGL(k_sumsq_slot, dim3((int)g), dim3(LSQ_NT), 0, c->stream, n, x, c->d_partials, lsq_ctr(c, ctr), d_out,
+                       pub);
     return LSQ_OK;
 }
 // sum((J d - f)^2) -> slot (f may be null: sum((J d)^2))
@@ -611,17 +622,23 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
         hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
                            lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN);   // :106
         LSQ_HIP(hipGetLastError());
-        CB(f(ftrial, xt, user));                                      // :107
-        f_calls++;
-        LSQ_TRY(sumsq_to_slot(c, exact, m, ftrial, 7, c->d_slots + SL_TRIAL));                 // :111
         double sl[5];
         if (exact) {
+            CB(f(ftrial, xt, user));                                      // :107
+            f_calls++;
+            LSQ_TRY(sumsq_to_slot(c, exact, m, ftrial, 7, c->d_slots + SL_TRIAL));                 // :111
             LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));   // :114-117
             LSQ_HIP(hipGetLastError());
             LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));   // the one host sync of the outer iteration
         } else {
+            // the predicted residual (:114-117) does not depend on f!(x_trial): formed first, while the
+            // row copy of J that the last LSMR iterations streamed is still (partly) in the Infinity Cache
+            LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));
+            CB(f(ftrial, xt, user));                                      // :107
+            f_calls++;
+            // the last kernel of the iteration hands the scalars to the host
             LsqSlotPublish pub = lsq_slots_ticket(c, SL_GRAD, 5);
-            LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED, pub));
+            LSQ_TRY(sumsq_to_slot(c, exact, m, ftrial, 7, c->d_slots + SL_TRIAL, pub));              // :111
             LSQ_HIP(hipGetLastError());
             LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, pub.seq, sl));
         }
@@ -871,8 +888,8 @@ struct lsq_model {
     lsq_ctx *ctx;
     lsq_mat *J;
     double *d_Acsc = nullptr;  // A values, CSC order (or dense column-major)
-    double *d_Acsr = nullptr;  // A values, CSR order
-    double *d_Ab = nullptr;    // A values, window-blocked CSC order
+    double *d_Acsr = nullptr;  // A values in J's row-mirror layout (CSR order or sliced rows)
+    double *d_Ab = nullptr;    // A values in J's column-mirror layout (window-blocked CSC or sliced columns)
     double *d_b = nullptr;
     double *d_t = nullptr;     // tanh(x)
 };
@@ -937,27 +954,35 @@ k_scale_bcsc(int nseg, int n, const int *__restrict__ ptr, const double *__restr
 
 // out[k] = A[k] * sfac[col16[k]] with the n scale factors staged in LDS: pure streaming
 // (16-byte value loads/stores, 8-byte index loads), one persistent 1024-thread workgroup per CU.
+// NT: the output is stored non-temporally (16-byte vector stores: 4.8 TB/s instead of 3.8 -- no
+// write-allocate next to the A stream); used for the copy that is not read back right away.
+typedef double lsq_d2 __attribute__((ext_vector_type(2)));
+template <bool NT>
 __global__ void __launch_bounds__(1024)
 k_scale_lds(long long nnz4, const unsigned short *__restrict__ col16, const double *__restrict__ A,
-            const double *__restrict__ x, int n, double *__restrict__ out) {
+            const double *__restrict__ sfac, int n, double *__restrict__ out) {
     extern __shared__ double sf[];
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        double t = tanh(x[i]);
-        sf[i] = 1.0 - t * t;
-    }
+    // (the factors 1 - tanh(x)^2 come from k_sfac: ten fp64 tanh per thread in every one of the 256
+    //  workgroups cost ~6 us before the first byte was streamed)
+    for (int i = threadIdx.x; i < n; i += 1024) sf[i] = sfac[i];
     __syncthreads();
     for (long long q = blockIdx.x * 1024LL + threadIdx.x; q < nnz4; q += (long long)gridDim.x * 1024) {
         const long long k = 4 * q;  // arrays are padded to a multiple of 4 (+8)
-        const double2 a0 = *reinterpret_cast<const double2 *>(A + k);
-        const double2 a1 = *reinterpret_cast<const double2 *>(A + k + 2);
+        const lsq_d2 a0 = *reinterpret_cast<const lsq_d2 *>(A + k);
+        const lsq_d2 a1 = *reinterpret_cast<const lsq_d2 *>(A + k + 2);
         const uint2 c = *reinterpret_cast<const uint2 *>(col16 + k);
-        double2 o0, o1;
+        lsq_d2 o0, o1;
         o0.x = a0.x * sf[c.x & 0xffffu];
         o0.y = a0.y * sf[c.x >> 16];
         o1.x = a1.x * sf[c.y & 0xffffu];
         o1.y = a1.y * sf[c.y >> 16];
-        *reinterpret_cast<double2 *>(out + k) = o0;
-        *reinterpret_cast<double2 *>(out + k + 2) = o1;
+        if constexpr (NT) {
+            __builtin_nontemporal_store(o0, reinterpret_cast<lsq_d2 *>(out + k));
+            __builtin_nontemporal_store(o1, reinterpret_cast<lsq_d2 *>(out + k + 2));
+        } else {
+            *reinterpret_cast<lsq_d2 *>(out + k) = o0;
+            *reinterpret_cast<lsq_d2 *>(out + k + 2) = o1;
+        }
     }
 }
 
@@ -978,7 +1003,9 @@ static int model_f(double *out, const double *x, void *user) {
     lsq_mat *J = md->J;
     hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     EpiResidual e{nullptr, 0, md->d_b, out, nullptr, nullptr};
-    if (J->kind == LSQ_MAT_CSC) {
+    if (J->kind == LSQ_MAT_CSC && J->srows.active) {
+        if (launch_sell_rows(J, md->d_Acsr, md->d_t, e) != LSQ_OK) return 1;   // same pattern, A's values
+    } else if (J->kind == LSQ_MAT_CSC) {
         LsqSegs A = J->csr;  // same pattern, A's values
         A.d_val = md->d_Acsr;
         if (launch_segs<false>(c, A, md->d_t, e) != LSQ_OK) return 1;
@@ -994,10 +1021,18 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
     if (J->kind == LSQ_MAT_CSC) {
+        // mirrors the products read: rows (CSR or sliced rows) and columns (window-blocked CSC or sliced
+        // columns), each with a 16-bit column per stored entry when the LDS-staged scaling applies
+        const bool have_cols = J->scols.active || J->nwin > 1;
+        const unsigned short *rcol = J->srows.active ? J->srows.d_idx16 : J->csr.d_idx16;
+        const unsigned short *ccol = J->scols.active ? J->scols.d_col16 : J->bcsc.d_col16;
+        double *rval = J->srows.active ? J->srows.d_val : J->csr.d_val;
+        double *cval = J->scols.active ? J->scols.d_val : J->bcsc.d_val;
+        const long long rlen = lsq_mirror_rows_len(J), clen = lsq_mirror_cols_len(J);
         const bool lds_ok = J->n <= 12000 && J->nnz >= (1 << 20);
-        // big problems: every product (and colsumabs2) reads the CSR / window-blocked mirrors, so
-        // only those are written; the CSC-ordered copy is rebuilt on demand (lsq_ensure_csc)
-        const bool lazy_csc = lds_ok && J->csr.d_idx16 && J->nwin > 1 && J->bcsc.d_col16 && lsq_can_fuse_grad_colsum(J);
+        // big problems: every product (and colsumabs2) reads the mirrors, so only those are written; the
+        // CSC-ordered copy is rebuilt on demand (lsq_ensure_csc)
+        const bool lazy_csc = lds_ok && rcol && have_cols && ccol && lsq_can_fuse_grad_colsum(J);
         if (!lazy_csc) {
             int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
             hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, md->d_Acsc,
@@ -1007,31 +1042,43 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         const size_t lds = (size_t)J->n * sizeof(double);
         static thread_local bool attr = false;
         if (lds_ok && !attr) {
-            hipFuncSetAttribute((const void *)k_scale_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 12000 * 8);
+            hipFuncSetAttribute((const void *)k_scale_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 12000 * 8);
+            hipFuncSetAttribute((const void *)k_scale_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 12000 * 8);
             attr = true;
         }
-        const long long nnz4 = (J->nnz + 3) / 4;
-        if (!(lds_ok && J->csr.d_idx16 && (J->nwin <= 1 || J->bcsc.d_col16)))
-            hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
-        long long g2 = std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
+        hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
         if (J->nnz > 0) {
-            if (lds_ok && J->csr.d_idx16)
-                hipLaunchKernelGGL(k_scale_lds, dim3(c->num_cus), dim3(1024), lds, c->stream, nnz4, J->csr.d_idx16,
-                                   md->d_Acsr, x, J->n, J->csr.d_val);
-            else
+            if (lds_ok && rcol) {
+                hipLaunchKernelGGL(k_scale_lds<true>, dim3(c->num_cus), dim3(1024), lds, c->stream, (rlen + 3) / 4, rcol,
+                                   md->d_Acsr, md->d_t, J->n, rval);
+            } else if (!J->srows.active) {
+                long long g2 = std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
                 hipLaunchKernelGGL(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
                                    md->d_Acsr, md->d_t, J->csr.d_val);
+            } else {
+                return 1;   // (sliced rows always carry 16-bit columns)
+            }
         }
-        if (J->nwin > 1) {
-            int nsegs = J->bcsc.nseg;
-            if (lds_ok && J->bcsc.d_col16) {
-                hipLaunchKernelGGL(k_scale_lds, dim3(c->num_cus), dim3(1024), lds, c->stream, nnz4, J->bcsc.d_col16,
-                                   md->d_Ab, x, J->n, J->bcsc.d_val);
-            } else if (J->nnz < 16LL * nsegs) {
+        if (have_cols) {
+            if (lds_ok && ccol) {
+                static const bool nt_cols = getenv("LSQ_SCALE_COLS_NT") != nullptr;
+                if (nt_cols)
+                    hipLaunchKernelGGL(k_scale_lds<true>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
+                                       ccol, md->d_Ab, md->d_t, J->n, cval);
+                else
+                    hipLaunchKernelGGL(k_scale_lds<false>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
+                                       ccol, md->d_Ab, md->d_t, J->n, cval);
+            } else if (J->scols.active) {
+                // n > 65535: no 16-bit columns; rebuild the sliced columns from the CSC copy instead
+                if (lazy_csc) return 1;
+                if (lsq_mirror_cols(J, J->csc.d_val, cval) != LSQ_OK) return 1;
+            } else if (J->nnz < 16LL * J->bcsc.nseg) {
+                int nsegs = J->bcsc.nseg;
                 int g3 = std::min(lsq_div_up(nsegs, LSQ_NT), c->num_cus * 16);
                 hipLaunchKernelGGL(k_scale_bcsc_thread, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n,
                                    J->bcsc.d_ptr, md->d_Ab, md->d_t, J->bcsc.d_val);
             } else {
+                int nsegs = J->bcsc.nseg;
                 int g3 = std::min(lsq_div_up(nsegs, LSQ_NT / 64), c->num_cus * 16);
                 hipLaunchKernelGGL(k_scale_bcsc, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n, J->bcsc.d_ptr,
                                    md->d_Ab, md->d_t, J->bcsc.d_val);
@@ -1064,14 +1111,16 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
     LSQ_HIP(hipMemcpy(md->d_b, hb, (size_t)J->m * sizeof(double), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&md->d_t, (size_t)(J->n > 0 ? J->n : 1) * sizeof(double)));
     if (J->kind == LSQ_MAT_CSC) {
-        LSQ_HIP(hipMalloc(&md->d_Acsr, vb));
-        LSQ_HIP(hipMemset(md->d_Acsr, 0, vb));
-        // reuse the CSC->CSR map of the pattern to permute A once
-        LSQ_TRY(lsq_permute_to_csr(J, md->d_Acsc, md->d_Acsr));
-        if (J->nwin > 1) {
-            LSQ_HIP(hipMalloc(&md->d_Ab, vb));
-            LSQ_HIP(hipMemset(md->d_Ab, 0, vb));
-            LSQ_TRY(lsq_permute_to_bcsc(J, md->d_Acsc, md->d_Ab));
+        // A in the layouts the products of J read (same maps as J's own mirrors), permuted once
+        const size_t rb = (size_t)(lsq_mirror_rows_len(J) + 1024) * sizeof(double);
+        LSQ_HIP(hipMalloc(&md->d_Acsr, rb));
+        LSQ_HIP(hipMemset(md->d_Acsr, 0, rb));
+        LSQ_TRY(lsq_mirror_rows(J, md->d_Acsc, md->d_Acsr));
+        if (lsq_mirror_cols_len(J) > 0) {
+            const size_t cbytes = (size_t)(lsq_mirror_cols_len(J) + 1024) * sizeof(double);
+            LSQ_HIP(hipMalloc(&md->d_Ab, cbytes));
+            LSQ_HIP(hipMemset(md->d_Ab, 0, cbytes));
+            LSQ_TRY(lsq_mirror_cols(J, md->d_Acsc, md->d_Ab));
         }
         LSQ_HIP(hipStreamSynchronize(c->stream));
     }

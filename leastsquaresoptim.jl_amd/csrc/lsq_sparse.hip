@@ -133,6 +133,103 @@ static void free_segs(LsqSegs &S) {
     S = LsqSegs();
 }
 
+// ---------------------------------------------------------------------------------------------
+// sliced layouts (lsq_sell.h)
+// ---------------------------------------------------------------------------------------------
+// Segments [first, first+count) of `ptr` are the outputs of block b (first/count from seg_range);
+// entry e of a segment gathers with index idx16_of(e), comes from CSC position srcmap[e] and
+// belongs to column col_of(e) (only stored when want_col16).
+template <class SegRange, class Idx16, class ColOf>
+static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, const std::vector<int> &srcmap,
+                      SegRange seg_range, Idx16 idx16_of, ColOf col_of, bool want_col16) {
+    std::vector<int> wslice(nblocks + 1, 0), map;
+    std::vector<int2> smeta;
+    std::vector<unsigned> info;
+    std::vector<unsigned short> idx16, col16;
+    long long nstore = 0;
+    std::vector<int> ord;
+    for (int b = 0; b < nblocks; ++b) {
+        int first, count;
+        seg_range(b, first, count);
+        wslice[b] = (int)smeta.size();
+        ord.resize(count);
+        for (int i = 0; i < count; ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int c2) {
+            return ptr[first + a + 1] - ptr[first + a] > ptr[first + c2 + 1] - ptr[first + c2];
+        });
+        const int ngroups = (count + 63) / 64;
+        for (int slot = 0; slot < ngroups; ++slot) {
+            // snake order: the 16 waves visit slices s0+wave, s0+wave+16, ...; alternate the direction of
+            // the deal every round so that every wave gets the same share of long and short slices
+            const int round = slot / 16, r = slot % 16;
+            const bool full = (round + 1) * 16 <= ngroups;
+            const int g = round * 16 + ((round & 1) && full ? 15 - r : r);   // sorted group stored at this slot
+            int L = 0;
+            for (int l = 0; l < 64 && g * 64 + l < count; ++l) {
+                const int sg = first + ord[g * 64 + l];
+                L = std::max(L, ptr[sg + 1] - ptr[sg]);
+            }
+            L = (L + 1) & ~1;
+            if (nstore + (long long)L * 64 > 2147480000LL) return LSQ_EDIM;
+            const long long off = nstore;
+            nstore += (long long)L * 64;
+            map.resize(nstore, -1);
+            idx16.resize(nstore, 0);
+            if (want_col16) col16.resize(nstore, 0);
+            smeta.push_back(make_int2((int)off, L));
+            for (int l = 0; l < 64; ++l) {
+                if (g * 64 + l >= count) {
+                    info.push_back(LSQ_SELL_POS_MASK);
+                    continue;
+                }
+                const int pos = ord[g * 64 + l], sg = first + pos;
+                const int len = ptr[sg + 1] - ptr[sg];
+                if (len >= (1 << (32 - LSQ_SELL_POS_BITS))) return LSQ_EDIM;
+                info.push_back((unsigned)pos | ((unsigned)len << LSQ_SELL_POS_BITS));
+                for (int j = 0; j < len; ++j) {
+                    const int e = ptr[sg] + j;
+                    const size_t slot_e = (size_t)off + ((size_t)(j / 2) * 64 + l) * 2 + (j & 1);
+                    map[slot_e] = srcmap[e];
+                    idx16[slot_e] = idx16_of(e);
+                    if (want_col16) col16[slot_e] = col_of(e);
+                }
+            }
+        }
+    }
+    wslice[nblocks] = (int)smeta.size();
+    S.nblocks = nblocks;
+    S.nslices = (int)smeta.size();
+    S.nstore = nstore;
+    const size_t pad = 1024;   // the unrolled loads of the last slice may run a few groups past the end
+    map.resize(nstore + pad, -1);
+    idx16.resize(nstore + pad, 0);
+    LSQ_HIP(hipMalloc(&S.d_wslice, wslice.size() * sizeof(int)));
+    LSQ_HIP(hipMemcpy(S.d_wslice, wslice.data(), wslice.size() * sizeof(int), hipMemcpyHostToDevice));
+    LSQ_HIP(hipMalloc(&S.d_smeta, (smeta.size() + 1) * sizeof(int2)));
+    LSQ_HIP(hipMemcpy(S.d_smeta, smeta.data(), smeta.size() * sizeof(int2), hipMemcpyHostToDevice));
+    LSQ_HIP(hipMalloc(&S.d_info, (info.size() + 64) * sizeof(unsigned)));
+    LSQ_HIP(hipMemcpy(S.d_info, info.data(), info.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    LSQ_HIP(hipMalloc(&S.d_idx16, idx16.size() * sizeof(unsigned short)));
+    LSQ_HIP(hipMemcpy(S.d_idx16, idx16.data(), idx16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    if (want_col16) {
+        col16.resize(nstore + pad, 0);
+        LSQ_HIP(hipMalloc(&S.d_col16, col16.size() * sizeof(unsigned short)));
+        LSQ_HIP(hipMemcpy(S.d_col16, col16.data(), col16.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    }
+    LSQ_HIP(hipMalloc(&S.d_map, map.size() * sizeof(int)));
+    LSQ_HIP(hipMemcpy(S.d_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    LSQ_HIP(hipMalloc(&S.d_val, (nstore + pad) * sizeof(double)));
+    LSQ_HIP(hipMemset(S.d_val, 0, (nstore + pad) * sizeof(double)));
+    S.active = true;
+    return LSQ_OK;
+}
+
+static void free_sell(LsqSell &S) {
+    hipFree(S.d_wslice); hipFree(S.d_smeta); hipFree(S.d_info); hipFree(S.d_idx16); hipFree(S.d_col16);
+    hipFree(S.d_val); hipFree(S.d_map); hipFree(S.d_part);
+    S = LsqSell();
+}
+
 extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const int *rowval, lsq_mat **out) {
     if (!c || !out || m < 0 || n < 0 || !colptr) {
         lsq_set_error("lsq_csc_create: bad arguments");
@@ -182,6 +279,76 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
     LSQ_HIP(hipMalloc(&J->d_map, (nnz + 4) * sizeof(int)));
     if (nnz) LSQ_HIP(hipMemcpy(J->d_map, map.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&J->d_colsum, (n > 0 ? n : 1) * sizeof(double)));
+    const bool sell_force = getenv("LSQ_SELL_FORCE") != nullptr;   // tests: sliced layouts on small patterns too
+    const bool sell_ok = !getenv("LSQ_NO_SELL") && (sell_force || nnz >= (1 << 20)) && nnz > 0;
+    // sliced rows for J*x: the whole gather vector must fit in LDS next to the 4096-row output window
+    if (sell_ok && !getenv("LSQ_NO_SELL_ROWS") && J->csr.plan == LSQ_PLAN_STREAM && n <= LSQ_LDS_X_MAX && n >= 1) {
+        int per_cu = (m + c->num_cus - 1) / c->num_cus;
+        int rounds = (per_cu + LSQ_SELL_ROWS_MAX - 1) / LSQ_SELL_ROWS_MAX;
+        int wrows = (m + rounds * c->num_cus - 1) / (rounds * c->num_cus);
+        wrows = std::min(LSQ_SELL_ROWS_MAX, (wrows + 63) & ~63);
+        if (const char *e = getenv("LSQ_SELL_ROWS")) wrows = std::min(LSQ_SELL_ROWS_MAX, std::max(64, atoi(e) & ~63));
+        const int nblocks = (m + wrows - 1) / wrows;
+        int st = build_sell(
+            J->srows, nblocks, rptr, map,
+            [&](int b, int &first, int &count) { first = b * wrows; count = std::min(wrows, m - first); },
+            [&](int e) { return (unsigned short)ridx[e]; }, [&](int e) { return (unsigned short)ridx[e]; }, false);
+        if (st == LSQ_OK) {
+            J->srows.wrows = wrows;
+            hipFree(J->csr.d_val);   // the sliced layout carries the values; misuse of the mirror must fail loudly
+            J->csr.d_val = nullptr;
+        } else if (st != LSQ_EDIM) {
+            return st;
+        } else {
+            free_sell(J->srows);
+        }
+    }
+    // sliced columns for J'*y: gather windows of <= 8192 rows of y in LDS, <= 5120 output columns per block
+    if (sell_ok && !getenv("LSQ_NO_SELL_COLS") && (sell_force || m > 131072) && n >= 1 && !getenv("LSQ_PLAN_BCSC") && !getenv("LSQ_WINDOW_ROWS")) {
+        const int ncb = (n + LSQ_SELL_CCOLS_MAX - 1) / LSQ_SELL_CCOLS_MAX;
+        const int ccols = (n + ncb - 1) / ncb;
+        const int ngw_min = (m + LSQ_SELL_GROWS_MAX - 1) / LSQ_SELL_GROWS_MAX;
+        const int k = std::max(1, (int)(((long long)ngw_min * ncb + c->num_cus - 1) / c->num_cus));
+        int ngw = std::max(ngw_min, (k * c->num_cus) / ncb);
+        int grows = (m + ngw - 1) / ngw;
+        grows = std::min(LSQ_SELL_GROWS_MAX, (grows + 7) & ~7);
+        if (const char *e = getenv("LSQ_SELL_GROWS")) grows = std::min(LSQ_SELL_GROWS_MAX, std::max(64, atoi(e) & ~7));
+        ngw = (m + grows - 1) / grows;
+        if ((long long)ngw * n < 200000000LL) {
+            std::vector<int> gptr((size_t)ngw * n + 1, 0), gidx(nnz), gmap(nnz);
+            for (int j = 0; j < n; ++j)
+                for (int k2 = colptr[j]; k2 < colptr[j + 1]; ++k2) gptr[(size_t)(rowval[k2] / grows) * n + j + 1]++;
+            for (size_t s2 = 0; s2 < (size_t)ngw * n; ++s2) gptr[s2 + 1] += gptr[s2];
+            {
+                std::vector<int> fill(gptr.begin(), gptr.end() - 1);
+                for (int j = 0; j < n; ++j)
+                    for (int k2 = colptr[j]; k2 < colptr[j + 1]; ++k2) {
+                        int p = fill[(size_t)(rowval[k2] / grows) * n + j]++;
+                        gidx[p] = rowval[k2];
+                        gmap[p] = k2;
+                    }
+            }
+            std::vector<unsigned short> gcol(nnz);
+            for (size_t sg = 0; sg < (size_t)ngw * n; ++sg)
+                for (int e = gptr[sg]; e < gptr[sg + 1]; ++e) gcol[e] = (unsigned short)(sg % n);
+            int st = build_sell(
+                J->scols, ngw * ncb, gptr, gmap,
+                [&](int b, int &first, int &count) {
+                    const int gw = b / ncb, cb = b % ncb;
+                    first = gw * n + cb * ccols;
+                    count = std::max(0, std::min(ccols, n - cb * ccols));
+                },
+                [&](int e) { return (unsigned short)(gidx[e] % grows); }, [&](int e) { return gcol[e]; }, n <= 65535);
+            if (st == LSQ_OK) {
+                J->scols.ncb = ncb; J->scols.ccols = ccols; J->scols.ngw = ngw; J->scols.grows = grows;
+                LSQ_HIP(hipMalloc(&J->scols.d_part, (size_t)ngw * n * 2 * sizeof(double)));
+            } else if (st != LSQ_EDIM) {
+                return st;
+            } else {
+                free_sell(J->scols);
+            }
+        }
+    }
     // window-blocked CSC when the gathered m-vector is larger than ~1 MiB.  Default plan: windows
     // of <= 4096 rows staged in LDS (k_bcsc_lds), sized so that every CU gets a whole number of
     // windows; LSQ_WINDOW_ROWS / LSQ_PLAN_BCSC select the L2-resident variants instead.
@@ -191,7 +358,7 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
         bool ldswin = !eplan || !strcmp(eplan, "ldswin");
         int rows_per_win = 131072;
         if (erows) rows_per_win = std::max(64, atoi(erows));
-        const bool wanted = erows ? m > rows_per_win : m > 131072;
+        const bool wanted = !J->scols.active && (erows ? m > rows_per_win : m > 131072);
         if (ldswin && wanted) {
             int per_cu = (m + c->num_cus - 1) / c->num_cus;
             int rounds = (per_cu + LSQ_WIN_ROWS_MAX - 1) / LSQ_WIN_ROWS_MAX;
@@ -298,6 +465,8 @@ extern "C" int lsq_mat_destroy(lsq_mat *J) {
     free_segs(J->csr);
     hipFree(J->d_map);
     free_segs(J->bcsc);
+    free_sell(J->srows);
+    free_sell(J->scols);
     hipFree(J->d_bmap);
     hipFree(J->d_bpart);
     hipFree(J->d_colsum);
@@ -327,23 +496,36 @@ k_permute(long long nnz, const int *__restrict__ map, const double *__restrict__
         dst[k] = src[map[k]];
 }
 
-int lsq_permute_to_csr(lsq_mat *J, const double *d_csc_vals, double *d_csr_vals) {
-    if (J->nnz > 0) {
-        int grid = (int)std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
-        hipLaunchKernelGGL(k_permute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, J->nnz, J->d_map,
-                           d_csc_vals, d_csr_vals);
-        LSQ_HIP(hipGetLastError());
+// dst[k] = src[map[k]], 0 where map[k] < 0 (padding of the sliced layouts)
+__global__ void __launch_bounds__(LSQ_NT)
+k_permute_pad(long long nstore, const int *__restrict__ map, const double *__restrict__ src, double *__restrict__ dst) {
+    for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < nstore;
+         k += (long long)gridDim.x * LSQ_NT) {
+        const int p = map[k];
+        dst[k] = p >= 0 ? src[p] : 0.0;
     }
+}
+
+static int permute_launch(lsq_mat *J, long long count, const int *map, const double *src, double *dst, bool pad) {
+    if (count <= 0) return LSQ_OK;
+    int grid = (int)std::min<long long>((count + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
+    if (pad) hipLaunchKernelGGL(k_permute_pad, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, map, src, dst);
+    else hipLaunchKernelGGL(k_permute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, map, src, dst);
+    LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 
-int lsq_permute_to_bcsc(lsq_mat *J, const double *d_csc_vals, double *d_bcsc_vals) {
-    if (J->nnz > 0 && J->nwin > 1) {
-        int grid = (int)std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
-        hipLaunchKernelGGL(k_permute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, J->nnz, J->d_bmap,
-                           d_csc_vals, d_bcsc_vals);
-        LSQ_HIP(hipGetLastError());
-    }
+long long lsq_mirror_rows_len(const lsq_mat *J) { return J->srows.active ? J->srows.nstore : J->nnz; }
+long long lsq_mirror_cols_len(const lsq_mat *J) {
+    return J->scols.active ? J->scols.nstore : (J->nwin > 1 ? J->nnz : 0);
+}
+int lsq_mirror_rows(lsq_mat *J, const double *d_csc_vals, double *d_out) {
+    if (J->srows.active) return permute_launch(J, J->srows.nstore, J->srows.d_map, d_csc_vals, d_out, true);
+    return permute_launch(J, J->nnz, J->d_map, d_csc_vals, d_out, false);
+}
+int lsq_mirror_cols(lsq_mat *J, const double *d_csc_vals, double *d_out) {
+    if (J->scols.active) return permute_launch(J, J->scols.nstore, J->scols.d_map, d_csc_vals, d_out, true);
+    if (J->nwin > 1) return permute_launch(J, J->nnz, J->d_bmap, d_csc_vals, d_out, false);
     return LSQ_OK;
 }
 
@@ -354,25 +536,39 @@ k_unpermute(long long nnz, const int *__restrict__ map, const double *__restrict
         dst[map[k]] = src[k];
 }
 
+__global__ void __launch_bounds__(LSQ_NT)
+k_unpermute_pad(long long nstore, const int *__restrict__ map, const double *__restrict__ src, double *__restrict__ dst) {
+    for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < nstore;
+         k += (long long)gridDim.x * LSQ_NT) {
+        const int p = map[k];
+        if (p >= 0) dst[p] = src[k];
+    }
+}
+
 // A device g! may write the mirrors the products read and leave the CSC-ordered copy stale
-// (csc_fresh = false); it is rebuilt from the CSR mirror the first time someone asks for it.
+// (csc_fresh = false); it is rebuilt from the row mirror the first time someone asks for it.
 int lsq_ensure_csc(lsq_mat *J) {
     if (J->kind != LSQ_MAT_CSC || J->csc_fresh) return LSQ_OK;
     if (J->nnz > 0) {
-        int grid = (int)std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
-        hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, J->nnz, J->d_map,
-                           J->csr.d_val, J->csc.d_val);
+        const long long count = J->srows.active ? J->srows.nstore : J->nnz;
+        int grid = (int)std::min<long long>((count + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
+        if (J->srows.active)
+            hipLaunchKernelGGL(k_unpermute_pad, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, J->srows.d_map,
+                               J->srows.d_val, J->csc.d_val);
+        else
+            hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, J->d_map,
+                               J->csr.d_val, J->csc.d_val);
         LSQ_HIP(hipGetLastError());
     }
     J->csc_fresh = true;
     return LSQ_OK;
 }
 
-// refreshes every mirror (CSR, window-blocked CSC) of the user-visible CSC values
+// refreshes every mirror of the user-visible CSC values
 int lsq_ensure_csr(lsq_mat *J) {
     if (J->kind != LSQ_MAT_CSC || J->csr_fresh) return LSQ_OK;
-    LSQ_TRY(lsq_permute_to_csr(J, J->csc.d_val, J->csr.d_val));
-    LSQ_TRY(lsq_permute_to_bcsc(J, J->csc.d_val, J->bcsc.d_val));
+    LSQ_TRY(lsq_mirror_rows(J, J->csc.d_val, J->srows.active ? J->srows.d_val : J->csr.d_val));
+    LSQ_TRY(lsq_mirror_cols(J, J->csc.d_val, J->scols.active ? J->scols.d_val : J->bcsc.d_val));
     J->csr_fresh = true;
     return LSQ_OK;
 }
@@ -469,6 +665,7 @@ struct EpiGradSq {
 
 bool lsq_can_fuse_grad_colsum(const lsq_mat *J) {
     static thread_local int ok = -1;  // 160 KiB of dynamic LDS: yl + products + squares
+    if (J->kind == LSQ_MAT_CSC && J->scols.active && !lsq_small_mat(J)) return true;
     if (J->kind != LSQ_MAT_CSC || J->nwin <= 1 || J->bcsc.plan != LSQ_PLAN_LDSWIN || lsq_small_mat(J)) return false;
     if (ok < 0) {
         const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + 2 * LSQ_BIG_WINDOW) * sizeof(double);
@@ -485,6 +682,17 @@ bool lsq_can_fuse_grad_colsum(const lsq_mat *J) {
 int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {
     lsq_ctx *c = J->ctx;
     LSQ_TRY(lsq_ensure_csr(J));
+    if (J->scols.active) {
+        LSQ_TRY(launch_sell_cols<true>(J, f, nullptr));
+        EpiGradSq e{nullptr, 0, J->n, g, J->d_colsum, nullptr, nullptr};
+        int nb = lsq_div_up(2 * J->n, LSQ_CMB_COLS);
+        int grid = std::min(nb, c->num_cus * 8);
+        hipLaunchKernelGGL((k_combine<EpiGradSq>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, 2 * J->n,
+                           J->scols.ngw, e, nb);
+        LSQ_HIP(hipGetLastError());
+        J->colsum_version = J->version;
+        return LSQ_OK;
+    }
     const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + 2 * LSQ_BIG_WINDOW) * sizeof(double);
     auto kern = J->bcsc.d_idx16 ? k_bcsc_lds<true, true> : k_bcsc_lds<false, true>;
     int g2 = std::max(1, std::min(J->bcsc.nwin, c->num_cus));

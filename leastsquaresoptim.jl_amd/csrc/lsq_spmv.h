@@ -759,6 +759,62 @@ __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ p
     finish_block(epi, racc, sh);
 }
 
+#include "lsq_sell.h"
+
+static inline SellDev sell_dev(const LsqSell &s, const double *val = nullptr) {
+    return SellDev{s.d_wslice, s.d_smeta, s.d_info, s.d_idx16, val ? val : s.d_val, s.nblocks};
+}
+
+// J*x over the sliced rows, with `val` optionally replacing J's values (same pattern, e.g. a model's A)
+template <class Epi>
+static inline int launch_sell_rows(lsq_mat *J, const double *val, const double *x, const Epi &epi) {
+    lsq_ctx *c = J->ctx;
+    const LsqSell &S = J->srows;
+    const int nxpad = (J->n + 1) & ~1;
+    const size_t lds = (size_t)(nxpad + LSQ_SELL_ROWS_MAX) * sizeof(double);
+    auto kern = k_sell_rows<Epi>;
+    static thread_local size_t configured = 0;
+    if (configured < lds) {
+        LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((LSQ_LDS_X_MAX + LSQ_SELL_ROWS_MAX) * sizeof(double))));
+        configured = (LSQ_LDS_X_MAX + LSQ_SELL_ROWS_MAX) * sizeof(double);
+    }
+    const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
+    hipEvent_t e0, e1;
+    if (lsq_prof_take(c, &e0, &e1))
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S, val), S.wrows,
+                              J->m, x, J->n, nxpad, epi);
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S, val), S.wrows, J->m, x,
+                           J->n, nxpad, epi);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+// first pass of J'*y over the sliced columns: per gather-window partials into J->scols.d_part
+template <bool SQ>
+static inline int launch_sell_cols(lsq_mat *J, const double *y, const int *done) {
+    lsq_ctx *c = J->ctx;
+    const LsqSell &S = J->scols;
+    const size_t lds = (size_t)(LSQ_SELL_GROWS_MAX + (SQ ? 2 : 1) * LSQ_SELL_CCOLS_MAX) * sizeof(double);
+    auto kern = k_sell_cols<SQ>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
+    hipEvent_t e0, e1;
+    if (lsq_prof_take(c, &e0, &e1))
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.ncb, S.ccols,
+                              S.grows, J->m, J->n, y, S.d_part, done);
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.ncb, S.ccols, S.grows,
+                           J->m, J->n, y, S.d_part, done);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
 // One entry point for "dot every row (trans=0) / column (trans=1) of J with x, then epilogue".
 template <class Epi>
 static inline int launch_product(lsq_mat *J, int trans, const double *x, const Epi &epi) {
@@ -768,7 +824,18 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
     if (J->kind == LSQ_MAT_CSC) {
         if (!trans) {
             LSQ_TRY(lsq_ensure_csr(J));
+            if (J->srows.active) return launch_sell_rows(J, nullptr, x, epi);
             return launch_segs<false>(c, J->csr, x, epi);
+        }
+        if (J->scols.active) {
+            LSQ_TRY(lsq_ensure_csr(J));
+            LSQ_TRY(launch_sell_cols<false>(J, x, epi.done));
+            int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
+            int grid = cap((long long)nb + epi.extra_blocks);
+            hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, J->n,
+                               J->scols.ngw, epi, nb);
+            LSQ_HIP(hipGetLastError());
+            return LSQ_OK;
         }
         if (J->nwin > 1) {
             LSQ_TRY(lsq_ensure_csr(J));

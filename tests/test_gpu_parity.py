@@ -84,6 +84,61 @@ def test_sparse_products(ctx, plan, m, n, density, window_rows):
     assert cs[1] == 0.0
 
 
+@pytest.mark.parametrize("rows,grows", [(None, None), (64, 64), (192, 256)])
+@pytest.mark.parametrize("m,n,density", [(3000, 200, 0.01), (700, 40, 0.5), (64, 3000, 0.02), (9000, 6000, 0.001)])
+def test_sliced_layouts(ctx, m, n, density, rows, grows):
+    """The sliced (SELL) layouts of J*x and J'*y, forced onto small ragged matrices (empty rows and
+    columns, one full row, several blocks / gather windows / column blocks) and compared with the
+    oracle and, bit for bit, with a sequential evaluation of sampled rows."""
+    S = rand_csc(m, n, density, m + 3 * n).tolil()
+    S[5, :] = np.random.default_rng(0).standard_normal(n)
+    S[:, 1] = 0
+    S[3, :] = 0
+    S = S.tocsc()
+    S.sort_indices()
+    S.eliminate_zeros()
+    os.environ["LSQ_SELL_FORCE"] = "1"
+    if rows:
+        os.environ["LSQ_SELL_ROWS"], os.environ["LSQ_SELL_GROWS"] = str(rows), str(grows)
+    try:
+        J = lsq.DeviceMatrix(ctx, S)
+    finally:
+        for k in ("LSQ_SELL_FORCE", "LSQ_SELL_ROWS", "LSQ_SELL_GROWS"):
+            os.environ.pop(k, None)
+    lsq.set_exact(False)
+    try:
+        A = O.Mat.from_scipy(S)
+        rng = np.random.default_rng(1)
+        x, y = rng.standard_normal(n), rng.standard_normal(m)
+        dx, dy = lsq.DeviceVector(ctx, n, x), lsq.DeviceVector(ctx, m, y)
+        scale = 1 + np.abs(S).sum(axis=1).max()
+        out = lsq.mul_(lsq.DeviceVector(ctx, m, y), J, dx, 1.5, -0.5).get()
+        assert np.max(np.abs(out - O.mul(A, x, 1.5, -0.5, y))) <= 1e-12 * scale
+        # every output is ONE lane's left-to-right sum over the row's entries: the reference's order
+        # (SparseArrays mul!), so sampled rows -- among them the full row 5 -- must match bit for bit
+        Sr = S.tocsr()
+        # (rows averaging >= 48 entries keep the wave-per-row plan, whose tree sums differ in the last bits)
+        for i in ([5, 3] + list(rng.integers(0, m, 40))) if S.nnz / m < 48 else []:
+            dot = 0.0
+            for k in range(Sr.indptr[i], Sr.indptr[i + 1]):
+                dot += Sr.data[k] * x[Sr.indices[k]]
+            assert out[i] == 1.5 * dot + -0.5 * y[i]
+        out = lsq.mul_(lsq.DeviceVector(ctx, m, np.full(m, np.nan)), J, dx, 1.0, 0.0).get()
+        assert np.max(np.abs(out - O.mul(A, x))) <= 1e-12 * scale
+        scale_t = 1 + np.abs(S).sum(axis=0).max()
+        out = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, dy, -2.0, 0.25, trans=True).get()
+        assert np.max(np.abs(out - O.mulT(A, y, -2.0, 0.25, x))) <= 1e-12 * scale_t
+        cs = lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get()
+        assert np.allclose(cs, O.colsumabs2(A), rtol=1e-13, atol=0) and cs[1] == 0.0
+        # values written after creation reach the sliced copies, and read back unchanged
+        J.set_values(2.0 * S.data)
+        out = lsq.mul_(lsq.DeviceVector(ctx, m), J, dx, 1.0, 0.0).get()
+        assert np.max(np.abs(out - 2.0 * O.mul(A, x))) <= 1e-12 * scale
+        assert np.array_equal(J.values(), 2.0 * S.data)
+    finally:
+        lsq.set_exact(None)
+
+
 def test_empty_and_tiny_sparse(ctx):
     S = sp.csc_matrix((5, 3))
     J = lsq.DeviceMatrix(ctx, S)
@@ -437,15 +492,19 @@ def test_nonfinite_raises():
 # --------------------------------------------------------------- synthetic model (bench family)
 @pytest.mark.parametrize("sparse,opt,sol,big", [(True, "lm", "lsmr", False), (False, "lm", "cholesky", False),
                                                 (False, "dogleg", "qr", False), (True, "dogleg", "lsmr", False),
-                                                (True, "lm", "lsmr", True), (True, "dogleg", "lsmr", True)])
-def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big):
+                                                (True, "lm", "lsmr", True), (True, "dogleg", "lsmr", True),
+                                                (True, "lm", "lsmr", "segments"), (True, "dogleg", "lsmr", "segments")])
+def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big, monkeypatch):
     """Reduced-size C4/C2/C3 family: device f!/g! + device solver vs the oracle's C model.
-    `big` is large enough (m > 131072 rows, nnz >= 2^20) to take the paths C4 takes: the
-    LDS-staged J*v kernel and the row-window-blocked J'*u."""
+    `big` is large enough (m > 131072 rows, nnz >= 2^20) to take the paths C4 takes: the sliced
+    layouts (lsq_sell.h), or with "segments" the LDS-staged J*v kernel and the row-window-blocked J'*u."""
     m, n, per_col = (20000, 200, 100) if sparse else (1500, 48, None)
     if big:
         m, n, per_col = 300000, 2000, 600
+    if big == "segments":   # the segment kernels (LDS-staged stream / row windows) instead of the sliced layouts
+        monkeypatch.setenv("LSQ_NO_SELL", "1")
     pr = lsq.synthetic.TanhProblem(m, n, sparse=sparse, per_col=per_col, seed=7, ctx=ctx)
+    monkeypatch.delenv("LSQ_NO_SELL", raising=False)
     pr.reset()
     okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
     skind = {"lsmr": lsq._lib.LSMR, "cholesky": lsq._lib.CHOLESKY, "qr": lsq._lib.QR}[sol]
