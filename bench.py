@@ -160,7 +160,7 @@ def main():
     k1_raw_ms = avg[0] if cnt[0] > 0 else float("nan")
     k1_ms = k1_raw_ms
     achieved = bytes_k1 / (k1_ms * 1e-3) / 1e9 if cnt[0] > 0 else None
-    roof = {"bound": "hbm", "kernel": "k_seg_stream<EpiU> (LSMR J*v: u <- J t - cu*u, + sum u^2)",
+    roof = {"bound": "hbm", "kernel": "k_sell_rows<EpiU> (LSMR J*v: u <- J t - cu*u, + sum u^2)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
             "algorithmic_bytes_per_launch": bytes_k1, "avg_launch_ms": k1_ms, "launches_timed": int(cnt[0]),

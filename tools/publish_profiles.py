@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof (tools/make_profiles.sh) -> profiles/<round>/: bench lines, --stats CSV, per-kernel
+summary with working launches separated, PMC traffic table and the JSON bench.py reads."""
+import json, os, shutil, subprocess, sys, csv, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01")
+os.makedirs(dst, exist_ok=True)
+for name in ("bench.json", "bench_under_rocprof.json"):
+    line = [l for l in open(os.path.join(src, name)) if l.startswith("{")][-1]
+    open(os.path.join(dst, name), "w").write(line)
+shutil.copy(os.path.join(src, "kt", "bench_kernel_stats.csv"), os.path.join(dst, "bench_kernel_stats.csv"))
+bench = json.loads(open(os.path.join(dst, "bench.json")).read())
+prof = json.loads(open(os.path.join(dst, "bench_under_rocprof.json")).read())
+table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_summary.py"),
+                        os.path.join(src, "kt", "bench_kernel_trace.csv")], capture_output=True, text=True).stdout
+k1 = [l for l in table.splitlines() if "k_sell_rows<EpiU>" in l]
+k1_work = float(k1[0].split("|")[5]) if k1 else float("nan")
+with open(os.path.join(dst, "kernel_summary.md"), "w") as fh:
+    fh.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu`, per kernel\n\n"
+             "`--stats` (bench_kernel_stats.csv) averages the early-exit launches of finished LSMR solves together\n"
+             "with the working launches; this table separates them.  The LSMR J*v kernel is `k_sell_rows<EpiU>`:\n"
+             "its working-launch average here (%.2f us) is what `roofline.avg_launch_ms` measures with the launch's\n"
+             "own start/stop events (%.2f us in the same profiled run, %.2f us in the un-profiled bench.json).\n\n"
+             % (k1_work, prof["roofline"]["avg_launch_ms"] * 1e3, bench["roofline"]["avg_launch_ms"] * 1e3))
+    fh.write(table)
+pm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"),
+                     os.path.join(src, "pmc_fetch", "f_counter_collection.csv"),
+                     os.path.join(src, "pmc_write", "w_counter_collection.csv")], capture_output=True, text=True).stdout
+rows = {l.split("|")[1].strip(): l.split("|") for l in pm.splitlines() if l.startswith("| `")}
+def find(sub):
+    for k, v in rows.items():
+        if sub in k:
+            return float(v[3]), float(v[4])
+    return None
+k1f = find("k_sell_rows<EpiU>")
+cal = find("k_scale_lds<true>")
+cfg = bench["config"]
+with open(os.path.join(dst, "pmc_traffic.md"), "w") as fh:
+    fh.write(pm)
+    fh.write("\nCollected with two separate passes of `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`\n"
+             "over `python bench.py --no-cpu --steps 16 --warmup 8` (working launches only; counters in KiB).\n"
+             "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE\n"
+             "reports half of the bytes of wide coalesced reads).  In-run calibration on a kernel with known traffic:\n")
+    if cal:
+        fh.write("`k_scale_lds<true>` reads (8+2) B and writes 8 B per stored entry -> raw FETCH %.1f MB (x2 = %.1f MB), raw WRITE %.1f MB.\n"
+                 % (cal[0] * 1024 / 1e6, 2 * cal[0] * 1024 / 1e6, cal[1] * 1024 / 1e6))
+    if k1f:
+        fh.write("LSMR J*v kernel (`k_sell_rows<EpiU>`): %.1f MB per launch against %.2f MB of algorithmic bytes.\n"
+                 % ((2 * k1f[0] + k1f[1]) * 1024 / 1e6, bench["roofline"]["algorithmic_bytes_per_launch"] / 1e6))
+if k1f:
+    json.dump({"kernel": "k_sell_rows<EpiU>", "config": {"m": cfg["m"], "n": cfg["n"], "nnz": cfg["nnz"]},
+               "fetch_size_kib_raw": k1f[0], "write_size_kib_raw": k1f[1],
+               "hbm_bytes_per_launch": int((2 * k1f[0] + k1f[1]) * 1024),
+               "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2*FETCH+WRITE)*1024 (gfx950 FETCH_SIZE halving, calibrated in-run)",
+               "source": "profiles/%s/pmc_traffic.md" % os.path.basename(dst)}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, "kernel_summary.md")).read()[:3000])
+print(open(os.path.join(dst, "pmc_traffic.md")).read()[:2500])

@@ -16,7 +16,7 @@ print("| kernel | launches | avg us (all) | working launches | avg us (working) 
 print("|---|---|---|---|---|---|---|---|")
 for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
     mn = min(v)
-    early = any(t in name for t in ("k_seg_", "k_combine", "k_lsmr_update"))
+    early = any(t in name for t in ("k_seg_", "k_sell_", "k_combine", "k_lsmr_update"))
     work = [d for d in v if (d > 3 * mn and d > 8.0)] if early and mn < 8.0 else v
     work = work or v
     print("| `%s` | %d | %.2f | %d | %.2f | %.2f | %.2f | %.1f |" % (
