@@ -55,11 +55,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch  # plumbing only: device selection, barrier, RCCL all-reduce
     dist = None
-    if world > 1:
+    # LSQ_BENCH_FORCE_EXCHANGE=1 (diagnostic): run the sharded protocol with its RCCL exchange even on one rank
+    force_x = world == 1 and os.environ.get("LSQ_BENCH_FORCE_EXCHANGE") == "1"
+    if force_x:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_x:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the per-iteration scalar exchange (80 bytes of host values) goes over a CPU group: an RCCL kernel
+        # would compete for CUs with the persistent one-workgroup-per-CU product kernels (measured with
+        # LSQ_BENCH_FORCE_EXCHANGE=1: 2370 -> 2190 it/s); RCCL stays the backend of barrier / reductions of
+        # device data.  LSQ_EXCHANGE_BACKEND=nccl switches back.
+        xgroup, xdev = None, "cuda"
+        if os.environ.get("LSQ_EXCHANGE_BACKEND", "gloo") == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the container hostname may not resolve
+            try:
+                xgroup, xdev = dist.new_group(backend="gloo"), "cpu"
+            except Exception as e:   # no CPU backend: fall back to RCCL for the scalars too
+                print("bench: gloo group unavailable (%s); scalar exchange over RCCL" % e, file=sys.stderr)
+                xgroup, xdev = None, "cuda"
     else:
         torch.cuda.set_device(local_rank)
     import numpy as np
@@ -77,9 +95,9 @@ def main():
     # one scalar all-reduce per outer iteration for the sharded (C5) case (sharding.py): sum of ssr,
     # max of the gradient norms, all-converged -- ONE RCCL all-reduce of world+2 doubles.
     allreduce = None
-    if world > 1:
+    if world > 1 or force_x:
         from lsq_amd import sharding
-        allreduce = sharding.make_allreduce_callback(dist, rank, world, "cuda")
+        allreduce = sharding.make_allreduce_callback(dist, rank, world, xdev, group=xgroup)
 
     LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
 

@@ -55,6 +55,11 @@ struct lsq_ctx {
     int num_cus;
     unsigned mail_epoch;  // bumps per inner solve; tags mailbox words
     void *workspace = nullptr;  // cached LsqWorkspace of lsq_optimize (lsq_optimize.hip)
+    // one-shot host work to run while the device is busy (the sharded loops' scalar exchange): the LSMR
+    // driver calls it once its look-ahead window is full, i.e. with >= 2 iterations of device work queued
+    int (*idle_hook)(void *) = nullptr;
+    void *idle_user = nullptr;
+    int idle_status = 0;
     // optional HIP-event instrumentation (lsq_prof_begin/end)
     int prof_max = 0;
     int prof_pending = -1;               // kernel id whose NEXT launch should carry dispatch timestamps
@@ -275,6 +280,13 @@ struct LsqSlotPublish {
 };
 LsqSlotPublish lsq_slots_ticket(lsq_ctx *c, int first, int count);
 int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, double *h_out);
+
+static inline void lsq_run_idle_hook(lsq_ctx *c) {
+    if (!c->idle_hook) return;
+    int (*h)(void *) = c->idle_hook;
+    c->idle_hook = nullptr;
+    c->idle_status = h(c->idle_user);
+}
 
 static inline unsigned *lsq_ctr(const lsq_ctx *c, int k) { return c->d_counters + (size_t)k * LSQ_CTR_SLOT; }
 static inline int lsq_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

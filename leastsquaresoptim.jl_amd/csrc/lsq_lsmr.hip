@@ -464,6 +464,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             spins = 0;
             continue;
         }
+        if (c->idle_hook) lsq_run_idle_hook(c);   // look-ahead window full: the device has work for a while
         if ((++spins & 0x3ffu) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
             // stream drained: whatever the mailbox shows now is final for the enqueued work
             w = *(volatile unsigned long long *)c->h_mail;

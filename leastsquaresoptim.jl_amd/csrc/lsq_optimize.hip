@@ -570,13 +570,14 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
     long long inner_total = 0;
     while (iter < o->iterations) {
         if (!o->allreduce && converged) break;
-        if (o->allreduce) {
+        if (o->allreduce && converged) {
             // frozen ranks keep taking part in the exchange until every problem has converged
-            int all = converged ? 1 : 0;
+            int all = 1;
             gssr = ssr; ggr = maxabs_gr;
             LSQ_TRY(global_exchange(o, &gssr, &ggr, &all));
             if (all) break;
-            if (converged) { ++iter; local_done = 1; continue; }
+            ++iter; local_done = 1;
+            continue;
         }
         iter++;
         if (nonfinite_at >= 0) {  // check_isfinite(x), utils.jl:70-75
@@ -613,9 +614,27 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
                                    c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             mul_calls++;
         }
+        // active ranks: the iteration's one exchange (same values as at the top of the iteration: ssr and
+        // the gradient norm change only at its end) runs on the host while the device is busy -- inside
+        // the LSMR driver once its look-ahead window is full, else right here behind the queued g!,
+        // gradient and damping launches.  "all converged" cannot come back true: this rank itself is not.
+        struct Xchg { const lsq_options *o; double *gssr, *ggr; } xchg{o, &gssr, &ggr};
+        if (o->allreduce) {
+            gssr = ssr; ggr = maxabs_gr;
+            c->idle_hook = [](void *p) -> int {
+                Xchg *q = (Xchg *)p;
+                int all = 0;
+                return global_exchange(q->o, q->gssr, q->ggr, &all);
+            };
+            c->idle_user = &xchg;
+            c->idle_status = 0;
+            if (sv->kind != LSQ_LSMR || exact) lsq_run_idle_hook(c);
+        }
         int lmiter = 0;
         if (sv->kind == LSQ_LSMR) LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr));  // :87
         else LSQ_TRY(lsq_ldiv_damped(sv, J, fcur, b.dtd, b.dx, &lmiter));
+        lsq_run_idle_hook(c);   // (a solve that never filled its window)
+        if (o->allreduce && c->idle_status != LSQ_OK) return c->idle_status;
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
         mul_calls += lmiter;
         inner_total += lmiter / 2;
@@ -701,12 +720,13 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
     long long inner_total = 0;
     while (iter < o->iterations) {
         if (!o->allreduce && converged) break;
-        if (o->allreduce) {
-            int all = converged ? 1 : 0;
+        if (o->allreduce && converged) {   // frozen rank (see optimize_lm)
+            int all = 1;
             gssr = ssr; ggr = maxabs_gr;
             LSQ_TRY(global_exchange(o, &gssr, &ggr, &all));
             if (all) break;
-            if (converged) { ++iter; continue; }
+            ++iter;
+            continue;
         }
         iter++;
         if (nonfinite_at >= 0) {
@@ -716,6 +736,7 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
             return LSQ_ENONFINITE;
         }
         int ls_iter = 0;
+        bool exchanged = false;
         if (!reuse) {
             LSQ_TRY(call_g(g, J, x, user));                               // :83
             g_calls++;
@@ -742,6 +763,12 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
             LSQ_TRY(predicted_to_slot(c, exact, J, b.dgr, nullptr, b.fpred, 6, c->d_slots + SL_SUM));  // :109-111
             mul_calls++;
             LSQ_TRY(lsq_fill(c, n, 0.0, b.dgn));
+            if (o->allreduce) {   // the iteration's exchange, hidden behind the queued g!/gradient work
+                int all = 0;
+                gssr = ssr; ggr = maxabs_gr;
+                LSQ_TRY(global_exchange(o, &gssr, &ggr, &all));
+                exchanged = true;
+            }
             LSQ_TRY(lsq_ldiv(sv, J, fcur, b.dgn, &ls_iter));              // :115
             mul_calls += ls_iter;
             inner_total += ls_iter / 2;
@@ -757,6 +784,11 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
             wnorm_dgn = std::sqrt(w[1]);
             alpha = wnorm_dgr * wnorm_dgr / w[3];
             wdot_gr_gn = w[2];  // wdot(dgr, dgn, dtd), needed only if case 3 is taken (:134)
+        }
+        if (o->allreduce && !exchanged) {   // iteration that reuses the Gauss-Newton step: nothing to hide behind
+            int all = 0;
+            gssr = ssr; ggr = maxabs_gr;
+            LSQ_TRY(global_exchange(o, &gssr, &ggr, &all));
         }
         double wnorm_dx;
         if (wnorm_dgn <= delta) {                                         // :120 case 1

@@ -27,18 +27,65 @@ def exchange(dist, rank, world, ssr, gnorm, converged, buf, host=None):
     return float(host[0]), float(host[2:].max()), bool(float(host[1]) >= world - 0.5)
 
 
-def make_allreduce_callback(dist, rank, world, device):
-    """ctypes callback for lsq_options.allreduce (vals = {ssr, maxabs_gr, converged})."""
+def make_allreduce_callback(dist, rank, world, device, group=None):
+    """ctypes callback for lsq_options.allreduce (vals = {ssr, maxabs_gr, converged}).
+
+    Called once per outer iteration by the loop kernels' host side (for active ranks: after g!, the
+    gradient pass and the damping have been queued).  Every call issues exactly one all-reduce, so the
+    collective sequence matches across ranks whatever their state.  What is returned differs:
+
+    * a rank that reports `converged` (a frozen rank, which acts on "all converged") waits for its
+      exchange and gets this iteration's global values;
+    * an ACTIVE rank never acts on the result inside the loop ("all converged" cannot be true while it
+      is not converged itself), so its all-reduce is left in flight and the call returns the values of
+      the PREVIOUS exchange: the latency of the collective overlaps the whole iteration.  (Its
+      reported global ssr is therefore one iteration old while it is active.)
+
+    The staging buffers are written through numpy views (no tensor indexing ops)."""
     import torch
-    buf = torch.zeros(world + 2, dtype=torch.float64, device=device)
-    host = torch.zeros(world + 2, dtype=torch.float64)
-    if str(device).startswith("cuda"):
-        host = host.pin_memory()
+    on_gpu = str(device).startswith("cuda")
+    bufs = [torch.zeros(world + 2, dtype=torch.float64, device=device) for _ in range(2)]
+    hosts = [torch.zeros(world + 2, dtype=torch.float64) for _ in range(2)]
+    if on_gpu:
+        hosts = [h.pin_memory() for h in hosts]
+    views = [h.numpy() for h in hosts]   # share memory with the (pinned) staging tensors
+    state = {"work": None, "slot": 0}
+
+    def _finish(work, k):
+        work.wait()
+        if on_gpu:
+            hosts[k].copy_(bufs[k], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        else:
+            hosts[k].copy_(bufs[k])
+        hv = views[k]
+        return float(hv[0]), float(hv[2:].max()), 1.0 if hv[1] >= world - 0.5 else 0.0
 
     def _cb(vals, count, _user):
         try:
-            s, g, allc = exchange(dist, rank, world, vals[0], vals[1], vals[2] > 0.5, buf, host)
-            vals[0], vals[1], vals[2] = s, g, 1.0 if allc else 0.0
+            k = state["slot"]
+            prev, pk = state["work"], k ^ 1
+            conv = vals[2] > 0.5
+            hv = views[k]
+            hv[:] = 0.0
+            hv[0] = vals[0]
+            hv[1] = 1.0 if conv else 0.0
+            hv[2 + rank] = vals[1]
+            bufs[k].copy_(hosts[k], non_blocking=True)
+            work = dist.all_reduce(bufs[k], async_op=True, group=group)
+            if conv or state.get("last") is None:
+                if prev is not None:
+                    _finish(prev, pk)            # drain the exchange left in flight while active
+                res = _finish(work, k)
+                state["work"] = None
+            else:
+                if prev is not None:
+                    state["last"] = _finish(prev, pk)
+                res = state["last"]
+                state["work"] = work
+            state["last"] = res
+            state["slot"] = k ^ 1
+            vals[0], vals[1], vals[2] = res
             return 0
         except Exception as e:  # pragma: no cover
             print("allreduce callback failed:", e, file=sys.stderr)

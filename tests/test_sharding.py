@@ -39,6 +39,15 @@ def _worker_exchange(rank, world, port, q):
     vals = (C.c_double * 3)(2.0 * (rank + 1), 3.0 - rank, 1.0)
     assert cb(vals, 3, None) == 0
     out.append((vals[0], vals[1], vals[2]))
+    # active ranks (converged = 0): the first call is synchronous, later ones return the PREVIOUS exchange
+    # while their own all-reduce stays in flight; a converged call drains it and is synchronous again
+    cb2 = lsq.sharding.make_allreduce_callback(dist, rank, world, "cpu")
+    seq = []
+    for it, conv in enumerate([0.0, 0.0, 0.0, 1.0]):
+        vals = (C.c_double * 3)(10.0 * it + rank, float(it + rank), conv)
+        assert cb2(vals, 3, None) == 0
+        seq.append((vals[0], vals[1], vals[2]))
+    out.append(seq)
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -58,6 +67,8 @@ def test_exchange_gloo_world2():
         assert res[r][0] == (3.0, 20.0, False)          # sum, max, not all converged
         assert res[r][1] == (1.0, 7.0, True)
         assert res[r][2] == (6.0, 3.0, 1.0)
+        # sums over ranks {0,1}: iteration it contributes 20*it + 1, max gnorm it + 1
+        assert res[r][3] == [(1.0, 1.0, 0.0), (1.0, 1.0, 0.0), (21.0, 2.0, 0.0), (61.0, 4.0, 1.0)]
 
 
 def _worker_lm(rank, world, port, q):
