@@ -120,6 +120,8 @@ def main():
 
     def barrier():
         if dist is not None:
+            from lsq_amd import sharding as _sh
+            _sh.drain_all()   # exchanges the active ranks left in flight
             dist.barrier()
         torch.cuda.synchronize()
         ctx.sync()

@@ -27,6 +27,15 @@ def exchange(dist, rank, world, ssr, gnorm, converged, buf, host=None):
     return float(host[0]), float(host[2:].max()), bool(float(host[1]) >= world - 0.5)
 
 
+_DRAINS = []
+
+
+def drain_all():
+    """Completes exchanges that active ranks left in flight (call before tearing the process group down)."""
+    for d in _DRAINS:
+        d()
+
+
 def make_allreduce_callback(dist, rank, world, device, group=None):
     """ctypes callback for lsq_options.allreduce (vals = {ssr, maxabs_gr, converged}).
 
@@ -91,4 +100,10 @@ def make_allreduce_callback(dist, rank, world, device, group=None):
             print("allreduce callback failed:", e, file=sys.stderr)
             return 1
 
+    def _drain():
+        if state["work"] is not None:
+            _finish(state["work"], state["slot"] ^ 1)
+            state["work"] = None
+
+    _DRAINS.append(_drain)
     return _lib.ALLREDUCE_CALLBACK(_cb)
