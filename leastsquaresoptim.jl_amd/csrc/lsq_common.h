@@ -173,6 +173,15 @@ struct lsq_mat {
     unsigned long long colsum_version = ~0ull;
 };
 
+// hipMemset runs on the NULL stream and is asynchronous to the host, while the library's stream is
+// non-blocking (not ordered against the NULL stream): a creation-time memset could therefore land
+// AFTER the first upload on the library stream and wipe it.  Creation paths are not hot: wait.
+#define LSQ_ZERO(ptr, val, bytes)                  \
+    do {                                           \
+        LSQ_HIP(hipMemset((ptr), (val), (bytes))); \
+        LSQ_HIP(hipStreamSynchronize(nullptr));    \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------

@@ -324,7 +324,7 @@ k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp
 int lsq_lsmr_alloc(lsq_solver *s) {
     size_t nb = (size_t)(s->n > 0 ? s->n : 1) * sizeof(double);
     LSQ_HIP(hipMalloc(&s->d_state, sizeof(LsmrState)));
-    LSQ_HIP(hipMemset(s->d_state, 0, sizeof(LsmrState)));
+    LSQ_ZERO(s->d_state, 0, sizeof(LsmrState));
     LSQ_HIP(hipMalloc(&s->d_u, (size_t)(s->m > 0 ? s->m : 1) * sizeof(double)));
     LSQ_HIP(hipMalloc(&s->d_ux, nb));
     LSQ_HIP(hipMalloc(&s->d_v, nb));
@@ -335,7 +335,7 @@ int lsq_lsmr_alloc(lsq_solver *s) {
     LSQ_HIP(hipMalloc(&s->d_dg, nb));
     LSQ_HIP(hipMalloc(&s->d_rhs, nb));  // LSMR iterate (un-preconditioned space)
     LSQ_HIP(hipMalloc(&s->d_red, 4 * 4096 * sizeof(double) + 64));  // pu, pv, px[2] (4096 each), counts
-    LSQ_HIP(hipMemset(s->d_red, 0, 4 * 4096 * sizeof(double) + 64));
+    LSQ_ZERO(s->d_red, 0, 4 * 4096 * sizeof(double) + 64);
     return LSQ_OK;
 }
 

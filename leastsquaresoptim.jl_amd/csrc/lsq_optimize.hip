@@ -1137,7 +1137,7 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
     md->J = J;
     size_t vb = (size_t)(J->nnz + 8) * sizeof(double);
     LSQ_HIP(hipMalloc(&md->d_Acsc, vb));
-    LSQ_HIP(hipMemset(md->d_Acsc, 0, vb));
+    LSQ_ZERO(md->d_Acsc, 0, vb);
     LSQ_HIP(hipMemcpy(md->d_Acsc, hA, (size_t)J->nnz * sizeof(double), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&md->d_b, (size_t)(J->m > 0 ? J->m : 1) * sizeof(double)));
     LSQ_HIP(hipMemcpy(md->d_b, hb, (size_t)J->m * sizeof(double), hipMemcpyHostToDevice));
@@ -1146,12 +1146,12 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
         // A in the layouts the products of J read (same maps as J's own mirrors), permuted once
         const size_t rb = (size_t)(lsq_mirror_rows_len(J) + 1024) * sizeof(double);
         LSQ_HIP(hipMalloc(&md->d_Acsr, rb));
-        LSQ_HIP(hipMemset(md->d_Acsr, 0, rb));
+        LSQ_ZERO(md->d_Acsr, 0, rb);
         LSQ_TRY(lsq_mirror_rows(J, md->d_Acsc, md->d_Acsr));
         if (lsq_mirror_cols_len(J) > 0) {
             const size_t cbytes = (size_t)(lsq_mirror_cols_len(J) + 1024) * sizeof(double);
             LSQ_HIP(hipMalloc(&md->d_Ab, cbytes));
-            LSQ_HIP(hipMemset(md->d_Ab, 0, cbytes));
+            LSQ_ZERO(md->d_Ab, 0, cbytes);
             LSQ_TRY(lsq_mirror_cols(J, md->d_Acsc, md->d_Ab));
         }
         LSQ_HIP(hipStreamSynchronize(c->stream));

@@ -68,8 +68,8 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
     LSQ_HIP(hipMalloc(&S.d_ptr, (S.nseg + 1) * sizeof(int)));
     LSQ_HIP(hipMalloc(&S.d_idx, (S.nnz + pad) * sizeof(int)));
     LSQ_HIP(hipMalloc(&S.d_val, (S.nnz + pad) * sizeof(double)));
-    LSQ_HIP(hipMemset(S.d_idx, 0, (S.nnz + pad) * sizeof(int)));
-    LSQ_HIP(hipMemset(S.d_val, 0, (S.nnz + pad) * sizeof(double)));
+    LSQ_ZERO(S.d_idx, 0, (S.nnz + pad) * sizeof(int));
+    LSQ_ZERO(S.d_val, 0, (S.nnz + pad) * sizeof(double));
     LSQ_HIP(hipMemcpy(S.d_ptr, ptr.data(), (S.nseg + 1) * sizeof(int), hipMemcpyHostToDevice));
     if (S.nnz) LSQ_HIP(hipMemcpy(S.d_idx, idx.data(), S.nnz * sizeof(int), hipMemcpyHostToDevice));
     std::vector<int> tiles;
@@ -219,7 +219,7 @@ static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, cons
     LSQ_HIP(hipMalloc(&S.d_map, map.size() * sizeof(int)));
     LSQ_HIP(hipMemcpy(S.d_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&S.d_val, (nstore + pad) * sizeof(double)));
-    LSQ_HIP(hipMemset(S.d_val, 0, (nstore + pad) * sizeof(double)));
+    LSQ_ZERO(S.d_val, 0, (nstore + pad) * sizeof(double));
     S.active = true;
     return LSQ_OK;
 }
@@ -447,7 +447,7 @@ extern "C" int lsq_dense_create(lsq_ctx *c, int m, int n, lsq_mat **out) {
     J->nnz = (long long)m * n;
     size_t bytes = (size_t)(J->nnz + 8) * sizeof(double);
     LSQ_HIP(hipMalloc(&J->d_dense, bytes));
-    LSQ_HIP(hipMemset(J->d_dense, 0, bytes));
+    LSQ_ZERO(J->d_dense, 0, bytes);
     LSQ_HIP(hipMalloc(&J->d_colsum, (n > 0 ? n : 1) * sizeof(double)));
     *out = J;
     return LSQ_OK;

@@ -40,14 +40,14 @@ extern "C" int lsq_ctx_create(int device, void *stream, lsq_ctx **out) {
         c->own_stream = true;
     }
     LSQ_HIP(hipMalloc(&c->d_slots, LSQ_NSLOTS * sizeof(double)));
-    LSQ_HIP(hipMemset(c->d_slots, 0, LSQ_NSLOTS * sizeof(double)));
+    LSQ_ZERO(c->d_slots, 0, LSQ_NSLOTS * sizeof(double));
     LSQ_HIP(hipHostMalloc((void **)&c->h_slots, (LSQ_NSLOTS + 1) * sizeof(double),
                           hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_slots, 0, (LSQ_NSLOTS + 1) * sizeof(double));
     LSQ_HIP(hipHostGetDevicePointer((void **)&c->d_hslots, c->h_slots, 0));
     LSQ_HIP(hipMalloc(&c->d_partials, LSQ_MAX_PARTIALS * sizeof(double)));
     LSQ_HIP(hipMalloc(&c->d_counters, (size_t)LSQ_NSLOTS * LSQ_CTR_SLOT * sizeof(unsigned)));
-    LSQ_HIP(hipMemset(c->d_counters, 0, (size_t)LSQ_NSLOTS * LSQ_CTR_SLOT * sizeof(unsigned)));
+    LSQ_ZERO(c->d_counters, 0, (size_t)LSQ_NSLOTS * LSQ_CTR_SLOT * sizeof(unsigned));
     LSQ_HIP(hipHostMalloc((void **)&c->h_mail, sizeof(LsqMailbox),
                           hipHostMallocMapped | hipHostMallocCoherent));
     memset((void *)c->h_mail, 0, sizeof(LsqMailbox));

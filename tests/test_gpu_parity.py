@@ -269,6 +269,37 @@ def test_ldiv_qr(ctx, m, n, rank):
         assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("m,n,rank", [(300, 65, 65), (1100, 130, 130), (900, 100, 37), (700, 200, 1), (640, 128, 128),
+                                      (2000, 321, 321), (2000, 321, 300), (500, 500, 500)])
+def test_ldiv_qr_two_stage(ctx, m, n, rank, monkeypatch):
+    """The two-stage factorisation (unpivoted blocked Householder with MFMA trailing updates, then the
+    pivoted sweep on R) forced onto small problems: panel tails (n not a multiple of 64), rank-deficient
+    inputs (rank decision and minimum-norm completion still come from the pivoted stage), square and
+    stacked [J; sqrt(damp)] operands.  Same expectations as the one-stage path."""
+    rng = np.random.default_rng(300 + m + n + rank)
+    A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n))
+    y = rng.standard_normal(m)
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    xr, rk, *_ = O.qr_solve(A, y)
+    sols = {}
+    for env in ("LSQ_QR_TWO_STAGE", "LSQ_QR_ONE_STAGE"):
+        monkeypatch.setenv(env, "1")
+        sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+        _, nmul = sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+        assert nmul == 1 and sv.info()["qr_rank"] == rk == rank, env
+        sols[env] = dxo.get()
+        assert np.allclose(sols[env], xr, rtol=1e-8, atol=1e-10), env
+        if rank == n:
+            damp = rng.random(n) + 0.01
+            svd = lsq.AllocatedSolver(J, lsq.QR(), for_lm=True)
+            svd.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+            st, xd, _, _ = O.ldiv(O.QR, O.Mat(dense=A), y, damp)
+            assert np.allclose(dxo.get(), xd, rtol=1e-9, atol=1e-12)
+        monkeypatch.delenv(env)
+    assert np.allclose(sols["LSQ_QR_TWO_STAGE"], sols["LSQ_QR_ONE_STAGE"], rtol=1e-8, atol=1e-10)
+
+
 # ------------------------------------------------------------------- trust-region trajectories
 def gpu_run(p, optimizer, solver, sparse=False, **kw):
     name, f, g, x0 = p[:4]
