@@ -330,6 +330,7 @@ k_qrcp_solve(double *__restrict__ A, int M, int n, double *__restrict__ b, int l
     double *vn1 = ws, *vn2 = ws + n, *tau = ws + 2 * n, *wmin = tau + mn, *wmax = wmin + mn;
     double *tz = wmax + mn, *perm = tz + n;
     const double tol3z = sqrt(DBL_EPSILON / 2);
+    if ((phase & 4) && *rank_out == n) return;   // k_qr_rank + k_qr_backsolve already produced x
     if (phase & 1) {
     // column norms
     for (int j = wv; j < n; j += NW) {
@@ -525,6 +526,109 @@ k_qrcp_solve(double *__restrict__ A, int M, int n, double *__restrict__ b, int l
     for (int k = tid; k < n; k += QR_NT) x[k] = perm[k];
     if (tid == 0) *rank_out = rnk;
     (void)lenb;
+}
+
+// ---- fast solve phase for n <= 2048 (after either factorisation) -------------------------------
+// (1) rank decision: the dlaic1 recurrence of xGELSY is a chain of n dependent steps; a 1024-thread
+//     workgroup pays two barriers per reduction (~4.5 us per step).  ONE wavefront with the two
+//     estimate vectors in LDS needs no barrier at all (~0.6 us per step).
+constexpr int QRK_MAXN = 2048;
+constexpr int QRK_RPL = QRK_MAXN / 64;   // column entries per lane
+__global__ void __launch_bounds__(64)
+k_qr_rank(const double *__restrict__ A, int ld, int mn, double rcond, int *__restrict__ rank_out) {
+    __shared__ double wmin[QRK_MAXN];
+    __shared__ double wmax[QRK_MAXN];
+    const int lane = threadIdx.x;
+    double smax = fabs(A[0]), smin = smax;
+    if (smax == 0.0) {
+        if (lane == 0) *rank_out = 0;
+        return;
+    }
+    if (lane == 0) { wmin[0] = 1.0; wmax[0] = 1.0; }
+    // the column of step rnk+1 is fetched (all loads of a lane at once) while step rnk computes: the chain
+    // of n dependent steps then costs the dlaic1 arithmetic, not a memory round trip per step
+    auto fetch = [&](double (&ck)[QRK_RPL], double &gamma, int col_idx) {
+        const int cc = col_idx < mn ? col_idx : mn - 1;
+        const double *col = A + (size_t)cc * ld;
+#pragma unroll
+        for (int q = 0; q < QRK_RPL; ++q) {
+            const int k = lane + 64 * q;
+            ck[q] = k < cc ? col[k] : 0.0;
+        }
+        gamma = col[cc];
+    };
+    double ca[QRK_RPL], cb[QRK_RPL], ga, gb;
+    fetch(ca, ga, 1);
+    int rnk = 1;
+    bool stop = false;
+    auto step = [&](double (&ck)[QRK_RPL], double gamma, double (&nx)[QRK_RPL], double &gnx) {
+        fetch(nx, gnx, rnk + 1);
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < QRK_RPL; ++q) {
+            const int k = lane + 64 * q;
+            if (k < rnk) {
+                a1 += wmin[k] * ck[q];
+                a2 += wmax[k] * ck[q];
+            }
+        }
+        a1 = __shfl(wave_sum(a1), 0, 64);
+        a2 = __shfl(wave_sum(a2), 0, 64);
+        double sminpr, s1, c1, smaxpr, s2, c2;
+        laic1_dev(2, a1, smin, gamma, &sminpr, &s1, &c1);
+        laic1_dev(1, a2, smax, gamma, &smaxpr, &s2, &c2);
+        if (smaxpr * rcond > sminpr) { stop = true; return; }
+        for (int k = lane; k < rnk; k += 64) { wmin[k] *= s1; wmax[k] *= s2; }
+        if (lane == 0) { wmin[rnk] = c1; wmax[rnk] = c2; }
+        smin = sminpr; smax = smaxpr;
+        rnk += 1;
+        __builtin_amdgcn_wave_barrier();
+    };
+    while (rnk < mn && !stop) {
+        step(ca, ga, cb, gb);
+        if (rnk < mn && !stop) step(cb, gb, ca, ga);
+    }
+    if (lane == 0) *rank_out = rnk;
+}
+
+// (2) full rank: R z = Q'b by 64-column blocks (diagonal block solved by one wavefront in LDS, the rows
+//     above updated by all threads), then x[jp[k]] = z[k].  Does nothing when rank < n (the general
+//     kernel with the minimum-norm completion runs instead).
+__global__ void __launch_bounds__(QR_NT)
+k_qr_backsolve(const double *__restrict__ A, int ld, int n, const double *__restrict__ b, const int *__restrict__ jp,
+               const int *__restrict__ rank, double *__restrict__ x) {
+    __shared__ double z[QRK_MAXN];
+    __shared__ double D[64][65];
+    if (*rank != n) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int k = tid; k < n; k += QR_NT) z[k] = b[k];
+    __syncthreads();
+    for (int c1 = n; c1 > 0; c1 -= 64) {
+        const int c0 = max(0, c1 - 64), nb = c1 - c0;
+        for (int e = tid; e < 64 * 64; e += QR_NT) {
+            const int r = e % 64, cidx = e / 64;
+            D[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? A[(size_t)(c0 + cidx) * ld + c0 + r] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) {   // back substitution inside the block, column oriented (dtrsv 'U','N')
+            for (int j = nb - 1; j >= 0; --j) {
+                const double zj = z[c0 + j] / D[j][j];
+                if (lane == j) z[c0 + j] = zj;
+                if (lane < j) z[c0 + lane] -= zj * D[lane][j];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < c0; r += QR_NT) {
+            double s = 0.0;
+            const double *row = A + r;
+#pragma unroll 8
+            for (int j = 0; j < nb; ++j) s += row[(size_t)(c0 + j) * ld] * z[c0 + j];
+            z[r] -= s;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < n; k += QR_NT) x[jp[k]] = z[k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,24 +928,22 @@ k_qr1_step_reg(double *__restrict__ A, int M, int cend, int i, int first, double
     if (j >= cend) return;
     double *cj = A + (size_t)j * M;
     const int base = (first ? i : i + 1);       // rows base + tid + q*QR_NT, q < RPT (rows below row i, or from row i when first)
+    // element q of a thread is (uniform pointer + q*QR_NT)[t] with ONE unsigned per-thread offset t: the
+    // loads take the scalar-base + 32-bit-offset form instead of RPT 64-bit address pairs in VGPRs
+    const unsigned t = (unsigned)(base + tid);
     double a[RPT];
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int k = base + tid + q * QR_NT;
-        a[q] = k < M ? cj[k] : 0.0;
-    }
+    for (int q = 0; q < RPT; ++q) a[q] = (int)t + q * QR_NT < M ? (cj + q * QR_NT)[t] : 0.0;
     if (!first) {
         const double *ci = A + (size_t)i * M;
         const double ti = tau[i];
         if (ti != 0.0) {
-            // only the column itself stays in registers: v_i is read twice (the second time from L2), which
-            // keeps the kernel at <= 64 VGPRs of payload even for 24 rows per thread
+            // only the column itself stays in registers: v_i is read twice (the second time from L2)
             const double cji = cj[i];
             double w = 0.0;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const int k = base + tid + q * QR_NT;
-                const double vq = k < M ? ci[k] : 0.0;
+                const double vq = (int)t + q * QR_NT < M ? (ci + q * QR_NT)[t] : 0.0;
                 w += vq * a[q];
             }
             w = blk_sum_qr(w, sh);
@@ -850,29 +952,23 @@ k_qr1_step_reg(double *__restrict__ A, int M, int cend, int i, int first, double
             const double tw = s_w;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const int k = base + tid + q * QR_NT;
-                const double vq = k < M ? ci[k] : 0.0;
+                const double vq = (int)t + q * QR_NT < M ? (ci + q * QR_NT)[t] : 0.0;
                 a[q] -= vq * tw;
             }
             if (tid == 0) cj[i] = cji - tw;
         }
         if (j != i + 1) {
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int k = base + tid + q * QR_NT;
-                if (k < M) cj[k] = a[q];
-            }
+            for (int q = 0; q < RPT; ++q)
+                if ((int)t + q * QR_NT < M) (cj + q * QR_NT)[t] = a[q];
             return;
         }
     }
-    // reflector of column j (dlarfg) on rows j..M-1: element a[q] of thread tid is row base + tid + q*QR_NT,
-    // and row j itself is base (thread 0, q = 0)
+    // reflector of column j (dlarfg) on rows j..M-1: row j itself is element 0 of thread 0
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int k = base + tid + q * QR_NT;
-        if (k > j) acc += a[q] * a[q];
-    }
+    for (int q = 0; q < RPT; ++q)
+        if ((int)t + q * QR_NT > j) acc += a[q] * a[q];
     const double xn = sqrt(blk_sum_qr(acc, sh));
     if (tid == 0) {
         const double alpha = a[0];              // row base == j
@@ -889,8 +985,8 @@ k_qr1_step_reg(double *__restrict__ A, int M, int cend, int i, int first, double
     const double sc = s_tau != 0.0 ? s_scale : 1.0;
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const int k = base + tid + q * QR_NT;
-        if (k < M) cj[k] = (k > j) ? a[q] * sc : a[q];
+        const int k = (int)t + q * QR_NT;
+        if (k < M) (cj + q * QR_NT)[t] = (k > j) ? a[q] * sc : a[q];
     }
 }
 
@@ -1091,14 +1187,214 @@ k_qr1_extract(const double *__restrict__ A, int M, int n, const double *__restri
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) rhs2[i] = rhs[i];
 }
 
+// ---- stage 2, one launch per column ----------------------------------------------------------
+// The pivoted sweep on the n x n triangle with LAZY column exchanges: physical columns never move;
+// colat[pos] names the column standing at position pos (dgeqp3's idamax runs over positions, so ties
+// -- e.g. the all-zero norms of a rank-deficient tail -- resolve exactly as with physical swaps).
+// Every workgroup of step i redundantly (a) finds the pivot position, (b) builds H_i from the pivot
+// column in registers, then (c) applies it to its own column and downdates that column's norm.
+// Norms and the position map are double-buffered (read *_in, write *_out): a block must see the
+// norms as they were when the step began.  Block 0 also records beta, tau and the new position map.
+constexpr int Q2S_NT = 256;
+constexpr int Q2S_RPT = 8;    // rows per thread: n - i <= 2048
+__device__ __forceinline__ double blk_sum_256(double v, double *sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __syncthreads();
+    return r;
+}
+__global__ void __launch_bounds__(Q2S_NT)
+k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const double *__restrict__ vn1_in,
+           const double *__restrict__ vn2_in, double *__restrict__ vn1_out, double *__restrict__ vn2_out,
+           const int *__restrict__ colat_in, int *__restrict__ colat_out, double *__restrict__ tau,
+           double *__restrict__ diag, double *__restrict__ ice /* wmin[n] wmax[n] smin smax stopped */, double rcond,
+           int *__restrict__ rank_out) {
+    __shared__ double sh[4];
+    __shared__ double s_best[4];
+    __shared__ int s_bpos[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (a) first maximum of the norms over positions i..n-1
+    double best = -1.0;
+    int bpos = n;
+    for (int pos = i + tid; pos < n; pos += Q2S_NT) {
+        const double v = vn1_in[colat_in[pos]];
+        if (v > best) { best = v; bpos = pos; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64);
+        const int op = __shfl_down(bpos, o, 64);
+        if (ob > best || (ob == best && op < bpos)) { best = ob; bpos = op; }
+    }
+    if (lane == 0) { s_best[wv] = best; s_bpos[wv] = bpos; }
+    __syncthreads();
+    best = s_best[0]; bpos = s_bpos[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (s_best[w] > best || (s_best[w] == best && s_bpos[w] < bpos)) { best = s_best[w]; bpos = s_bpos[w]; }
+    const int ppos = bpos < n ? bpos : i;
+    const int pcol = colat_in[ppos], icol = colat_in[i];
+    // (b) reflector of the pivot column on rows i..n-1
+    const double *cp = R + (size_t)pcol * n;
+    double v[Q2S_RPT];
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q2S_RPT; ++q) {
+        const int k = i + 1 + tid + q * Q2S_NT;
+        v[q] = k < n ? cp[k] : 0.0;
+        acc += v[q] * v[q];
+    }
+    const double alpha = cp[i];
+    const double xn = sqrt(blk_sum_256(acc, sh));
+    double ti = 0.0, beta = alpha;
+    if (xn != 0.0) {
+        beta = -copysign(hypot(alpha, xn), alpha);
+        ti = (beta - alpha) / beta;
+        const double sc = 1.0 / (alpha - beta);
+#pragma unroll
+        for (int q = 0; q < Q2S_RPT; ++q) v[q] *= sc;
+    }
+    // (c) own column: position i+1+b (the column displaced by the exchange when that is the pivot's place)
+    const int npos = n - i - 1;
+    if ((int)blockIdx.x == npos + 1) {
+        // the extra workgroup: step i of xGELSY's incremental condition estimate (dlaic1) on the column that
+        // has just become final -- R(0:i-1, i) = rows above the diagonal of the pivot column, R(i,i) = beta --
+        // so the rank is known when the sweep ends instead of after n more dependent steps
+        double *wmin = ice, *wmax = ice + n, *sc = ice + 2 * n;   // sc: smin, smax, stopped
+        if (i == 0) {
+            if (tid == 0) {
+                const double a0 = fabs(beta);
+                sc[0] = a0; sc[1] = a0;
+                sc[2] = a0 == 0.0 ? 1.0 : 0.0;
+                wmin[0] = 1.0; wmax[0] = 1.0;
+                *rank_out = a0 == 0.0 ? 0 : 1;
+            }
+            return;
+        }
+        if (sc[2] != 0.0) return;   // rank already decided
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = tid; k < i; k += Q2S_NT) {
+            const double ck = cp[k];
+            a1 += wmin[k] * ck;
+            a2 += wmax[k] * ck;
+        }
+        a1 = blk_sum_256(a1, sh);
+        a2 = blk_sum_256(a2, sh);
+        double sminpr, s1, c1, smaxpr, s2, c2;
+        laic1_dev(2, a1, sc[0], beta, &sminpr, &s1, &c1);
+        laic1_dev(1, a2, sc[1], beta, &smaxpr, &s2, &c2);
+        __syncthreads();   // every thread has read sc[] before thread 0 rewrites it
+        if (smaxpr * rcond > sminpr) {
+            if (tid == 0) sc[2] = 1.0;
+            return;
+        }
+        for (int k = tid; k < i; k += Q2S_NT) { wmin[k] *= s1; wmax[k] *= s2; }
+        if (tid == 0) {
+            wmin[i] = c1; wmax[i] = c2;
+            sc[0] = sminpr; sc[1] = smaxpr;
+            *rank_out = i + 1;
+        }
+        return;
+    }
+    const bool is_rhs = (int)blockIdx.x == npos;
+    int own = -1;
+    if (!is_rhs) {
+        const int pos = i + 1 + blockIdx.x;
+        own = pos == ppos ? icol : colat_in[pos];
+    }
+    double *cj = is_rhs ? rhs : R + (size_t)own * n;
+    double a[Q2S_RPT];
+    double w = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q2S_RPT; ++q) {
+        const int k = i + 1 + tid + q * Q2S_NT;
+        a[q] = k < n ? cj[k] : 0.0;
+        w += v[q] * a[q];
+    }
+    double cji = cj[i];
+    if (ti != 0.0) {
+        w = blk_sum_256(w, sh) + cji;      // v_i = 1
+        const double tw = ti * w;
+#pragma unroll
+        for (int q = 0; q < Q2S_RPT; ++q) {
+            const int k = i + 1 + tid + q * Q2S_NT;
+            a[q] -= v[q] * tw;
+            if (k < n) cj[k] = a[q];
+        }
+        cji -= tw;
+        if (tid == 0) cj[i] = cji;
+    }
+    if (!is_rhs) {   // partial-norm downdate (dlaqp2), by physical column
+        const double tol3z = sqrt(DBL_EPSILON / 2);
+        const double v1 = vn1_in[own], v2 = vn2_in[own];
+        double n1 = v1, n2 = v2;
+        if (v1 != 0.0) {
+            const double r = fabs(cji) / v1;
+            const double temp = fmax(1.0 - r * r, 0.0);
+            const double qq = v1 / v2;
+            const double temp2 = temp * qq * qq;
+            if (temp2 <= tol3z) {
+                double a2 = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q2S_RPT; ++q) a2 += a[q] * a[q];
+                a2 = blk_sum_256(a2, sh);
+                n1 = i < n - 1 ? sqrt(a2) : 0.0;
+                n2 = n1;
+            } else {
+                n1 = v1 * sqrt(temp);
+            }
+        }
+        if (tid == 0) { vn1_out[own] = n1; vn2_out[own] = n2; }
+    }
+    if (blockIdx.x == 0) {   // bookkeeping of the step
+        if (tid == 0) {
+            diag[i] = beta;   // (not into R: other workgroups of this step still read the pivot column)
+            tau[i] = ti;
+        }
+        for (int pos = tid; pos < n; pos += Q2S_NT) {
+            int cidx = colat_in[pos];
+            if (pos == i) cidx = pcol;
+            else if (pos == ppos) cidx = icol;
+            colat_out[pos] = cidx;
+        }
+    }
+}
+
+// R in pivoted order for the solve: G(0:pos, pos) = R(0:pos, colat[pos]); jp[pos] = colat[pos]
+__global__ void __launch_bounds__(256)
+k_qr2_gather(const double *__restrict__ R, int n, const int *__restrict__ colat, const double *__restrict__ diag,
+             double *__restrict__ G, int *__restrict__ jp) {
+    const long long tot = (long long)n * n;
+    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e % n), pos = (int)(e / n);
+        G[e] = r < pos ? R[(size_t)colat[pos] * n + r] : (r == pos ? diag[pos] : 0.0);
+    }
+    for (int pos = blockIdx.x * 256 + threadIdx.x; pos < n; pos += gridDim.x * 256) jp[pos] = colat[pos];
+}
+__global__ void __launch_bounds__(256)
+k_qr2_init(const double *__restrict__ R, int n, double *__restrict__ vn1, double *__restrict__ vn2, int *__restrict__ colat) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double *c = R + (size_t)j * n;
+    double acc = 0.0;
+    for (int k = lane; k < n; k += 64) acc += c[k] * c[k];
+    acc = wave_sum(acc);
+    if (lane == 0) { double v = sqrt(acc); vn1[j] = v; vn2[j] = v; colat[j] = j; }
+}
+
 struct Qr2Work {
     double *Vb = nullptr, *Wp = nullptr, *W = nullptr, *W2 = nullptr, *R = nullptr, *rhs2 = nullptr, *tau1 = nullptr;
+    double *vn = nullptr;     // stage 2: vn1/vn2 double-buffered (4n)
+    double *ice = nullptr;    // stage 2: condition-estimate vectors + scalars (2n + 8)
+    int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
     int kslices = 0, M = 0, n = 0;
 };
 static void qr2_free(void *p) {
     Qr2Work *q = (Qr2Work *)p;
     if (!q) return;
     hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
+    hipFree(q->vn); hipFree(q->colat); hipFree(q->ice);
     delete q;
 }
 
@@ -1106,7 +1402,7 @@ static bool qr2_applies(int M, int n) {
     const bool off = getenv("LSQ_QR_ONE_STAGE") != nullptr;     // (read per call: the tests flip them)
     const bool force = getenv("LSQ_QR_TWO_STAGE") != nullptr;
     if (off || M < n || n < 2) return false;
-    return force || (n >= 256 && (long long)M * n >= (1LL << 22));
+    return force || (n >= 256 && (long long)M * n >= (1LL << 21));
 }
 
 // factors [A | b] (s->d_qr, s->d_qu) and leaves R2, pivots (jp) and Q'b for k_qrcp_solve(phase 0) in the
@@ -1128,6 +1424,9 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         LSQ_HIP(hipMalloc(&q->R, ((size_t)n * n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->rhs2, ((size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->tau1, ((size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->vn, (4 * (size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->ice, (2 * (size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->colat, (2 * (size_t)n + 8) * sizeof(int)));
         s->qr2 = q;
         s->qr2_free = qr2_free;
     }
@@ -1203,18 +1502,47 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
         if (qr2_applies(M, n)) {
             double *R2 = nullptr, *rhs2 = nullptr;
             LSQ_TRY(qr2_factor(s, M, n, &R2, &rhs2));
-            // stage 2: the pivoted sweep on the n x n triangle, Q1'b riding along as column n
+            // stage 2: the pivoted sweep on the n x n triangle, Q1'b riding along
             double *ws = s->d_work;
-            double *vn1 = ws, *vn2 = ws + n, *tau = ws + 2 * n;
+            double *tau = ws + 2 * n;
             int *jp = (int *)s->d_tau;
-            hipLaunchKernelGGL(k_qr_norms, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, R2, n, n, vn1, vn2, jp);
-            for (int i = 0; i < n; ++i) {
-                hipLaunchKernelGGL(k_qr_pivot, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, i, vn1, vn2, jp, tau);
-                hipLaunchKernelGGL(k_qr_apply, dim3(lsq_div_up(n - i, 4)), dim3(256), 0, c->stream, R2, n, n, i, rhs2, tau,
-                                   vn1, vn2);
+            Qr2Work *q = (Qr2Work *)s->qr2;
+            bool have_rank = false;
+            if (n <= Q2S_NT * Q2S_RPT && !getenv("LSQ_QR2_TWO_LAUNCH")) {
+                // one launch per column, lazy exchanges (k_qr2_step)
+                double *vn1[2] = {q->vn, q->vn + 2 * n}, *vn2[2] = {q->vn + n, q->vn + 3 * n};
+                int *colat[2] = {q->colat, q->colat + n};
+                hipLaunchKernelGGL(k_qr2_init, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, R2, n, vn1[0], vn2[0], colat[0]);
+                for (int i = 0; i < n; ++i) {
+                    const int a = i & 1, b = a ^ 1;
+                    hipLaunchKernelGGL(k_qr2_step, dim3(n - i + 1), dim3(Q2S_NT), 0, c->stream, R2, n, i, rhs2, vn1[a], vn2[a],
+                                       vn1[b], vn2[b], colat[a], colat[b], tau, ws + 7 * n, q->ice,
+                                       (double)mn * DBL_EPSILON, s->d_info);
+                }
+                // the solve wants R in pivoted order: gather it into the (now free) factor buffer
+                long long tot = (long long)n * n;
+                int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 8);
+                hipLaunchKernelGGL(k_qr2_gather, dim3(g), dim3(256), 0, c->stream, R2, n, colat[n & 1], ws + 7 * n, s->d_qr, jp);
+                R2 = s->d_qr;
+                have_rank = true;
+            } else {
+                double *vn1 = ws, *vn2 = ws + n;
+                hipLaunchKernelGGL(k_qr_norms, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, R2, n, n, vn1, vn2, jp);
+                for (int i = 0; i < n; ++i) {
+                    hipLaunchKernelGGL(k_qr_pivot, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, i, vn1, vn2, jp, tau);
+                    hipLaunchKernelGGL(k_qr_apply, dim3(lsq_div_up(n - i, 4)), dim3(256), 0, c->stream, R2, n, n, i, rhs2, tau,
+                                       vn1, vn2);
+                }
+            }
+            int ph = 0;
+            if (n <= QRK_MAXN && !getenv("LSQ_QR_SLOW_SOLVE")) {
+                if (!have_rank)
+                    hipLaunchKernelGGL(k_qr_rank, dim3(1), dim3(64), 0, c->stream, R2, n, n, (double)mn * DBL_EPSILON, s->d_info);
+                hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
+                ph = 4;
             }
             hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, n, d_x, s->d_work, jp,
-                               s->d_T, (double)mn * DBL_EPSILON, s->d_info, 0);
+                               s->d_T, (double)mn * DBL_EPSILON, s->d_info, ph);
         } else if (n >= 64 && (long long)M * n >= 65536 && !getenv("LSQ_QR_SMALL")) {
             // multi-CU column-pivoted Householder (BLAS-2 per column, the rhs rides along as column n)
             double *ws = s->d_work;
@@ -1226,8 +1554,15 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
                 hipLaunchKernelGGL(k_qr_apply, dim3(lsq_div_up(n - i, 4)), dim3(256), 0, c->stream, s->d_qr, M, n, i,
                                    s->d_qu, tau, vn1, vn2);
             }
+            int ph = 0;
+            if (n <= QRK_MAXN && M >= n && !getenv("LSQ_QR_SLOW_SOLVE")) {
+                hipLaunchKernelGGL(k_qr_rank, dim3(1), dim3(64), 0, c->stream, s->d_qr, M, mn, (double)mn * DBL_EPSILON, s->d_info);
+                hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, jp, s->d_info,
+                                   d_x);
+                ph = 4;
+            }
             hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
-                               s->d_work, jp, s->d_T, (double)mn * DBL_EPSILON, s->d_info, 0);
+                               s->d_work, jp, s->d_T, (double)mn * DBL_EPSILON, s->d_info, ph);
         } else {
             hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
                                s->d_work, (int *)s->d_tau, s->d_T, (double)mn * DBL_EPSILON, s->d_info, 3);
