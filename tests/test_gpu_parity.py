@@ -85,10 +85,12 @@ def test_sparse_products(ctx, plan, m, n, density, window_rows):
 
 
 @pytest.mark.parametrize("rows,grows", [(None, None), (64, 64), (192, 256)])
-@pytest.mark.parametrize("m,n,density", [(3000, 200, 0.01), (700, 40, 0.5), (64, 3000, 0.02), (9000, 6000, 0.001)])
+@pytest.mark.parametrize("m,n,density", [(3000, 200, 0.01), (700, 40, 0.5), (64, 3000, 0.02), (9000, 6000, 0.001),
+                                         (20000, 300, 0.004)])
 def test_sliced_layouts(ctx, m, n, density, rows, grows):
     """The sliced (SELL) layouts of J*x and J'*y, forced onto small ragged matrices (empty rows and
-    columns, one full row, several blocks / gather windows / column blocks) and compared with the
+    columns, one full row, several blocks / gather windows / column blocks; m = 20000 with 64-row blocks
+    gives more blocks than CUs, i.e. workgroups that loop over several blocks) and compared with the
     oracle and, bit for bit, with a sequential evaluation of sampled rows."""
     S = rand_csc(m, n, density, m + 3 * n).tolil()
     S[5, :] = np.random.default_rng(0).standard_normal(n)
