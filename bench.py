@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--per-col", type=int, default=1000)
     ap.add_argument("--cpu-steps", type=int, default=96, help="outer iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the secondary dense-path timings (C2/C3 ldiv!)")
     return ap.parse_args()
 
 
@@ -204,6 +205,9 @@ def main():
     cpu = None
     if not a.no_cpu and a.cpu_steps > 0:
         cpu = cpu_baseline(a, pr, inputs)
+    dense = None
+    if not a.no_cpu and world == 1 and not a.no_dense:
+        dense = dense_secondary(ctx, lsq)
 
     value = a.steps * world / dt
     out = {"metric": "lm_lsmr_outer_iterations_per_sec", "value": value, "unit": "LM outer iterations/s",
@@ -217,11 +221,54 @@ def main():
                       "lsmr_inner_per_outer": inner_total / (a.steps * world),
                       "lsmr_inner_iterations_per_sec": inner_total / dt, "iters_per_solve": a.iters_per_solve,
                       "final_ssr": r.ssr, "setup_seconds": t_setup},
-           "roofline": roof, "cpu_baseline": cpu}
+           "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense}
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dense_secondary(ctx, lsq):
+    """BASELINE.json's secondary figures: time per ldiv! of the dense solvers at the C2 / C3 sizes,
+    measured after the timed region on fresh N(0,1)/sqrt(m) matrices, next to the host's LAPACK (numpy/scipy, all threads)
+    on the same operands.  Not part of `value`."""
+    import numpy as np
+    out = {}
+    rng = np.random.default_rng(lsq.synthetic.BASE_SEED)
+    for name, m, n, solver, for_lm in (("c2_cholesky_damped_4096x512", 4096, 512, lsq.Cholesky(), True),
+                                       ("c3_qr_16384x2048", 16384, 2048, lsq.QR(), False)):
+        A = rng.standard_normal((m, n)) / np.sqrt(m)
+        yh = rng.standard_normal(m)
+        J = lsq.DeviceMatrix(ctx, A)
+        y = lsq.DeviceVector(ctx, m, yh)
+        x = lsq.DeviceVector(ctx, n)
+        sv = lsq.AllocatedSolver(J, solver, for_lm=for_lm)
+
+        def go():
+            if for_lm:
+                sv.ldiv_(x, y, lsq.DeviceVector(ctx, n, np.full(n, 0.1)))
+            else:
+                sv.ldiv_(x, y)
+            ctx.sync()
+        go()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            go()
+        gpu_ms = (time.perf_counter() - t0) / reps * 1e3
+        t0 = time.perf_counter()
+        if for_lm:
+            ref = np.linalg.solve(A.T @ A + 0.1 * np.eye(n), A.T @ yh)
+        else:   # the reference's algorithm: dgeqp3 + Q'b + triangular solve (full rank here)
+            import scipy.linalg as sla
+            Q, R, piv = sla.qr(A, mode="economic", pivoting=True)
+            ref = np.empty(n)
+            ref[piv] = sla.solve_triangular(R, Q.T @ yh)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        err = float(np.linalg.norm(x.get() - ref) / np.linalg.norm(ref))
+        out[name] = {"ldiv_ms": gpu_ms, "host_lapack_ms": cpu_ms, "rel_err_vs_host_lapack": err}
+        J.free()
+    return out
 
 
 def cpu_baseline(a, pr, inputs):
