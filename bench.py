@@ -203,7 +203,7 @@ def main():
         pass
 
     cpu = None
-    if not a.no_cpu and a.cpu_steps > 0:
+    if not a.no_cpu and a.cpu_steps > 0 and world == 1:   # reported at N = 1 only
         cpu = cpu_baseline(a, pr, inputs)
     dense = None
     if not a.no_cpu and world == 1 and not a.no_dense:
