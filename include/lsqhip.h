@@ -120,10 +120,16 @@ int lsq_solver_info(const lsq_solver *s, int *lsmr_iter, int *lsmr_istop, int *q
  * the CSR mirror afterwards).  Return non-zero to abort with LSQ_ECALLBACK. */
 typedef int (*lsq_f_callback)(double *d_out, const double *d_x, void *user);
 typedef int (*lsq_g_callback)(lsq_mat *J, const double *d_x, void *user);
-/* optional global reduction hook for sharded problems: called once per outer
- * iteration with vals = {ssr_local, maxabs_gr_local, converged_local}; the implementation
- * (RCCL all-reduce via torch.distributed in bench.py) overwrites them with the global
- * {sum, max, min}.  NULL = single problem. */
+/* optional global reduction hook for sharded problems: called exactly once per outer
+ * iteration with vals = {ssr_local, maxabs_gr_local, converged_local} (the values the rank held at
+ * the top of the iteration); it overwrites them with the global {sum, max, min}.  NULL = single
+ * problem.  A rank that reports converged_local = 1 is frozen: it is called at the top of the
+ * iteration and leaves the loop when the returned min is 1.  A rank that is still iterating is
+ * called LATER in the iteration, once device work has been queued (inside the LSMR driver when its
+ * look-ahead window is full), so the exchange overlaps the device; it never acts on the result
+ * ("all converged" cannot hold while it is not converged itself), which lets an implementation
+ * return the previous exchange's values to such a rank and leave the new one in flight
+ * (leastsquaresoptim.jl_amd/sharding.py does; bench.py carries it over a CPU process group). */
 typedef int (*lsq_allreduce_callback)(double *h_vals, int count, void *user);
 
 typedef struct {
