@@ -1215,11 +1215,26 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
     __shared__ double s_best[4];
     __shared__ int s_bpos[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int npos = n - i - 1;
+    const bool is_ice = (int)blockIdx.x == npos + 1, is_rhs = (int)blockIdx.x == npos;
+    const int mypos = i + 1 + (int)blockIdx.x;
+    // the column standing at this block's position is fetched right away (the norms are indexed by POSITION,
+    // so the pivot search needs no indirection); only the block sitting at the pivot's position has to
+    // fetch again -- it works on the column the exchange brings there
+    const int guess = (is_ice || is_rhs) ? 0 : colat_in[mypos];
+    const double *cg = is_rhs ? rhs : R + (size_t)guess * n;
+    double a[Q2S_RPT];
+#pragma unroll
+    for (int q = 0; q < Q2S_RPT; ++q) {
+        const int k = i + 1 + tid + q * Q2S_NT;
+        a[q] = (k < n && !is_ice) ? cg[k] : 0.0;
+    }
+    double cji = is_ice ? 0.0 : cg[i];
     // (a) first maximum of the norms over positions i..n-1
     double best = -1.0;
     int bpos = n;
     for (int pos = i + tid; pos < n; pos += Q2S_NT) {
-        const double v = vn1_in[colat_in[pos]];
+        const double v = vn1_in[pos];
         if (v > best) { best = v; bpos = pos; }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -1246,6 +1261,17 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
         acc += v[q] * v[q];
     }
     const double alpha = cp[i];
+    int own = guess;
+    if (!is_ice && !is_rhs && mypos == ppos) {   // this position receives the displaced column
+        own = icol;
+        const double *co = R + (size_t)own * n;
+#pragma unroll
+        for (int q = 0; q < Q2S_RPT; ++q) {
+            const int k = i + 1 + tid + q * Q2S_NT;
+            a[q] = k < n ? co[k] : 0.0;
+        }
+        cji = co[i];
+    }
     const double xn = sqrt(blk_sum_256(acc, sh));
     double ti = 0.0, beta = alpha;
     if (xn != 0.0) {
@@ -1255,9 +1281,7 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
 #pragma unroll
         for (int q = 0; q < Q2S_RPT; ++q) v[q] *= sc;
     }
-    // (c) own column: position i+1+b (the column displaced by the exchange when that is the pivot's place)
-    const int npos = n - i - 1;
-    if ((int)blockIdx.x == npos + 1) {
+    if (is_ice) {
         // the extra workgroup: step i of xGELSY's incremental condition estimate (dlaic1) on the column that
         // has just become final -- R(0:i-1, i) = rows above the diagonal of the pivot column, R(i,i) = beta --
         // so the rank is known when the sweep ends instead of after n more dependent steps
@@ -1297,22 +1321,11 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
         }
         return;
     }
-    const bool is_rhs = (int)blockIdx.x == npos;
-    int own = -1;
-    if (!is_rhs) {
-        const int pos = i + 1 + blockIdx.x;
-        own = pos == ppos ? icol : colat_in[pos];
-    }
+    // (c) apply H_i to the own column
     double *cj = is_rhs ? rhs : R + (size_t)own * n;
-    double a[Q2S_RPT];
     double w = 0.0;
 #pragma unroll
-    for (int q = 0; q < Q2S_RPT; ++q) {
-        const int k = i + 1 + tid + q * Q2S_NT;
-        a[q] = k < n ? cj[k] : 0.0;
-        w += v[q] * a[q];
-    }
-    double cji = cj[i];
+    for (int q = 0; q < Q2S_RPT; ++q) w += v[q] * a[q];
     if (ti != 0.0) {
         w = blk_sum_256(w, sh) + cji;      // v_i = 1
         const double tw = ti * w;
@@ -1325,9 +1338,10 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
         cji -= tw;
         if (tid == 0) cj[i] = cji;
     }
-    if (!is_rhs) {   // partial-norm downdate (dlaqp2), by physical column
+    if (!is_rhs) {   // partial-norm downdate (dlaqp2); the norms travel with the POSITION
         const double tol3z = sqrt(DBL_EPSILON / 2);
-        const double v1 = vn1_in[own], v2 = vn2_in[own];
+        const int from = mypos == ppos ? i : mypos;      // where this column stood when the step began
+        const double v1 = vn1_in[from], v2 = vn2_in[from];
         double n1 = v1, n2 = v2;
         if (v1 != 0.0) {
             const double r = fabs(cji) / v1;
@@ -1345,7 +1359,7 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
                 n1 = v1 * sqrt(temp);
             }
         }
-        if (tid == 0) { vn1_out[own] = n1; vn2_out[own] = n2; }
+        if (tid == 0) { vn1_out[mypos] = n1; vn2_out[mypos] = n2; }
     }
     if (blockIdx.x == 0) {   // bookkeeping of the step
         if (tid == 0) {
