@@ -268,6 +268,20 @@ def dense_secondary(ctx, lsq):
         err = float(np.linalg.norm(x.get() - ref) / np.linalg.norm(ref))
         out[name] = {"ldiv_ms": gpu_ms, "host_lapack_ms": cpu_ms, "rel_err_vs_host_lapack": err}
         J.free()
+    # time per OUTER iteration of the dense tanh problems (f!, g! and the trust-region bookkeeping included)
+    for name, m, n, opt, sol in (("c2_lm_cholesky_4096x512", 4096, 512, lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.CHOLESKY),
+                                 ("c3_dogleg_qr_16384x2048", 16384, 2048, lsq._lib.DOGLEG, lsq._lib.QR)):
+        pr = lsq.synthetic.TanhProblem(m, n, sparse=False, seed=lsq.synthetic.BASE_SEED, ctx=ctx)
+        pr.reset()
+        pr.optimize(opt, sol, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=2, fetch_x=False)   # warm-up
+        pr.reset()
+        k = 6
+        t0 = time.perf_counter()
+        r = pr.optimize(opt, sol, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, fetch_x=False)
+        ctx.sync()
+        out[name] = {"outer_iteration_ms": (time.perf_counter() - t0) / max(r.iterations, 1) * 1e3,
+                     "iterations": r.iterations, "ssr": r.ssr}
+        pr.close()
     return out
 
 
