@@ -610,13 +610,21 @@ k_qr_backsolve(const double *__restrict__ A, int ld, int n, const double *__rest
             D[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? A[(size_t)(c0 + cidx) * ld + c0 + r] : 0.0;
         }
         __syncthreads();
-        if (tid < 64) {   // back substitution inside the block, column oriented (dtrsv 'U','N')
-            for (int j = nb - 1; j >= 0; --j) {
-                const double zj = z[c0 + j] / D[j][j];
-                if (lane == j) z[c0 + j] = zj;
-                if (lane < j) z[c0 + lane] -= zj * D[lane][j];
-                __builtin_amdgcn_wave_barrier();
+        if (tid < 64) {   // back substitution inside the block, column oriented (dtrsv 'U','N'): the lane's row of
+                          // the block and its unknown live in registers, shuffles broadcast each solved value
+            double drow[64];
+#pragma unroll
+            for (int j = 0; j < 64; ++j) drow[j] = D[lane][j];
+            double v = lane < nb ? z[c0 + lane] : 0.0;
+#pragma unroll
+            for (int j = 63; j >= 0; --j) {
+                const double zj = __shfl(v, j, 64) / __shfl(drow[j], j, 64);
+                if (j < nb) {
+                    if (lane == j) v = zj;
+                    else if (lane < j) v -= zj * drow[j];
+                }
             }
+            if (lane < nb) z[c0 + lane] = v;
         }
         __syncthreads();
         for (int r = tid; r < c0; r += QR_NT) {

@@ -9,6 +9,7 @@
 // (J is column-major, so a column's k-run is contiguous in global memory and in LDS).
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "lsq_solver.h"
 
@@ -182,6 +183,142 @@ k_chol_diag(double *__restrict__ C, int n, int j0, int *__restrict__ info) {
     }
 }
 
+// (a2) the same factorisation with 16-column sub-panels: the 16 x 16 diagonal sub-block is factored by ONE
+// wavefront in registers (lane = column, shuffles hand the pivot row around: 16 short unrolled steps),
+// its row panel by one thread per column, the trailing block by all threads -- 3 barriers per 16
+// columns instead of 16.  The working copy stays UNSCALED (pivot row j is applied as (U[j][i]/a_jj)*U[j][k],
+// in pivot order) and is divided by sqrt(a_jj) only at the end: every entry sees exactly the operations
+// of k_chol_diag in the same order, so the result is bit-identical.
+constexpr int SB = 16;
+__global__ void __launch_bounds__(256)
+k_chol_diag16(double *__restrict__ C, int n, int j0, int *__restrict__ info) {
+    __shared__ double U[NB][NB + 1];
+    __shared__ double s_inv[NB], s_root[NB];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nb = min(NB, n - j0);
+    if (*info != 0) return;  // an earlier panel failed
+    if (tid == 0) s_fail = 0;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int s0 = 0; s0 < NB; s0 += SB) {
+        // (1) 16 x 16 diagonal sub-block, one wavefront, registers
+        if (tid < 64) {
+            double u[SB];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) u[r] = (lane < SB && r <= lane) ? U[s0 + r][s0 + lane] : 0.0;
+            int fail = 0;
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const double ajj = __shfl(u[j], j, 64);
+                if (!fail && s0 + j < nb && (ajj <= 0.0 || isnan(ajj))) fail = s0 + j + 1;
+                const double inv = 1.0 / ajj;
+                if (lane == 0) { s_inv[s0 + j] = inv; s_root[s0 + j] = sqrt(ajj); }
+                const double rowj = u[j];
+#pragma unroll
+                for (int i = j + 1; i < SB; ++i) {
+                    const double uji = __shfl(rowj, i, 64) * inv;
+                    if (lane >= i) u[i] -= uji * rowj;
+                }
+            }
+            if (lane < SB) {
+#pragma unroll
+                for (int r = 0; r < SB; ++r)
+                    if (r <= lane) U[s0 + r][s0 + lane] = u[r];
+            }
+            if (fail && lane == 0) s_fail = fail;
+        }
+        __syncthreads();
+        if (s_fail) break;
+        const int rem = NB - s0 - SB;   // columns to the right of the sub-block
+        // (2) row panel of the sub-block: column c, pivots in order
+        if (tid < rem) {
+            const int cidx = s0 + SB + tid;
+            double x[SB];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) x[r] = U[s0 + r][cidx];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const double inv = s_inv[s0 + j];
+#pragma unroll
+                for (int r = j + 1; r < SB; ++r) x[r] -= (U[s0 + j][s0 + r] * inv) * x[j];
+            }
+#pragma unroll
+            for (int r = 0; r < SB; ++r) U[s0 + r][cidx] = x[r];
+        }
+        __syncthreads();
+        // (3) trailing block: U[i][k] -= (U[j][i]/a_jj) * U[j][k], j over the sub-panel in order
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int i = s0 + SB + e / rem, k = s0 + SB + e % rem;
+            if (i <= k) {
+                double v = U[i][k];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) v -= (U[s0 + j][i] * s_inv[s0 + j]) * U[s0 + j][k];
+                U[i][k] = v;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) *info = j0 + s_fail;   // PosDefException position (1-based)
+        return;
+    }
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int r = e % nb, cidx = e / nb;
+        if (r <= cidx) C[(size_t)(j0 + cidx) * n + j0 + r] = (r == cidx) ? s_root[r] : U[r][cidx] / s_root[r];
+    }
+}
+
+// (b2) row panel with 16-row sub-steps: same operations per entry, in the same order, as k_chol_trsm
+// (X[q][c] -= U[r][q] * x_r for r ascending), 2 barriers per 16 rows instead of 2 per row.
+__global__ void __launch_bounds__(256)
+k_chol_trsm16(double *__restrict__ C, int n, int j0, const int *__restrict__ info) {
+    __shared__ double U[NB][NB + 1];
+    __shared__ double X[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const int nb = min(NB, n - j0);
+    if (*info != 0) return;
+    const int c0 = j0 + nb + blockIdx.x * NB;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
+        X[r][cidx] = (r < nb && c0 + cidx < n) ? C[(size_t)(c0 + cidx) * n + j0 + r] : 0.0;
+    }
+    __syncthreads();
+    const int cc = tid & 63, qg = tid >> 6;
+    for (int s0 = 0; s0 < NB; s0 += SB) {
+        if (tid < 64) {   // rows s0..s0+15 of column cc, forward substitution in registers
+            double x[SB];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) x[r] = X[s0 + r][cc];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) {
+                x[r] = x[r] / U[s0 + r][s0 + r];
+#pragma unroll
+                for (int q = r + 1; q < SB; ++q) x[q] -= U[s0 + r][s0 + q] * x[r];
+            }
+#pragma unroll
+            for (int r = 0; r < SB; ++r) X[s0 + r][cc] = x[r];
+        }
+        __syncthreads();
+        for (int q = s0 + SB + qg; q < NB; q += 4) {   // rows below: subtract the 16 solved rows, r ascending
+            double v = X[q][cc];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) v -= U[s0 + r][q] * X[s0 + r][cc];
+            X[q][cc] = v;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        if (r < nb && c0 + cidx < n) C[(size_t)(c0 + cidx) * n + j0 + r] = X[r][cidx];
+    }
+}
+
 // (b) row panel: U12 = U11^{-T} A12.  A workgroup owns 64 columns of A12; the 64 x 64 chunk X and
 // U11 live in LDS; row r of X is finished and its multiples subtracted from the rows below, one
 // barrier per row (thread = (column, row group)).
@@ -235,11 +372,19 @@ k_chol_trsv(const double *__restrict__ U, int n, double *__restrict__ b) {
         const int nb = min(NB, n - j0);
         load_diag(j0, nb);
         if (tid < 64) {
+            // the lane's column of the block sits in registers: the 64-step dependent chain is then
+            // shuffle + multiply + FMA per step, with no LDS read on it
+            double dcol[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) dcol[r] = D[r][lane];
             double v = lane < nb ? b[j0 + lane] : 0.0;
-            for (int r = 0; r < nb; ++r) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
                 const double zr = __shfl(v, r, 64) * Dinv[r];
-                if (lane == r) v = zr;
-                else if (lane > r && lane < nb) v -= D[r][lane] * zr;
+                if (r < nb) {
+                    if (lane == r) v = zr;
+                    else if (lane > r && lane < nb) v -= dcol[r] * zr;
+                }
             }
             if (lane < nb) { b[j0 + lane] = v; zb[lane] = v; }
         }
@@ -257,11 +402,17 @@ k_chol_trsv(const double *__restrict__ U, int n, double *__restrict__ b) {
         const int j0 = jb * NB, nb = min(NB, n - j0);
         load_diag(j0, nb);
         if (tid < 64) {
+            double drow[NB];   // D[lane][r]: the lane's row of the block
+#pragma unroll
+            for (int r = 0; r < NB; ++r) drow[r] = D[lane][r];
             double v = lane < nb ? b[j0 + lane] : 0.0;
-            for (int r = nb - 1; r >= 0; --r) {
+#pragma unroll
+            for (int r = NB - 1; r >= 0; --r) {
                 const double xr = __shfl(v, r, 64) * Dinv[r];
-                if (lane == r) v = xr;
-                else if (lane < r) v -= D[lane][r] * xr;
+                if (r < nb) {
+                    if (lane == r) v = xr;
+                    else if (lane < r) v -= drow[r] * xr;
+                }
             }
             if (lane < nb) { b[j0 + lane] = v; zb[lane] = v; }
         }
@@ -294,10 +445,12 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = std::min(NB, n - j0), rest = n - j0 - nb;
-        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, j0, s->d_info);
+        static const bool per_column = getenv("LSQ_CHOL_PER_COLUMN") != nullptr;   // the one-barrier-per-column kernels
+        hipLaunchKernelGGL(per_column ? k_chol_diag : k_chol_diag16, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, j0,
+                           s->d_info);
         if (rest > 0) {
-            hipLaunchKernelGGL(k_chol_trsm, dim3((rest + NB - 1) / NB), dim3(256), 0, c->stream, s->d_chol, n, j0,
-                               (const int *)s->d_info);
+            hipLaunchKernelGGL(per_column ? k_chol_trsm : k_chol_trsm16, dim3((rest + NB - 1) / NB), dim3(256), 0, c->stream,
+                               s->d_chol, n, j0, (const int *)s->d_info);
             const int nt2 = (rest + MT - 1) / MT;
             // A22 -= U12' U12 : "A" = rows j0..j0+nb of chol (lda n), columns from j0+nb
             hipLaunchKernelGGL((k_syrk_mfma<1>), dim3(nt2 * (nt2 + 1) / 2), dim3(256), 0, c->stream, s->d_chol + j0, n, nb,
