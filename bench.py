@@ -51,6 +51,11 @@ def parse():
 
 def main():
     a = parse()
+    # Exactly ONE line on stdout: native libraries (RCCL's version banner, rocm notices) also write to fd 1,
+    # so everything but the final JSON line is sent to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,10 +227,11 @@ def main():
                       "lsmr_inner_iterations_per_sec": inner_total / dt, "iters_per_solve": a.iters_per_solve,
                       "final_ssr": r.ssr, "setup_seconds": t_setup},
            "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense}
-    print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())   # fd 1 stays on stderr: RCCL prints its banner at exit
 
 
 def dense_secondary(ctx, lsq):
