@@ -141,6 +141,48 @@ def test_sliced_layouts(ctx, m, n, density, rows, grows):
         lsq.set_exact(None)
 
 
+def test_sliced_layouts_random_patterns(ctx):
+    """Twenty random shapes / densities / block sizes, with columns and rows emptied at random and duplicate-free
+    ragged rows: J*x, J'*y and colsumabs2 of the sliced layouts against scipy."""
+    rng = np.random.default_rng(20260928)
+    lsq.set_exact(False)
+    try:
+        for case in range(20):
+            m = int(rng.integers(1, 4000))
+            n = int(rng.integers(1, 600))
+            density = float(rng.choice([0.0005, 0.005, 0.05, 0.3]))
+            S = sp.random(m, n, density=density, format="lil", random_state=rng, data_rvs=rng.standard_normal)
+            for _ in range(int(rng.integers(0, 4))):
+                S[:, int(rng.integers(0, n))] = 0
+                S[int(rng.integers(0, m)), :] = 0
+            if rng.random() < 0.5:
+                S[int(rng.integers(0, m)), :] = rng.standard_normal(n)     # one full row
+            S = S.tocsc()
+            S.sort_indices()
+            S.eliminate_zeros()
+            os.environ["LSQ_SELL_FORCE"] = "1"
+            os.environ["LSQ_SELL_ROWS"] = str(int(rng.choice([64, 128, 4096])))
+            os.environ["LSQ_SELL_GROWS"] = str(int(rng.choice([64, 512, 8192])))
+            try:
+                J = lsq.DeviceMatrix(ctx, S)
+            finally:
+                for k in ("LSQ_SELL_FORCE", "LSQ_SELL_ROWS", "LSQ_SELL_GROWS"):
+                    os.environ.pop(k, None)
+            x, y = rng.standard_normal(n), rng.standard_normal(m)
+            dx, dy = lsq.DeviceVector(ctx, n, x), lsq.DeviceVector(ctx, m, y)
+            out = lsq.mul_(lsq.DeviceVector(ctx, m, y), J, dx, 0.75, 1.25).get()
+            ref = 0.75 * (S @ x) + 1.25 * y
+            assert np.max(np.abs(out - ref)) <= 1e-12 * (1 + np.abs(S).sum(axis=1).max() + np.abs(y).max()), (case, m, n, density)
+            out = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, dy, 1.0, -1.0, trans=True).get()
+            ref = S.T @ y - x
+            assert np.max(np.abs(out - ref)) <= 1e-12 * (1 + np.abs(S).sum(axis=0).max() + np.abs(x).max()), (case, m, n, density)
+            cs = lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get()
+            assert np.allclose(cs, np.asarray(S.multiply(S).sum(axis=0)).ravel(), rtol=1e-13, atol=0), (case, m, n, density)
+            J.free()
+    finally:
+        lsq.set_exact(None)
+
+
 def test_empty_and_tiny_sparse(ctx):
     S = sp.csc_matrix((5, 3))
     J = lsq.DeviceMatrix(ctx, S)
