@@ -76,6 +76,8 @@ int lsq_mat_refresh(lsq_mat *J);
 int lsq_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);
 /* colsumabs2!(out, J): utils.jl:139-151 */
 int lsq_colsumabs2(lsq_mat *J, double *d_out);
+/* rowsumabs2!(out, J) = colsumabs2!(out, J') for adjoint Jacobians: utils.jl:153-161 (out has m entries) */
+int lsq_rowsumabs2(lsq_mat *J, double *d_out);
 
 /* BLAS-1 on device vectors (what lsmr.jl:30-44 and the optimizer loops need from a vector type) */
 int lsq_axpy(lsq_ctx *ctx, int n, double a, const double *d_x, double *d_y);       /* axpy!   */

@@ -96,6 +96,7 @@ def lib():
         "lsq_mat_refresh": (i, [vp]),
         "lsq_mul": (i, [vp, i, d, vp, d, vp]),
         "lsq_colsumabs2": (i, [vp, vp]),
+        "lsq_rowsumabs2": (i, [vp, vp]),
         "lsq_axpy": (i, [vp, i, d, vp, vp]),
         "lsq_scal": (i, [vp, i, d, vp]),
         "lsq_copy": (i, [vp, i, vp, vp]),

@@ -225,6 +225,12 @@ def colsumabs2_(out, J):
     return out
 
 
+def rowsumabs2_(out, J):
+    """rowsumabs2!(out, J) (utils.jl:153-161): what colsumabs2! of an adjoint Jacobian computes."""
+    check(lib().lsq_rowsumabs2(J.h, out.ptr))
+    return out
+
+
 # BLAS-1 on device vectors -- exactly what lsmr.jl:30-44 and the optimizer loops ask of a vector type
 def axpy_(a, x, y):
     """axpy!(a, x, y): y += a*x"""

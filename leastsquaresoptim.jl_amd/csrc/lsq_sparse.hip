@@ -736,6 +736,63 @@ extern "C" int lsq_colsumabs2(lsq_mat *J, double *out) {
     return lsq_d2d(J->ctx, out, cs, (size_t)J->n * sizeof(double));
 }
 
+// ---- rowsumabs2! (utils.jl:153-161): sums of squares along the rows -------------------------------
+// sliced rows: the lane that owns a row adds its squares left to right (the reference's order: the
+// CSC sweep reaches a row's entries in column order)
+__global__ void __launch_bounds__(256)
+k_sell_rowsq(SellDev S, int wrows, int m, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int w = blockIdx.x; w < S.nblocks; w += gridDim.x) {
+        const int base = w * wrows;
+        for (int s = S.wslice[w] + wv; s < S.wslice[w + 1]; s += 4) {
+            const int2 sm = S.smeta[s];
+            const unsigned inf = S.info[(size_t)s * 64 + lane];
+            const unsigned pos = inf & LSQ_SELL_POS_MASK;
+            const int len = (int)(inf >> LSQ_SELL_POS_BITS);
+            const double *vp = S.val + (size_t)sm.x + lane * 2;
+            double acc = 0.0;
+            for (int j = 0; j < len; ++j) {
+                const double a = vp[(size_t)(j / 2) * 128 + (j & 1)];
+                acc += a * a;
+            }
+            if (pos != LSQ_SELL_POS_MASK && base + (int)pos < m) out[base + pos] = acc;
+        }
+    }
+}
+// dense column-major: thread per row, columns in order
+__global__ void __launch_bounds__(LSQ_NT)
+k_dense_rowsq(const double *__restrict__ A, int m, int n, double *__restrict__ out) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < m; i += gridDim.x * LSQ_NT) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double a = A[(size_t)j * m + i];
+            acc += a * a;
+        }
+        out[i] = acc;
+    }
+}
+
+extern "C" int lsq_rowsumabs2(lsq_mat *J, double *out) {
+    if (!J || !out) return LSQ_EARG;
+    lsq_ctx *c = J->ctx;
+    if (J->m <= 0) return LSQ_OK;
+    if (J->kind == LSQ_MAT_DENSE) {
+        int grid = std::min(lsq_div_up(J->m, LSQ_NT), c->num_cus * 8);
+        hipLaunchKernelGGL(k_dense_rowsq, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, out);
+    } else {
+        LSQ_TRY(lsq_ensure_csr(J));
+        if (J->srows.active) {
+            int grid = std::max(1, std::min(J->srows.nblocks, c->num_cus * 4));
+            hipLaunchKernelGGL(k_sell_rowsq, dim3(grid), dim3(256), 0, c->stream, sell_dev(J->srows), J->srows.wrows, J->m, out);
+        } else {
+            EpiStore e{nullptr, 0, out, nullptr, nullptr};
+            LSQ_TRY(launch_segs<true>(c, J->csr, nullptr, e));
+        }
+    }
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
 extern "C" int lsq_bench_mul(lsq_mat *J, int trans, int reps, const double *x, double *y, double beta,
                              float *ms) {
     hipEvent_t e0, e1;

@@ -183,6 +183,36 @@ def test_sliced_layouts_random_patterns(ctx):
         lsq.set_exact(None)
 
 
+@pytest.mark.parametrize("kind", ["dense", "csr", "sliced"])
+def test_rowsumabs2(ctx, kind):
+    """rowsumabs2! (utils.jl:153-161, what colsumabs2! of an adjoint Jacobian computes) against the oracle:
+    dense, CSR mirror and sliced rows."""
+    m, n = (700, 90) if kind == "dense" else (5000, 300)
+    if kind == "dense":
+        A = np.random.default_rng(3).standard_normal((m, n))
+        J, ref = lsq.DeviceMatrix(ctx, A), O.rowsumabs2(O.Mat(dense=A))
+    else:
+        S = rand_csc(m, n, 0.02, 77).tolil()
+        S[7, :] = 0
+        S[11, :] = np.random.default_rng(4).standard_normal(n)
+        S = S.tocsc()
+        S.sort_indices()
+        S.eliminate_zeros()
+        if kind == "sliced":
+            os.environ["LSQ_SELL_FORCE"] = "1"
+        try:
+            J = lsq.DeviceMatrix(ctx, S)
+        finally:
+            os.environ.pop("LSQ_SELL_FORCE", None)
+        ref = O.rowsumabs2(O.Mat.from_scipy(S))
+    out = lsq.rowsumabs2_(lsq.DeviceVector(ctx, m, np.full(m, np.nan)), J).get()
+    assert np.allclose(out, ref, rtol=1e-13, atol=0)
+    if kind != "dense":
+        assert out[7] == 0.0
+    if kind in ("dense", "sliced"):      # left-to-right sums: the reference's order, bit for bit
+        assert np.array_equal(out, ref)
+
+
 def test_empty_and_tiny_sparse(ctx):
     S = sp.csc_matrix((5, 3))
     J = lsq.DeviceMatrix(ctx, S)
