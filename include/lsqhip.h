@@ -114,6 +114,15 @@ int lsq_ldiv(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_x, int *nmu
  *                                          leaves sqrt(damp) in it, iterative_lsmr.jl:252). */
 int lsq_ldiv_damped(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x,
                     int *nmul);
+/* LSMR(preconditioner!, P) (types.jl:82-86; README.md:47; default iterative_lsmr.jl:129-141): replace the
+ * built-in Jacobi preconditioner of an LSMR solver.  Before every solve the callback must fill d_P (n
+ * entries) with the factors the preconditioner solve MULTIPLIES by (an InverseDiagonal stores the
+ * inverse, iterative_lsmr.jl:117-122) for the operator J'J + diag(damp); d_damp is the un-rooted
+ * damping, NULL for the undamped (Dogleg) solve.  Diagonal preconditioners only.  The callback runs
+ * on the host after the library's stream has been drained (the reference's slow path too); the
+ * reference-order small-problem path is not used with a custom preconditioner.  NULL restores the default. */
+typedef int (*lsq_precond_callback)(double *d_P, lsq_mat *J, const double *d_damp, void *user);
+int lsq_solver_set_preconditioner(lsq_solver *s, lsq_precond_callback cb, void *user);
 /* diagnostics of the last solve: LSMR istop / iterations, QR numerical rank */
 int lsq_solver_info(const lsq_solver *s, int *lsmr_iter, int *lsmr_istop, int *qr_rank);
 
@@ -147,6 +156,8 @@ typedef struct {
     double *trace_ssr, *trace_gnorm, *trace_delta, *trace_rho;
     int *trace_inner, *trace_accept;
     double *trace_x;            /* trace_cap * n, or NULL */
+    lsq_precond_callback preconditioner;   /* LSMR only; NULL = default Jacobi */
+    void *preconditioner_user;
 } lsq_options;
 
 typedef struct {

@@ -19,6 +19,7 @@ c_ip = C.POINTER(C.c_int)
 F_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 G_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 ALLREDUCE_CALLBACK = C.CFUNCTYPE(C.c_int, c_dp, C.c_int, C.c_void_p)
+PRECOND_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)   # (d_P, J, d_damp, user)
 
 OK, EDIM, ENOTPD, ERANK, ENONFINITE, EBOUNDS, EHIP, EARG, ECALLBACK = range(9)
 QR, CHOLESKY, LSMR = 0, 1, 2
@@ -31,7 +32,8 @@ class Options(C.Structure):
                 ("allreduce", ALLREDUCE_CALLBACK), ("allreduce_user", C.c_void_p),
                 ("trace_cap", C.c_int), ("trace_ssr", c_dp), ("trace_gnorm", c_dp),
                 ("trace_delta", c_dp), ("trace_rho", c_dp), ("trace_inner", c_ip),
-                ("trace_accept", c_ip), ("trace_x", c_dp)]
+                ("trace_accept", c_ip), ("trace_x", c_dp),
+                ("preconditioner", PRECOND_CALLBACK), ("preconditioner_user", C.c_void_p)]
 
 
 class Result(C.Structure):
@@ -95,6 +97,7 @@ def lib():
         "lsq_mat_values": (vp, [vp]),
         "lsq_mat_refresh": (i, [vp]),
         "lsq_mul": (i, [vp, i, d, vp, d, vp]),
+        "lsq_solver_set_preconditioner": (i, [vp, PRECOND_CALLBACK, vp]),
         "lsq_colsumabs2": (i, [vp, vp]),
         "lsq_rowsumabs2": (i, [vp, vp]),
         "lsq_axpy": (i, [vp, i, d, vp, vp]),

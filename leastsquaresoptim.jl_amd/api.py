@@ -38,14 +38,35 @@ class Cholesky(AbstractSolver):
 
 
 class LSMR(AbstractSolver):
+    """LSMR(preconditioner!, P) (types.jl:82-86).  `preconditioner(P, J, damp)` is the reference's
+    preconditioner!(P, x, J, damp) for DIAGONAL preconditioners: it must fill the DeviceVector P with the
+    factors the preconditioner solve multiplies by (an InverseDiagonal stores the inverse,
+    iterative_lsmr.jl:117-122) for J'J + diag(damp); damp is a DeviceVector with the un-rooted damping or
+    None (Dogleg).  It runs on the host before every solve (the slow path of the reference as well);
+    None = the built-in Jacobi preconditioner (iterative_lsmr.jl:129-141).  The storage argument P of the
+    reference is not needed: the solver owns it."""
     kind = _lib.LSMR
 
     def __init__(self, preconditioner=None, P=None):
-        if preconditioner is not None or P is not None:
-            raise NotImplementedError(
-                "custom LSMR preconditioners stay a host callback in the reference "
-                "(types.jl:82-86); only the default Jacobi preconditioner "
-                "(iterative_lsmr.jl:129-141) is implemented on the device")
+        if P is not None:
+            raise NotImplementedError("LSMR(preconditioner!, P): the solver owns the (diagonal) storage; pass "
+                                      "only the callable")
+        self.preconditioner = preconditioner
+
+
+def _precond_trampoline(fn, ctx, J):
+    """ctypes callback (d_P, J_handle, d_damp, user) -> fn(P, J, damp) on borrowed DeviceVector views."""
+    def _cb(d_p, _jh, d_damp, _user):
+        try:
+            P = DeviceVector.borrow(ctx, J.n, d_p)
+            damp = DeviceVector.borrow(ctx, J.n, d_damp) if d_damp else None
+            fn(P, J, damp)
+            return 0
+        except Exception as e:   # pragma: no cover
+            import sys
+            print("preconditioner callback failed:", e, file=sys.stderr)
+            return 1
+    return _lib.PRECOND_CALLBACK(_cb)
 
 
 class AbstractOptimizer:
@@ -133,6 +154,13 @@ class DeviceVector:
         else:
             check(lib().lsq_fill(ctx.h, self.n, 0.0, self.ptr))
 
+    @classmethod
+    def borrow(cls, ctx, n, ptr):
+        """A view of device memory owned by someone else (never freed here)."""
+        v = cls.__new__(cls)
+        v.ctx, v.n, v.ptr, v._borrowed = ctx, int(n), ptr, True
+        return v
+
     def set(self, data):
         a = np.ascontiguousarray(data, dtype=np.float64)
         if a.size != self.n:
@@ -145,9 +173,9 @@ class DeviceVector:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and not getattr(self, "_borrowed", False):
             lib().lsq_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -328,6 +356,10 @@ class AllocatedSolver:
         h = C.c_void_p()
         check(lib().lsq_solver_create(J.ctx.h, J.h, solver.kind, 1 if for_lm else 0, C.byref(h)))
         self.h, self.J = h, J
+        self._pc = None
+        if getattr(solver, "preconditioner", None) is not None:
+            self._pc = _precond_trampoline(solver.preconditioner, J.ctx, J)
+            check(lib().lsq_solver_set_preconditioner(self.h, self._pc, None))
 
     def ldiv_(self, x, y, damp=None):
         """ldiv!(x, J, y[, damp], A) -> (x, nmul)"""
@@ -452,7 +484,7 @@ def converged(r):
 
 
 def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_tol, f_tol, g_tol,
-                iterations, delta, lower, upper, trace, n, allreduce=None):
+                iterations, delta, lower, upper, trace, n, allreduce=None, preconditioner=None):
     L = lib()
     opt = _lib.Options()
     L.lsq_options_default(C.byref(opt))
@@ -477,6 +509,9 @@ def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_
     if allreduce is not None:
         opt.allreduce = allreduce
         keep.append(allreduce)
+    if preconditioner is not None:
+        opt.preconditioner = preconditioner
+        keep.append(preconditioner)
     tr = None
     if trace:
         cap = int(iterations)
@@ -539,8 +574,11 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
 
     F, G = _lib.F_CALLBACK(fcb), _lib.G_CALLBACK(gcb)
     tracing = store_trace or show_trace or full_trace
+    pc = None
+    if getattr(solver, "preconditioner", None) is not None:
+        pc = _precond_trampoline(solver.preconditioner, ctx, Jd)
     st, res, tr = _run_native(ctx, optimizer.kind, solver.kind, Jd, dx, dy, F, G, None, x_tol, f_tol,
-                              g_tol, iterations, delta, lower, upper, tracing, n)
+                              g_tol, iterations, delta, lower, upper, tracing, n, preconditioner=pc)
     if err:
         raise err[0]
     if st == _lib.ENONFINITE:

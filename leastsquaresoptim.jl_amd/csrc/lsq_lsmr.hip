@@ -34,7 +34,7 @@ __device__ __forceinline__ void publish(LsqMailbox *mail, const LsmrState *st) {
 // ---- setup: P, sqrt(damp) (iterative_lsmr.jl:129-141, 251-252) ------------------------------
 __global__ void __launch_bounds__(LSQ_NT)
 k_lsmr_prep(int n, const double *__restrict__ colsum, double *__restrict__ damp, double *__restrict__ P,
-            double *__restrict__ dg, double *__restrict__ ux) {
+            double *__restrict__ dg, double *__restrict__ ux, int custom_p) {
     for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT) {
         double s = colsum[j];
         if (damp) {
@@ -45,7 +45,7 @@ k_lsmr_prep(int n, const double *__restrict__ colsum, double *__restrict__ damp,
             damp[j] = r;             // the reference clobbers the caller's damp (:252)
             ux[j] = 0.0;             // zerosvector (:246)
         }
-        P[j] = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+        if (!custom_p) P[j] = s > 0.0 ? 1.0 / sqrt(s) : 0.0;   // (custom_p: the caller's preconditioner! filled P)
     }
 }
 
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(LSQ_NT)
 k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp, double *__restrict__ P,
              double *__restrict__ dg, double *__restrict__ ux, const double *__restrict__ Jty,
              double *__restrict__ v, LsmrState *st, double *pu, int *npu, double ysumsq, double *pv, int *npv,
-             double atol, double btol, double ctol, int maxiter, unsigned epoch) {
+             double atol, double btol, double ctol, int maxiter, unsigned epoch, int custom_p) {
     __shared__ double sh[LSQ_NT / 64];
     const double beta2 = ysumsq >= 0.0 ? ysumsq : ordered_sum256(pu, *npu);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -306,7 +306,7 @@ k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp
             damp[j] = r;
             ux[j] = 0.0;             // zerosvector (:246)
         }
-        const double Pj = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+        const double Pj = custom_p ? P[j] : (s > 0.0 ? 1.0 / sqrt(s) : 0.0);
         P[j] = Pj;
         if (!beta_zero) {            // lsmr.jl:76 (beta == 0: v is left untouched, :120)
             const double w = Jty[j] * inv_beta * Pj;
@@ -361,7 +361,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         lsq_set_error("lsmr: solver allocated for %dx%d, Jacobian is %dx%d", s->m, s->n, m, n);
         return LSQ_EDIM;
     }
-    if (lsq_small_mat(J)) return lsq_lsmr_exact_solve(s, J, d_y, d_damp, d_x, nmul);  // reference-order kernel
+    if (lsq_small_mat(J) && !s->precond_cb) return lsq_lsmr_exact_solve(s, J, d_y, d_damp, d_x, nmul);  // reference-order kernel
     static const int lookahead = [] {
         const char *e = getenv("LSQ_LOOKAHEAD");
         int v = e ? atoi(e) : LSQ_LOOKAHEAD_DEFAULT;
@@ -384,6 +384,14 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     if (J->kind == LSQ_MAT_CSC) LSQ_TRY(lsq_ensure_csr(J));
     const double *colsum = lsq_cached_colsum(J);  // computed once per Jacobian (reference: twice)
     if (!colsum) return LSQ_EHIP;
+    const int custom_p = s->precond_cb ? 1 : 0;
+    if (custom_p) {   // preconditioner!(P, x, J, damp) on the host, damp still un-rooted (iterative_lsmr.jl:251-252)
+        LSQ_HIP(hipStreamSynchronize(c->stream));
+        if (s->precond_cb(s->d_P, J, d_damp, s->precond_user) != 0) {
+            lsq_set_error("preconditioner callback reported failure");
+            return LSQ_ECALLBACK;
+        }
+    }
     *(volatile unsigned long long *)c->h_mail = 0ull;
     const int gn = nvec_grid(c, n);
     const double *dgk = damped ? s->d_dg : nullptr;
@@ -399,14 +407,14 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         if (!(y_sumsq >= 0.0)) launch_begin();
         hipLaunchKernelGGL(k_lsmr_setup, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P, s->d_dg,
                            s->d_ux, d_Jty, s->d_v, st, pu, npu, y_sumsq >= 0.0 ? y_sumsq : -1.0, pv, npv, atol, btol,
-                           1.0 / conlim, maxiter, epoch);
+                           1.0 / conlim, maxiter, epoch, custom_p);
         hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
                            s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
         LSQ_HIP(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_lsmr_prep, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P,
-                           s->d_dg, s->d_ux);
+                           s->d_dg, s->d_ux, custom_p);
         launch_begin();
         LSQ_HIP(hipGetLastError());
         // v~ = A'u (setup), then K3 in "first" mode

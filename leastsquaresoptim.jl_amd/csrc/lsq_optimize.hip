@@ -78,6 +78,17 @@ extern "C" int lsq_ldiv_damped(lsq_solver *s, lsq_mat *J, const double *y, doubl
     }
 }
 
+extern "C" int lsq_solver_set_preconditioner(lsq_solver *s, lsq_precond_callback cb, void *user) {
+    if (!s) return LSQ_EARG;
+    if (s->kind != LSQ_LSMR && cb) {
+        lsq_set_error("preconditioners apply to the LSMR solver only (types.jl:82-86)");
+        return LSQ_EARG;
+    }
+    s->precond_cb = cb;
+    s->precond_user = user;
+    return LSQ_OK;
+}
+
 extern "C" int lsq_solver_info(const lsq_solver *s, int *iter, int *istop, int *rank) {
     if (iter) *iter = s->last_iter;
     if (istop) *istop = s->last_istop;
@@ -903,6 +914,10 @@ extern "C" int lsq_optimize(lsq_ctx *c, int optimizer, int solver_kind, lsq_mat 
         if (opt->h_lower) LSQ_HIP(hipMemcpyAsync(w->buf->lo, opt->h_lower, nb, hipMemcpyHostToDevice, c->stream));
         if (opt->h_upper) LSQ_HIP(hipMemcpyAsync(w->buf->hi, opt->h_upper, nb, hipMemcpyHostToDevice, c->stream));
         if (opt->h_lower || opt->h_upper) LSQ_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (w->solver->kind == LSQ_LSMR) {   // LSMR(preconditioner!, P): per call, the cached solver may have had another one
+        w->solver->precond_cb = opt->preconditioner;
+        w->solver->precond_user = opt->preconditioner_user;
     }
     auto t0 = std::chrono::steady_clock::now();
     int st = lm ? optimize_lm(c, w->solver, *w->buf, J, x, fcur, f, g, user, opt, res)

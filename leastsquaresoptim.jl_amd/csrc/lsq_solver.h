@@ -48,6 +48,8 @@ struct lsq_solver {
     size_t work_elems = 0;
     std::vector<double> h_R;   // n*n host copy for pivoting / rank decisions
     int last_rank = -1;
+    int (*precond_cb)(double *, lsq_mat *, const double *, void *) = nullptr;   // LSMR(preconditioner!, P)
+    void *precond_user = nullptr;
     void *qr2 = nullptr;            // two-stage QR workspace (lsq_dense.hip), allocated on first use
     void (*qr2_free)(void *) = nullptr;
 };

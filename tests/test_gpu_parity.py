@@ -374,6 +374,65 @@ def test_ldiv_qr_two_stage(ctx, m, n, rank, monkeypatch):
     assert np.allclose(sols["LSQ_QR_TWO_STAGE"], sols["LSQ_QR_ONE_STAGE"], rtol=1e-8, atol=1e-10)
 
 
+def test_lsmr_custom_preconditioner(ctx):
+    """LSMR(preconditioner!, P) (types.jl:82-86): a host callback that restates the default Jacobi rule
+    (iterative_lsmr.jl:129-141) must reproduce the built-in solver bit for bit; the identity preconditioner
+    must reach the same least-squares solution; both through ldiv! and through optimize!."""
+    lsq.set_exact(False)
+    try:
+        m, n = 3000, 120
+        S = rand_csc(m, n, 0.05, 314)
+        rng = np.random.default_rng(15)
+        y = rng.standard_normal(m)
+        damp = rng.random(n) + 0.05
+        J = lsq.DeviceMatrix(ctx, S)
+        calls = []
+
+        def jacobi(P, Jm, dmp):
+            cs = lsq.colsumabs2_(lsq.DeviceVector(ctx, n), Jm).get()
+            if dmp is not None:
+                cs = cs + dmp.get()
+            calls.append(dmp is not None)
+            P.set(np.where(cs > 0, 1.0 / np.sqrt(cs), 0.0))
+
+        def identity(P, Jm, dmp):
+            P.set(np.ones(n))
+
+        for damped in (True, False):
+            ref = lsq.DeviceVector(ctx, n)
+            sv0 = lsq.AllocatedSolver(J, lsq.LSMR(), for_lm=damped)
+            args = (lsq.DeviceVector(ctx, m, y),) + ((lsq.DeviceVector(ctx, n, damp),) if damped else ())
+            _, nm0 = sv0.ldiv_(ref, *args)
+            out = lsq.DeviceVector(ctx, n)
+            sv1 = lsq.AllocatedSolver(J, lsq.LSMR(jacobi), for_lm=damped)
+            args = (lsq.DeviceVector(ctx, m, y),) + ((lsq.DeviceVector(ctx, n, damp),) if damped else ())
+            _, nm1 = sv1.ldiv_(out, *args)
+            assert nm1 == nm0 and np.array_equal(out.get(), ref.get())
+            sv2 = lsq.AllocatedSolver(J, lsq.LSMR(identity), for_lm=damped)
+            args = (lsq.DeviceVector(ctx, m, y),) + ((lsq.DeviceVector(ctx, n, damp),) if damped else ())
+            sv2.ldiv_(out, *args)
+            if not damped:   # Dogleg's tolerances (atol = btol = 1e-6): same minimiser up to the stopping rule
+                assert np.allclose(out.get(), ref.get(), rtol=1e-3, atol=1e-4)
+        assert calls == [True, False]
+        # only LSMR takes a preconditioner (types.jl:82-86)
+        svc = lsq.AllocatedSolver(lsq.DeviceMatrix(ctx, np.eye(4)), lsq.Cholesky(), for_lm=True)
+        cb = lsq._lib.PRECOND_CALLBACK(lambda *a: 0)
+        assert lsq.lib().lsq_solver_set_preconditioner(svc.h, cb, None) == lsq._lib.EARG
+        # whole loop: optimize! with LevenbergMarquardt(LSMR(jacobi)) == default
+        p = list(P.minpack_all())[0]
+        name, f, g, x0 = p[:4]
+        nn = len(x0)
+        res = []
+        for solver in (lsq.LSMR(), lsq.LSMR(lambda Pv, Jm, dmp: Pv.set(
+                (lambda cs: np.where(cs > 0, 1.0 / np.sqrt(cs), 0.0))(lsq.colsumabs2_(lsq.DeviceVector(ctx, nn), Jm).get()
+                                                                     + (dmp.get() if dmp is not None else 0.0))))):
+            nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(nn), f_=f, g_=g, J=np.zeros((nn, nn), order="F"))
+            res.append(lsq.optimize_(nls, lsq.LevenbergMarquardt(solver)))
+        assert res[0].iterations == res[1].iterations and res[0].ssr == pytest.approx(res[1].ssr, rel=1e-9)
+    finally:
+        lsq.set_exact(None)
+
+
 # ------------------------------------------------------------------- trust-region trajectories
 def gpu_run(p, optimizer, solver, sparse=False, **kw):
     name, f, g, x0 = p[:4]
