@@ -69,6 +69,20 @@ double *lsq_mat_values(lsq_mat *J);
 /* ... after which the CSR mirror must be refreshed (no-op for dense). */
 int lsq_mat_refresh(lsq_mat *J);
 
+/* ---- custom Jacobian operators (README.md:37-47: any type with mul!, mul! of the adjoint, colsumabs2!,
+ *      size, eltype works with LSMR) ----
+ * A matrix-free handle: `mul(trans, d_x, d_out, user)` must write J*x (trans = 0, m entries) or J'*x
+ * (trans = 1, n entries) into d_out; `colsumabs2(d_out, user)` the n column sums of squares.  Both
+ * are HOST callbacks operating on device pointers; the library drains its stream before calling and
+ * the callback must have finished its device work when it returns (slow path, like any host-defined
+ * operator in the reference).  All fusions of the solvers still apply: the library runs its epilogue
+ * over the vector the callback produced.  Works with LSMR (ldiv, lsq_optimize); QR / Cholesky need
+ * the entries and refuse it. */
+typedef int (*lsq_op_mul_callback)(int trans, const double *d_x, double *d_out, void *user);
+typedef int (*lsq_op_colsum_callback)(double *d_out, void *user);
+int lsq_op_create(lsq_ctx *ctx, int m, int n, lsq_op_mul_callback mul, lsq_op_colsum_callback colsumabs2,
+                  void *user, lsq_mat **out);
+
 /* ---- operator interface (README.md:37-47; used at lsmr.jl:73,76,118,122 and by the optimizers) ---- */
 /* mul!(y, J, x, alpha, beta) / mul!(x, J', y, alpha, beta): trans = 0 / 1.
  * Replaces SparseArrays/BLAS mul! at levenberg_marquardt.jl:102,114; dogleg.jl:99,109,171;

@@ -19,6 +19,8 @@ c_ip = C.POINTER(C.c_int)
 F_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 G_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 ALLREDUCE_CALLBACK = C.CFUNCTYPE(C.c_int, c_dp, C.c_int, C.c_void_p)
+OP_MUL_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)   # (trans, d_x, d_out, user)
+OP_COLSUM_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)                  # (d_out, user)
 PRECOND_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)   # (d_P, J, d_damp, user)
 
 OK, EDIM, ENOTPD, ERANK, ENONFINITE, EBOUNDS, EHIP, EARG, ECALLBACK = range(9)
@@ -98,6 +100,7 @@ def lib():
         "lsq_mat_refresh": (i, [vp]),
         "lsq_mul": (i, [vp, i, d, vp, d, vp]),
         "lsq_solver_set_preconditioner": (i, [vp, PRECOND_CALLBACK, vp]),
+        "lsq_op_create": (i, [vp, i, i, OP_MUL_CALLBACK, OP_COLSUM_CALLBACK, vp, C.POINTER(vp)]),
         "lsq_colsumabs2": (i, [vp, vp]),
         "lsq_rowsumabs2": (i, [vp, vp]),
         "lsq_axpy": (i, [vp, i, d, vp, vp]),

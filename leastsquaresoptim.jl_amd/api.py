@@ -92,8 +92,11 @@ def _is_sparse(J):
 
 def default_solver(solver, J):
     """types.jl:114-121"""
+    matrix_free = type(J).__name__ == "DeviceOperator"
     if solver is None:
-        return LSMR() if _is_sparse(J) else QR()
+        return LSMR() if (_is_sparse(J) or matrix_free) else QR()
+    if matrix_free and not isinstance(solver, LSMR):
+        raise ArgumentError(_lib.EARG, "a matrix-free Jacobian works with LSMR() only (README.md:37-47)")
     if isinstance(solver, QR) and _is_sparse(J):
         raise ArgumentError(_lib.EARG, "solver QR() is not available for sparse Jacobians. "
                                        "Choose between Cholesky() and LSMR()")
@@ -349,6 +352,59 @@ def set_exact(on=None):
     check(lib().lsq_set_exact(-1 if on is None else (1 if on else 0)))
 
 
+class DeviceOperator:
+    """A matrix-free Jacobian (README.md:37-47 of the reference: any type with mul!, the adjoint's mul!,
+    colsumabs2!, size and eltype works with LSMR).  `mul(trans, x, out)` writes J*x (trans = False, m
+    entries) or J'*x (trans = True, n entries) into the DeviceVector `out`; `colsumabs2(out)` the n column
+    sums of squares.  Both are called on the host with device vectors; use `refresh()` after the operator
+    changed (what g! does for a stored Jacobian).  LSMR only."""
+    sparse = True   # (types.jl:114-121: a non-dense Jacobian defaults to LSMR)
+
+    def __init__(self, ctx, m, n, mul, colsumabs2):
+        self.ctx, self.m, self.n = ctx, int(m), int(n)
+        self.shape = (self.m, self.n)
+        self._errors = []
+
+        def _mul(trans, d_x, d_out, _user):
+            try:
+                t = bool(trans)
+                mul(t, DeviceVector.borrow(ctx, self.m if t else self.n, d_x),
+                    DeviceVector.borrow(ctx, self.n if t else self.m, d_out))
+                ctx.sync()
+                return 0
+            except Exception as e:
+                self._errors.append(e)
+                return 1
+
+        def _cs(d_out, _user):
+            try:
+                colsumabs2(DeviceVector.borrow(ctx, self.n, d_out))
+                ctx.sync()
+                return 0
+            except Exception as e:
+                self._errors.append(e)
+                return 1
+
+        self._cbs = (_lib.OP_MUL_CALLBACK(_mul), _lib.OP_COLSUM_CALLBACK(_cs))
+        h = C.c_void_p()
+        check(lib().lsq_op_create(ctx.h, self.m, self.n, self._cbs[0], self._cbs[1], None, C.byref(h)))
+        self.h = h
+
+    def refresh(self):
+        check(lib().lsq_mat_refresh(self.h))
+
+    def free(self):
+        if self.h:
+            lib().lsq_mat_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class AllocatedSolver:
     """AbstractAllocatedSolver(nls, optimizer) + ldiv! (the L2 plug point)."""
 
@@ -417,7 +473,10 @@ class LeastSquaresProblem:
         self.y = np.asarray(y, dtype=np.float64)
         if J is None:
             J = np.zeros((len(self.y), len(self.x)), order="F")
-        if _is_sparse(J):
+        if type(J).__name__ == "DeviceOperator":
+            if g_ is None:
+                raise ValueError("a matrix-free Jacobian needs g_ (it updates the operator's own state)")
+        elif _is_sparse(J):
             J = J.tocsc()
             J.sort_indices()  # g_ writes J.data in this (canonical CSC) order
         else:
@@ -544,7 +603,8 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
     solver = default_solver(optimizer.solver if optimizer is not None else None, nls.J)
     optimizer = default_optimizer(optimizer, solver)
     n, m = len(nls.x), len(nls.y)
-    Jd = DeviceMatrix(ctx, nls.J)
+    is_op = isinstance(nls.J, DeviceOperator)
+    Jd = nls.J if is_op else DeviceMatrix(ctx, nls.J)
     dx, dy = DeviceVector(ctx, n, nls.x), DeviceVector(ctx, m, nls.y)
     L = lib()
     xh, yh = np.zeros(n), np.zeros(m)
@@ -564,6 +624,8 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
         try:
             check(L.lsq_d2h(ctx.h, xh.ctypes.data_as(C.c_void_p), d_x, n * 8))
             nls.g_(nls.J, xh)
+            if is_op:   # g! updated the operator's own state; nothing to upload
+                return 0
             vals = nls.J.data if Jd.sparse else nls.J.reshape(-1, order="F")
             vals = np.ascontiguousarray(vals, dtype=np.float64)
             check(L.lsq_h2d(ctx.h, L.lsq_mat_values(Jh), vals.ctypes.data_as(C.c_void_p), vals.size * 8))
@@ -612,7 +674,8 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
                 if s_.iteration % show_every == 0:
                     print(s_)
     r.tr = states if store_trace else []
-    Jd.free()
+    if not is_op:
+        Jd.free()
     return r
 
 

@@ -100,7 +100,7 @@ static inline bool lsq_prof_take(lsq_ctx *c, hipEvent_t *start, hipEvent_t *stop
 // ---------------------------------------------------------------------------------------------
 // sparse / dense matrix handle
 // ---------------------------------------------------------------------------------------------
-enum { LSQ_MAT_DENSE = 0, LSQ_MAT_CSC = 1 };
+enum { LSQ_MAT_DENSE = 0, LSQ_MAT_CSC = 1, LSQ_MAT_OP = 2 };
 enum { LSQ_PLAN_STREAM = 0, LSQ_PLAN_WAVE = 1, LSQ_PLAN_BLOCK = 2, LSQ_PLAN_LDSWIN = 3 };
 
 // One direction of a sparse product: segments (rows for J*x via the CSR mirror, columns for
@@ -167,6 +167,11 @@ struct lsq_mat {
     int *d_bmap = nullptr;  // bcsc position -> csc position
     double *d_bpart = nullptr;
     LsqSell srows, scols;   // when active they carry the values instead of csr / bcsc (whose d_val is freed)
+    // matrix-free operator (LSQ_MAT_OP): host callbacks on device pointers + one scratch vector of max(m, n)
+    int (*op_mul)(int, const double *, double *, void *) = nullptr;
+    int (*op_colsum)(double *, void *) = nullptr;
+    void *op_user = nullptr;
+    double *d_optmp = nullptr;
     unsigned long long version = 0;  // bumps whenever values change
     // cached colsumabs2 (utils.jl:139-151 is called twice per LM iteration by the reference)
     double *d_colsum = nullptr;

@@ -33,7 +33,7 @@ static bool exact_enabled() { return g_exact_override >= 0 ? g_exact_override !=
 
 bool lsq_small_vec(long long n) { return exact_enabled() && n <= LSQ_EXACT_MAX_DIM; }
 bool lsq_small_mat(const lsq_mat *J) {
-    return exact_enabled() && J->m <= LSQ_EXACT_MAX_DIM && J->n <= LSQ_EXACT_MAX_DIM && J->nnz <= LSQ_EXACT_MAX_NNZ;
+    return J->kind != LSQ_MAT_OP && exact_enabled() && J->m <= LSQ_EXACT_MAX_DIM && J->n <= LSQ_EXACT_MAX_DIM && J->nnz <= LSQ_EXACT_MAX_NNZ;
 }
 
 // ---------------------------------------------------------------------------------------------

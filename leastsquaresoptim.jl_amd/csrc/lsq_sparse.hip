@@ -453,6 +453,28 @@ extern "C" int lsq_dense_create(lsq_ctx *c, int m, int n, lsq_mat **out) {
     return LSQ_OK;
 }
 
+extern "C" int lsq_op_create(lsq_ctx *c, int m, int n, lsq_op_mul_callback mul, lsq_op_colsum_callback colsumabs2,
+                             void *user, lsq_mat **out) {
+    if (!c || !out || m < 0 || n < 0 || !mul || !colsumabs2) {
+        lsq_set_error("lsq_op_create: bad arguments");
+        return LSQ_EARG;
+    }
+    LSQ_HIP(hipSetDevice(c->device));
+    lsq_mat *J = new lsq_mat();
+    J->ctx = c;
+    J->kind = LSQ_MAT_OP;
+    J->m = m;
+    J->n = n;
+    J->nnz = (long long)m * n;   // (logical size; keeps the small-problem reference-order path off for big operators)
+    J->op_mul = mul;
+    J->op_colsum = colsumabs2;
+    J->op_user = user;
+    LSQ_HIP(hipMalloc(&J->d_optmp, (size_t)(std::max(std::max(m, n), 1) + 8) * sizeof(double)));
+    LSQ_HIP(hipMalloc(&J->d_colsum, (n > 0 ? n : 1) * sizeof(double)));
+    *out = J;
+    return LSQ_OK;
+}
+
 extern "C" int lsq_mat_destroy(lsq_mat *J) {
     if (!J) return LSQ_OK;
     hipStreamSynchronize(J->ctx->stream);
@@ -469,6 +491,7 @@ extern "C" int lsq_mat_destroy(lsq_mat *J) {
     free_sell(J->scols);
     hipFree(J->d_bmap);
     hipFree(J->d_bpart);
+    hipFree(J->d_optmp);
     hipFree(J->d_colsum);
     delete J;
     return LSQ_OK;
@@ -483,6 +506,7 @@ extern "C" int lsq_mat_size(const lsq_mat *J, int *m, int *n, long long *nnz) {
 
 extern "C" double *lsq_mat_values(lsq_mat *J) {
     J->version++;
+    if (J->kind == LSQ_MAT_OP) return nullptr;   // no entries to expose
     if (J->kind == LSQ_MAT_DENSE) return J->d_dense;
     if (lsq_ensure_csc(J) != LSQ_OK) return nullptr;
     J->csr_fresh = false;
@@ -583,6 +607,10 @@ extern "C" int lsq_mat_refresh(lsq_mat *J) {
 }
 
 extern "C" int lsq_mat_set_values(lsq_mat *J, const double *h) {
+    if (J->kind == LSQ_MAT_OP) {
+        lsq_set_error("a matrix-free operator has no stored values");
+        return LSQ_EARG;
+    }
     double *dst = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
     if (J->nnz)
         LSQ_HIP(hipMemcpyAsync(dst, h, J->nnz * sizeof(double), hipMemcpyHostToDevice, J->ctx->stream));
@@ -591,6 +619,10 @@ extern "C" int lsq_mat_set_values(lsq_mat *J, const double *h) {
 }
 
 extern "C" int lsq_mat_get_values(const lsq_mat *J, double *h) {
+    if (J->kind == LSQ_MAT_OP) {
+        lsq_set_error("a matrix-free operator has no stored values");
+        return LSQ_EARG;
+    }
     LSQ_TRY(lsq_ensure_csc(const_cast<lsq_mat *>(J)));
     const double *src = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
     if (J->nnz)
@@ -709,6 +741,17 @@ int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {
 }
 
 const double *lsq_cached_colsum(lsq_mat *J) {
+    if (J->kind == LSQ_MAT_OP) {   // the operator owns its state: ask every time a new version is announced
+        if (J->colsum_version != J->version) {
+            if (hipStreamSynchronize(J->ctx->stream) != hipSuccess) return nullptr;
+            if (J->op_colsum(J->d_colsum, J->op_user) != 0) {
+                lsq_set_error("operator colsumabs2 callback reported failure");
+                return nullptr;
+            }
+            J->colsum_version = J->version;
+        }
+        return J->d_colsum;
+    }
     if (J->colsum_version != J->version) {
         int st = lsq_small_mat(J) ? lsq_exact_colsumabs2(J, J->d_colsum)
                  : J->kind == LSQ_MAT_DENSE ? lsq_dense_colsumabs2(J, J->d_colsum)
@@ -724,6 +767,7 @@ extern "C" int lsq_mul(lsq_mat *J, int trans, double alpha, const double *x, dou
         lsq_set_error("lsq_mul: null argument");
         return LSQ_EARG;
     }
+    if (J->kind == LSQ_MAT_OP) return lsq_sparse_mul(J, trans, alpha, x, beta, y);   // (launch_product dispatches on the kind)
     if (lsq_small_mat(J) && x != y) return lsq_exact_mul(J, trans, alpha, x, beta, y);  // reference order
     return J->kind == LSQ_MAT_DENSE ? lsq_dense_mul(J, trans, alpha, x, beta, y)
                                     : lsq_sparse_mul(J, trans, alpha, x, beta, y);
@@ -774,6 +818,10 @@ k_dense_rowsq(const double *__restrict__ A, int m, int n, double *__restrict__ o
 
 extern "C" int lsq_rowsumabs2(lsq_mat *J, double *out) {
     if (!J || !out) return LSQ_EARG;
+    if (J->kind == LSQ_MAT_OP) {
+        lsq_set_error("rowsumabs2 of a matrix-free operator: not provided by its callbacks");
+        return LSQ_EARG;
+    }
     lsq_ctx *c = J->ctx;
     if (J->m <= 0) return LSQ_OK;
     if (J->kind == LSQ_MAT_DENSE) {

@@ -821,6 +821,22 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
     lsq_ctx *c = J->ctx;
     constexpr int maxg = Epi::REDUCE ? 2048 : LSQ_MAX_GRID;
     auto cap = [](long long w) { return (int)(w > maxg ? maxg : w); };
+    if (J->kind == LSQ_MAT_OP) {
+        // matrix-free operator: the host callback produces the plain product, then the epilogue runs over it
+        // (k_combine with a single "window" is exactly "apply the epilogue to a vector of dot products")
+        LSQ_HIP(hipStreamSynchronize(c->stream));
+        if (J->op_mul(trans, x, J->d_optmp, J->op_user) != 0) {
+            lsq_set_error("operator mul callback reported failure");
+            return LSQ_ECALLBACK;
+        }
+        const int len = trans ? J->n : J->m;
+        int nb = lsq_div_up(len, LSQ_CMB_COLS);
+        int grid = cap((long long)nb + epi.extra_blocks);
+        if (grid > 0)
+            hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_optmp, len, 1, epi, nb);
+        LSQ_HIP(hipGetLastError());
+        return LSQ_OK;
+    }
     if (J->kind == LSQ_MAT_CSC) {
         if (!trans) {
             LSQ_TRY(lsq_ensure_csr(J));
