@@ -599,13 +599,26 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
               full_trace=False):
     """optimize!(nls, optimizer; kwargs...)  -- types.jl:207-209 then
     levenberg_marquardt.jl:39-144 / dogleg.jl:41-203.  Mutates nls.x, nls.y, nls.J in place."""
-    ctx = ctx or default_context()
-    solver = default_solver(optimizer.solver if optimizer is not None else None, nls.J)
-    optimizer = default_optimizer(optimizer, solver)
+    allocated = nls if isinstance(nls, LeastSquaresProblemAllocated) else None
+    if allocated is not None:
+        # optimize!(nls::LeastSquaresProblemAllocated; kwargs...): buffers, solver and optimizer were chosen at
+        # allocation (types.jl:141-160); nothing is allocated here, on the host or on the device
+        if optimizer is not None:
+            raise TypeError("an allocated problem carries its optimizer (types.jl:152-157)")
+        ctx, optimizer, solver = allocated.ctx, allocated.optimizer, allocated.solver
+    else:
+        ctx = ctx or default_context()
+        solver = default_solver(optimizer.solver if optimizer is not None else None, nls.J)
+        optimizer = default_optimizer(optimizer, solver)
     n, m = len(nls.x), len(nls.y)
     is_op = isinstance(nls.J, DeviceOperator)
-    Jd = nls.J if is_op else DeviceMatrix(ctx, nls.J)
-    dx, dy = DeviceVector(ctx, n, nls.x), DeviceVector(ctx, m, nls.y)
+    if allocated is not None:
+        Jd, dx, dy = allocated._Jd, allocated._dx, allocated._dy
+        dx.set(nls.x)
+        dy.set(nls.y)
+    else:
+        Jd = nls.J if is_op else DeviceMatrix(ctx, nls.J)
+        dx, dy = DeviceVector(ctx, n, nls.x), DeviceVector(ctx, m, nls.y)
     L = lib()
     xh, yh = np.zeros(n), np.zeros(m)
     err = []
@@ -674,9 +687,32 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
                 if s_.iteration % show_every == 0:
                     print(s_)
     r.tr = states if store_trace else []
-    if not is_op:
+    if not is_op and allocated is None:
         Jd.free()
     return r
+
+
+class LeastSquaresProblemAllocated:
+    """LeastSquaresProblemAllocated(nls, optimizer) (types.jl:141-160, exported by the reference): the problem
+    together with its optimizer, its solver and every buffer they need, allocated once; `optimize_(nlsa)` can then
+    be called repeatedly (e.g. from different starting points written into `nlsa.x`) without allocating -- the
+    device Jacobian handle, the vectors and, inside the library, the loop/solver workspace are all reused."""
+
+    def __init__(self, nls, optimizer=None, ctx=None):
+        if not isinstance(nls, LeastSquaresProblem):
+            raise TypeError("LeastSquaresProblemAllocated(nls::LeastSquaresProblem, optimizer)")
+        self.ctx = ctx or default_context()
+        self.solver = default_solver(optimizer.solver if optimizer is not None else None, nls.J)
+        self.optimizer = default_optimizer(optimizer, self.solver)
+        self.x, self.y, self.f_, self.J, self.g_ = nls.x, nls.y, nls.f_, nls.J, nls.g_
+        self._Jd = nls.J if isinstance(nls.J, DeviceOperator) else DeviceMatrix(self.ctx, nls.J)
+        self._dx = DeviceVector(self.ctx, len(nls.x), nls.x)
+        self._dy = DeviceVector(self.ctx, len(nls.y), nls.y)
+
+    def free(self):
+        if self._Jd is not None and not isinstance(self._Jd, DeviceOperator):
+            self._Jd.free()
+        self._Jd = None
 
 
 def optimize(f, x, optimizer, autodiff="central", **kwargs):

@@ -433,6 +433,30 @@ def test_lsmr_custom_preconditioner(ctx):
         lsq.set_exact(None)
 
 
+def test_allocated_problem_is_reusable(ctx):
+    """LeastSquaresProblemAllocated (types.jl:141-160; exported): allocate once, optimize! repeatedly -- same
+    results as fresh problems, from the same and from a different start."""
+    p = list(P.minpack_all())[2]
+    name, f, g, x0 = p[:4]
+    n = len(x0)
+    nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(n), f_=f, g_=g, J=np.zeros((n, n), order="F"))
+    nlsa = lsq.LeastSquaresProblemAllocated(nls, lsq.Dogleg(lsq.QR()))
+    assert isinstance(nlsa.optimizer, lsq.Dogleg) and isinstance(nlsa.solver, lsq.QR)
+    r1 = lsq.optimize_(nlsa)
+    fresh = lsq.optimize_(lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(n), f_=f, g_=g, J=np.zeros((n, n), order="F")),
+                          lsq.Dogleg(lsq.QR()))
+    assert r1.iterations == fresh.iterations and r1.ssr == fresh.ssr and np.array_equal(r1.minimizer, fresh.minimizer)
+    x1 = x0 * 1.5 + 0.1
+    nlsa.x[:] = x1
+    r2 = lsq.optimize_(nlsa)
+    fresh2 = lsq.optimize_(lsq.LeastSquaresProblem(x=x1.copy(), y=np.zeros(n), f_=f, g_=g, J=np.zeros((n, n), order="F")),
+                           lsq.Dogleg(lsq.QR()))
+    assert r2.iterations == fresh2.iterations and r2.ssr == fresh2.ssr
+    with pytest.raises(TypeError):
+        lsq.optimize_(nlsa, lsq.LevenbergMarquardt())
+    nlsa.free()
+
+
 def test_matrix_free_operator(ctx):
     """A custom Jacobian type (README.md:37-47 of the reference): host callbacks for mul!, the adjoint's mul!
     and colsumabs2!.  Wrapping a stored matrix in such an operator must give the SAME LSMR solve (the library
