@@ -1213,6 +1213,10 @@ __device__ __forceinline__ double blk_sum_256(double v, double *sh) {
     __syncthreads();
     return r;
 }
+// Q2S_CPB columns per workgroup: the pivot column (fetched and turned into the reflector by every workgroup) is
+// shared by that many updates and a step has that many times fewer workgroups (worth it while the trailing
+// matrix is wide; near the end one column per workgroup has the shorter critical path)
+template <int Q2S_CPB>
 __global__ void __launch_bounds__(Q2S_NT)
 k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const double *__restrict__ vn1_in,
            const double *__restrict__ vn2_in, double *__restrict__ vn1_out, double *__restrict__ vn2_out,
@@ -1220,24 +1224,33 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
            double *__restrict__ diag, double *__restrict__ ice /* wmin[n] wmax[n] smin smax stopped */, double rcond,
            int *__restrict__ rank_out) {
     __shared__ double sh[4];
+    __shared__ double shv[4][Q2S_CPB];
     __shared__ double s_best[4];
     __shared__ int s_bpos[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int npos = n - i - 1;
-    const bool is_ice = (int)blockIdx.x == npos + 1, is_rhs = (int)blockIdx.x == npos;
-    const int mypos = i + 1 + (int)blockIdx.x;
-    // the column standing at this block's position is fetched right away (the norms are indexed by POSITION,
-    // so the pivot search needs no indirection); only the block sitting at the pivot's position has to
-    // fetch again -- it works on the column the exchange brings there
-    const int guess = (is_ice || is_rhs) ? 0 : colat_in[mypos];
-    const double *cg = is_rhs ? rhs : R + (size_t)guess * n;
-    double a[Q2S_RPT];
+    const int npos = n - i - 1;                 // positions i+1 .. n-1; item npos is the right-hand side
+    const int nitems = npos + 1;
+    const int nblk = (nitems + Q2S_CPB - 1) / Q2S_CPB;
+    const bool is_ice = (int)blockIdx.x == nblk;
+    // the columns standing at this block's positions are fetched right away (the norms are indexed by POSITION,
+    // so the pivot search needs no indirection); only a column sitting at the pivot's position has to be
+    // fetched again -- that slot works on the column the exchange brings there
+    double a[Q2S_CPB][Q2S_RPT], cji[Q2S_CPB];
+    int own[Q2S_CPB];
 #pragma unroll
-    for (int q = 0; q < Q2S_RPT; ++q) {
-        const int k = i + 1 + tid + q * Q2S_NT;
-        a[q] = (k < n && !is_ice) ? cg[k] : 0.0;
+    for (int c = 0; c < Q2S_CPB; ++c) {
+        const int item = (int)blockIdx.x * Q2S_CPB + c;
+        own[c] = -1;                                            // -1: nothing, -2: rhs
+        const double *cg = nullptr;
+        if (!is_ice && item < npos) { own[c] = colat_in[i + 1 + item]; cg = R + (size_t)own[c] * n; }
+        else if (!is_ice && item == npos) { own[c] = -2; cg = rhs; }
+#pragma unroll
+        for (int q = 0; q < Q2S_RPT; ++q) {
+            const int k = i + 1 + tid + q * Q2S_NT;
+            a[c][q] = (cg && k < n) ? cg[k] : 0.0;
+        }
+        cji[c] = cg ? cg[i] : 0.0;
     }
-    double cji = is_ice ? 0.0 : cg[i];
     // (a) first maximum of the norms over positions i..n-1
     double best = -1.0;
     int bpos = n;
@@ -1269,16 +1282,19 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
         acc += v[q] * v[q];
     }
     const double alpha = cp[i];
-    int own = guess;
-    if (!is_ice && !is_rhs && mypos == ppos) {   // this position receives the displaced column
-        own = icol;
-        const double *co = R + (size_t)own * n;
 #pragma unroll
-        for (int q = 0; q < Q2S_RPT; ++q) {
-            const int k = i + 1 + tid + q * Q2S_NT;
-            a[q] = k < n ? co[k] : 0.0;
+    for (int c = 0; c < Q2S_CPB; ++c) {
+        const int item = (int)blockIdx.x * Q2S_CPB + c;
+        if (own[c] >= 0 && i + 1 + item == ppos) {   // this position receives the displaced column
+            own[c] = icol;
+            const double *co = R + (size_t)icol * n;
+#pragma unroll
+            for (int q = 0; q < Q2S_RPT; ++q) {
+                const int k = i + 1 + tid + q * Q2S_NT;
+                a[c][q] = k < n ? co[k] : 0.0;
+            }
+            cji[c] = co[i];
         }
-        cji = co[i];
     }
     const double xn = sqrt(blk_sum_256(acc, sh));
     double ti = 0.0, beta = alpha;
@@ -1329,37 +1345,56 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
         }
         return;
     }
-    // (c) apply H_i to the own column
-    double *cj = is_rhs ? rhs : R + (size_t)own * n;
-    double w = 0.0;
-#pragma unroll
-    for (int q = 0; q < Q2S_RPT; ++q) w += v[q] * a[q];
+    // (c) apply H_i to the block's columns: the four dot products share one reduction
     if (ti != 0.0) {
-        w = blk_sum_256(w, sh) + cji;      // v_i = 1
-        const double tw = ti * w;
+        double w[Q2S_CPB];
 #pragma unroll
-        for (int q = 0; q < Q2S_RPT; ++q) {
-            const int k = i + 1 + tid + q * Q2S_NT;
-            a[q] -= v[q] * tw;
-            if (k < n) cj[k] = a[q];
+        for (int c = 0; c < Q2S_CPB; ++c) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q2S_RPT; ++q) t += v[q] * a[c][q];
+            w[c] = wave_sum(t);
         }
-        cji -= tw;
-        if (tid == 0) cj[i] = cji;
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < Q2S_CPB; ++c) shv[wv][c] = w[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < Q2S_CPB; ++c) {
+            if (own[c] == -1) continue;
+            const double wt = (((shv[0][c] + shv[1][c]) + shv[2][c]) + shv[3][c]) + cji[c];      // v_i = 1
+            const double tw = ti * wt;
+            double *cj = own[c] == -2 ? rhs : R + (size_t)own[c] * n;
+#pragma unroll
+            for (int q = 0; q < Q2S_RPT; ++q) {
+                const int k = i + 1 + tid + q * Q2S_NT;
+                a[c][q] -= v[q] * tw;
+                if (k < n) cj[k] = a[c][q];
+            }
+            cji[c] -= tw;
+            if (tid == 0) cj[i] = cji[c];
+        }
+        __syncthreads();
     }
-    if (!is_rhs) {   // partial-norm downdate (dlaqp2); the norms travel with the POSITION
-        const double tol3z = sqrt(DBL_EPSILON / 2);
-        const int from = mypos == ppos ? i : mypos;      // where this column stood when the step began
+    // partial-norm downdate (dlaqp2); the norms travel with the POSITION
+    const double tol3z = sqrt(DBL_EPSILON / 2);
+#pragma unroll
+    for (int c = 0; c < Q2S_CPB; ++c) {
+        if (own[c] < 0) continue;                            // nothing, or the right-hand side
+        const int mypos = i + 1 + (int)blockIdx.x * Q2S_CPB + c;
+        const int from = mypos == ppos ? i : mypos;          // where this column stood when the step began
         const double v1 = vn1_in[from], v2 = vn2_in[from];
         double n1 = v1, n2 = v2;
         if (v1 != 0.0) {
-            const double r = fabs(cji) / v1;
+            const double r = fabs(cji[c]) / v1;
             const double temp = fmax(1.0 - r * r, 0.0);
             const double qq = v1 / v2;
             const double temp2 = temp * qq * qq;
             if (temp2 <= tol3z) {
                 double a2 = 0.0;
 #pragma unroll
-                for (int q = 0; q < Q2S_RPT; ++q) a2 += a[q] * a[q];
+                for (int q = 0; q < Q2S_RPT; ++q) a2 += a[c][q] * a[c][q];
                 a2 = blk_sum_256(a2, sh);
                 n1 = i < n - 1 ? sqrt(a2) : 0.0;
                 n2 = n1;
@@ -1537,9 +1572,14 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
                 hipLaunchKernelGGL(k_qr2_init, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, R2, n, vn1[0], vn2[0], colat[0]);
                 for (int i = 0; i < n; ++i) {
                     const int a = i & 1, b = a ^ 1;
-                    hipLaunchKernelGGL(k_qr2_step, dim3(n - i + 1), dim3(Q2S_NT), 0, c->stream, R2, n, i, rhs2, vn1[a], vn2[a],
-                                       vn1[b], vn2[b], colat[a], colat[b], tau, ws + 7 * n, q->ice,
-                                       (double)mn * DBL_EPSILON, s->d_info);
+                    auto go = [&](auto kern, int cpb) {
+                        hipLaunchKernelGGL(kern, dim3((n - i + cpb - 1) / cpb + 1), dim3(Q2S_NT), 0, c->stream, R2, n, i, rhs2,
+                                           vn1[a], vn2[a], vn1[b], vn2[b], colat[a], colat[b], tau, ws + 7 * n, q->ice,
+                                           (double)mn * DBL_EPSILON, s->d_info);
+                    };
+                    if (n - i >= 768) go(k_qr2_step<4>, 4);
+                    else if (n - i >= 320) go(k_qr2_step<2>, 2);
+                    else go(k_qr2_step<1>, 1);
                 }
                 // the solve wants R in pivoted order: gather it into the (now free) factor buffer
                 long long tot = (long long)n * n;
