@@ -792,7 +792,8 @@ int lsq_dense_solver_alloc(lsq_solver *s) {
     } else {
         const size_t M = s->for_lm ? (size_t)m + n : (size_t)m;       // dense_qr.jl:25-28, 50-54
         const size_t lu = s->for_lm ? M : (size_t)std::max(m, n);
-        LSQ_HIP(hipMalloc(&s->d_qr, (M * n1 + 8) * sizeof(double)));
+        // (+32768: the register-resident panel steps fetch whole row slabs unconditionally, up to 20480 rows past a column)
+        LSQ_HIP(hipMalloc(&s->d_qr, (M * n1 + 8 + 32768) * sizeof(double)));
         LSQ_HIP(hipMalloc(&s->d_qu, (lu + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&s->d_work, (8 * n1 + 3 * M + 64) * sizeof(double)));
         LSQ_HIP(hipMalloc(&s->d_tau, n1 * sizeof(int) + 16));         // jpvt
@@ -998,17 +999,225 @@ k_qr1_step_reg(double *__restrict__ A, int M, int cend, int i, int first, double
     }
 }
 
+// Lazy-reflector variant of the step: column i is left UNSCALED by the launch that finished it; every
+// workgroup of launch i forms H_i itself from it (sum v^2 and v'a share ONE block reduction), so a step has
+// a single reduction round on its critical path instead of two (apply, then form the next reflector).
+// beta_i, tau_i and the scale 1/(alpha - beta) go to side arrays: R(i,i) is not written while others read it,
+// and the V materialisation applies the scale.  bookkeeping-only launch (nblocks == 0 columns): i = cend-1.
+template <int RPT>
+__global__ void __launch_bounds__(QR_NT)
+k_qr1_step_lazy(double *__restrict__ A, int M, int cend, int i, double *__restrict__ tau, double *__restrict__ beta_out,
+                double *__restrict__ scale_out) {
+    __shared__ double sh2[QR_NT / 64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = i + 1 + blockIdx.x;
+    const bool has_col = j < cend;             // (the last column of a panel has nobody to update: bookkeeping only)
+    const double *ci = A + (size_t)i * M;
+    double *cj = A + (size_t)(has_col ? j : i) * M;
+    const unsigned t = (unsigned)(i + 1 + tid);
+    double a[RPT], v[RPT];
+    double svv = 0.0, sva = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const bool in = (int)t + q * QR_NT < M;
+        v[q] = in ? (ci + q * QR_NT)[t] : 0.0;
+        a[q] = (in && has_col) ? (cj + q * QR_NT)[t] : 0.0;
+        svv += v[q] * v[q];
+        sva += v[q] * a[q];
+    }
+    const double alpha = ci[i];
+    const double aji = has_col ? cj[i] : 0.0;
+    svv = wave_sum(svv);
+    sva = wave_sum(sva);
+    if (lane == 0) { sh2[wv][0] = svv; sh2[wv][1] = sva; }
+    __syncthreads();
+    double tvv = 0.0, tva = 0.0;
+#pragma unroll
+    for (int w = 0; w < QR_NT / 64; ++w) { tvv += sh2[w][0]; tva += sh2[w][1]; }
+    const double xn = sqrt(tvv);
+    double ti = 0.0, beta = alpha, sc = 0.0;
+    if (xn != 0.0) {
+        beta = -copysign(hypot(alpha, xn), alpha);
+        ti = (beta - alpha) / beta;
+        sc = 1.0 / (alpha - beta);
+    }
+    if (blockIdx.x == 0 && tid == 0) { tau[i] = ti; beta_out[i] = beta; scale_out[i] = sc; }
+    if (!has_col || ti == 0.0) return;
+    const double tw = ti * (sc * tva + aji);      // v_i(i) = 1, v_i(k) = sc * column_i(k)
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        a[q] -= (v[q] * sc) * tw;
+        if ((int)t + q * QR_NT < M) (cj + q * QR_NT)[t] = a[q];
+    }
+    if (tid == 0) cj[i] = aji - tw;
+}
+
+// DPP all-reductions (no LDS round trips): after row_allsum every lane of a 16-lane row holds the row's sum
+// (rotations pair the same operands in every lane, so the lanes agree bit for bit); wave_allsum adds the four
+// row sums in a fixed order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_allsum(double x) {
+    x += dpp_mov_f64<0x128>(x);   // row_ror:8
+    x += dpp_mov_f64<0x124>(x);   // row_ror:4
+    x += dpp_mov_f64<0x122>(x);   // row_ror:2
+    x += dpp_mov_f64<0x121>(x);   // row_ror:1
+    return x;
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double wave_allsum(double x) {
+    x = row_allsum(x);
+    return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+
+// K lazy reflectors per launch.  A launch's fixed cost (dispatch + the fetch of the columns) dominates a step,
+// so one launch carries the K pivot columns i .. i+K-1 through K reduction rounds: every workgroup fetches
+// the K pivot columns and its own target column i+K+blockIdx.x, and in round r forms H_{i+r} from pivot
+// column r (as k_qr1_step_lazy does) and applies it to the later pivot columns and to the target, all in
+// registers.  The pivot columns are updated redundantly by every workgroup (identical arithmetic); workgroup
+// 0 stores them and the side arrays.  Thread rows start at row i so that the pivot element of every round is
+// an ordinary masked element: "alpha" and the row-(i+r) entries of the other columns come out of the same
+// block reduction as the dot products (sums with a single non-zero term are exact).
+template <int NT, int RPT, int K>
+__global__ void __launch_bounds__(NT)
+k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live pivots, <= K */, double *__restrict__ tau,
+                 double *__restrict__ beta_out, double *__restrict__ scale_out) {
+    constexpr int NW = NT / 64;
+    constexpr int NS = 2 * (K + 1);
+    __shared__ double sh[NW][NS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = i + kk + (int)blockIdx.x;
+    const bool has_col = j < cend;
+    // one buffer descriptor per column (scalar base, byte count M*8): every fetch and store is descriptor +
+    // ONE shared 32-bit VGPR offset + a scalar offset; rows beyond M read as zero and their stores are dropped by
+    // the bounds check, and a dead column (ragged last launch, no target) gets an empty descriptor
+    typedef unsigned v2u_qr __attribute__((ext_vector_type(2)));
+    const unsigned tb = (unsigned)(i + tid) * 8u;
+    const unsigned colbytes = (unsigned)M * 8u;
+    const int t = i + tid;
+    double pv[K][RPT], a[RPT];
+    __amdgpu_buffer_rsrc_t rp[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        rp[r] = __builtin_amdgcn_make_buffer_rsrc(A + (size_t)(i + (r < kk ? r : 0)) * M, 0, r < kk ? colbytes : 0u, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rp[r], tb, q * NT * 8, 0);
+            pv[r][q] = __builtin_bit_cast(double, w);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rj =
+        __builtin_amdgcn_make_buffer_rsrc(A + (size_t)(has_col ? j : i) * M, 0, has_col ? colbytes : 0u, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rj, tb, q * NT * 8, 0);
+        a[q] = __builtin_bit_cast(double, w);
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const bool live = r < kk;                   // (uniform; a dead round of a ragged last launch is a no-op)
+        const int c = i + r;                        // pivot column == pivot row of this round
+        // sums: [0] v'v  [1] alpha  then per later column x (pivots r+1.., target): v'x and x(c)
+        double sm[NS];
+        // only element 0 of a thread can sit at or above the pivot row (rows i .. i+K-1 belong to threads 0 .. K-1)
+        {
+            const double v = t > c ? pv[r][0] : 0.0;
+            const bool at = t == c;
+            sm[0] = v * v;
+            sm[1] = at ? pv[r][0] : 0.0;
+#pragma unroll
+            for (int x = r + 1; x < K; ++x) {
+                sm[2 * (x - r)] = v * pv[x][0];
+                sm[2 * (x - r) + 1] = at ? pv[x][0] : 0.0;
+            }
+            sm[2 * (K - r)] = v * a[0];
+            sm[2 * (K - r) + 1] = at ? a[0] : 0.0;
+        }
+#pragma unroll
+        for (int q = 1; q < RPT; ++q) {
+            const double v = pv[r][q];
+            sm[0] = __builtin_fma(v, v, sm[0]);
+#pragma unroll
+            for (int x = r + 1; x < K; ++x) sm[2 * (x - r)] = __builtin_fma(v, pv[x][q], sm[2 * (x - r)]);
+            sm[2 * (K - r)] = __builtin_fma(v, a[q], sm[2 * (K - r)]);
+        }
+#pragma unroll
+        for (int e = 0; e < NS; ++e)
+            if (e < 2 * (K - r) + 2) sm[e] = wave_allsum(sm[e]);
+        __syncthreads();                             // (the previous round's readers are done)
+        if (lane == 0) {
+#pragma unroll
+            for (int e = 0; e < NS; ++e)
+                if (e < 2 * (K - r) + 2) sh[wv][e] = sm[e];
+        }
+        __syncthreads();
+        static_assert(NW <= 16, "one 16-lane row sums the wave partials");
+#pragma unroll
+        for (int e = 0; e < NS; ++e)
+            if (e < 2 * (K - r) + 2) sm[e] = row_allsum((lane & 15) < NW ? sh[lane & 15][e] : 0.0);
+        const double alpha = sm[1];
+        double ti = 0.0, beta = alpha, sc = 0.0;
+        if (sm[0] != 0.0) {
+            // (sum v^2 is already formed unscaled, so dlapy2's overflow guard has nothing left to protect)
+            beta = -copysign(sqrt(__builtin_fma(alpha, alpha, sm[0])), alpha);
+            ti = (beta - alpha) / beta;
+            sc = 1.0 / (alpha - beta);
+        }
+        if (!live) ti = 0.0;
+        if (live && blockIdx.x == 0 && tid == 0) { tau[c] = ti; beta_out[c] = beta; scale_out[c] = sc; }
+        if (ti != 0.0) {
+            double tw[K + 1];
+#pragma unroll
+            for (int x = r + 1; x <= K; ++x) tw[x] = ti * (sc * sm[2 * (x - r)] + sm[2 * (x - r) + 1]);
+            {
+                const double vs = t > c ? pv[r][0] * sc : (t == c ? 1.0 : 0.0);
+#pragma unroll
+                for (int x = r + 1; x < K; ++x) pv[x][0] -= vs * tw[x];
+                a[0] -= vs * tw[K];
+            }
+#pragma unroll
+            for (int q = 1; q < RPT; ++q) {
+                const double vs = pv[r][q] * sc;
+#pragma unroll
+                for (int x = r + 1; x < K; ++x) pv[x][q] = __builtin_fma(-vs, tw[x], pv[x][q]);
+                a[q] = __builtin_fma(-vs, tw[K], a[q]);
+            }
+        }
+    }
+    if (blockIdx.x == 0) {                           // pivot columns 1 .. kk-1 are final (unscaled) now
+#pragma unroll
+        for (int r = 1; r < K; ++r)
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_qr, pv[r][q]), rp[r], tb, q * NT * 8, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_qr, a[q]), rj, tb, q * NT * 8, 0);
+}
+
 // V (unit lower trapezoid of the panel, zeros above, zero columns beyond nb) -> Vb[row - c0][col], ld = ldv
 __global__ void __launch_bounds__(256)
-k_qr1_vbuf(const double *__restrict__ A, int M, int c0, int nb, double *__restrict__ Vb, int ldv) {
+k_qr1_vbuf(double *__restrict__ A, int M, int c0, int nb, double *__restrict__ Vb, int ldv,
+           const double *__restrict__ beta, const double *__restrict__ scale /* lazy reflectors: column c0+c is stored
+           unscaled and its R(c,c) = beta is put on the diagonal here, once nobody reads the old pivot element */) {
     const int rows = M - c0;
     const long long tot = (long long)rows * Q2_NB;
     for (long long e = blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
         const int r = (int)(e % rows), cidx = (int)(e / rows);
         double v = 0.0;
         if (cidx < nb) {
-            if (r > cidx) v = A[(size_t)(c0 + cidx) * M + c0 + r];
-            else if (r == cidx) v = 1.0;
+            if (r > cidx) v = A[(size_t)(c0 + cidx) * M + c0 + r] * (scale ? scale[c0 + cidx] : 1.0);
+            else if (r == cidx) {
+                v = 1.0;
+                if (beta) A[(size_t)(c0 + cidx) * M + c0 + r] = beta[c0 + cidx];
+            }
         }
         Vb[(size_t)cidx * ldv + r] = v;
     }
@@ -1444,6 +1653,7 @@ struct Qr2Work {
     double *Vb = nullptr, *Wp = nullptr, *W = nullptr, *W2 = nullptr, *R = nullptr, *rhs2 = nullptr, *tau1 = nullptr;
     double *vn = nullptr;     // stage 2: vn1/vn2 double-buffered (4n)
     double *ice = nullptr;    // stage 2: condition-estimate vectors + scalars (2n + 8)
+    double *lazy = nullptr;   // stage 1, lazy reflectors: beta[n] | scale[n]
     int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
     int kslices = 0, M = 0, n = 0;
 };
@@ -1451,7 +1661,7 @@ static void qr2_free(void *p) {
     Qr2Work *q = (Qr2Work *)p;
     if (!q) return;
     hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
-    hipFree(q->vn); hipFree(q->colat); hipFree(q->ice);
+    hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
     delete q;
 }
 
@@ -1483,6 +1693,7 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         LSQ_HIP(hipMalloc(&q->tau1, ((size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->vn, (4 * (size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->ice, (2 * (size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->lazy, (2 * (size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->colat, (2 * (size_t)n + 8) * sizeof(int)));
         s->qr2 = q;
         s->qr2_free = qr2_free;
@@ -1490,12 +1701,37 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
     double *A = s->d_qr, *rhs = s->d_qu;
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
+        bool lazy = false;
         auto steps = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(1), dim3(QR_NT), 0, c->stream, A, M, cend, c0, 1, q->tau1);
             for (int i = c0; i + 1 < cend; ++i)
                 hipLaunchKernelGGL(kern, dim3(cend - i - 1), dim3(QR_NT), 0, c->stream, A, M, cend, i, 0, q->tau1);
         };
+        auto steps_lazy = [&](auto kern) {
+            for (int i = c0; i < cend; ++i)
+                hipLaunchKernelGGL(kern, dim3(std::max(1, cend - i - 1)), dim3(QR_NT), 0, c->stream, A, M, cend, i, q->tau1,
+                                   q->lazy, q->lazy + n);
+            lazy = true;
+        };
+        const bool want_lazy = !getenv("LSQ_QR1_EAGER");
+        const bool want_multi = want_lazy && !getenv("LSQ_QR1_SINGLE");
+        auto steps_multi = [&](auto kern, int nt, int K) {
+            for (int i = c0; i < cend; i += K) {
+                const int kk = std::min(K, cend - i);
+                hipLaunchKernelGGL(kern, dim3(std::max(1, cend - i - kk)), dim3(nt), 0, c->stream, A, M, cend, i, kk, q->tau1,
+                                   q->lazy, q->lazy + n);
+            }
+            lazy = true;
+        };
+        const int prow = M - c0;
         if (getenv("LSQ_QR1_LOOP")) steps(k_qr1_step);
+        else if (want_multi && prow <= 8 * 512) steps_multi(k_qr1_step_multi<512, 8, 4>, 512, 4);
+        else if (want_multi && prow <= 8 * 1024) steps_multi(k_qr1_step_multi<512, 16, 4>, 512, 4);
+        else if (want_multi && prow <= 32 * 512) steps_multi(k_qr1_step_multi<512, 32, 2>, 512, 2);
+        else if (want_multi && prow <= 40 * 512) steps_multi(k_qr1_step_multi<512, 40, 2>, 512, 2);
+        else if (want_lazy && M - c0 <= 8 * QR_NT) steps_lazy(k_qr1_step_lazy<8>);
+        else if (want_lazy && M - c0 <= 16 * QR_NT) steps_lazy(k_qr1_step_lazy<16>);
+        else if (want_lazy && M - c0 <= 20 * QR_NT) steps_lazy(k_qr1_step_lazy<20>);
         else if (M - c0 <= 8 * QR_NT) steps(k_qr1_step_reg<8>);          // the column fits the registers of one workgroup
         else if (M - c0 <= 16 * QR_NT) steps(k_qr1_step_reg<16>);
         else if (M - c0 <= 24 * QR_NT) steps(k_qr1_step_reg<24>);
@@ -1507,7 +1743,9 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         {
             long long tot = (long long)rows * Q2_NB;
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 8);
-            hipLaunchKernelGGL(k_qr1_vbuf, dim3(g), dim3(256), 0, c->stream, A, M, c0, nb, q->Vb, ldv);
+            hipLaunchKernelGGL(k_qr1_vbuf, dim3(g), dim3(256), 0, c->stream, A, M, c0, nb, q->Vb, ldv,
+                               lazy ? (const double *)q->lazy : (const double *)nullptr,
+                               lazy ? (const double *)(q->lazy + n) : (const double *)nullptr);
         }
         int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
         hipLaunchKernelGGL(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
