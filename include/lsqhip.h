@@ -139,6 +139,11 @@ typedef int (*lsq_precond_callback)(double *d_P, lsq_mat *J, const double *d_dam
 int lsq_solver_set_preconditioner(lsq_solver *s, lsq_precond_callback cb, void *user);
 /* diagnostics of the last solve: LSMR istop / iterations, QR numerical rank */
 int lsq_solver_info(const lsq_solver *s, int *lsmr_iter, int *lsmr_istop, int *qr_rank);
+/* which factorisation the last QR solve used (dense_qr.jl:37,83 always runs geqp3; this build only needs the
+ * pivoted sweep when the rank decision is open):  0 none yet, 1 one-stage pivoted Householder,
+ * 2 blocked unpivoted QR + pivoted sweep on R,  3 blocked unpivoted QR + full-rank certificate
+ * (||R||_F ||inv(R)||_F * rcond * 16 <= 1 proves xGELSY's rank = n; no pivoting needed) */
+int lsq_solver_qr_path(const lsq_solver *s, int *path);
 
 /* ---- whole trust-region loop on device buffers (host control, device arrays) ---- */
 /* f!(out, x) and g!(J, x) on DEVICE pointers; g writes lsq_mat_values(J) (the library refreshes

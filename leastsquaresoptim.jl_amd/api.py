@@ -429,7 +429,10 @@ class AllocatedSolver:
     def info(self):
         it, st, rk = C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().lsq_solver_info(self.h, C.byref(it), C.byref(st), C.byref(rk)))
-        return dict(lsmr_iter=it.value, lsmr_istop=st.value, qr_rank=rk.value)
+        path = C.c_int(0)
+        check(lib().lsq_solver_qr_path(self.h, C.byref(path)))
+        return dict(lsmr_iter=it.value, lsmr_istop=st.value, qr_rank=rk.value,
+                    qr_path={0: None, 1: "one-stage", 2: "two-stage-pivoted", 3: "two-stage-certified"}[path.value])
 
     def free(self):
         if self.h:

@@ -1649,11 +1649,150 @@ k_qr2_init(const double *__restrict__ R, int n, double *__restrict__ vn1, double
     if (lane == 0) { double v = sqrt(acc); vn1[j] = v; vn2[j] = v; colat[j] = j; }
 }
 
+// ---- full-rank certificate --------------------------------------------------------------------
+// The pivoted sweep (stage 2) is n dependent launches; it only matters when xGELSY's rank decision can come out
+// below n.  That decision compares dlaic1's estimates on the pivoted triangle: smaxpr is ||R11'x|| for a unit x,
+// so smaxpr <= sigma_max(R11) <= sigma_max(A), and sminpr >= sigma_min(R11) >= sigma_min(A) (R11 spans a
+// subset of A's columns).  Hence  cond_2(A) * rcond <= 1  PROVES that every step keeps the column, i.e.
+// rank = n, and then the solution is the unique least-squares solution, which the unpivoted triangle of
+// stage 1 yields just as well.  cond_2(A) = cond_2(R) <= ||R||_F ||inv(R)||_F is computed rigorously from the
+// explicit inverse X of the stage-1 triangle: 64 x 64 diagonal blocks inverted one workgroup each, then
+// log2(n/64) levels of  X12 = -X11 (R12 X22)  as batched fp64-MFMA tile products (n^3/3 flops in all).
+// If the bound (with a safety factor) does not certify full rank -- or is not finite -- stage 2 runs as before.
+__global__ void __launch_bounds__(64)
+k_tri_diaginv(const double *__restrict__ R, int n, double *__restrict__ X) {
+    __shared__ double sR[64][65];
+    __shared__ double sX[64][65];
+    const int o = blockIdx.x * 64, nb = min(64, n - o), j = threadIdx.x;
+    for (int cidx = 0; cidx < 64; ++cidx) {
+        const int r = j;   // (lane = row: coalesced)
+        sR[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? R[(size_t)(o + cidx) * n + o + r] : (r == cidx ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    // lane j: column j of the inverse by back substitution (entries below row j are zero)
+    for (int r = 63; r >= 0; --r) {
+        double sacc = r == j ? 1.0 : 0.0;
+        for (int k = r + 1; k < 64; ++k) sacc -= sR[r][k] * sX[k][j];
+        sX[r][j] = r <= j ? sacc / sR[r][r] : 0.0;
+    }
+    __syncthreads();
+    for (int cidx = 0; cidx < nb; ++cidx)
+        if (j < nb) X[(size_t)(o + cidx) * n + o + j] = sX[j][cidx];
+}
+
+// one level of the recursion, blocks of size s: phase 0  T12 = R12 * X22,  phase 1  X12 = -X11 * T12
+// (64 x 64 output tile per workgroup; the k-range is cut to the non-zero part of the triangular factor)
+__global__ void __launch_bounds__(256)
+k_tri_level(const double *__restrict__ R, double *__restrict__ X, double *__restrict__ T, int n, int s, int phase) {
+    __shared__ double sA[Q2_NB * Q2_KS];
+    __shared__ double sB[Q2_NB * Q2_KS];
+    const int tps = s / 64, tpp = tps * tps;
+    const int p = blockIdx.x / tpp, tt = blockIdx.x % tpp;
+    const int tm = tt % tps, tn = tt / tps;
+    const int o = 2 * p * s;
+    const int N2 = min(s, n - o - s);
+    if (N2 <= 0 || tn * 64 >= N2) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    // C(m, c) = alpha * sum_k A(m, k) B(k, c);  A(m, k) = Ap[k * n + m], B(k, c) = Bp[c * n + k]
+    const double *Ap, *Bp;
+    double *Cp;
+    int kb, ke;
+    if (phase == 0) {
+        Ap = R + (size_t)(o + s) * n + o;          // R12
+        Bp = X + (size_t)(o + s) * n + o + s;      // X22 (upper triangular: k <= c)
+        Cp = T + (size_t)(o + s) * n + o;
+        kb = 0; ke = min(N2, tn * 64 + 64);
+    } else {
+        Ap = X + (size_t)o * n + o;                // X11 (upper triangular: k >= m)
+        Bp = T + (size_t)(o + s) * n + o;
+        Cp = X + (size_t)(o + s) * n + o;
+        kb = tm * 64; ke = s;
+    }
+    const double alpha = phase == 0 ? 1.0 : -1.0;
+    v4d_qr acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d_qr){0.0, 0.0, 0.0, 0.0};
+    const int am = tid & 63, akq = (tid >> 6) * 8;           // A staging: lane = row (coalesced), 8 k's per thread
+    const int lc = tid >> 2, lk = (tid & 3) * 8;             // B staging: 8 consecutive k's of one column
+    const int m0 = tm * 64, c0 = tn * 64;
+    const bool cin = c0 + lc < N2;
+    for (int k0 = kb; k0 < ke; k0 += Q2_KC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ka = k0 + akq + q;
+            sA[am * Q2_KS + akq + q] = ka < ke ? Ap[(size_t)ka * n + m0 + am] : 0.0;
+            const int k = k0 + lk + q;
+            sB[lc * Q2_KS + lk + q] = (cin && k < ke) ? Bp[(size_t)(c0 + lc) * n + k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < Q2_KC; kk += 4) {
+            const int ko = kk + (lane >> 4);
+            const double a0 = sA[(wr + (lane & 15)) * Q2_KS + ko];
+            const double a1 = sA[(wr + 16 + (lane & 15)) * Q2_KS + ko];
+            const double b0 = sB[(wc + (lane & 15)) * Q2_KS + ko];
+            const double b1 = sB[(wc + 16 + (lane & 15)) * Q2_KS + ko];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr + a * 16 + (lane >> 4) + 4 * r;
+                const int col = c0 + wc + b * 16 + (lane & 15);
+                if (col < N2) Cp[(size_t)col * n + row] = alpha * acc[a][b][r];
+            }
+}
+
+// partial sums of squares over the upper triangles of R and X (fixed order; the host adds the partials in order)
+__global__ void __launch_bounds__(256)
+k_tri_fro(const double *__restrict__ R, const double *__restrict__ X, int n, double *__restrict__ part) {
+    __shared__ double sh[4];
+    double a = 0.0, b = 0.0;
+    for (int cidx = blockIdx.x; cidx < n; cidx += gridDim.x)
+        for (int r = threadIdx.x; r <= cidx; r += 256) {
+            const double x = R[(size_t)cidx * n + r], y = X[(size_t)cidx * n + r];
+            a += x * x;
+            b += y * y;
+        }
+    a = block_sum<256>(a, sh);
+    __syncthreads();
+    b = block_sum<256>(b, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+}
+
+__global__ void k_tri_identity(int *__restrict__ jp, int n, int *__restrict__ rank) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) jp[k] = k;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rank = n;
+}
+
+// x = X c for the upper-triangular inverse (n beyond the single-workgroup substitution): one wavefront per row
+__global__ void __launch_bounds__(256)
+k_tri_matvec(const double *__restrict__ X, int n, const double *__restrict__ cvec, double *__restrict__ x) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    double acc = 0.0;
+    for (int k = r + lane; k < n; k += 64) acc += X[(size_t)k * n + r] * cvec[k];
+    acc = wave_sum(acc);
+    if (lane == 0) x[r] = acc;
+}
+
 struct Qr2Work {
     double *Vb = nullptr, *Wp = nullptr, *W = nullptr, *W2 = nullptr, *R = nullptr, *rhs2 = nullptr, *tau1 = nullptr;
     double *vn = nullptr;     // stage 2: vn1/vn2 double-buffered (4n)
     double *ice = nullptr;    // stage 2: condition-estimate vectors + scalars (2n + 8)
     double *lazy = nullptr;   // stage 1, lazy reflectors: beta[n] | scale[n]
+    double *Xinv = nullptr, *T2 = nullptr, *fro = nullptr, *h_fro = nullptr;   // full-rank certificate (h_fro pinned)
     int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
     int kslices = 0, M = 0, n = 0;
 };
@@ -1662,6 +1801,8 @@ static void qr2_free(void *p) {
     if (!q) return;
     hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
     hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
+    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro);
+    if (q->h_fro) hipHostFree(q->h_fro);
     delete q;
 }
 
@@ -1774,6 +1915,37 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
     return LSQ_OK;
 }
 
+// true when ||R||_F ||inv(R)||_F certifies that xGELSY would keep all n columns (see k_tri_diaginv); X = inv(R)
+// is left in q->Xinv.  One small device-to-host copy: the caller picks its launch sequence from the answer.
+static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double rcond, bool *certified) {
+    lsq_ctx *c = s->ctx;
+    Qr2Work *q = (Qr2Work *)s->qr2;
+    *certified = false;
+    constexpr int FRO_BLOCKS = 256;
+    if (!q->Xinv) {
+        LSQ_HIP(hipMalloc(&q->Xinv, ((size_t)n * n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->T2, ((size_t)n * n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->fro, 2 * FRO_BLOCKS * sizeof(double)));
+        LSQ_HIP(hipHostMalloc(&q->h_fro, 2 * FRO_BLOCKS * sizeof(double)));
+    }
+    hipLaunchKernelGGL(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(64), 0, c->stream, R2, n, q->Xinv);
+    for (long long sz = 64; sz < n; sz *= 2) {
+        const int sb = (int)sz, npairs = (int)((n + 2 * sz - 1) / (2 * sz)), tps = sb / 64;
+        const int grid = npairs * tps * tps;
+        hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, R2, q->Xinv, q->T2, n, sb, 0);
+        hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, R2, q->Xinv, q->T2, n, sb, 1);
+    }
+    hipLaunchKernelGGL(k_tri_fro, dim3(FRO_BLOCKS), dim3(256), 0, c->stream, R2, q->Xinv, n, q->fro);
+    LSQ_HIP(hipMemcpyAsync(q->h_fro, q->fro, 2 * FRO_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    double fr = 0.0, fx = 0.0;
+    for (int b = 0; b < FRO_BLOCKS; ++b) { fr += q->h_fro[2 * b]; fx += q->h_fro[2 * b + 1]; }
+    const double bound = sqrt(fr) * sqrt(fx);       // >= cond_2(R); NaN/Inf (singular or overflowing R) fail the test
+    // safety factor 16: rounding in the computed inverse and in dlaic1's own estimates
+    *certified = std::isfinite(bound) && bound * rcond * 16.0 <= 1.0;
+    return LSQ_OK;
+}
+
 // dense_qr.jl:30-42 (d_damp == nullptr) and :56-88
 int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_damp, double *d_x, int *nmul) {
     lsq_ctx *c = s->ctx;
@@ -1794,6 +1966,7 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
         hipLaunchKernelGGL(k_stack, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, m, n, d_damp, s->d_qr);
         hipLaunchKernelGGL(k_rhs, dim3(lsq_div_up(lu, LSQ_NT)), dim3(LSQ_NT), 0, c->stream, d_y, m, lu, s->d_qu);
         const int mn = std::min(M, n);
+        s->last_qr_path = 1;
         if (qr2_applies(M, n)) {
             double *R2 = nullptr, *rhs2 = nullptr;
             LSQ_TRY(qr2_factor(s, M, n, &R2, &rhs2));
@@ -1803,6 +1976,22 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
             int *jp = (int *)s->d_tau;
             Qr2Work *q = (Qr2Work *)s->qr2;
             bool have_rank = false;
+            bool full_rank = false;
+            if (!getenv("LSQ_QR_ALWAYS_PIVOT")) LSQ_TRY(qr2_certify_full_rank(s, R2, n, (double)mn * DBL_EPSILON, &full_rank));
+            if (full_rank) {
+                // rank = n is certain: the unpivoted triangle gives the same (unique) solution, jp = identity
+                hipLaunchKernelGGL(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
+                if (n <= QRK_MAXN)
+                    hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
+                else
+                    hipLaunchKernelGGL(k_tri_matvec, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, q->Xinv, n, rhs2, d_x);
+                LSQ_HIP(hipGetLastError());
+                s->last_rank = -1;
+                s->last_qr_path = 3;
+                if (nmul) *nmul = 1;
+                return LSQ_OK;
+            }
+            s->last_qr_path = 2;
             if (n <= Q2S_NT * Q2S_RPT && !getenv("LSQ_QR2_TWO_LAUNCH")) {
                 // one launch per column, lazy exchanges (k_qr2_step)
                 double *vn1[2] = {q->vn, q->vn + 2 * n}, *vn2[2] = {q->vn + n, q->vn + 3 * n};

@@ -89,6 +89,12 @@ extern "C" int lsq_solver_set_preconditioner(lsq_solver *s, lsq_precond_callback
     return LSQ_OK;
 }
 
+extern "C" int lsq_solver_qr_path(const lsq_solver *s, int *path) {
+    if (!s || !path) { lsq_set_error("lsq_solver_qr_path: null argument"); return LSQ_EARG; }
+    *path = s->last_qr_path;
+    return LSQ_OK;
+}
+
 extern "C" int lsq_solver_info(const lsq_solver *s, int *iter, int *istop, int *rank) {
     if (iter) *iter = s->last_iter;
     if (istop) *istop = s->last_istop;

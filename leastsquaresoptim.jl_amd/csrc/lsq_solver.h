@@ -40,6 +40,7 @@ struct lsq_solver {
     double *d_rhs = nullptr;   // n
     int *d_info = nullptr;
     // --- dense QR (dense_qr.jl:6-28, 50-54) ---
+    int last_qr_path = 0;      // lsq_solver_qr_path
     double *d_qr = nullptr;    // (m [+n]) * n
     double *d_qu = nullptr;    // max(m,n) or m+n
     double *d_tau = nullptr;

@@ -346,10 +346,11 @@ def test_ldiv_qr(ctx, m, n, rank):
 @pytest.mark.parametrize("m,n,rank", [(300, 65, 65), (1100, 130, 130), (900, 100, 37), (700, 200, 1), (640, 128, 128),
                                       (2000, 321, 321), (2000, 321, 300), (500, 500, 500)])
 def test_ldiv_qr_two_stage(ctx, m, n, rank, monkeypatch):
-    """The two-stage factorisation (unpivoted blocked Householder with MFMA trailing updates, then the
-    pivoted sweep on R) forced onto small problems: panel tails (n not a multiple of 64), rank-deficient
-    inputs (rank decision and minimum-norm completion still come from the pivoted stage), square and
-    stacked [J; sqrt(damp)] operands.  Same expectations as the one-stage path."""
+    """The two-stage factorisation (unpivoted blocked Householder with MFMA trailing updates, then either the
+    full-rank certificate or the pivoted sweep on R) forced onto small problems: panel tails (n not a
+    multiple of 64), rank-deficient inputs (rank decision and minimum-norm completion come from the
+    pivoted stage: the certificate must refuse them), square and stacked [J; sqrt(damp)] operands.
+    Same expectations as the one-stage path."""
     rng = np.random.default_rng(300 + m + n + rank)
     A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n))
     y = rng.standard_normal(m)
@@ -357,21 +358,82 @@ def test_ldiv_qr_two_stage(ctx, m, n, rank, monkeypatch):
     dxo = lsq.DeviceVector(ctx, n)
     xr, rk, *_ = O.qr_solve(A, y)
     sols = {}
-    for env in ("LSQ_QR_TWO_STAGE", "LSQ_QR_ONE_STAGE"):
-        monkeypatch.setenv(env, "1")
+    for envs in (("LSQ_QR_TWO_STAGE",), ("LSQ_QR_TWO_STAGE", "LSQ_QR_ALWAYS_PIVOT"), ("LSQ_QR_ONE_STAGE",)):
+        for env in envs:
+            monkeypatch.setenv(env, "1")
         sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
         _, nmul = sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
-        assert nmul == 1 and sv.info()["qr_rank"] == rk == rank, env
-        sols[env] = dxo.get()
-        assert np.allclose(sols[env], xr, rtol=1e-8, atol=1e-10), env
+        info = sv.info()
+        assert nmul == 1 and info["qr_rank"] == rk == rank, envs
+        want = ("one-stage" if "LSQ_QR_ONE_STAGE" in envs else
+                "two-stage-certified" if rank == n and "LSQ_QR_ALWAYS_PIVOT" not in envs else "two-stage-pivoted")
+        assert info["qr_path"] == want, (envs, info)
+        sols[envs] = dxo.get()
+        assert np.allclose(sols[envs], xr, rtol=1e-8, atol=1e-10), envs
         if rank == n:
             damp = rng.random(n) + 0.01
             svd = lsq.AllocatedSolver(J, lsq.QR(), for_lm=True)
             svd.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
             st, xd, _, _ = O.ldiv(O.QR, O.Mat(dense=A), y, damp)
             assert np.allclose(dxo.get(), xd, rtol=1e-9, atol=1e-12)
-        monkeypatch.delenv(env)
-    assert np.allclose(sols["LSQ_QR_TWO_STAGE"], sols["LSQ_QR_ONE_STAGE"], rtol=1e-8, atol=1e-10)
+        for env in envs:
+            monkeypatch.delenv(env)
+    ref = sols[("LSQ_QR_ONE_STAGE",)]
+    for k, v in sols.items():
+        assert np.allclose(v, ref, rtol=1e-8, atol=1e-10), k
+
+
+@pytest.mark.parametrize("cond,certified", [(1e2, True), (1e6, True), (1e11, True), (1e12, False)])
+def test_ldiv_qr_certificate_decision(ctx, cond, certified, monkeypatch):
+    """The full-rank certificate (||R||_F ||inv(R)||_F * rcond * 16 <= 1) may only skip the pivoted sweep when
+    xGELSY's rank decision (dense_qr.jl:37,83 -> geqp3 + laic1, rcond = min(m,n) eps) is certain to be n.
+    Singular values graded from 1 down to 1/cond (n = 192: 1/rcond = 2.3e13, the certificate needs a
+    Frobenius bound <= 1.5e12): inside the threshold the certificate fires; at cond 1e12 the reference still
+    finds rank n but the bound (about 4e12) cannot prove it, so the pivoted sweep must run -- and in every
+    case rank and solution are the oracle's."""
+    m, n = 700, 192
+    rng = np.random.default_rng(int(np.log10(cond)) + 77)
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    sv_ = np.logspace(0, -np.log10(cond), n)
+    A = (U * sv_) @ V.T
+    y = rng.standard_normal(m)
+    xr, rk, *_ = O.qr_solve(A, y)
+    monkeypatch.setenv("LSQ_QR_TWO_STAGE", "1")
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+    sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+    info = sv.info()
+    assert info["qr_path"] == ("two-stage-certified" if certified else "two-stage-pivoted"), info
+    assert info["qr_rank"] == rk
+    if certified:
+        assert rk == n
+    # forward error of a backward-stable solve: cond * eps (relative to the solution's size)
+    tol = max(1e-9, 50 * min(cond, 1e13) * np.finfo(float).eps)
+    assert np.linalg.norm(dxo.get() - xr) <= tol * np.linalg.norm(xr)
+
+
+def test_ldiv_qr_certificate_wide_triangle(ctx):
+    """n beyond the single-workgroup substitution (n > 2048): the certified path solves with the explicit
+    inverse; the pivoted path is the reference order.  Both must satisfy the normal equations
+    J'(Jx - y) = 0 to rounding and agree with each other (size-independent property; the oracle's
+    unblocked sweep would take minutes here)."""
+    m, n = 2304, 2112
+    rng = np.random.default_rng(2112)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y = rng.standard_normal(m)
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+    sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+    info = sv.info()
+    assert info["qr_path"] == "two-stage-certified" and info["qr_rank"] == n
+    x = dxo.get()
+    g = A.T @ (A @ x - y)
+    assert np.linalg.norm(g) <= 1e-10 * np.linalg.norm(A.T @ y)
+    xl = np.linalg.lstsq(A, y, rcond=None)[0]
+    assert np.linalg.norm(x - xl) <= 1e-9 * np.linalg.norm(xl)
 
 
 def test_lsmr_custom_preconditioner(ctx):
