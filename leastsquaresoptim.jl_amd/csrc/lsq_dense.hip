@@ -2,6 +2,7 @@
 // (dense_cholesky.jl:29-59) and the column-pivoted Householder QR solver with the rank-revealing
 // minimum-norm solve (dense_qr.jl:30-88; LinearAlgebra.ldiv!(::QRPivoted, b) [stdlib] = xGELSY).
 // Everything here runs on the device; the host only reads back status words.
+#include <type_traits>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -1085,23 +1086,50 @@ __device__ __forceinline__ double wave_allsum(double x) {
 // 0 stores them and the side arrays.  Thread rows start at row i so that the pivot element of every round is
 // an ordinary masked element: "alpha" and the row-(i+r) entries of the other columns come out of the same
 // block reduction as the dot products (sums with a single non-zero term are exact).
-template <int NT, int RPT, int K>
-__global__ void __launch_bounds__(NT)
+//
+// S > 1: the rows of a column are cut into S slabs of RPT*NT rows, one workgroup each -- S times more CUs
+// stream the panel, a workgroup holds 1/S of a column per array (so K can be larger), and the S workgroups of
+// a target column ("group") add their partial sums through memory once per round: each publishes its NS
+// partials with agent-scope stores, then picks up all S sets (its own included, so every member adds the
+// same values in the same order) and goes on.  The members of a group sit at block
+// indices 8 apart -- the same XCD under the round-robin dispatch -- and a launch never has more workgroups
+// than the device holds at once (host side), so the members of a group are always co-resident; the wait is
+// bounded anyway and reports through *err instead of hanging.
+constexpr int QR1_SPIN_LIMIT = 1 << 22;
+template <int N, class F>
+__device__ __forceinline__ void qr_static_for(F &&f) {
+    if constexpr (N > 0) {
+        qr_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+template <int NT, int RPT, int K, int S>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live pivots, <= K */, double *__restrict__ tau,
-                 double *__restrict__ beta_out, double *__restrict__ scale_out) {
+                 double *__restrict__ beta_out, double *__restrict__ scale_out, int G /* groups = target columns (>= 1) */,
+                 unsigned long long *__restrict__ xslot, unsigned long long epoch,
+                 int *__restrict__ err, double *__restrict__ Pn /* side panel: column (col - c0) * M */, int c0) {
     constexpr int NW = NT / 64;
     constexpr int NS = 2 * (K + 1);
     __shared__ double sh[NW][NS];
+    __shared__ double sx[S][NS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int j = i + kk + (int)blockIdx.x;
+    int g = (int)blockIdx.x, sidx = 0;
+    if (S > 1) {
+        const int kq = (int)blockIdx.x >> 3;
+        sidx = kq % S;
+        g = (kq / S) * 8 + ((int)blockIdx.x & 7);
+        if (g >= G) return;
+    }
+    const int j = i + kk + g;
     const bool has_col = j < cend;
     // one buffer descriptor per column (scalar base, byte count M*8): every fetch and store is descriptor +
     // ONE shared 32-bit VGPR offset + a scalar offset; rows beyond M read as zero and their stores are dropped by
     // the bounds check, and a dead column (ragged last launch, no target) gets an empty descriptor
     typedef unsigned v2u_qr __attribute__((ext_vector_type(2)));
-    const unsigned tb = (unsigned)(i + tid) * 8u;
+    const int t = i + sidx * (RPT * NT) + tid;    // row of element 0
+    const unsigned tb = (unsigned)t * 8u;
     const unsigned colbytes = (unsigned)M * 8u;
-    const int t = i + tid;
     double pv[K][RPT], a[RPT];
     __amdgpu_buffer_rsrc_t rp[K];
 #pragma unroll
@@ -1120,8 +1148,10 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rj, tb, q * NT * 8, 0);
         a[q] = __builtin_bit_cast(double, w);
     }
-#pragma unroll
-    for (int r = 0; r < K; ++r) {
+    // (rounds as instantiations, not as a loop: the unroller gives up on a body of this size for K >= 6 and the
+    // register arrays would land in scratch)
+    auto round = [&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
         const bool live = r < kk;                   // (uniform; a dead round of a ragged last launch is a no-op)
         const int c = i + r;                        // pivot column == pivot row of this round
         // sums: [0] v'v  [1] alpha  then per later column x (pivots r+1.., target): v'x and x(c)
@@ -1133,9 +1163,11 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
             sm[0] = v * v;
             sm[1] = at ? pv[r][0] : 0.0;
 #pragma unroll
-            for (int x = r + 1; x < K; ++x) {
-                sm[2 * (x - r)] = v * pv[x][0];
-                sm[2 * (x - r) + 1] = at ? pv[x][0] : 0.0;
+            for (int x = 0; x < K; ++x) {       // (constant trip counts: the unroller must not depend on r)
+                if (x > r) {
+                    sm[2 * (x - r)] = v * pv[x][0];
+                    sm[2 * (x - r) + 1] = at ? pv[x][0] : 0.0;
+                }
             }
             sm[2 * (K - r)] = v * a[0];
             sm[2 * (K - r) + 1] = at ? a[0] : 0.0;
@@ -1145,7 +1177,8 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
             const double v = pv[r][q];
             sm[0] = __builtin_fma(v, v, sm[0]);
 #pragma unroll
-            for (int x = r + 1; x < K; ++x) sm[2 * (x - r)] = __builtin_fma(v, pv[x][q], sm[2 * (x - r)]);
+            for (int x = 0; x < K; ++x)
+                if (x > r) sm[2 * (x - r)] = __builtin_fma(v, pv[x][q], sm[2 * (x - r)]);
             sm[2 * (K - r)] = __builtin_fma(v, a[q], sm[2 * (K - r)]);
         }
 #pragma unroll
@@ -1162,6 +1195,51 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
 #pragma unroll
         for (int e = 0; e < NS; ++e)
             if (e < 2 * (K - r) + 2) sm[e] = row_allsum((lane & 15) < NW ? sh[lane & 15][e] : 0.0);
+        if (S > 1) {
+            constexpr int NSr = 2 * (K - r) + 2;
+            static_assert(S * NS <= NT, "one thread per exchanged value");
+            // flag-in-data exchange (the low-latency protocol of the collectives libraries): every 64-bit word
+            // carries 32 bits of payload and the 32-bit epoch, so a reader that sees the epoch has the payload --
+            // one store and one load on the critical path, no fences, no separate flag
+            const unsigned ep = (unsigned)epoch;
+            if (tid < NS) {
+                double val = 0.0;
+#pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    if (e < NSr && tid == e) val = sm[e];
+                if (tid < NSr) {
+                    unsigned long long *mine = xslot + ((((size_t)g * S + sidx) * K + r) * NS + tid) * 2;
+                    const unsigned long long hi = (unsigned long long)ep << 32;
+                    __hip_atomic_store(mine, hi | (unsigned)__double2loint(val), RLX_AGENT);
+                    __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(val), RLX_AGENT);
+                }
+            }
+            if (tid < S * NS) {
+                const int sp = tid / NS, e = tid % NS;
+                if (e < NSr) {
+                    const unsigned long long *f = xslot + ((((size_t)g * S + sp) * K + r) * NS + e) * 2;
+                    unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+                    int spins = 0;
+                    while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
+                        if (++spins > QR1_SPIN_LIMIT) { *err = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        w0 = __hip_atomic_load(f, RLX_AGENT);
+                        w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+                    }
+                    sx[sp][e] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                if (e < NSr) {
+                    double tot = 0.0;
+#pragma unroll
+                    for (int sp = 0; sp < S; ++sp) tot += sx[sp][e];
+                    sm[e] = tot;
+                }
+            }
+        }
         const double alpha = sm[1];
         double ti = 0.0, beta = alpha, sc = 0.0;
         if (sm[0] != 0.0) {
@@ -1171,32 +1249,42 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
             sc = 1.0 / (alpha - beta);
         }
         if (!live) ti = 0.0;
-        if (live && blockIdx.x == 0 && tid == 0) { tau[c] = ti; beta_out[c] = beta; scale_out[c] = sc; }
+        if (live && g == 0 && sidx == 0 && tid == 0) { tau[c] = ti; beta_out[c] = beta; scale_out[c] = sc; }
         if (ti != 0.0) {
             double tw[K + 1];
 #pragma unroll
-            for (int x = r + 1; x <= K; ++x) tw[x] = ti * (sc * sm[2 * (x - r)] + sm[2 * (x - r) + 1]);
+            for (int x = 0; x <= K; ++x)
+                if (x > r) tw[x] = ti * (sc * sm[2 * (x - r)] + sm[2 * (x - r) + 1]);
             {
                 const double vs = t > c ? pv[r][0] * sc : (t == c ? 1.0 : 0.0);
 #pragma unroll
-                for (int x = r + 1; x < K; ++x) pv[x][0] -= vs * tw[x];
+                for (int x = 0; x < K; ++x)
+                    if (x > r) pv[x][0] -= vs * tw[x];
                 a[0] -= vs * tw[K];
             }
 #pragma unroll
             for (int q = 1; q < RPT; ++q) {
                 const double vs = pv[r][q] * sc;
 #pragma unroll
-                for (int x = r + 1; x < K; ++x) pv[x][q] = __builtin_fma(-vs, tw[x], pv[x][q]);
+                for (int x = 0; x < K; ++x)
+                    if (x > r) pv[x][q] = __builtin_fma(-vs, tw[x], pv[x][q]);
                 a[q] = __builtin_fma(-vs, tw[K], a[q]);
             }
         }
-    }
-    if (blockIdx.x == 0) {                           // pivot columns 1 .. kk-1 are final (unscaled) now
+    };
+    qr_static_for<K>(round);
+    if (g == 0) {
+        // pivot columns 1 .. kk-1 are final (unscaled) now.  They go to the SIDE panel, not in place: other groups
+        // may not have fetched them yet (a launch can be larger than what the device holds at once), and
+        // nobody but k_qr1_vbuf needs them again -- it moves them back while it builds V
 #pragma unroll
-        for (int r = 1; r < K; ++r)
+        for (int r = 1; r < K; ++r) {
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(Pn + (size_t)(i + (r < kk ? r : 0) - c0) * M, 0, r < kk ? colbytes : 0u, 0x00020000);
 #pragma unroll
             for (int q = 0; q < RPT; ++q)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_qr, pv[r][q]), rp[r], tb, q * NT * 8, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_qr, pv[r][q]), rs, tb, q * NT * 8, 0);
+        }
     }
 #pragma unroll
     for (int q = 0; q < RPT; ++q) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_qr, a[q]), rj, tb, q * NT * 8, 0);
@@ -1206,17 +1294,21 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
 __global__ void __launch_bounds__(256)
 k_qr1_vbuf(double *__restrict__ A, int M, int c0, int nb, double *__restrict__ Vb, int ldv,
            const double *__restrict__ beta, const double *__restrict__ scale /* lazy reflectors: column c0+c is stored
-           unscaled and its R(c,c) = beta is put on the diagonal here, once nobody reads the old pivot element */) {
+           unscaled and its R(c,c) = beta is put on the diagonal here, once nobody reads the old pivot element */,
+           const double *__restrict__ Pn, int K /* k_qr1_step_multi: the later pivot columns of a launch (c % K != 0)
+           were left in the side panel from the launch's first pivot row on; they return to A here */) {
     const int rows = M - c0;
     const long long tot = (long long)rows * Q2_NB;
     for (long long e = blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
         const int r = (int)(e % rows), cidx = (int)(e / rows);
         double v = 0.0;
         if (cidx < nb) {
-            if (r > cidx) v = A[(size_t)(c0 + cidx) * M + c0 + r] * (scale ? scale[c0 + cidx] : 1.0);
+            double *pa = A + (size_t)(c0 + cidx) * M + c0 + r;
+            if (Pn && cidx % K != 0 && r >= cidx / K * K) *pa = Pn[(size_t)cidx * M + c0 + r];
+            if (r > cidx) v = *pa * (scale ? scale[c0 + cidx] : 1.0);
             else if (r == cidx) {
                 v = 1.0;
-                if (beta) A[(size_t)(c0 + cidx) * M + c0 + r] = beta[c0 + cidx];
+                if (beta) *pa = beta[c0 + cidx];
             }
         }
         Vb[(size_t)cidx * ldv + r] = v;
@@ -1793,6 +1885,10 @@ struct Qr2Work {
     double *ice = nullptr;    // stage 2: condition-estimate vectors + scalars (2n + 8)
     double *lazy = nullptr;   // stage 1, lazy reflectors: beta[n] | scale[n]
     double *Xinv = nullptr, *T2 = nullptr, *fro = nullptr, *h_fro = nullptr;   // full-rank certificate (h_fro pinned)
+    unsigned long long *xslot = nullptr;   // stage 1, slab exchange: [64 groups][8 slabs][8 rounds][18 sums][2 words]
+    unsigned long long epoch = 0;
+    int *d_err = nullptr;                  //   set when a slab wait gave up
+    double *Pn = nullptr;                  // stage 1: side panel (M x 64) for the later pivot columns of a launch
     int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
     int kslices = 0, M = 0, n = 0;
 };
@@ -1801,7 +1897,7 @@ static void qr2_free(void *p) {
     if (!q) return;
     hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
     hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
-    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro);
+    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->d_err); hipFree(q->Pn);
     if (q->h_fro) hipHostFree(q->h_fro);
     delete q;
 }
@@ -1835,6 +1931,11 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         LSQ_HIP(hipMalloc(&q->vn, (4 * (size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->ice, (2 * (size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->lazy, (2 * (size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->xslot, (size_t)64 * 8 * 8 * 18 * 2 * sizeof(unsigned long long)));
+        LSQ_HIP(hipMalloc(&q->d_err, sizeof(int)));
+        LSQ_HIP(hipMalloc(&q->Pn, ((size_t)M * Q2_NB + 32768) * sizeof(double)));
+        LSQ_ZERO(q->xslot, 0, (size_t)64 * 8 * 8 * 18 * 2 * sizeof(unsigned long long));
+        LSQ_ZERO(q->d_err, 0, sizeof(int));
         LSQ_HIP(hipMalloc(&q->colat, (2 * (size_t)n + 8) * sizeof(int)));
         s->qr2 = q;
         s->qr2_free = qr2_free;
@@ -1843,6 +1944,7 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
         bool lazy = false;
+        int side_k = 0;   // > 0: later pivot columns of a launch sit in the side panel
         auto steps = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(1), dim3(QR_NT), 0, c->stream, A, M, cend, c0, 1, q->tau1);
             for (int i = c0; i + 1 < cend; ++i)
@@ -1856,20 +1958,29 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         };
         const bool want_lazy = !getenv("LSQ_QR1_EAGER");
         const bool want_multi = want_lazy && !getenv("LSQ_QR1_SINGLE");
-        auto steps_multi = [&](auto kern, int nt, int K) {
+        auto steps_multi = [&](auto kern, int nt, int K, int S) {
             for (int i = c0; i < cend; i += K) {
-                const int kk = std::min(K, cend - i);
-                hipLaunchKernelGGL(kern, dim3(std::max(1, cend - i - kk)), dim3(nt), 0, c->stream, A, M, cend, i, kk, q->tau1,
-                                   q->lazy, q->lazy + n);
+                const int kk = std::min(K, cend - i), G = std::max(1, cend - i - kk);
+                const int grid = S > 1 ? 8 * S * ((G + 7) / 8) : G;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), 0, c->stream, A, M, cend, i, kk, q->tau1, q->lazy, q->lazy + n, G,
+                                   q->xslot, ++q->epoch, q->d_err, q->Pn, c0);
             }
             lazy = true;
+            side_k = K;
         };
         const int prow = M - c0;
+        // slabs (S > 1) need every CU of an unpartitioned device; LSQ_QR1_COOP=0 keeps one workgroup per column
+        const char *cv = getenv("LSQ_QR1_COOP");
+        const int coop = !want_multi || c->num_cus < 256 ? 0 : cv ? atoi(cv) : 1;
         if (getenv("LSQ_QR1_LOOP")) steps(k_qr1_step);
-        else if (want_multi && prow <= 8 * 512) steps_multi(k_qr1_step_multi<512, 8, 4>, 512, 4);
-        else if (want_multi && prow <= 8 * 1024) steps_multi(k_qr1_step_multi<512, 16, 4>, 512, 4);
-        else if (want_multi && prow <= 32 * 512) steps_multi(k_qr1_step_multi<512, 32, 2>, 512, 2);
-        else if (want_multi && prow <= 40 * 512) steps_multi(k_qr1_step_multi<512, 40, 2>, 512, 2);
+        else if (coop && prow > 2 * 8 * 256 && prow <= 4 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 4>, 256, 4, 4);
+        else if (coop && prow > 4 * 8 * 256 && prow <= 8 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 8>, 256, 4, 8);
+        else if (coop && prow > 8 * 8 * 256 && prow <= 8 * 10 * 256) steps_multi(k_qr1_step_multi<256, 10, 4, 8>, 256, 4, 8);
+        else if (coop && prow > 8 * 256 && prow <= 2 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 2>, 256, 4, 2);
+        else if (want_multi && prow <= 8 * 512) steps_multi(k_qr1_step_multi<512, 8, 4, 1>, 512, 4, 1);
+        else if (want_multi && prow <= 8 * 1024) steps_multi(k_qr1_step_multi<512, 16, 4, 1>, 512, 4, 1);
+        else if (want_multi && prow <= 32 * 512) steps_multi(k_qr1_step_multi<512, 32, 2, 1>, 512, 2, 1);
+        else if (want_multi && prow <= 40 * 512) steps_multi(k_qr1_step_multi<512, 40, 2, 1>, 512, 2, 1);
         else if (want_lazy && M - c0 <= 8 * QR_NT) steps_lazy(k_qr1_step_lazy<8>);
         else if (want_lazy && M - c0 <= 16 * QR_NT) steps_lazy(k_qr1_step_lazy<16>);
         else if (want_lazy && M - c0 <= 20 * QR_NT) steps_lazy(k_qr1_step_lazy<20>);
@@ -1886,7 +1997,8 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 8);
             hipLaunchKernelGGL(k_qr1_vbuf, dim3(g), dim3(256), 0, c->stream, A, M, c0, nb, q->Vb, ldv,
                                lazy ? (const double *)q->lazy : (const double *)nullptr,
-                               lazy ? (const double *)(q->lazy + n) : (const double *)nullptr);
+                               lazy ? (const double *)(q->lazy + n) : (const double *)nullptr,
+                               side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
         }
         int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
         hipLaunchKernelGGL(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
@@ -1926,7 +2038,7 @@ static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double 
         LSQ_HIP(hipMalloc(&q->Xinv, ((size_t)n * n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->T2, ((size_t)n * n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->fro, 2 * FRO_BLOCKS * sizeof(double)));
-        LSQ_HIP(hipHostMalloc(&q->h_fro, 2 * FRO_BLOCKS * sizeof(double)));
+        LSQ_HIP(hipHostMalloc(&q->h_fro, (2 * FRO_BLOCKS + 1) * sizeof(double)));
     }
     hipLaunchKernelGGL(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(64), 0, c->stream, R2, n, q->Xinv);
     for (long long sz = 64; sz < n; sz *= 2) {
@@ -1937,7 +2049,14 @@ static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double 
     }
     hipLaunchKernelGGL(k_tri_fro, dim3(FRO_BLOCKS), dim3(256), 0, c->stream, R2, q->Xinv, n, q->fro);
     LSQ_HIP(hipMemcpyAsync(q->h_fro, q->fro, 2 * FRO_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipMemcpyAsync(q->h_fro + 2 * FRO_BLOCKS, q->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
+    if (*(const int *)(q->h_fro + 2 * FRO_BLOCKS) != 0) {
+        LSQ_ZERO(q->d_err, 0, sizeof(int));
+        lsq_set_error("qr: a slab exchange of the panel factorisation timed out (workgroups of a group not co-resident?); "
+                      "set LSQ_QR1_COOP=0");
+        return LSQ_EHIP;
+    }
     double fr = 0.0, fx = 0.0;
     for (int b = 0; b < FRO_BLOCKS; ++b) { fr += q->h_fro[2 * b]; fx += q->h_fro[2 * b + 1]; }
     const double bound = sqrt(fr) * sqrt(fx);       // >= cond_2(R); NaN/Inf (singular or overflowing R) fail the test

@@ -383,6 +383,37 @@ def test_ldiv_qr_two_stage(ctx, m, n, rank, monkeypatch):
         assert np.allclose(v, ref, rtol=1e-8, atol=1e-10), k
 
 
+@pytest.mark.parametrize("m", [3000, 6000, 12000, 18000, 22000])
+@pytest.mark.parametrize("coop", ["1", "0"])
+def test_ldiv_qr_panel_variants(ctx, m, coop, monkeypatch):
+    """Stage 1's panel steps pick their kernel by the number of active rows: one workgroup per column
+    (<= 2048 rows, or LSQ_QR1_COOP=0), 2 / 4 / 8 row slabs per column with the in-kernel exchange of partial
+    sums (<= 4096 / 8192 / 20480 rows), the looping kernel beyond.  Every variant must reproduce the oracle's
+    pivoted-QR solve (n = 130: two full panels and a ragged one; the later pivot columns of a launch travel
+    through the side panel)."""
+    n = 130
+    rng = np.random.default_rng(m)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y = rng.standard_normal(m)
+    xr, rk, *_ = O.qr_solve(A, y)
+    monkeypatch.setenv("LSQ_QR_TWO_STAGE", "1")
+    monkeypatch.setenv("LSQ_QR1_COOP", coop)
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    for pivot in (False, True):
+        if pivot:
+            monkeypatch.setenv("LSQ_QR_ALWAYS_PIVOT", "1")
+        sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+        sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+        info = sv.info()
+        assert info["qr_rank"] == rk == n
+        assert info["qr_path"] == ("two-stage-pivoted" if pivot else "two-stage-certified")
+        assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12), (m, coop, pivot)
+        # repeated solves reuse the exchange slots (epoch advances)
+        sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+        assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12), (m, coop, pivot, "second solve")
+
+
 @pytest.mark.parametrize("cond,certified", [(1e2, True), (1e6, True), (1e11, True), (1e12, False)])
 def test_ldiv_qr_certificate_decision(ctx, cond, certified, monkeypatch):
     """The full-rank certificate (||R||_F ||inv(R)||_F * rcond * 16 <= 1) may only skip the pivoted sweep when
