@@ -1345,15 +1345,26 @@ k_qr1_vtb(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, 
     const int cb = tile * Q2_NB + lc;
     const double *pbcol = cb < ncolsB ? q2_bcol(Vb, ldv, A, M, c0, cend, n, rhs, cb) : nullptr;
     const double *pacol = Vb + (size_t)lc * ldv;
-    for (int k0 = kb; k0 < ke; k0 += Q2_KC) {
+    // the next 32-row slab is fetched into registers while the MFMAs of the current one run
+    double ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = k0 + lk + q;
             const bool kin = k < ke;
-            sA[lc * Q2_KS + lk + q] = kin ? pacol[k] : 0.0;
-            sB[lc * Q2_KS + lk + q] = (kin && pbcol) ? pbcol[k] : 0.0;
+            ra[q] = kin ? pacol[k] : 0.0;
+            rb[q] = (kin && pbcol) ? pbcol[k] : 0.0;
+        }
+    };
+    if (kb < ke) fetch(kb);
+    for (int k0 = kb; k0 < ke; k0 += Q2_KC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sA[lc * Q2_KS + lk + q] = ra[q];
+            sB[lc * Q2_KS + lk + q] = rb[q];
         }
         __syncthreads();
+        if (k0 + Q2_KC < ke) fetch(k0 + Q2_KC);
 #pragma unroll
         for (int kk = 0; kk < Q2_KC; kk += 4) {
             const int ko = kk + (lane >> 4);
@@ -1427,61 +1438,86 @@ k_qr1_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ ta
 }
 
 // A2(rows, 64 columns of tile) -= V(rows, :) * W2(:, columns)      (fp64 MFMA, K = 64)
+constexpr int Q2_UCT = 4;   // column tiles per workgroup of the update: the V tile is staged once for all of them
 __global__ void __launch_bounds__(256)
 k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int M, int c0, int cend, int n,
              double *__restrict__ rhs, int ncols /* n - cend + 1 */, const double *__restrict__ W2) {
-    __shared__ double sV[Q2_NB * (Q2_NB)];   // [k][row]: row contiguous
-    __shared__ double sW[Q2_NB * (Q2_NB)];   // [col][k]
+    constexpr int CS = Q2_NB + 1;             // product image [col][row], padded
+    __shared__ double sV[Q2_NB * Q2_NB];     // [k][row]: row contiguous
+    __shared__ double sW[Q2_NB * CS];        // [col][k] (64 x 64 used); after the MFMAs the product image
     const int rows = M - c0;
     const int nrt = (rows + Q2_NB - 1) / Q2_NB;
-    const int rt = blockIdx.x % nrt, ct = blockIdx.x / nrt;
-    const int r0 = rt * Q2_NB, j0 = ct * Q2_NB;
+    const int rt = blockIdx.x % nrt, cg = blockIdx.x / nrt;
+    const int r0 = rt * Q2_NB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    // both images are exactly 64 x 64 doubles (2 x 32 KiB: the static LDS budget); bank conflicts are
+    const bool rin = r0 + lane < rows;
+    // V and W2 images are exactly 64 x 64 doubles; bank conflicts are
     // avoided by rotation instead of padding: V column k is stored rotated by 16*(k&3) rows (the four
     // k-groups of an MFMA operand read then hit four different 128-byte segments), W2 column j by
     // 2*(j&15) entries (the 16 columns of an operand read hit 16 different bank pairs)
     for (int e = tid; e < Q2_NB * Q2_NB; e += 256) {
         const int k = e / Q2_NB, r = e % Q2_NB;        // V column k, row r0 + r
         sV[k * Q2_NB + ((r + 16 * (k & 3)) & 63)] = (r0 + r < rows) ? Vb[(size_t)k * ldv + r0 + r] : 0.0;
-        const int cidx = e / Q2_NB, kk = e % Q2_NB;     // W2 column j0 + cidx, entry kk
-        sW[cidx * Q2_NB + ((kk + 2 * (cidx & 15)) & 63)] = (j0 + cidx < ncols) ? W2[(size_t)(j0 + cidx) * Q2_NB + kk] : 0.0;
     }
-    __syncthreads();
-    v4d_qr acc[2][2];
+    for (int t = 0; t < Q2_UCT; ++t) {
+        const int j0 = (cg * Q2_UCT + t) * Q2_NB;
+        if (j0 >= ncols) break;                        // (uniform)
+        // the tile of A2 is fetched first, row-contiguous (thread = row, 16 columns each): its latency hides
+        // behind the staging and the MFMAs, and the read-modify-write is coalesced
+        double at[16];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int q = 0; q < 16; ++q) {
+            const int cidx = j0 + w * 16 + q;
+            const int ac = cend + cidx;
+            at[q] = (rin && cidx < ncols) ? ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] : 0.0;
+        }
+        for (int e = tid; e < Q2_NB * Q2_NB; e += 256) {
+            const int cidx = e / Q2_NB, kk = e % Q2_NB;     // W2 column j0 + cidx, entry kk
+            sW[cidx * Q2_NB + ((kk + 2 * (cidx & 15)) & 63)] = (j0 + cidx < ncols) ? W2[(size_t)(j0 + cidx) * Q2_NB + kk] : 0.0;
+        }
+        __syncthreads();
+        v4d_qr acc[2][2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d_qr){0.0, 0.0, 0.0, 0.0};
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int kk = 0; kk < Q2_NB; kk += 4) {
-        const int ko = kk + (lane >> 4);
-        const int rot = 16 * (ko & 3);
-        const int c0w = wc + (lane & 15), c1w = wc + 16 + (lane & 15);
-        const double a0 = sV[ko * Q2_NB + ((wr + (lane & 15) + rot) & 63)];
-        const double a1 = sV[ko * Q2_NB + ((wr + 16 + (lane & 15) + rot) & 63)];
-        const double b0 = sW[c0w * Q2_NB + ((ko + 2 * (c0w & 15)) & 63)];
-        const double b1 = sW[c1w * Q2_NB + ((ko + 2 * (c1w & 15)) & 63)];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
+            for (int b = 0; b < 2; ++b) acc[a][b] = (v4d_qr){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int kk = 0; kk < Q2_NB; kk += 4) {
+            const int ko = kk + (lane >> 4);
+            const int rot = 16 * (ko & 3);
+            const int c0w = wc + (lane & 15), c1w = wc + 16 + (lane & 15);
+            const double a0 = sV[ko * Q2_NB + ((wr + (lane & 15) + rot) & 63)];
+            const double a1 = sV[ko * Q2_NB + ((wr + 16 + (lane & 15) + rot) & 63)];
+            const double b0 = sW[c0w * Q2_NB + ((ko + 2 * (c0w & 15)) & 63)];
+            const double b1 = sW[c1w * Q2_NB + ((ko + 2 * (c1w & 15)) & 63)];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();                                 // every wave is done with the W2 image
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + wr + a * 16 + (lane >> 4) + 4 * r;
-                const int cidx = j0 + wc + b * 16 + (lane & 15);
-                if (row < rows && cidx < ncols) {
-                    const int ac = cend + cidx;
-                    double *p = (ac < n ? A + (size_t)ac * M : rhs) + c0 + row;
-                    *p -= acc[a][b][r];
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wr + a * 16 + (lane >> 4) + 4 * r;
+                    const int cidx = wc + b * 16 + (lane & 15);
+                    sW[cidx * CS + row] = acc[a][b][r];
                 }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cl = w * 16 + q, cidx = j0 + cl;
+            if (rin && cidx < ncols) {
+                const int ac = cend + cidx;
+                ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] = at[q] - sW[cl * CS + lane];
             }
+        }
+        __syncthreads();                                 // the product image is consumed before the next W2 tile lands
+    }
 }
 
 // R (upper triangle of the factored A, zeros below) and the first n entries of Q1'b -> stage-2 operands
@@ -2012,7 +2048,7 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
                            q->tau1, c0, nb, q->W2);
         {
             const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
-            hipLaunchKernelGGL(k_qr1_update, dim3(nrt * nct), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols,
+            hipLaunchKernelGGL(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols,
                                q->W2);
         }
     }
