@@ -1460,23 +1460,31 @@ k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int
         const int k = e / Q2_NB, r = e % Q2_NB;        // V column k, row r0 + r
         sV[k * Q2_NB + ((r + 16 * (k & 3)) & 63)] = (r0 + r < rows) ? Vb[(size_t)k * ldv + r0 + r] : 0.0;
     }
-    for (int t = 0; t < Q2_UCT; ++t) {
-        const int j0 = (cg * Q2_UCT + t) * Q2_NB;
-        if (j0 >= ncols) break;                        // (uniform)
-        // the tile of A2 is fetched first, row-contiguous (thread = row, 16 columns each): its latency hides
-        // behind the staging and the MFMAs, and the read-modify-write is coalesced
-        double at[16];
+    // tile t+1's operands (the A2 tile, row-contiguous: thread = row, 16 columns each; the W2 tile) are fetched
+    // into registers while tile t is multiplied and written back: latency hidden, read-modify-write coalesced
+    double at[16], wt[16], atn[16];
+    auto fetch = [&](int j0, double *ta, double *tw2) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int cidx = j0 + w * 16 + q;
             const int ac = cend + cidx;
-            at[q] = (rin && cidx < ncols) ? ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] : 0.0;
+            ta[q] = (rin && cidx < ncols) ? ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] : 0.0;
+            const int e = tid + q * 256, cw = e / Q2_NB, kk = e % Q2_NB;     // W2 column j0 + cw, entry kk
+            tw2[q] = (j0 + cw < ncols) ? W2[(size_t)(j0 + cw) * Q2_NB + kk] : 0.0;
         }
-        for (int e = tid; e < Q2_NB * Q2_NB; e += 256) {
-            const int cidx = e / Q2_NB, kk = e % Q2_NB;     // W2 column j0 + cidx, entry kk
-            sW[cidx * Q2_NB + ((kk + 2 * (cidx & 15)) & 63)] = (j0 + cidx < ncols) ? W2[(size_t)(j0 + cidx) * Q2_NB + kk] : 0.0;
+    };
+    if (cg * Q2_UCT * Q2_NB < ncols) fetch(cg * Q2_UCT * Q2_NB, at, wt);
+    for (int t = 0; t < Q2_UCT; ++t) {
+        const int j0 = (cg * Q2_UCT + t) * Q2_NB;
+        if (j0 >= ncols) break;                        // (uniform)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + q * 256, cw = e / Q2_NB, kk = e % Q2_NB;
+            sW[cw * Q2_NB + ((kk + 2 * (cw & 15)) & 63)] = wt[q];
         }
         __syncthreads();
+        const bool more = t + 1 < Q2_UCT && j0 + Q2_NB < ncols;
+        if (more) fetch(j0 + Q2_NB, atn, wt);
         v4d_qr acc[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1517,6 +1525,8 @@ k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int
             }
         }
         __syncthreads();                                 // the product image is consumed before the next W2 tile lands
+#pragma unroll
+        for (int q = 0; q < 16; ++q) at[q] = atn[q];
     }
 }
 
