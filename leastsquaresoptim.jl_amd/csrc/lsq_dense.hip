@@ -1437,6 +1437,109 @@ k_qr1_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ ta
     }
 }
 
+// The same W2 = T'W with the 64-step recurrence taken off the critical path: the recurrence reads
+//      (I + D N) x = D w,      D = diag(tau), N = strict lower triangle of G
+// so T' = inv(I + D N) D, the inverse of a UNIT lower-triangular matrix (no divisions; tau_j = 0 gives a zero row
+// as before).  Every workgroup builds it in LDS -- 16 x 16 diagonal blocks by substitution (one thread per
+// column, 120 dependent FMAs instead of 2016), then two levels of  X_BA = -X_BB (Y_BA X_AA)  -- and multiplies
+// its 64 columns of W by it on the MFMA units.  One launch, ~10 us instead of 54.
+__global__ void __launch_bounds__(256)
+k_qr1_tw_mfma(const double *__restrict__ W, int ncolsB, const double *__restrict__ tau, int c0, int nb,
+              double *__restrict__ W2) {
+    constexpr int LS = Q2_NB + 1;
+    __shared__ double Y[Q2_NB * LS];      // D N (strictly lower)
+    __shared__ double X[Q2_NB * LS];      // inv(I + Y), then T' = X D
+    __shared__ double Tm[32 * 33];        // Y_BA X_AA of the current level
+    __shared__ double st[Q2_NB];
+    __shared__ double sB[Q2_NB * Q2_KS];
+    __shared__ double sA[Q2_NB * Q2_KS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < Q2_NB) st[tid] = tid < nb ? tau[c0 + tid] : 0.0;
+    __syncthreads();
+    for (int e = tid; e < Q2_NB * Q2_NB; e += 256) {
+        const int j = e / Q2_NB, k = e % Q2_NB;
+        Y[j * LS + k] = k < j ? st[j] * W[(size_t)j * Q2_NB + k] : 0.0;    // W[cb = j][row = k] = v_k'v_j
+        X[j * LS + k] = 0.0;
+    }
+    __syncthreads();
+    if (tid < Q2_NB) {                    // 16 x 16 diagonal blocks: column c of inv(I + Y_bb)
+        const int o = (tid >> 4) * 16, cc = tid & 15;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = r == cc ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) acc -= Y[(o + r) * LS + o + k] * x[k];
+            x[r] = r >= cc ? acc : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[(o + r) * LS + o + cc] = x[r];
+    }
+    __syncthreads();
+    for (int sz = 16; sz < Q2_NB; sz *= 2) {
+        const int npair = Q2_NB / (2 * sz);
+        // Tm(pair)[r][c] = sum_k Y[B r][A k] X[A k][A c]   (X_AA lower triangular: k >= c)
+        for (int e = tid; e < npair * sz * sz; e += 256) {
+            const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
+            double acc = 0.0;
+            for (int k = cc; k < sz; ++k) acc += Y[(ob + r) * LS + oa + k] * X[(oa + k) * LS + oa + cc];
+            Tm[(pr * sz + r) * 33 + cc] = acc;     // (two pairs of 16 rows or one of 32: 32 x 32 in all)
+        }
+        __syncthreads();
+        // X_BA[r][c] = -sum_k X[B r][B k] Tm[k][c]       (X_BB lower triangular: k <= r)
+        for (int e = tid; e < npair * sz * sz; e += 256) {
+            const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
+            double acc = 0.0;
+            for (int k = 0; k <= r; ++k) acc += X[(ob + r) * LS + ob + k] * Tm[(pr * sz + k) * 33 + cc];
+            X[(ob + r) * LS + oa + cc] = -acc;
+        }
+        __syncthreads();
+    }
+    // W2(:, 64 columns of this workgroup) = (X D) W(:, columns)
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int ncols = ncolsB - Q2_NB;
+    const int j0 = blockIdx.x * Q2_NB;
+    v4d_qr acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d_qr){0.0, 0.0, 0.0, 0.0};
+    const int lc = tid >> 2, lk = (tid & 3) * 8;
+    const double *wcol = j0 + lc < ncols ? W + (size_t)(Q2_NB + j0 + lc) * Q2_NB : nullptr;
+    for (int k0 = 0; k0 < Q2_NB; k0 += Q2_KC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + lk + q;
+            sA[lc * Q2_KS + lk + q] = X[lc * LS + k] * st[k];       // T'[m = lc][k]
+            sB[lc * Q2_KS + lk + q] = wcol ? wcol[k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < Q2_KC; kk += 4) {
+            const int ko = kk + (lane >> 4);
+            const double a0 = sA[(wr + (lane & 15)) * Q2_KS + ko];
+            const double a1 = sA[(wr + 16 + (lane & 15)) * Q2_KS + ko];
+            const double b0 = sB[(wc + (lane & 15)) * Q2_KS + ko];
+            const double b1 = sB[(wc + 16 + (lane & 15)) * Q2_KS + ko];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + a * 16 + (lane >> 4) + 4 * r;   // entry of W2's column
+                const int col = j0 + wc + b * 16 + (lane & 15);
+                if (col < ncols) W2[(size_t)col * Q2_NB + row] = acc[a][b][r];
+            }
+}
+
 // A2(rows, 64 columns of tile) -= V(rows, :) * W2(:, columns)      (fp64 MFMA, K = 64)
 constexpr int Q2_UCT = 4;   // column tiles per workgroup of the update: the V tile is staged once for all of them
 __global__ void __launch_bounds__(256)
@@ -1914,6 +2017,72 @@ __global__ void k_tri_identity(int *__restrict__ jp, int n, int *__restrict__ ra
     if (blockIdx.x == 0 && threadIdx.x == 0) *rank = n;
 }
 
+// R z = c with the inverted diagonal blocks of the certificate, ONE launch: workgroup t owns rows 64t .. 64t+63,
+// subtracts R(t, e) z_e for e = last .. t+1 as the z_e arrive (flag-in-data slots, as in k_qr1_step_multi),
+// then forms z_t = X_tt (c_t - ...) and publishes it.  Workgroups are numbered so that a workgroup only waits
+// for workgroups dispatched BEFORE it (no co-residency assumption); the next R tile is fetched before the wait,
+// so the chain  z_e -> z_{e-1}  costs one exchange plus two 64 x 64 products from registers and LDS.
+__global__ void __launch_bounds__(256)
+k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int n, const double *__restrict__ cvec,
+             double *__restrict__ x, unsigned long long *__restrict__ slot /* [nblk][64][2] */, unsigned long long epoch,
+             int *__restrict__ err) {
+    __shared__ double sc[64], sz[64], sp[4][64];
+    const int nblk = (n + 63) / 64;
+    const int t = nblk - 1 - (int)blockIdx.x;
+    const int tid = threadIdx.x, row = tid & 63, part = tid >> 6;
+    const int r0 = t * 64;
+    const bool rin = r0 + row < n;
+    const unsigned ep = (unsigned)epoch;
+    if (tid < 64) sc[tid] = rin ? cvec[r0 + tid] : 0.0;
+    double tile[16];
+    auto fetch = [&](const double *Mx, int e) {      // rows r0.., columns 64e + 16 part + q
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cidx = e * 64 + part * 16 + q;
+            tile[q] = (rin && cidx < n) ? Mx[(size_t)cidx * n + r0 + row] : 0.0;
+        }
+    };
+    auto apply = [&](double sign) {                  // sc += sign * tile * sz   (sz: 64 entries in LDS)
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += tile[q] * sz[part * 16 + q];
+        sp[part][row] = acc;
+        __syncthreads();
+        if (tid < 64) sc[tid] += sign * (((sp[0][tid] + sp[1][tid]) + sp[2][tid]) + sp[3][tid]);
+        __syncthreads();
+    };
+    for (int e = nblk - 1; e > t; --e) {
+        fetch(R, e);
+        if (tid < 64) {
+            const unsigned long long *f = slot + ((size_t)e * 64 + tid) * 2;
+            unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+            int spins = 0;
+            while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
+                if (++spins > QR1_SPIN_LIMIT) { *err = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+                w0 = __hip_atomic_load(f, RLX_AGENT);
+                w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+            }
+            sz[tid] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+        }
+        __syncthreads();
+        apply(-1.0);
+    }
+    // z_t = X_tt c_t (X_tt upper triangular with zeros below: the certificate wrote the full block)
+    fetch(X, t);
+    if (tid < 64) { sz[tid] = sc[tid]; sc[tid] = 0.0; }
+    __syncthreads();
+    apply(1.0);
+    if (tid < 64) {
+        const double z = sc[tid];
+        unsigned long long *mine = slot + ((size_t)t * 64 + tid) * 2;
+        const unsigned long long hi = (unsigned long long)ep << 32;
+        __hip_atomic_store(mine, hi | (unsigned)__double2loint(z), RLX_AGENT);
+        __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(z), RLX_AGENT);
+        if (rin) x[r0 + tid] = z;
+    }
+}
+
 // x = X c for the upper-triangular inverse (n beyond the single-workgroup substitution): one wavefront per row
 __global__ void __launch_bounds__(256)
 k_tri_matvec(const double *__restrict__ X, int n, const double *__restrict__ cvec, double *__restrict__ x) {
@@ -1931,6 +2100,7 @@ struct Qr2Work {
     double *ice = nullptr;    // stage 2: condition-estimate vectors + scalars (2n + 8)
     double *lazy = nullptr;   // stage 1, lazy reflectors: beta[n] | scale[n]
     double *Xinv = nullptr, *T2 = nullptr, *fro = nullptr, *h_fro = nullptr;   // full-rank certificate (h_fro pinned)
+    unsigned long long *bslot = nullptr;   // certified solve: z blocks in flight [256][64][2 words]
     unsigned long long *xslot = nullptr;   // stage 1, slab exchange: [64 groups][8 slabs][8 rounds][18 sums][2 words]
     unsigned long long epoch = 0;
     int *d_err = nullptr;                  //   set when a slab wait gave up
@@ -1943,7 +2113,7 @@ static void qr2_free(void *p) {
     if (!q) return;
     hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
     hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
-    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->d_err); hipFree(q->Pn);
+    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn);
     if (q->h_fro) hipHostFree(q->h_fro);
     delete q;
 }
@@ -2054,8 +2224,12 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
             hipLaunchKernelGGL(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
         }
-        hipLaunchKernelGGL(k_qr1_tw, dim3(std::max(1, lsq_div_up(ncols, 256))), dim3(256), 0, c->stream, q->W, ncolsB,
-                           q->tau1, c0, nb, q->W2);
+        if (getenv("LSQ_QR1_TW_SUBST"))
+            hipLaunchKernelGGL(k_qr1_tw, dim3(std::max(1, lsq_div_up(ncols, 256))), dim3(256), 0, c->stream, q->W, ncolsB,
+                               q->tau1, c0, nb, q->W2);
+        else
+            hipLaunchKernelGGL(k_qr1_tw_mfma, dim3(std::max(1, lsq_div_up(ncols, Q2_NB))), dim3(256), 0, c->stream, q->W, ncolsB,
+                               q->tau1, c0, nb, q->W2);
         {
             const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
             hipLaunchKernelGGL(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols,
@@ -2146,7 +2320,14 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
             if (full_rank) {
                 // rank = n is certain: the unpivoted triangle gives the same (unique) solution, jp = identity
                 hipLaunchKernelGGL(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
-                if (n <= QRK_MAXN)
+                if (lsq_div_up(n, 64) <= 256 && !getenv("LSQ_QR_SUBST_SOLVE")) {
+                    if (!q->bslot) {
+                        LSQ_HIP(hipMalloc(&q->bslot, (size_t)256 * 64 * 2 * sizeof(unsigned long long)));
+                        LSQ_ZERO(q->bslot, 0, (size_t)256 * 64 * 2 * sizeof(unsigned long long));
+                    }
+                    hipLaunchKernelGGL(k_tri_bsolve, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, q->Xinv, n, rhs2, d_x,
+                                       q->bslot, ++q->epoch, q->d_err);
+                } else if (n <= QRK_MAXN)
                     hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
                 else
                     hipLaunchKernelGGL(k_tri_matvec, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, q->Xinv, n, rhs2, d_x);
