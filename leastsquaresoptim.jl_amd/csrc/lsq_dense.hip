@@ -807,6 +807,7 @@ void lsq_dense_solver_free(lsq_solver *s) {
     hipFree(s->d_info); hipFree(s->d_chol); hipFree(s->d_rhs); hipFree(s->d_work); hipFree(s->d_tau);
     hipFree(s->d_qr); hipFree(s->d_qu); hipFree(s->d_T);
     if (s->qr2 && s->qr2_free) s->qr2_free(s->qr2);
+    if (s->tripipe && s->tripipe_free) s->tripipe_free(s->tripipe);
     s->qr2 = nullptr;
 }
 
@@ -1900,25 +1901,60 @@ k_qr2_init(const double *__restrict__ R, int n, double *__restrict__ vn1, double
 // explicit inverse X of the stage-1 triangle: 64 x 64 diagonal blocks inverted one workgroup each, then
 // log2(n/64) levels of  X12 = -X11 (R12 X22)  as batched fp64-MFMA tile products (n^3/3 flops in all).
 // If the bound (with a safety factor) does not certify full rank -- or is not finite -- stage 2 runs as before.
-__global__ void __launch_bounds__(64)
-k_tri_diaginv(const double *__restrict__ R, int n, double *__restrict__ X) {
-    __shared__ double sR[64][65];
-    __shared__ double sX[64][65];
-    const int o = blockIdx.x * 64, nb = min(64, n - o), j = threadIdx.x;
-    for (int cidx = 0; cidx < 64; ++cidx) {
-        const int r = j;   // (lane = row: coalesced)
-        sR[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? R[(size_t)(o + cidx) * n + o + r] : (r == cidx ? 1.0 : 0.0);
+__global__ void __launch_bounds__(256)
+k_tri_diaginv(const double *__restrict__ R, int n, double *__restrict__ X, int ldx, size_t bstride) {
+    // block d -> X + d * bstride, element (r, c) at [c * ldx + r]  (in place in an n x n image: ldx = n, bstride = 64 n + 64)
+    // 16 x 16 diagonal sub-blocks by back substitution (one thread per column, registers), then two levels of
+    // X_AB = -X_AA (R_AB X_BB) with all threads: the dependent chain is 16 steps instead of 64
+    constexpr int LS = 65;
+    __shared__ double sR[64 * LS];
+    __shared__ double sX[64 * LS];
+    __shared__ double Tm[32 * 33];
+    const int o = blockIdx.x * 64, nb = min(64, n - o), tid = threadIdx.x;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e % 64, cidx = e / 64;
+        sR[r * LS + cidx] = (r < nb && cidx < nb && r <= cidx) ? R[(size_t)(o + cidx) * n + o + r] : (r == cidx ? 1.0 : 0.0);
+        sX[r * LS + cidx] = 0.0;
     }
     __syncthreads();
-    // lane j: column j of the inverse by back substitution (entries below row j are zero)
-    for (int r = 63; r >= 0; --r) {
-        double sacc = r == j ? 1.0 : 0.0;
-        for (int k = r + 1; k < 64; ++k) sacc -= sR[r][k] * sX[k][j];
-        sX[r][j] = r <= j ? sacc / sR[r][r] : 0.0;
+    if (tid < 64) {
+        const int ob = (tid >> 4) * 16, cc = tid & 15;
+        double x[16];
+#pragma unroll
+        for (int r = 15; r >= 0; --r) {
+            double acc = r == cc ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = r + 1; k < 16; ++k) acc -= sR[(ob + r) * LS + ob + k] * x[k];
+            x[r] = r <= cc ? acc / sR[(ob + r) * LS + ob + r] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sX[(ob + r) * LS + ob + cc] = x[r];
     }
     __syncthreads();
-    for (int cidx = 0; cidx < nb; ++cidx)
-        if (j < nb) X[(size_t)(o + cidx) * n + o + j] = sX[j][cidx];
+    for (int sz = 16; sz < 64; sz *= 2) {
+        const int npair = 64 / (2 * sz);
+        // Tm(pair)[r][c] = sum_k R[A r][B k] X[B k][B c]     (X_BB upper triangular: k <= c)
+        for (int e = tid; e < npair * sz * sz; e += 256) {
+            const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
+            double acc = 0.0;
+            for (int k = 0; k <= cc; ++k) acc += sR[(oa + r) * LS + ob + k] * sX[(ob + k) * LS + ob + cc];
+            Tm[(pr * sz + r) * 33 + cc] = acc;
+        }
+        __syncthreads();
+        // X_AB[r][c] = -sum_k X[A r][A k] Tm[k][c]            (X_AA upper triangular: k >= r)
+        for (int e = tid; e < npair * sz * sz; e += 256) {
+            const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
+            double acc = 0.0;
+            for (int k = r; k < sz; ++k) acc += sX[(oa + r) * LS + oa + k] * Tm[(pr * sz + k) * 33 + cc];
+            sX[(oa + r) * LS + ob + cc] = -acc;
+        }
+        __syncthreads();
+    }
+    double *out = X + (size_t)blockIdx.x * bstride;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e % 64, cidx = e / 64;
+        if (r < nb && cidx < nb) out[(size_t)cidx * ldx + r] = sX[r * LS + cidx];
+    }
 }
 
 // one level of the recursion, blocks of size s: phase 0  T12 = R12 * X22,  phase 1  X12 = -X11 * T12
@@ -2023,9 +2059,9 @@ __global__ void k_tri_identity(int *__restrict__ jp, int n, int *__restrict__ ra
 // for workgroups dispatched BEFORE it (no co-residency assumption); the next R tile is fetched before the wait,
 // so the chain  z_e -> z_{e-1}  costs one exchange plus two 64 x 64 products from registers and LDS.
 __global__ void __launch_bounds__(256)
-k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int n, const double *__restrict__ cvec,
-             double *__restrict__ x, unsigned long long *__restrict__ slot /* [nblk][64][2] */, unsigned long long epoch,
-             int *__restrict__ err) {
+k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int ldx, size_t bstride /* as k_tri_diaginv */,
+             int n, const double *__restrict__ cvec, double *__restrict__ x,
+             unsigned long long *__restrict__ slot /* [nblk][64][2] */, unsigned long long epoch, int *__restrict__ err) {
     __shared__ double sc[64], sz[64], sp[4][64];
     const int nblk = (n + 63) / 64;
     const int t = nblk - 1 - (int)blockIdx.x;
@@ -2040,6 +2076,14 @@ k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int n, 
         for (int q = 0; q < 16; ++q) {
             const int cidx = e * 64 + part * 16 + q;
             tile[q] = (rin && cidx < n) ? Mx[(size_t)cidx * n + r0 + row] : 0.0;
+        }
+    };
+    auto fetch_diag = [&]() {
+        const double *Xt = X + (size_t)t * bstride;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cl = part * 16 + q;
+            tile[q] = (rin && r0 + cl < n) ? Xt[(size_t)cl * ldx + row] : 0.0;
         }
     };
     auto apply = [&](double sign) {                  // sc += sign * tile * sz   (sz: 64 entries in LDS)
@@ -2069,7 +2113,7 @@ k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int n, 
         apply(-1.0);
     }
     // z_t = X_tt c_t (X_tt upper triangular with zeros below: the certificate wrote the full block)
-    fetch(X, t);
+    fetch_diag();
     if (tid < 64) { sz[tid] = sc[tid]; sc[tid] = 0.0; }
     __syncthreads();
     apply(1.0);
@@ -2080,6 +2124,69 @@ k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int n, 
         __hip_atomic_store(mine, hi | (unsigned)__double2loint(z), RLX_AGENT);
         __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(z), RLX_AGENT);
         if (rin) x[r0 + tid] = z;
+    }
+}
+
+// U'z = b, the forward half of a Cholesky solve, same scheme: workgroup t owns unknowns 64t .., subtracts
+// U(e, t)' z_e for e = 0 .. t-1 as they arrive and applies X_tt' (thread = column of the tile, 16 rows each:
+// the transposed product needs no cross-lane sums; the tiles are L2-resident)
+__global__ void __launch_bounds__(256)
+k_tri_fsolve_t(const double *__restrict__ U, const double *__restrict__ X, int ldx, size_t bstride, int n,
+               const double *__restrict__ bvec, double *__restrict__ z, unsigned long long *__restrict__ slot,
+               unsigned long long epoch, int *__restrict__ err) {
+    __shared__ double sc[64], sz[64], sp[4][64];
+    const int t = (int)blockIdx.x;
+    const int tid = threadIdx.x, col = tid & 63, part = tid >> 6;
+    const int c0 = t * 64;
+    const bool cin = c0 + col < n;
+    const unsigned ep = (unsigned)epoch;
+    if (tid < 64) sc[tid] = cin ? bvec[c0 + tid] : 0.0;
+    double tile[16];
+    auto apply = [&](double sign) {                  // sc += sign * tile' * sz
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += tile[q] * sz[part * 16 + q];
+        sp[part][col] = acc;
+        __syncthreads();
+        if (tid < 64) sc[tid] += sign * (((sp[0][tid] + sp[1][tid]) + sp[2][tid]) + sp[3][tid]);
+        __syncthreads();
+    };
+    for (int e = 0; e < t; ++e) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[q] = cin ? U[(size_t)(c0 + col) * n + e * 64 + part * 16 + q] : 0.0;
+        if (tid < 64) {
+            const unsigned long long *f = slot + ((size_t)e * 64 + tid) * 2;
+            unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+            int spins = 0;
+            while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
+                if (++spins > QR1_SPIN_LIMIT) { *err = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+                w0 = __hip_atomic_load(f, RLX_AGENT);
+                w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+            }
+            sz[tid] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+        }
+        __syncthreads();
+        apply(-1.0);
+    }
+    {
+        const double *Xt = X + (size_t)t * bstride;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = part * 16 + q;
+            tile[q] = (cin && c0 + r < n) ? Xt[(size_t)col * ldx + r] : 0.0;     // X_tt(r, col)
+        }
+    }
+    if (tid < 64) { sz[tid] = sc[tid]; sc[tid] = 0.0; }
+    __syncthreads();
+    apply(1.0);
+    if (tid < 64) {
+        const double v = sc[tid];
+        unsigned long long *mine = slot + ((size_t)t * 64 + tid) * 2;
+        const unsigned long long hi = (unsigned long long)ep << 32;
+        __hip_atomic_store(mine, hi | (unsigned)__double2loint(v), RLX_AGENT);
+        __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(v), RLX_AGENT);
+        if (cin) z[c0 + tid] = v;
     }
 }
 
@@ -2260,7 +2367,7 @@ static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double 
         LSQ_HIP(hipMalloc(&q->fro, 2 * FRO_BLOCKS * sizeof(double)));
         LSQ_HIP(hipHostMalloc(&q->h_fro, (2 * FRO_BLOCKS + 1) * sizeof(double)));
     }
-    hipLaunchKernelGGL(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(64), 0, c->stream, R2, n, q->Xinv);
+    hipLaunchKernelGGL(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, n, q->Xinv, n, (size_t)64 * n + 64);
     for (long long sz = 64; sz < n; sz *= 2) {
         const int sb = (int)sz, npairs = (int)((n + 2 * sz - 1) / (2 * sz)), tps = sb / 64;
         const int grid = npairs * tps * tps;
@@ -2282,6 +2389,53 @@ static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double 
     const double bound = sqrt(fr) * sqrt(fx);       // >= cond_2(R); NaN/Inf (singular or overflowing R) fail the test
     // safety factor 16: rounding in the computed inverse and in dlaic1's own estimates
     *certified = std::isfinite(bound) && bound * rcond * 16.0 <= 1.0;
+    return LSQ_OK;
+}
+
+// U'U x = b for the blocked Cholesky (dense_cholesky.jl:56-57): inverted diagonal blocks, then the two pipelined
+// block solves; b is overwritten by x.  Returns LSQ_EARG when the scheme does not apply (caller falls back).
+struct TriPipe {
+    double *Xd = nullptr, *z = nullptr;          // [nblk][64][64] inverted diagonal blocks; intermediate z
+    unsigned long long *slot_f = nullptr, *slot_b = nullptr;
+    unsigned long long epoch = 0;
+    int *d_err = nullptr;
+    int n = 0;
+};
+static void tripipe_free(void *p) {
+    TriPipe *t = (TriPipe *)p;
+    if (!t) return;
+    hipFree(t->Xd); hipFree(t->z); hipFree(t->slot_f); hipFree(t->slot_b); hipFree(t->d_err);
+    delete t;
+}
+int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
+    lsq_ctx *c = s->ctx;
+    const int nblk = lsq_div_up(n, 64);
+    if (nblk > 256 || getenv("LSQ_CHOL_SUBST_SOLVE")) return LSQ_EARG;
+    TriPipe *t = (TriPipe *)s->tripipe;
+    if (!t || t->n != n) {
+        if (t) tripipe_free(t);
+        t = new TriPipe();
+        t->n = n;
+        const size_t sl = (size_t)nblk * 64 * 2 * sizeof(unsigned long long);
+        LSQ_HIP(hipMalloc(&t->Xd, (size_t)nblk * 4096 * sizeof(double)));
+        LSQ_HIP(hipMalloc(&t->z, ((size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&t->slot_f, sl));
+        LSQ_HIP(hipMalloc(&t->slot_b, sl));
+        LSQ_HIP(hipMalloc(&t->d_err, sizeof(int)));
+        LSQ_ZERO(t->slot_f, 0, sl);
+        LSQ_ZERO(t->slot_b, 0, sl);
+        LSQ_ZERO(t->d_err, 0, sizeof(int));
+        LSQ_ZERO(t->Xd, 0, (size_t)nblk * 4096 * sizeof(double));
+        s->tripipe = t;
+        s->tripipe_free = tripipe_free;
+    }
+    ++t->epoch;
+    hipLaunchKernelGGL(k_tri_diaginv, dim3(nblk), dim3(256), 0, c->stream, U, n, t->Xd, 64, (size_t)4096);
+    hipLaunchKernelGGL(k_tri_fsolve_t, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, d_bx, t->z, t->slot_f,
+                       t->epoch, t->d_err);
+    hipLaunchKernelGGL(k_tri_bsolve, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, t->z, d_bx, t->slot_b,
+                       t->epoch, t->d_err);
+    LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 
@@ -2325,7 +2479,8 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
                         LSQ_HIP(hipMalloc(&q->bslot, (size_t)256 * 64 * 2 * sizeof(unsigned long long)));
                         LSQ_ZERO(q->bslot, 0, (size_t)256 * 64 * 2 * sizeof(unsigned long long));
                     }
-                    hipLaunchKernelGGL(k_tri_bsolve, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, q->Xinv, n, rhs2, d_x,
+                    hipLaunchKernelGGL(k_tri_bsolve, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, q->Xinv, n,
+                                       (size_t)64 * n + 64, n, rhs2, d_x,
                                        q->bslot, ++q->epoch, q->d_err);
                 } else if (n <= QRK_MAXN)
                     hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);

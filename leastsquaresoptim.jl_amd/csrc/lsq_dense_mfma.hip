@@ -457,7 +457,9 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
                                rest, j0 + nb, 1, (double *)nullptr, s->d_chol, n);
         }
     }
-    hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
+    // U'z = b, U x = z: pipelined over the 64-blocks on several CUs; the single-workgroup kernel otherwise
+    if (lsq_tri_chol_solve(s, s->d_chol, n, d_x) != LSQ_OK)
+        hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

@@ -53,7 +53,10 @@ struct lsq_solver {
     void *precond_user = nullptr;
     void *qr2 = nullptr;            // two-stage QR workspace (lsq_dense.hip), allocated on first use
     void (*qr2_free)(void *) = nullptr;
+    void *tripipe = nullptr;        // pipelined triangular solves of the blocked Cholesky (lsq_dense.hip)
+    void (*tripipe_free)(void *) = nullptr;
 };
+int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx);
 
 #ifdef __HIPCC__
 // the scalar recurrence of one iteration (lsmr.jl:127-196, :205), on a private copy of the state
