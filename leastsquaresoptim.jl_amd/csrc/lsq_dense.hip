@@ -787,6 +787,7 @@ int lsq_dense_solver_alloc(lsq_solver *s) {
     LSQ_HIP(hipMalloc(&s->d_info, 4 * sizeof(int)));
     if (s->kind == LSQ_CHOLESKY) {
         LSQ_HIP(hipMalloc(&s->d_chol, n1 * n1 * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->d_Ds, ((size_t)((n + 63) / 64) * 4096 + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&s->d_rhs, n1 * sizeof(double)));
         LSQ_HIP(hipMalloc(&s->d_work, 4 * n1 * sizeof(double)));
         LSQ_HIP(hipMalloc(&s->d_tau, n1 * sizeof(int) + 16));  // pivots
@@ -804,7 +805,7 @@ int lsq_dense_solver_alloc(lsq_solver *s) {
 }
 
 void lsq_dense_solver_free(lsq_solver *s) {
-    hipFree(s->d_info); hipFree(s->d_chol); hipFree(s->d_rhs); hipFree(s->d_work); hipFree(s->d_tau);
+    hipFree(s->d_info); hipFree(s->d_chol); hipFree(s->d_Ds); hipFree(s->d_rhs); hipFree(s->d_work); hipFree(s->d_tau);
     hipFree(s->d_qr); hipFree(s->d_qu); hipFree(s->d_T);
     if (s->qr2 && s->qr2_free) s->qr2_free(s->qr2);
     if (s->tripipe && s->tripipe_free) s->tripipe_free(s->tripipe);

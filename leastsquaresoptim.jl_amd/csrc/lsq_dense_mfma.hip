@@ -189,6 +189,11 @@ k_chol_diag(double *__restrict__ C, int n, int j0, int *__restrict__ info) {
 // columns instead of 16.  The working copy stays UNSCALED (pivot row j is applied as (U[j][i]/a_jj)*U[j][k],
 // in pivot order) and is divided by sqrt(a_jj) only at the end: every entry sees exactly the operations
 // of k_chol_diag in the same order, so the result is bit-identical.
+// broadcast of one lane's double through SGPRs (v_readlane): lane index known at compile time after unrolling,
+// far shorter latency than the LDS-crossbar shuffle on the dependent chain of a factorisation
+__device__ __forceinline__ double lane_bcast(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
 constexpr int SB = 16;
 __global__ void __launch_bounds__(256)
 k_chol_diag16(double *__restrict__ C, int n, int j0, int *__restrict__ info) {
@@ -319,6 +324,140 @@ k_chol_trsm16(double *__restrict__ C, int n, int j0, const int *__restrict__ inf
     }
 }
 
+// (a2)+(b2) in ONE launch per panel: every workgroup factors the diagonal block itself (identical arithmetic, the
+// block is 32 KB) while the loads of its own 64 columns of the row panel are in flight, then runs the row-panel
+// substitution against the factor it holds in LDS -- one dependent launch and one reload of the block less per
+// panel.  The factored diagonal block is NOT written in place (a workgroup that starts late would read it as
+// input): workgroup 0 parks it in Ds[j0 / 64] and k_chol_diag_restore moves all blocks back after the last panel.
+__global__ void __launch_bounds__(256)
+k_chol_panel16(double *__restrict__ C, int n, int j0, int *__restrict__ info, double *__restrict__ Ds) {
+    __shared__ double U[NB][NB + 1];
+    __shared__ double X[NB][NB + 1];
+    __shared__ double s_inv[NB], s_root[NB];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nb = min(NB, n - j0);
+    if (*info != 0) return;  // an earlier panel failed
+    if (tid == 0) s_fail = 0;
+    const int c0 = j0 + nb + blockIdx.x * NB;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
+        X[r][cidx] = (r < nb && c0 + cidx < n) ? C[(size_t)(c0 + cidx) * n + j0 + r] : 0.0;
+    }
+    __syncthreads();
+    for (int s0 = 0; s0 < NB; s0 += SB) {
+        if (tid < 64) {
+            double u[SB];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) u[r] = (lane < SB && r <= lane) ? U[s0 + r][s0 + lane] : 0.0;
+            int fail = 0;
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const double ajj = lane_bcast(u[j], j);
+                if (!fail && s0 + j < nb && (ajj <= 0.0 || isnan(ajj))) fail = s0 + j + 1;
+                const double inv = 1.0 / ajj;
+                if (lane == 0) { s_inv[s0 + j] = inv; s_root[s0 + j] = sqrt(ajj); }
+                const double rowj = u[j];
+#pragma unroll
+                for (int i = j + 1; i < SB; ++i) {
+                    const double uji = lane_bcast(rowj, i) * inv;
+                    if (lane >= i) u[i] -= uji * rowj;
+                }
+            }
+            if (lane < SB) {
+#pragma unroll
+                for (int r = 0; r < SB; ++r)
+                    if (r <= lane) U[s0 + r][s0 + lane] = u[r];
+            }
+            if (fail && lane == 0) s_fail = fail;
+        }
+        __syncthreads();
+        if (s_fail) break;
+        const int rem = NB - s0 - SB;
+        if (tid < rem) {
+            const int cidx = s0 + SB + tid;
+            double x[SB];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) x[r] = U[s0 + r][cidx];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const double inv = s_inv[s0 + j];
+#pragma unroll
+                for (int r = j + 1; r < SB; ++r) x[r] -= (U[s0 + j][s0 + r] * inv) * x[j];
+            }
+#pragma unroll
+            for (int r = 0; r < SB; ++r) U[s0 + r][cidx] = x[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int i = s0 + SB + e / rem, k = s0 + SB + e % rem;
+            if (i <= k) {
+                double v = U[i][k];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) v -= (U[s0 + j][i] * s_inv[s0 + j]) * U[s0 + j][k];
+                U[i][k] = v;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0 && blockIdx.x == 0) *info = j0 + s_fail;   // PosDefException position (1-based)
+        return;
+    }
+    // the factor as k_chol_diag16 stores it (same values), kept in LDS for the row panel
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        if (r <= cidx) {
+            const double v = (r == cidx) ? s_root[r] : U[r][cidx] / s_root[r];
+            U[r][cidx] = v;
+            if (blockIdx.x == 0 && r < nb && cidx < nb) Ds[(size_t)(j0 / NB) * NB * NB + (size_t)cidx * NB + r] = v;
+        }
+    }
+    __syncthreads();
+    if (c0 >= n) return;   // last panel: nothing to the right
+    const int cc = tid & 63, qg = tid >> 6;
+    for (int s0 = 0; s0 < NB; s0 += SB) {
+        if (tid < 64) {   // rows s0..s0+15 of column cc, forward substitution in registers
+            double x[SB];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) x[r] = X[s0 + r][cc];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) {
+                x[r] = x[r] / U[s0 + r][s0 + r];
+#pragma unroll
+                for (int q = r + 1; q < SB; ++q) x[q] -= U[s0 + r][s0 + q] * x[r];
+            }
+#pragma unroll
+            for (int r = 0; r < SB; ++r) X[s0 + r][cc] = x[r];
+        }
+        __syncthreads();
+        for (int q = s0 + SB + qg; q < NB; q += 4) {   // rows below: subtract the 16 solved rows, r ascending
+            double v = X[q][cc];
+#pragma unroll
+            for (int r = 0; r < SB; ++r) v -= U[s0 + r][q] * X[s0 + r][cc];
+            X[q][cc] = v;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        if (r < nb && c0 + cidx < n) C[(size_t)(c0 + cidx) * n + j0 + r] = X[r][cidx];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_chol_diag_restore(double *__restrict__ C, int n, const double *__restrict__ Ds, const int *__restrict__ info) {
+    const int j0 = blockIdx.x * NB, nb = min(NB, n - j0);
+    const int failed = *info;               // panels from the failing one on were never parked
+    if (failed != 0 && j0 + NB >= failed) return;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e % NB, cidx = e / NB;
+        if (r <= cidx && cidx < nb) C[(size_t)(j0 + cidx) * n + j0 + r] = Ds[(size_t)blockIdx.x * NB * NB + (size_t)cidx * NB + r];
+    }
+}
+
 // (b) row panel: U12 = U11^{-T} A12.  A workgroup owns 64 columns of A12; the 64 x 64 chunk X and
 // U11 live in LDS; row r of X is finished and its multiples subtracted from the rows below, one
 // barrier per row (thread = (column, row group)).
@@ -443,20 +582,34 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices), dim3(256), 0, c->stream, J->d_dense, m, m, n, 0, kslices,
                        s->d_T, (double *)nullptr, 0);
     hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
+    // parking space for the factored diagonal blocks (k_chol_panel16): the tail of the SYRK slice buffer is free by now
+    bool merged = false;
+    double *Ds = s->d_Ds;
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = std::min(NB, n - j0), rest = n - j0 - nb;
         static const bool per_column = getenv("LSQ_CHOL_PER_COLUMN") != nullptr;   // the one-barrier-per-column kernels
-        hipLaunchKernelGGL(per_column ? k_chol_diag : k_chol_diag16, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, j0,
-                           s->d_info);
+        static const bool two_launch = getenv("LSQ_CHOL_TWO_LAUNCH") != nullptr;   // diagonal block and row panel separately
+        if (!per_column && !two_launch) {
+            hipLaunchKernelGGL(k_chol_panel16, dim3(std::max(1, (rest + NB - 1) / NB)), dim3(256), 0, c->stream, s->d_chol, n, j0,
+                               s->d_info, Ds);
+            merged = true;
+        } else {
+            hipLaunchKernelGGL(per_column ? k_chol_diag : k_chol_diag16, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, j0,
+                               s->d_info);
+            if (rest > 0)
+                hipLaunchKernelGGL(per_column ? k_chol_trsm : k_chol_trsm16, dim3((rest + NB - 1) / NB), dim3(256), 0, c->stream,
+                                   s->d_chol, n, j0, (const int *)s->d_info);
+        }
         if (rest > 0) {
-            hipLaunchKernelGGL(per_column ? k_chol_trsm : k_chol_trsm16, dim3((rest + NB - 1) / NB), dim3(256), 0, c->stream,
-                               s->d_chol, n, j0, (const int *)s->d_info);
             const int nt2 = (rest + MT - 1) / MT;
             // A22 -= U12' U12 : "A" = rows j0..j0+nb of chol (lda n), columns from j0+nb
             hipLaunchKernelGGL((k_syrk_mfma<1>), dim3(nt2 * (nt2 + 1) / 2), dim3(256), 0, c->stream, s->d_chol + j0, n, nb,
                                rest, j0 + nb, 1, (double *)nullptr, s->d_chol, n);
         }
     }
+    if (merged)
+        hipLaunchKernelGGL(k_chol_diag_restore, dim3((n + NB - 1) / NB), dim3(256), 0, c->stream, s->d_chol, n, Ds,
+                           (const int *)s->d_info);
     // U'z = b, U x = z: pipelined over the 64-blocks on several CUs; the single-workgroup kernel otherwise
     if (lsq_tri_chol_solve(s, s->d_chol, n, d_x) != LSQ_OK)
         hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);

@@ -37,6 +37,7 @@ struct lsq_solver {
     int last_iter = 0, last_istop = 0;
     // --- dense Cholesky (dense_cholesky.jl:7-21) ---
     double *d_chol = nullptr;  // n*n
+    double *d_Ds = nullptr;    // ceil(n/64) factored 64 x 64 diagonal blocks in flight (blocked Cholesky)
     double *d_rhs = nullptr;   // n
     int *d_info = nullptr;
     // --- dense QR (dense_qr.jl:6-28, 50-54) ---
