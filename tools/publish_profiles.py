@@ -56,3 +56,6 @@ if k1f:
                "source": "profiles/%s/pmc_traffic.md" % os.path.basename(dst)}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, "kernel_summary.md")).read()[:3000])
 print(open(os.path.join(dst, "pmc_traffic.md")).read()[:2500])
+dense = os.path.join(ROOT, "gpurun_out", "denseprof", "dense_kernel_summary.md")   # tools/make_dense_profiles.sh
+if os.path.exists(dense):
+    shutil.copy(dense, os.path.join(dst, "dense_kernel_summary.md"))
