@@ -1115,6 +1115,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     constexpr int NS = 2 * (K + 1);
     __shared__ double sh[NW][NS];
     __shared__ double sx[S][NS];
+    __shared__ double sat[NS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int g = (int)blockIdx.x, sidx = 0;
     if (S > 1) {
@@ -1156,23 +1157,25 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         constexpr int r = decltype(rc)::value;
         const bool live = r < kk;                   // (uniform; a dead round of a ragged last launch is a no-op)
         const int c = i + r;                        // pivot column == pivot row of this round
-        // sums: [0] v'v  [1] alpha  then per later column x (pivots r+1.., target): v'x and x(c)
+        // sm: [0] v'v  [1] alpha  then per later column x (pivots r+1.., target): v'x and x(c).  The even entries are
+        // sums over all rows; the odd ones are single elements of row c, all owned by ONE thread (slab 0, thread r:
+        // only element 0 of a thread can sit at or above the pivot row) which hands them out directly
         double sm[NS];
-        // only element 0 of a thread can sit at or above the pivot row (rows i .. i+K-1 belong to threads 0 .. K-1)
+        constexpr int NSr = 2 * (K - r) + 2;
         {
             const double v = t > c ? pv[r][0] : 0.0;
-            const bool at = t == c;
             sm[0] = v * v;
-            sm[1] = at ? pv[r][0] : 0.0;
 #pragma unroll
-            for (int x = 0; x < K; ++x) {       // (constant trip counts: the unroller must not depend on r)
-                if (x > r) {
-                    sm[2 * (x - r)] = v * pv[x][0];
-                    sm[2 * (x - r) + 1] = at ? pv[x][0] : 0.0;
-                }
-            }
+            for (int x = 0; x < K; ++x)       // (constant trip counts: the unroller must not depend on r)
+                if (x > r) sm[2 * (x - r)] = v * pv[x][0];
             sm[2 * (K - r)] = v * a[0];
-            sm[2 * (K - r) + 1] = at ? a[0] : 0.0;
+            if (t == c) {
+                sat[1] = pv[r][0];
+#pragma unroll
+                for (int x = 0; x < K; ++x)
+                    if (x > r) sat[2 * (x - r) + 1] = pv[x][0];
+                sat[2 * (K - r) + 1] = a[0];
+            }
         }
 #pragma unroll
         for (int q = 1; q < RPT; ++q) {
@@ -1184,41 +1187,43 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
             sm[2 * (K - r)] = __builtin_fma(v, a[q], sm[2 * (K - r)]);
         }
 #pragma unroll
-        for (int e = 0; e < NS; ++e)
-            if (e < 2 * (K - r) + 2) sm[e] = wave_allsum(sm[e]);
+        for (int e = 0; e < NS; e += 2)
+            if (e < NSr) sm[e] = wave_allsum(sm[e]);
         __syncthreads();                             // (the previous round's readers are done)
         if (lane == 0) {
 #pragma unroll
-            for (int e = 0; e < NS; ++e)
-                if (e < 2 * (K - r) + 2) sh[wv][e] = sm[e];
+            for (int e = 0; e < NS; e += 2)
+                if (e < NSr) sh[wv][e] = sm[e];
         }
         __syncthreads();
         static_assert(NW <= 16, "one 16-lane row sums the wave partials");
 #pragma unroll
-        for (int e = 0; e < NS; ++e)
-            if (e < 2 * (K - r) + 2) sm[e] = row_allsum((lane & 15) < NW ? sh[lane & 15][e] : 0.0);
-        if (S > 1) {
-            constexpr int NSr = 2 * (K - r) + 2;
+        for (int e = 0; e < NS; e += 2)
+            if (e < NSr) sm[e] = row_allsum((lane & 15) < NW ? sh[lane & 15][e] : 0.0);
+        if (S == 1) {
+#pragma unroll
+            for (int e = 1; e < NS; e += 2)
+                if (e < NSr) sm[e] = sat[e];
+        } else {
             static_assert(S * NS <= NT, "one thread per exchanged value");
             // flag-in-data exchange (the low-latency protocol of the collectives libraries): every 64-bit word
             // carries 32 bits of payload and the 32-bit epoch, so a reader that sees the epoch has the payload --
-            // one store and one load on the critical path, no fences, no separate flag
+            // one store and one load on the critical path, no fences, no separate flag.  Sums: every slab publishes
+            // its partial; row-c elements: slab 0 alone publishes them.
             const unsigned ep = (unsigned)epoch;
-            if (tid < NS) {
+            if (tid < NSr && ((tid & 1) == 0 || sidx == 0)) {
                 double val = 0.0;
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
-                    if (e < NSr && tid == e) val = sm[e];
-                if (tid < NSr) {
-                    unsigned long long *mine = xslot + ((((size_t)g * S + sidx) * K + r) * NS + tid) * 2;
-                    const unsigned long long hi = (unsigned long long)ep << 32;
-                    __hip_atomic_store(mine, hi | (unsigned)__double2loint(val), RLX_AGENT);
-                    __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(val), RLX_AGENT);
-                }
+                    if (e < NSr && tid == e) val = (e & 1) ? sat[e] : sm[e];
+                unsigned long long *mine = xslot + ((((size_t)g * S + sidx) * K + r) * NS + tid) * 2;
+                const unsigned long long hi = (unsigned long long)ep << 32;
+                __hip_atomic_store(mine, hi | (unsigned)__double2loint(val), RLX_AGENT);
+                __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(val), RLX_AGENT);
             }
             if (tid < S * NS) {
                 const int sp = tid / NS, e = tid % NS;
-                if (e < NSr) {
+                if (e < NSr && ((e & 1) == 0 || sp == 0)) {
                     const unsigned long long *f = xslot + ((((size_t)g * S + sp) * K + r) * NS + e) * 2;
                     unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
                     int spins = 0;
@@ -1235,10 +1240,13 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
 #pragma unroll
             for (int e = 0; e < NS; ++e) {
                 if (e < NSr) {
-                    double tot = 0.0;
+                    if (e & 1) sm[e] = sx[0][e];
+                    else {
+                        double tot = 0.0;
 #pragma unroll
-                    for (int sp = 0; sp < S; ++sp) tot += sx[sp][e];
-                    sm[e] = tot;
+                        for (int sp = 0; sp < S; ++sp) tot += sx[sp][e];
+                        sm[e] = tot;
+                    }
                 }
             }
         }
@@ -2230,7 +2238,9 @@ static bool qr2_applies(int M, int n) {
     const bool off = getenv("LSQ_QR_ONE_STAGE") != nullptr;     // (read per call: the tests flip them)
     const bool force = getenv("LSQ_QR_TWO_STAGE") != nullptr;
     if (off || M < n || n < 2) return false;
-    return force || (n >= 256 && (long long)M * n >= (1LL << 21));
+    // (measured crossover against the one-workgroup / two-launch pivoted kernels: 20 x 5 0.06 vs 0.13 ms,
+    //  100 x 20 0.24 vs 0.17, 200 x 50 0.78 vs 0.25, 2000 x 400 10.1 vs 1.7)
+    return force || (n >= 16 && (long long)M * n >= 1600);
 }
 
 // factors [A | b] (s->d_qr, s->d_qu) and leaves R2, pivots (jp) and Q'b for k_qrcp_solve(phase 0) in the

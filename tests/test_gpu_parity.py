@@ -344,7 +344,8 @@ def test_ldiv_qr(ctx, m, n, rank):
 
 
 @pytest.mark.parametrize("m,n,rank", [(300, 65, 65), (1100, 130, 130), (900, 100, 37), (700, 200, 1), (640, 128, 128),
-                                      (2000, 321, 321), (2000, 321, 300), (500, 500, 500)])
+                                      (2000, 321, 321), (2000, 321, 300), (500, 500, 500),
+                                      (100, 20, 20), (100, 20, 7), (64, 64, 64), (40, 33, 33), (70, 17, 16), (33, 16, 16)])
 def test_ldiv_qr_two_stage(ctx, m, n, rank, monkeypatch):
     """The two-stage factorisation (unpivoted blocked Householder with MFMA trailing updates, then either the
     full-rank certificate or the pivoted sweep on R) forced onto small problems: panel tails (n not a
