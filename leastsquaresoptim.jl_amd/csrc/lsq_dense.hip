@@ -821,8 +821,10 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
         return LSQ_EARG;
     }
     if (n != s->n || m != s->m) { lsq_set_error("cholesky: size mismatch"); return LSQ_EDIM; }
-    if (n >= 128 && d_damp && !getenv("LSQ_NO_MFMA")) {
-        // C2 scale: MFMA SYRK + blocked Cholesky + blocked solves (lsq_dense_mfma.hip)
+    const char *mn_env = getenv("LSQ_CHOL_MIN_N");
+    if (n >= (mn_env ? atoi(mn_env) : 32) && d_damp && !getenv("LSQ_NO_MFMA")) {
+        // MFMA SYRK + blocked Cholesky + pipelined solves (lsq_dense_mfma.hip); measured crossover against the
+        // single-workgroup kernel: 200 x 16 0.15 vs 0.11 ms, 300 x 32 0.15 vs 0.18, 500 x 64 0.16 vs 0.32, 2000 x 127 0.24 vs 0.93
         LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
         LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x));
         int info = 0;
@@ -1169,13 +1171,6 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
             for (int x = 0; x < K; ++x)       // (constant trip counts: the unroller must not depend on r)
                 if (x > r) sm[2 * (x - r)] = v * pv[x][0];
             sm[2 * (K - r)] = v * a[0];
-            if (t == c) {
-                sat[1] = pv[r][0];
-#pragma unroll
-                for (int x = 0; x < K; ++x)
-                    if (x > r) sat[2 * (x - r) + 1] = pv[x][0];
-                sat[2 * (K - r) + 1] = a[0];
-            }
         }
 #pragma unroll
         for (int q = 1; q < RPT; ++q) {
@@ -1189,11 +1184,18 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
 #pragma unroll
         for (int e = 0; e < NS; e += 2)
             if (e < NSr) sm[e] = wave_allsum(sm[e]);
-        __syncthreads();                             // (the previous round's readers are done)
+        __syncthreads();                             // (the previous round's readers of sh, sx and sat are done)
         if (lane == 0) {
 #pragma unroll
             for (int e = 0; e < NS; e += 2)
                 if (e < NSr) sh[wv][e] = sm[e];
+        }
+        if (t == c) {                                // the owner of row c (slab 0, thread r)
+            sat[1] = pv[r][0];
+#pragma unroll
+            for (int x = 0; x < K; ++x)
+                if (x > r) sat[2 * (x - r) + 1] = pv[x][0];
+            sat[2 * (K - r) + 1] = a[0];
         }
         __syncthreads();
         static_assert(NW <= 16, "one 16-lane row sums the wave partials");

@@ -415,6 +415,39 @@ def test_ldiv_qr_panel_variants(ctx, m, coop, monkeypatch):
         assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12), (m, coop, pivot, "second solve")
 
 
+@pytest.mark.parametrize("m,n,rank,solver", [(700, 200, 1, "qr"), (3000, 130, 130, "qr"), (9000, 200, 200, "qr"),
+                                             (700, 200, 200, "chol"), (3000, 500, 500, "chol")])
+def test_dense_solves_are_repeatable(ctx, m, n, rank, solver, monkeypatch):
+    """Every reduction of the dense factorisations runs in a fixed order (block reductions, slab exchanges,
+    split-K slices, pipelined block solves), so repeated solves must agree BIT FOR BIT -- which also makes this
+    the detector for races between workgroups or between the rounds of a panel launch (an unsynchronised
+    hand-off shows up as a result that changes from run to run)."""
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n)) if rank < n else rng.standard_normal((m, n))
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    cases = [()] if solver == "chol" else [("LSQ_QR_TWO_STAGE",), ("LSQ_QR_TWO_STAGE", "LSQ_QR_ALWAYS_PIVOT")]
+    for envs in cases:
+        for env in envs:
+            monkeypatch.setenv(env, "1")
+        first = None
+        for rep in range(12):
+            if solver == "chol":
+                sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+                sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+            else:
+                sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+                sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+            x = dxo.get()
+            if first is None:
+                first = x
+            assert np.array_equal(x, first), (envs, rep, np.abs(x - first).max())
+        for env in envs:
+            monkeypatch.delenv(env)
+
+
 @pytest.mark.parametrize("cond,certified", [(1e2, True), (1e6, True), (1e11, True), (1e12, False)])
 def test_ldiv_qr_certificate_decision(ctx, cond, certified, monkeypatch):
     """The full-rank certificate (||R||_F ||inv(R)||_F * rcond * 16 <= 1) may only skip the pivoted sweep when
