@@ -257,11 +257,12 @@ def dense_secondary(ctx, lsq):
                 sv.ldiv_(x, y)
             ctx.sync()
         go()
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        times = []
+        for _ in range(5):          # median of 5: one stray host/runtime hiccup must not colour the figure
+            t0 = time.perf_counter()
             go()
-        gpu_ms = (time.perf_counter() - t0) / reps * 1e3
+            times.append((time.perf_counter() - t0) * 1e3)
+        gpu_ms = sorted(times)[len(times) // 2]
         t0 = time.perf_counter()
         if for_lm:
             ref = np.linalg.solve(A.T @ A + 0.1 * np.eye(n), A.T @ yh)
@@ -280,13 +281,16 @@ def dense_secondary(ctx, lsq):
         pr = lsq.synthetic.TanhProblem(m, n, sparse=False, seed=lsq.synthetic.BASE_SEED, ctx=ctx)
         pr.reset()
         pr.optimize(opt, sol, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=2, fetch_x=False)   # warm-up
-        pr.reset()
         k = 6
-        t0 = time.perf_counter()
-        r = pr.optimize(opt, sol, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, fetch_x=False)
-        ctx.sync()
-        out[name] = {"outer_iteration_ms": (time.perf_counter() - t0) / max(r.iterations, 1) * 1e3,
-                     "iterations": r.iterations, "ssr": r.ssr}
+        best = None
+        for _ in range(3):          # best of 3 identical runs (same trajectory every time)
+            pr.reset()
+            t0 = time.perf_counter()
+            r = pr.optimize(opt, sol, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, fetch_x=False)
+            ctx.sync()
+            ms = (time.perf_counter() - t0) / max(r.iterations, 1) * 1e3
+            best = ms if best is None else min(best, ms)
+        out[name] = {"outer_iteration_ms": best, "iterations": r.iterations, "ssr": r.ssr}
         pr.close()
     return out
 
