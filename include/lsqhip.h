@@ -144,6 +144,10 @@ int lsq_solver_info(const lsq_solver *s, int *lsmr_iter, int *lsmr_istop, int *q
  * 2 blocked unpivoted QR + pivoted sweep on R,  3 blocked unpivoted QR + full-rank certificate
  * (||R||_F ||inv(R)||_F * rcond * 16 <= 1 proves xGELSY's rank = n; no pivoting needed) */
 int lsq_solver_qr_path(const lsq_solver *s, int *path);
+/* the same for Cholesky() (dense_cholesky.jl:29-59):  0 none yet, 1 one-workgroup kernel (dpotf2 / pivoted dpstf2),
+ * 2 blocked unpivoted factorisation (LM: J'J + damp),  3 blocked unpivoted factorisation + full-rank certificate
+ * (Dogleg: 1 / ||inv(U)||_F^2 > 16 n eps max diag proves that cholesky!(.., Val(true)) would not stop early) */
+int lsq_solver_chol_path(const lsq_solver *s, int *path);
 
 /* ---- whole trust-region loop on device buffers (host control, device arrays) ---- */
 /* f!(out, x) and g!(J, x) on DEVICE pointers; g writes lsq_mat_values(J) (the library refreshes

@@ -431,8 +431,11 @@ class AllocatedSolver:
         check(lib().lsq_solver_info(self.h, C.byref(it), C.byref(st), C.byref(rk)))
         path = C.c_int(0)
         check(lib().lsq_solver_qr_path(self.h, C.byref(path)))
+        cpath = C.c_int(0)
+        check(lib().lsq_solver_chol_path(self.h, C.byref(cpath)))
         return dict(lsmr_iter=it.value, lsmr_istop=st.value, qr_rank=rk.value,
-                    qr_path={0: None, 1: "one-stage", 2: "two-stage-pivoted", 3: "two-stage-certified"}[path.value])
+                    qr_path={0: None, 1: "one-stage", 2: "two-stage-pivoted", 3: "two-stage-certified"}[path.value],
+                    chol_path={0: None, 1: "one-workgroup", 2: "blocked", 3: "blocked-certified"}[cpath.value])
 
     def free(self):
         if self.h:

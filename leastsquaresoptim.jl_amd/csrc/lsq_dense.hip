@@ -12,7 +12,9 @@
 #include "lsq_solver.h"
 #include "lsq_spmv.h"
 
-int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x);  // lsq_dense_mfma.hip
+int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax);
+int lsq_cholesky_blocked_solve(lsq_solver *s, int n, double *d_x);
+int lsq_tri_inv_fro2(lsq_solver *s, const double *U, int n, double *fro2_inv);  // lsq_dense_mfma.hip
 
 // ---------------------------------------------------------------------------------------------
 // generic dense products
@@ -809,7 +811,39 @@ void lsq_dense_solver_free(lsq_solver *s) {
     hipFree(s->d_qr); hipFree(s->d_qu); hipFree(s->d_T);
     if (s->qr2 && s->qr2_free) s->qr2_free(s->qr2);
     if (s->tripipe && s->tripipe_free) s->tripipe_free(s->tripipe);
+    hipFree(s->tri_X); hipFree(s->tri_T); hipFree(s->tri_fro);
+    if (s->tri_hfro) hipHostFree(s->tri_hfro);
     s->qr2 = nullptr;
+}
+
+// Dogleg's solver is the PIVOTED factorisation cholesky!(Symmetric(J'J), Val(true)) (dense_cholesky.jl:33; tol = 0,
+// check = true): dpstrf picks the largest remaining diagonal entry as pivot and gives up (RankDeficientException)
+// when that pivot is not positive.  Every such pivot is a diagonal entry of a Schur complement, hence
+// >= lambda_min(J'J).  So if lambda_min(J'J) exceeds the rounding error a factorisation can commit
+// (16 n eps max_j (J'J)_jj, generous), no pivot can fail: the reference returns the unique solution of the
+// normal equations -- which the unpivoted blocked factorisation J'J = U'U delivers as well.
+// lambda_min(J'J) = 1 / ||inv(U)||_2^2 >= 1 / ||inv(U)||_F^2, from the explicit inverse of U (the machinery of
+// the QR certificate).  Returns true when the solve was done here (x in d_x, *rc = status); false: the caller runs
+// the pivoted single-workgroup kernel, which also produces the reference's exception on a deficient matrix.
+static bool chol_certified(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_x, int *rc) {
+    const int n = J->n;
+    *rc = LSQ_OK;
+    auto fail = [&](int code) { *rc = code; return true; };
+    if (lsq_cholesky_blocked(s, J, nullptr, nullptr, s->d_work) != LSQ_OK) return fail(LSQ_EHIP);
+    double fro2 = 0.0;
+    if (lsq_tri_inv_fro2(s, s->d_chol, n, &fro2) != LSQ_OK) return fail(LSQ_EHIP);   // (synchronises the stream)
+    int info = 0;
+    double dmax = 0.0;
+    if (hipMemcpy(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&dmax, s->d_work, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(LSQ_EHIP);
+    const bool ok = info == 0 && std::isfinite(fro2) && fro2 > 0.0 && std::isfinite(dmax) &&
+                    1.0 / fro2 > 16.0 * n * DBL_EPSILON * dmax;
+    if (!ok) return false;
+    if (lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x) != LSQ_OK) return fail(LSQ_EHIP);   // mul!(x, J', y)
+    if (lsq_cholesky_blocked_solve(s, n, d_x) != LSQ_OK) return fail(LSQ_EHIP);
+    s->last_chol_path = 3;
+    return true;
 }
 
 // dense_cholesky.jl:29-35 (d_damp == nullptr: pivoted) and :43-59 (damped, unpivoted)
@@ -822,11 +856,13 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
     }
     if (n != s->n || m != s->m) { lsq_set_error("cholesky: size mismatch"); return LSQ_EDIM; }
     const char *mn_env = getenv("LSQ_CHOL_MIN_N");
+    int rc_cert = LSQ_OK;
     if (n >= (mn_env ? atoi(mn_env) : 32) && d_damp && !getenv("LSQ_NO_MFMA")) {
         // MFMA SYRK + blocked Cholesky + pipelined solves (lsq_dense_mfma.hip); measured crossover against the
         // single-workgroup kernel: 200 x 16 0.15 vs 0.11 ms, 300 x 32 0.15 vs 0.18, 500 x 64 0.16 vs 0.32, 2000 x 127 0.24 vs 0.93
         LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
-        LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x));
+        LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr));
+        s->last_chol_path = 2;
         int info = 0;
         LSQ_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         LSQ_HIP(hipStreamSynchronize(c->stream));
@@ -834,7 +870,14 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
             lsq_set_error("PosDefException: matrix is not positive definite; Cholesky failed at %d", info);
             return LSQ_ENOTPD;
         }
+    } else if (n >= (mn_env ? atoi(mn_env) : 32) && !d_damp && !getenv("LSQ_NO_MFMA") && !getenv("LSQ_CHOL_ALWAYS_PIVOT") &&
+               chol_certified(s, J, d_y, d_x, &rc_cert)) {
+        // Dogleg (dense_cholesky.jl:29-35): the unpivoted blocked factorisation gave the solution and the
+        // certificate proved that cholesky!(.., Val(true)) would not have stopped early (see chol_certified)
+        if (rc_cert != LSQ_OK) return rc_cert;
     } else if (n > 0) {
+        if (rc_cert != LSQ_OK) return rc_cert;
+        s->last_chol_path = 1;
         const int nt = (n + SY_T - 1) / SY_T;
         hipLaunchKernelGGL(k_syrk_upper, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, J->d_dense, m, n,
                            s->d_chol, d_damp);
@@ -2449,6 +2492,33 @@ int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
     hipLaunchKernelGGL(k_tri_bsolve, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, t->z, d_bx, t->slot_b,
                        t->epoch, t->d_err);
     LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+// sum of squares of inv(U) for the n x n upper triangle U (explicit inverse: k_tri_diaginv + k_tri_level levels);
+// synchronises the stream.  NaN / Inf when U is singular.
+int lsq_tri_inv_fro2(lsq_solver *s, const double *U, int n, double *fro2_inv) {
+    lsq_ctx *c = s->ctx;
+    constexpr int FRO_BLOCKS = 256;
+    if (!s->tri_X) {
+        LSQ_HIP(hipMalloc(&s->tri_X, ((size_t)n * n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->tri_T, ((size_t)n * n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&s->tri_fro, 2 * FRO_BLOCKS * sizeof(double)));
+        LSQ_HIP(hipHostMalloc(&s->tri_hfro, 2 * FRO_BLOCKS * sizeof(double)));
+    }
+    hipLaunchKernelGGL(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, U, n, s->tri_X, n, (size_t)64 * n + 64);
+    for (long long sz = 64; sz < n; sz *= 2) {
+        const int sb = (int)sz, npairs = (int)((n + 2 * sz - 1) / (2 * sz)), tps = sb / 64;
+        const int grid = npairs * tps * tps;
+        hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, U, s->tri_X, s->tri_T, n, sb, 0);
+        hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, U, s->tri_X, s->tri_T, n, sb, 1);
+    }
+    hipLaunchKernelGGL(k_tri_fro, dim3(FRO_BLOCKS), dim3(256), 0, c->stream, U, s->tri_X, n, s->tri_fro);
+    LSQ_HIP(hipMemcpyAsync(s->tri_hfro, s->tri_fro, 2 * FRO_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    double fx = 0.0;
+    for (int b = 0; b < FRO_BLOCKS; ++b) fx += s->tri_hfro[2 * b + 1];
+    *fro2_inv = fx;
     return LSQ_OK;
 }
 

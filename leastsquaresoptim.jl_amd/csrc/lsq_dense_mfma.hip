@@ -565,8 +565,19 @@ k_chol_trsv(const double *__restrict__ U, int n, double *__restrict__ b) {
     }
 }
 
-// dense_cholesky.jl:43-59 for n >= 128: returns LSQ_ENOTPD through *info like the small kernel
-int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x) {
+// largest diagonal entry of the n x n matrix C (one workgroup): the reference point of the full-rank certificate
+__global__ void __launch_bounds__(256)
+k_diag_max(const double *__restrict__ C, int n, double *__restrict__ out) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) v = fmax(v, C[(size_t)j * n + j]);
+    v = block_max<256>(v, sh);
+    if (threadIdx.x == 0) *out = v;
+}
+
+// dense_cholesky.jl:43-59: returns LSQ_ENOTPD through *info like the small kernel.  d_x == nullptr: factor only
+// (the caller decides about the solves); d_dmax != nullptr: also max_j (J'J + damp)_jj before the factorisation.
+int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax) {
     lsq_ctx *c = s->ctx;
     const int m = J->m, n = J->n;
     const int nt = (n + MT - 1) / MT, ntiles = nt * (nt + 1) / 2;
@@ -582,6 +593,7 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices), dim3(256), 0, c->stream, J->d_dense, m, m, n, 0, kslices,
                        s->d_T, (double *)nullptr, 0);
     hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
+    if (d_dmax) hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);
     // parking space for the factored diagonal blocks (k_chol_panel16): the tail of the SYRK slice buffer is free by now
     bool merged = false;
     double *Ds = s->d_Ds;
@@ -610,7 +622,17 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     if (merged)
         hipLaunchKernelGGL(k_chol_diag_restore, dim3((n + NB - 1) / NB), dim3(256), 0, c->stream, s->d_chol, n, Ds,
                            (const int *)s->d_info);
+    if (!d_x) { LSQ_HIP(hipGetLastError()); return LSQ_OK; }
     // U'z = b, U x = z: pipelined over the 64-blocks on several CUs; the single-workgroup kernel otherwise
+    if (lsq_tri_chol_solve(s, s->d_chol, n, d_x) != LSQ_OK)
+        hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+// the two triangular solves on an already factored s->d_chol (b overwritten by x)
+int lsq_cholesky_blocked_solve(lsq_solver *s, int n, double *d_x) {
+    lsq_ctx *c = s->ctx;
     if (lsq_tri_chol_solve(s, s->d_chol, n, d_x) != LSQ_OK)
         hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
     LSQ_HIP(hipGetLastError());

@@ -95,6 +95,12 @@ extern "C" int lsq_solver_qr_path(const lsq_solver *s, int *path) {
     return LSQ_OK;
 }
 
+extern "C" int lsq_solver_chol_path(const lsq_solver *s, int *path) {
+    if (!s || !path) { lsq_set_error("lsq_solver_chol_path: null argument"); return LSQ_EARG; }
+    *path = s->last_chol_path;
+    return LSQ_OK;
+}
+
 extern "C" int lsq_solver_info(const lsq_solver *s, int *iter, int *istop, int *rank) {
     if (iter) *iter = s->last_iter;
     if (istop) *istop = s->last_istop;

@@ -56,6 +56,8 @@ struct lsq_solver {
     void (*qr2_free)(void *) = nullptr;
     void *tripipe = nullptr;        // pipelined triangular solves of the blocked Cholesky (lsq_dense.hip)
     void (*tripipe_free)(void *) = nullptr;
+    double *tri_X = nullptr, *tri_T = nullptr, *tri_fro = nullptr, *tri_hfro = nullptr;   // explicit inverse of the Cholesky factor (Dogleg certificate)
+    int last_chol_path = 0;         // lsq_solver_chol_path
 };
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx);
 

@@ -307,6 +307,47 @@ def test_ldiv_cholesky(ctx, n):
     assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("cond,certified", [(1e1, True), (1e4, True), (1e7, False)])
+def test_ldiv_cholesky_dogleg_certificate(ctx, cond, certified):
+    """Dogleg's Cholesky() is the pivoted cholesky!(Symmetric(J'J), Val(true)) (dense_cholesky.jl:33).  The blocked
+    unpivoted factorisation may replace it only when 1/||inv(U)||_F^2 > 16 n eps max diag(J'J) proves that no
+    pivot of dpstrf can fail; otherwise the pivoted kernel runs.  Singular values of J graded down to 1/cond
+    (cond(J'J) = cond^2): certified at 1e1 and 1e4, not at 1e7 -- the oracle's pivoted solve is matched in
+    every case; a duplicated column must still raise RankDeficientException through the fallback."""
+    m, n = 400, 96
+    rng = np.random.default_rng(int(np.log10(cond)) + 5)
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    D = (U * np.logspace(0, -np.log10(cond), n)) @ V.T
+    y = rng.standard_normal(m)
+    J = lsq.DeviceMatrix(ctx, D)
+    dxo = lsq.DeviceVector(ctx, n)
+    sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=False)
+    sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+    assert sv.info()["chol_path"] == ("blocked-certified" if certified else "one-workgroup")
+    st, xr, _ = O.ldiv(O.CHOLESKY, O.Mat(dense=D), y)
+    tol = max(1e-9, 100 * cond * cond * np.finfo(float).eps)
+    assert np.linalg.norm(dxo.get() - xr) <= tol * np.linalg.norm(xr)
+    # an exactly zero column gives an exactly zero pivot: dpstrf (tol = 0) stops, and so must the fallback
+    D2 = D.copy()
+    D2[:, 40] = 0.0
+    assert O.ldiv(O.CHOLESKY, O.Mat(dense=D2), y)[0] != 0
+    sv2 = lsq.AllocatedSolver(lsq.DeviceMatrix(ctx, D2), lsq.Cholesky(), for_lm=False)
+    with pytest.raises(lsq.RankDeficientException):
+        sv2.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+    assert sv2.info()["chol_path"] == "one-workgroup"
+    # a duplicated column leaves a pivot of rounding noise: with tol = 0 the reference only stops if the noise
+    # happens to be non-positive -- the certificate must refuse either way, the outcome is the pivoted kernel's
+    D3 = D.copy()
+    D3[:, 40] = D3[:, 7]
+    sv3 = lsq.AllocatedSolver(lsq.DeviceMatrix(ctx, D3), lsq.Cholesky(), for_lm=False)
+    try:
+        sv3.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+    except lsq.RankDeficientException:
+        pass
+    assert sv3.info()["chol_path"] == "one-workgroup"
+
+
 def test_cholesky_failures(ctx):
     rng = np.random.default_rng(33)
     D = rng.standard_normal((30, 6))
