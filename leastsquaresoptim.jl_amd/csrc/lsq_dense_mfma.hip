@@ -45,19 +45,28 @@ k_syrk_mfma(const double *__restrict__ A, int lda, int krows, int ncols, int col
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
     const int lc = tid >> 2, lk = (tid & 3) * 8;        // loader: column lc (0..63), 8 consecutive k
-    for (int k0 = kb; k0 < ke; k0 += KC) {
-        {
-            const int ci = i0 + lc, cj = j0 + lc;
-            const double *pa = A + (size_t)(col0 + ci) * lda + k0 + lk;
-            const double *pb = A + (size_t)(col0 + cj) * lda + k0 + lk;
+    const int ci = i0 + lc, cj = j0 + lc;
+    const double *pa0 = A + (size_t)(col0 + min(ci, ncols - 1)) * lda + lk;
+    const double *pb0 = A + (size_t)(col0 + min(cj, ncols - 1)) * lda + lk;
+    // the next k-slab is fetched into registers while the MFMAs of the current one run
+    double ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const bool kin = (k0 + lk + q) < ke;
-                sA[lc * KS + lk + q] = (kin && ci < ncols) ? pa[q] : 0.0;
-                sB[lc * KS + lk + q] = (kin && cj < ncols) ? pb[q] : 0.0;
-            }
+        for (int q = 0; q < 8; ++q) {
+            const bool kin = (k0 + lk + q) < ke;
+            ra[q] = (kin && ci < ncols) ? pa0[k0 + q] : 0.0;
+            rb[q] = (kin && cj < ncols) ? pb0[k0 + q] : 0.0;
+        }
+    };
+    if (kb < ke) fetch(kb);
+    for (int k0 = kb; k0 < ke; k0 += KC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sA[lc * KS + lk + q] = ra[q];
+            sB[lc * KS + lk + q] = rb[q];
         }
         __syncthreads();
+        if (k0 + KC < ke) fetch(k0 + KC);
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
             const int ko = kk + (lane >> 4);
