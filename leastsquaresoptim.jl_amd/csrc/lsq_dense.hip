@@ -2050,15 +2050,25 @@ k_tri_level(const double *__restrict__ R, double *__restrict__ X, double *__rest
     const int lc = tid >> 2, lk = (tid & 3) * 8;             // B staging: 8 consecutive k's of one column
     const int m0 = tm * 64, c0 = tn * 64;
     const bool cin = c0 + lc < N2;
-    for (int k0 = kb; k0 < ke; k0 += Q2_KC) {
+    double ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int ka = k0 + akq + q;
-            sA[am * Q2_KS + akq + q] = ka < ke ? Ap[(size_t)ka * n + m0 + am] : 0.0;
+            ra[q] = ka < ke ? Ap[(size_t)ka * n + m0 + am] : 0.0;
             const int k = k0 + lk + q;
-            sB[lc * Q2_KS + lk + q] = (cin && k < ke) ? Bp[(size_t)(c0 + lc) * n + k] : 0.0;
+            rb[q] = (cin && k < ke) ? Bp[(size_t)(c0 + lc) * n + k] : 0.0;
+        }
+    };
+    if (kb < ke) fetch(kb);
+    for (int k0 = kb; k0 < ke; k0 += Q2_KC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sA[am * Q2_KS + akq + q] = ra[q];
+            sB[lc * Q2_KS + lk + q] = rb[q];
         }
         __syncthreads();
+        if (k0 + Q2_KC < ke) fetch(k0 + Q2_KC);
 #pragma unroll
         for (int kk = 0; kk < Q2_KC; kk += 4) {
             const int ko = kk + (lane >> 4);
