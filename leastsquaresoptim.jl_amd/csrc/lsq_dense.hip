@@ -1402,13 +1402,24 @@ k_qr1_vtb(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, 
     const double *pacol = Vb + (size_t)lc * ldv;
     // the next 32-row slab is fetched into registers while the MFMAs of the current one run
     double ra[8], rb[8];
+    const double *pb = pbcol ? pbcol : Vb;     // (a dummy column for tiles past the last one: fetched, then zeroed)
+    const bool bok = pbcol != nullptr;
     auto fetch = [&](int k0) {
+        if (k0 + Q2_KC <= ke) {                // full slab: unconditional fetches, nothing to branch on
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = k0 + lk + q;
-            const bool kin = k < ke;
-            ra[q] = kin ? pacol[k] : 0.0;
-            rb[q] = (kin && pbcol) ? pbcol[k] : 0.0;
+            for (int q = 0; q < 8; ++q) {
+                ra[q] = pacol[k0 + lk + q];
+                const double y = pb[k0 + lk + q];
+                rb[q] = bok ? y : 0.0;
+            }
+        } else {                               // the ragged last slab: clamped addresses, zeroed by selection
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + lk + q, ks = min(k, ke - 1);
+                const double x = pacol[ks], y = pb[ks];
+                ra[q] = k < ke ? x : 0.0;
+                rb[q] = (k < ke && bok) ? y : 0.0;
+            }
         }
     };
     if (kb < ke) fetch(kb);
@@ -1614,21 +1625,38 @@ k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int
     // avoided by rotation instead of padding: V column k is stored rotated by 16*(k&3) rows (the four
     // k-groups of an MFMA operand read then hit four different 128-byte segments), W2 column j by
     // 2*(j&15) entries (the 16 columns of an operand read hit 16 different bank pairs)
-    for (int e = tid; e < Q2_NB * Q2_NB; e += 256) {
-        const int k = e / Q2_NB, r = e % Q2_NB;        // V column k, row r0 + r
-        sV[k * Q2_NB + ((r + 16 * (k & 3)) & 63)] = (r0 + r < rows) ? Vb[(size_t)k * ldv + r0 + r] : 0.0;
+    if (r0 + Q2_NB <= rows) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = w + 4 * q;                       // V column k, row r0 + lane
+            sV[k * Q2_NB + ((lane + 16 * (k & 3)) & 63)] = Vb[(size_t)k * ldv + r0 + lane];
+        }
+    } else {
+        for (int e = tid; e < Q2_NB * Q2_NB; e += 256) {
+            const int k = e / Q2_NB, r = e % Q2_NB;        // V column k, row r0 + r
+            sV[k * Q2_NB + ((r + 16 * (k & 3)) & 63)] = (r0 + r < rows) ? Vb[(size_t)k * ldv + r0 + r] : 0.0;
+        }
     }
     // tile t+1's operands (the A2 tile, row-contiguous: thread = row, 16 columns each; the W2 tile) are fetched
     // into registers while tile t is multiplied and written back: latency hidden, read-modify-write coalesced
     double at[16], wt[16], atn[16];
     auto fetch = [&](int j0, double *ta, double *tw2) {
+        if (r0 + Q2_NB <= rows && j0 + Q2_NB < ncols) {      // interior tile of A2: unconditional fetches
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int cidx = j0 + w * 16 + q;
-            const int ac = cend + cidx;
-            ta[q] = (rin && cidx < ncols) ? ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] : 0.0;
-            const int e = tid + q * 256, cw = e / Q2_NB, kk = e % Q2_NB;     // W2 column j0 + cw, entry kk
-            tw2[q] = (j0 + cw < ncols) ? W2[(size_t)(j0 + cw) * Q2_NB + kk] : 0.0;
+            for (int q = 0; q < 16; ++q) {
+                ta[q] = (A + (size_t)(cend + j0 + w * 16 + q) * M + c0 + r0)[lane];
+                const int e = tid + q * 256;
+                tw2[q] = W2[(size_t)j0 * Q2_NB + e];                  // (column j0 + e / 64, entry e % 64)
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cidx = j0 + w * 16 + q;
+                const int ac = cend + cidx;
+                ta[q] = (rin && cidx < ncols) ? ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] : 0.0;
+                const int e = tid + q * 256, cw = e / Q2_NB, kk = e % Q2_NB;     // W2 column j0 + cw, entry kk
+                tw2[q] = (j0 + cw < ncols) ? W2[(size_t)(j0 + cw) * Q2_NB + kk] : 0.0;
+            }
         }
     };
     if (cg * Q2_UCT * Q2_NB < ncols) fetch(cg * Q2_UCT * Q2_NB, at, wt);
@@ -1674,12 +1702,20 @@ k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int
                     sW[cidx * CS + row] = acc[a][b][r];
                 }
         __syncthreads();
+        if (r0 + Q2_NB <= rows && j0 + Q2_NB < ncols) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int cl = w * 16 + q, cidx = j0 + cl;
-            if (rin && cidx < ncols) {
-                const int ac = cend + cidx;
-                ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] = at[q] - sW[cl * CS + lane];
+            for (int q = 0; q < 16; ++q) {
+                const int cl = w * 16 + q;
+                (A + (size_t)(cend + j0 + cl) * M + c0 + r0)[lane] = at[q] - sW[cl * CS + lane];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cl = w * 16 + q, cidx = j0 + cl;
+                if (rin && cidx < ncols) {
+                    const int ac = cend + cidx;
+                    ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] = at[q] - sW[cl * CS + lane];
+                }
             }
         }
         __syncthreads();                                 // the product image is consumed before the next W2 tile lands
@@ -2051,13 +2087,23 @@ k_tri_level(const double *__restrict__ R, double *__restrict__ X, double *__rest
     const int m0 = tm * 64, c0 = tn * 64;
     const bool cin = c0 + lc < N2;
     double ra[8], rb[8];
+    const double *bcol = Bp + (size_t)(c0 + (cin ? lc : 0)) * n;
     auto fetch = [&](int k0) {
+        if (k0 + Q2_KC <= ke) {                // full slab: unconditional fetches
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int ka = k0 + akq + q;
-            ra[q] = ka < ke ? Ap[(size_t)ka * n + m0 + am] : 0.0;
-            const int k = k0 + lk + q;
-            rb[q] = (cin && k < ke) ? Bp[(size_t)(c0 + lc) * n + k] : 0.0;
+            for (int q = 0; q < 8; ++q) {
+                ra[q] = Ap[(size_t)(k0 + akq + q) * n + m0 + am];
+                const double y = bcol[k0 + lk + q];
+                rb[q] = cin ? y : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ka = k0 + akq + q;
+                ra[q] = ka < ke ? Ap[(size_t)ka * n + m0 + am] : 0.0;
+                const int k = k0 + lk + q;
+                rb[q] = (cin && k < ke) ? Bp[(size_t)(c0 + lc) * n + k] : 0.0;
+            }
         }
     };
     if (kb < ke) fetch(kb);

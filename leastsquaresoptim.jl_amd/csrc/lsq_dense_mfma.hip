@@ -51,11 +51,20 @@ k_syrk_mfma(const double *__restrict__ A, int lda, int krows, int ncols, int col
     // the next k-slab is fetched into registers while the MFMAs of the current one run
     double ra[8], rb[8];
     auto fetch = [&](int k0) {
+        if (k0 + KC <= ke) {                   // full slab: unconditional fetches (columns past the end are clamped, then zeroed)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool kin = (k0 + lk + q) < ke;
-            ra[q] = (kin && ci < ncols) ? pa0[k0 + q] : 0.0;
-            rb[q] = (kin && cj < ncols) ? pb0[k0 + q] : 0.0;
+            for (int q = 0; q < 8; ++q) {
+                const double x = pa0[k0 + q], y = pb0[k0 + q];
+                ra[q] = ci < ncols ? x : 0.0;
+                rb[q] = cj < ncols ? y : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool kin = (k0 + lk + q) < ke;
+                ra[q] = (kin && ci < ncols) ? pa0[k0 + q] : 0.0;
+                rb[q] = (kin && cj < ncols) ? pb0[k0 + q] : 0.0;
+            }
         }
     };
     if (kb < ke) fetch(kb);
