@@ -54,28 +54,39 @@ __device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, con
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const double p0 = a[u].x * xl[c[u] & 0xffffu], p1 = a[u].y * xl[c[u] >> 16];
-            if (j + 2 * u < len) {
-                sum += p0;
-                if constexpr (SQ) sq += a[u].x * a[u].x;
-            }
-            if (j + 2 * u + 1 < len) {
-                sum += p1;
-                if constexpr (SQ) sq += a[u].y * a[u].y;
+            // every operand is fetched and every sum formed unconditionally; padding is dropped by SELECTION (a
+            // conditional add lets the compiler sink the value fetch into an exec-masked block behind a full
+            // s_waitcnt vmcnt(0) inside this loop).  Same additions in the same order as before.
+            double p0 = a[u].x * xl[c[u] & 0xffffu], p1 = a[u].y * xl[c[u] >> 16];
+            asm volatile("" : "+v"(p0), "+v"(p1));   // (the products exist here, whatever the selections below)
+            const bool in0 = j + 2 * u < len, in1 = j + 2 * u + 1 < len;
+            const double t0 = sum + p0;
+            sum = in0 ? t0 : sum;
+            const double t1 = sum + p1;
+            sum = in1 ? t1 : sum;
+            if constexpr (SQ) {
+                const double q0 = sq + a[u].x * a[u].x;
+                sq = in0 ? q0 : sq;
+                const double q1 = sq + a[u].y * a[u].y;
+                sq = in1 ? q1 : sq;
             }
         }
     }
     for (; j < L; j += 2) {
         const double2 a = *reinterpret_cast<const double2 *>(vp + (size_t)(j / 2) * 128);
         const unsigned c = *reinterpret_cast<const unsigned *>(ip + (size_t)(j / 2) * 128);
-        const double p0 = a.x * xl[c & 0xffffu], p1 = a.y * xl[c >> 16];
-        if (j < len) {
-            sum += p0;
-            if constexpr (SQ) sq += a.x * a.x;
-        }
-        if (j + 1 < len) {
-            sum += p1;
-            if constexpr (SQ) sq += a.y * a.y;
+        double p0 = a.x * xl[c & 0xffffu], p1 = a.y * xl[c >> 16];
+        asm volatile("" : "+v"(p0), "+v"(p1));
+        const bool in0 = j < len, in1 = j + 1 < len;
+        const double t0 = sum + p0;
+        sum = in0 ? t0 : sum;
+        const double t1 = sum + p1;
+        sum = in1 ? t1 : sum;
+        if constexpr (SQ) {
+            const double q0 = sq + a.x * a.x;
+            sq = in0 ? q0 : sq;
+            const double q1 = sq + a.y * a.y;
+            sq = in1 ? q1 : sq;
         }
     }
 }
