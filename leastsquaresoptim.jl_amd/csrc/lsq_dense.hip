@@ -857,7 +857,10 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
     if (n != s->n || m != s->m) { lsq_set_error("cholesky: size mismatch"); return LSQ_EDIM; }
     const char *mn_env = getenv("LSQ_CHOL_MIN_N");
     int rc_cert = LSQ_OK;
-    if (n >= (mn_env ? atoi(mn_env) : 32) && d_damp && !getenv("LSQ_NO_MFMA")) {
+    // blocked path from n = 32, or earlier when the rows make the SYRK the whole cost (tall and thin: 10^6 x 20 takes
+    // 1.8 ms blocked, 90 ms with the one-workgroup kernels; 300 x 8 0.15 vs 0.09)
+    const bool blocked = mn_env ? n >= atoi(mn_env) : (n >= 32 || (n >= 2 && (long long)m * n >= 20000));
+    if (blocked && d_damp && !getenv("LSQ_NO_MFMA")) {
         // MFMA SYRK + blocked Cholesky + pipelined solves (lsq_dense_mfma.hip); measured crossover against the
         // single-workgroup kernel: 200 x 16 0.15 vs 0.11 ms, 300 x 32 0.15 vs 0.18, 500 x 64 0.16 vs 0.32, 2000 x 127 0.24 vs 0.93
         LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
@@ -870,7 +873,7 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
             lsq_set_error("PosDefException: matrix is not positive definite; Cholesky failed at %d", info);
             return LSQ_ENOTPD;
         }
-    } else if (n >= (mn_env ? atoi(mn_env) : 32) && !d_damp && !getenv("LSQ_NO_MFMA") && !getenv("LSQ_CHOL_ALWAYS_PIVOT") &&
+    } else if (blocked && !d_damp && !getenv("LSQ_NO_MFMA") && !getenv("LSQ_CHOL_ALWAYS_PIVOT") &&
                chol_certified(s, J, d_y, d_x, &rc_cert)) {
         // Dogleg (dense_cholesky.jl:29-35): the unpivoted blocked factorisation gave the solution and the
         // certificate proved that cholesky!(.., Val(true)) would not have stopped early (see chol_certified)
@@ -1155,7 +1158,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live pivots, <= K */, double *__restrict__ tau,
                  double *__restrict__ beta_out, double *__restrict__ scale_out, int G /* groups = target columns (>= 1) */,
                  unsigned long long *__restrict__ xslot, unsigned long long epoch,
-                 int *__restrict__ err, double *__restrict__ Pn /* side panel: column (col - c0) * M */, int c0) {
+                 int *__restrict__ err, double *__restrict__ Pn /* side panel: column (col - c0) * M */, int c0,
+                 double *__restrict__ rhs_col /* last panel: the right-hand side rides along as target column "cend" */) {
     constexpr int NW = NT / 64;
     constexpr int NS = 2 * (K + 1);
     __shared__ double sh[NW][NS];
@@ -1163,14 +1167,18 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     __shared__ double sat[NS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int g = (int)blockIdx.x, sidx = 0;
-    if (S > 1) {
+    if (S > 1 && S < 64) {           // members 8 apart: one XCD; 8 * S workgroups must be resident together
         const int kq = (int)blockIdx.x >> 3;
         sidx = kq % S;
         g = (kq / S) * 8 + ((int)blockIdx.x & 7);
         if (g >= G) return;
+    } else if (S >= 64) {            // members consecutive (all XCDs): a group spans S <= 256 indices (the device holds 512)
+        g = (int)blockIdx.x / S;
+        sidx = (int)blockIdx.x % S;
     }
     const int j = i + kk + g;
-    const bool has_col = j < cend;
+    const bool is_rhs = rhs_col != nullptr && j == cend;
+    const bool has_col = j < cend || is_rhs;
     // one buffer descriptor per column (scalar base, byte count M*8): every fetch and store is descriptor +
     // ONE shared 32-bit VGPR offset + a scalar offset; rows beyond M read as zero and their stores are dropped by
     // the bounds check, and a dead column (ragged last launch, no target) gets an empty descriptor
@@ -1190,7 +1198,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         }
     }
     const __amdgpu_buffer_rsrc_t rj =
-        __builtin_amdgcn_make_buffer_rsrc(A + (size_t)(has_col ? j : i) * M, 0, has_col ? colbytes : 0u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(is_rhs ? rhs_col : A + (size_t)(has_col ? j : i) * M, 0, has_col ? colbytes : 0u, 0x00020000);
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rj, tb, q * NT * 8, 0);
@@ -1250,7 +1258,6 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
             for (int e = 1; e < NS; e += 2)
                 if (e < NSr) sm[e] = sat[e];
         } else {
-            static_assert(S * NS <= NT, "one thread per exchanged value");
             // flag-in-data exchange (the low-latency protocol of the collectives libraries): every 64-bit word
             // carries 32 bits of payload and the 32-bit epoch, so a reader that sees the epoch has the payload --
             // one store and one load on the critical path, no fences, no separate flag.  Sums: every slab publishes
@@ -1266,8 +1273,8 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
                 __hip_atomic_store(mine, hi | (unsigned)__double2loint(val), RLX_AGENT);
                 __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(val), RLX_AGENT);
             }
-            if (tid < S * NS) {
-                const int sp = tid / NS, e = tid % NS;
+            for (int idx = tid; idx < S * NS; idx += NT) {
+                const int sp = idx / NS, e = idx % NS;
                 if (e < NSr && ((e & 1) == 0 || sp == 0)) {
                     const unsigned long long *f = xslot + ((((size_t)g * S + sp) * K + r) * NS + e) * 2;
                     unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
@@ -1288,8 +1295,8 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
                     if (e & 1) sm[e] = sx[0][e];
                     else {
                         double tot = 0.0;
-#pragma unroll
-                        for (int sp = 0; sp < S; ++sp) tot += sx[sp][e];
+#pragma unroll 8
+                        for (int sp = 0; sp < S; ++sp) tot += sx[sp][e];   // (fixed order: every member gets the same bits)
                         sm[e] = tot;
                     }
                 }
@@ -1367,6 +1374,19 @@ k_qr1_vbuf(double *__restrict__ A, int M, int c0, int nb, double *__restrict__ V
             }
         }
         Vb[(size_t)cidx * ldv + r] = v;
+    }
+}
+
+// last panel, right-hand side already transformed by the steps: nobody needs V any more, only the panel's part of R --
+// the rows c0 .. c0+nb-1 of the side-panel columns go back to A and beta goes on the diagonal
+__global__ void __launch_bounds__(256)
+k_qr1_fin(double *__restrict__ A, int M, int c0, int nb, const double *__restrict__ beta, const double *__restrict__ Pn, int K) {
+    for (int e = threadIdx.x; e < Q2_NB * Q2_NB; e += 256) {
+        const int r = e % Q2_NB, cidx = e / Q2_NB;
+        if (cidx >= nb || r > cidx || c0 + r >= M) continue;
+        double *pa = A + (size_t)(c0 + cidx) * M + c0 + r;
+        if (r == cidx) *pa = beta[c0 + cidx];
+        else if (Pn && cidx % K != 0 && r >= cidx / K * K) *pa = Pn[(size_t)cidx * M + c0 + r];
     }
 }
 
@@ -2341,7 +2361,7 @@ static bool qr2_applies(int M, int n) {
     if (off || M < n || n < 2) return false;
     // (measured crossover against the one-workgroup / two-launch pivoted kernels: 20 x 5 0.06 vs 0.13 ms,
     //  100 x 20 0.24 vs 0.17, 200 x 50 0.78 vs 0.25, 2000 x 400 10.1 vs 1.7)
-    return force || (n >= 16 && (long long)M * n >= 1600);
+    return force || (n >= 16 && (long long)M * n >= 1600) || (n >= 2 && (long long)M * n >= 20000);   // (tall and thin: 100000 x 10 1.2 vs 8.0 ms)
 }
 
 // factors [A | b] (s->d_qr, s->d_qu) and leaves R2, pivots (jp) and Q'b for k_qrcp_solve(phase 0) in the
@@ -2366,10 +2386,12 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         LSQ_HIP(hipMalloc(&q->vn, (4 * (size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->ice, (2 * (size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->lazy, (2 * (size_t)n + 8) * sizeof(double)));
-        LSQ_HIP(hipMalloc(&q->xslot, (size_t)64 * 8 * 8 * 18 * 2 * sizeof(unsigned long long)));
+        const size_t smax = M > 64 * 32 * 256 ? 256 : M > 8 * 10 * 256 ? 64 : 8;
+        const size_t xs = (size_t)64 * smax * 8 * 18 * 2 * sizeof(unsigned long long);
+        LSQ_HIP(hipMalloc(&q->xslot, xs));
         LSQ_HIP(hipMalloc(&q->d_err, sizeof(int)));
         LSQ_HIP(hipMalloc(&q->Pn, ((size_t)M * Q2_NB + 32768) * sizeof(double)));
-        LSQ_ZERO(q->xslot, 0, (size_t)64 * 8 * 8 * 18 * 2 * sizeof(unsigned long long));
+        LSQ_ZERO(q->xslot, 0, xs);
         LSQ_ZERO(q->d_err, 0, sizeof(int));
         LSQ_HIP(hipMalloc(&q->colat, (2 * (size_t)n + 8) * sizeof(int)));
         s->qr2 = q;
@@ -2380,6 +2402,9 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
         bool lazy = false;
         int side_k = 0;   // > 0: later pivot columns of a launch sit in the side panel
+        // last panel: b rides through the steps as one more target column, so no block update is left to do
+        const bool ride = cend == n && !getenv("LSQ_QR1_NO_RIDE");
+        bool rode = false;
         auto steps = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(1), dim3(QR_NT), 0, c->stream, A, M, cend, c0, 1, q->tau1);
             for (int i = c0; i + 1 < cend; ++i)
@@ -2395,13 +2420,14 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         const bool want_multi = want_lazy && !getenv("LSQ_QR1_SINGLE");
         auto steps_multi = [&](auto kern, int nt, int K, int S) {
             for (int i = c0; i < cend; i += K) {
-                const int kk = std::min(K, cend - i), G = std::max(1, cend - i - kk);
-                const int grid = S > 1 ? 8 * S * ((G + 7) / 8) : G;
+                const int kk = std::min(K, cend - i), G = std::max(1, cend - i - kk + (ride ? 1 : 0));
+                const int grid = S >= 64 ? G * S : S > 1 ? 8 * S * ((G + 7) / 8) : G;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), 0, c->stream, A, M, cend, i, kk, q->tau1, q->lazy, q->lazy + n, G,
-                                   q->xslot, ++q->epoch, q->d_err, q->Pn, c0);
+                                   q->xslot, ++q->epoch, q->d_err, q->Pn, c0, ride ? rhs : (double *)nullptr);
             }
             lazy = true;
             side_k = K;
+            rode = ride;
         };
         const int prow = M - c0;
         // slabs (S > 1) need every CU of an unpartitioned device; LSQ_QR1_COOP=0 keeps one workgroup per column
@@ -2411,6 +2437,11 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         else if (coop && prow > 2 * 8 * 256 && prow <= 4 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 4>, 256, 4, 4);
         else if (coop && prow > 4 * 8 * 256 && prow <= 8 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 8>, 256, 4, 8);
         else if (coop && prow > 8 * 8 * 256 && prow <= 8 * 10 * 256) steps_multi(k_qr1_step_multi<256, 10, 4, 8>, 256, 4, 8);
+        // tall operands: more slabs (the exchange of a round grows with S; there are few columns to pay it)
+        else if (coop && prow > 8 * 10 * 256 && prow <= 16 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 16>, 256, 4, 16);
+        else if (coop && prow > 16 * 8 * 256 && prow <= 64 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 64>, 256, 4, 64);
+        else if (coop && prow > 64 * 8 * 256 && prow <= 64 * 32 * 256) steps_multi(k_qr1_step_multi<256, 32, 2, 64>, 256, 2, 64);
+        else if (coop && prow > 64 * 32 * 256 && prow <= 256 * 32 * 256) steps_multi(k_qr1_step_multi<256, 32, 2, 256>, 256, 2, 256);
         else if (coop && prow > 8 * 256 && prow <= 2 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 2>, 256, 4, 2);
         else if (want_multi && prow <= 8 * 512) steps_multi(k_qr1_step_multi<512, 8, 4, 1>, 512, 4, 1);
         else if (want_multi && prow <= 8 * 1024) steps_multi(k_qr1_step_multi<512, 16, 4, 1>, 512, 4, 1);
@@ -2423,6 +2454,11 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         else if (M - c0 <= 16 * QR_NT) steps(k_qr1_step_reg<16>);
         else if (M - c0 <= 24 * QR_NT) steps(k_qr1_step_reg<24>);
         else steps(k_qr1_step);
+        if (rode) {
+            hipLaunchKernelGGL(k_qr1_fin, dim3(1), dim3(256), 0, c->stream, A, M, c0, nb, (const double *)q->lazy,
+                               side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
+            continue;
+        }
         // block update of the trailing columns and of b
         const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
         const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;

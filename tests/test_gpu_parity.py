@@ -456,6 +456,34 @@ def test_ldiv_qr_panel_variants(ctx, m, coop, monkeypatch):
         assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12), (m, coop, pivot, "second solve")
 
 
+@pytest.mark.parametrize("m,n", [(30000, 20), (100000, 20), (300000, 12), (1200000, 8), (2200000, 6), (50000, 70)])
+def test_ldiv_qr_tall_thin(ctx, m, n):
+    """Tall, thin operands (the usual shape of a fitting problem: many residuals, few parameters): 16 / 64 / 64 x 4 /
+    256 row slabs per column with the generalised exchange, the right-hand side riding through the last panel's
+    steps as one more target column (no block update at all when n <= 64), one full panel + ragged rider
+    (n = 70).  Oracle = the reference's pivoted-QR solve; repeated solve bit-identical (fixed-order exchange)."""
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y = rng.standard_normal(m)
+    xr, rk, *_ = O.qr_solve(A, y)
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+    sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+    info = sv.info()
+    assert info["qr_rank"] == rk == n and info["qr_path"] == "two-stage-certified"
+    x1 = dxo.get()
+    assert np.allclose(x1, xr, rtol=1e-9, atol=1e-12)
+    sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+    assert np.array_equal(dxo.get(), x1)
+    # LM's stacked operand [J; sqrt(damp)] through the same kernels
+    damp = rng.random(n) + 0.01
+    svd = lsq.AllocatedSolver(J, lsq.QR(), for_lm=True)
+    svd.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+    st, xd, _, _ = O.ldiv(O.QR, O.Mat(dense=A), y, damp)
+    assert np.allclose(dxo.get(), xd, rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("m,n,rank,solver", [(700, 200, 1, "qr"), (3000, 130, 130, "qr"), (9000, 200, 200, "qr"),
                                              (700, 200, 200, "chol"), (3000, 500, 500, "chol")])
 def test_dense_solves_are_repeatable(ctx, m, n, rank, solver, monkeypatch):
