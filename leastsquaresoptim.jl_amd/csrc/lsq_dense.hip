@@ -51,9 +51,30 @@ struct EpiStoreD {
     __device__ void finalize(double) const {}
 };
 
+int lsq_dense_part(lsq_mat *J, int nwin) {
+    const int need = nwin * J->n;
+    if (J->dpart_cap < need) {
+        hipFree(J->d_dpart);
+        J->d_dpart = nullptr;
+        LSQ_HIP(hipMalloc(&J->d_dpart, ((size_t)need + 8) * sizeof(double)));
+        J->dpart_cap = need;
+    }
+    return LSQ_OK;
+}
+
 int lsq_dense_colsumabs2(lsq_mat *J, double *out) {  // utils.jl:139-144
     if (J->n <= 0) return LSQ_OK;
     EpiStoreD e{nullptr, 0, out, nullptr, nullptr};
+    if (const int nwin = lsq_dense_t_windows(J->ctx, J->m, J->n)) {   // few columns: (window, column) blocks + combine
+        LSQ_TRY(lsq_dense_part(J, nwin));
+        const int wrows = ((J->m + nwin - 1) / nwin + 3) / 4 * 4;
+        hipLaunchKernelGGL((k_dense_t_win<true>), dim3(nwin * J->n), dim3(LSQ_NT), 0, J->ctx->stream, J->d_dense, J->m, J->n,
+                           (const double *)nullptr, wrows, J->d_dpart, (const int *)nullptr);
+        const int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
+        hipLaunchKernelGGL((k_combine<EpiStoreD>), dim3(nb), dim3(LSQ_NT), 0, J->ctx->stream, J->d_dpart, J->n, nwin, e, nb);
+        LSQ_HIP(hipGetLastError());
+        return LSQ_OK;
+    }
     int grid = J->n > LSQ_MAX_GRID ? LSQ_MAX_GRID : J->n;
     hipLaunchKernelGGL((k_dense_t<EpiStoreD, true>), dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream,
                        J->d_dense, J->m, J->n, nullptr, e);

@@ -985,6 +985,15 @@ k_scale_cols(int n, const int *__restrict__ colptr, int m_dense, const double *_
         for (long long k = k0 + threadIdx.x; k < k1; k += LSQ_NT) out[k] = A[k] * s;
     }
 }
+// dense J = A diag(1 - tanh(x)^2): block (column j, row chunk)
+__global__ void __launch_bounds__(LSQ_NT)
+k_scale_dense(int m, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ out) {
+    const int j = blockIdx.x;
+    const double t = tanh(x[j]);
+    const double sfac = 1.0 - t * t;
+    const size_t base = (size_t)j * m;
+    for (int i = blockIdx.y * LSQ_NT + threadIdx.x; i < m; i += gridDim.y * LSQ_NT) out[base + i] = A[base + i] * sfac;
+}
 // the CSR mirror: scale by the column of each entry
 __global__ void __launch_bounds__(LSQ_NT)
 k_scale_csr(long long nnz, const int *__restrict__ colidx, const double *__restrict__ A, const double *__restrict__ sfac,
@@ -1145,9 +1154,12 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         }
         J->csr_fresh = true;  // every mirror written directly: no permutation pass needed
     } else {
-        int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
-        hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, (const int *)nullptr, J->m,
-                           md->d_Acsc, x, J->d_dense);
+        // dense columns: every block takes a (column, row chunk) pair, so that a matrix with few columns still fills the chip
+        const long long tot = (long long)J->m * J->n;
+        const int chunks = std::max(1, (int)std::min<long long>((J->m + 4 * LSQ_NT - 1) / (4 * LSQ_NT),
+                                                               std::max<long long>(1, (long long)c->num_cus * 16 / std::max(1, J->n))));
+        if (tot > 0)
+            hipLaunchKernelGGL(k_scale_dense, dim3(J->n, chunks), dim3(LSQ_NT), 0, c->stream, J->m, md->d_Acsc, x, J->d_dense);
     }
     J->version++;
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -491,6 +491,7 @@ extern "C" int lsq_mat_destroy(lsq_mat *J) {
     free_sell(J->scols);
     hipFree(J->d_bmap);
     hipFree(J->d_bpart);
+    hipFree(J->d_dpart);
     hipFree(J->d_optmp);
     hipFree(J->d_colsum);
     delete J;

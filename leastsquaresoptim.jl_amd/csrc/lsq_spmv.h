@@ -700,6 +700,40 @@ __global__ void __launch_bounds__(LSQ_NT) k_dense_t(const double *__restrict__ A
     finish_block(epi, racc, sh);
 }
 
+// The same for a dense matrix with FEW columns (fewer than the device has CUs): one block per column would leave most
+// of the chip idle, so a block takes (row window w, column j) and writes its partial to part[w * n + j]; k_combine
+// adds the windows in index order and runs the caller's epilogue.
+template <bool SQ>
+__global__ void __launch_bounds__(LSQ_NT) k_dense_t_win(const double *__restrict__ A, int m, int n, const double *__restrict__ y,
+                                                         int wrows, double *__restrict__ part, const int *done) {
+    __shared__ double sh[LSQ_NT / 64];
+    if (done && *done) return;
+    const int j = blockIdx.x % n, w = blockIdx.x / n;
+    const int r0 = w * wrows, rows = min(wrows, m - r0);
+    const double *col = A + (size_t)j * m + r0;
+    const double *yy = SQ ? nullptr : y + r0;
+    double a0 = 0.0, a1 = 0.0;
+    int i = threadIdx.x;
+    for (; i + LSQ_NT < rows; i += 2 * LSQ_NT) {
+        double c0 = col[i], c1 = col[i + LSQ_NT];
+        a0 += SQ ? c0 * c0 : c0 * yy[i];
+        a1 += SQ ? c1 * c1 : c1 * yy[i + LSQ_NT];
+    }
+    if (i < rows) {
+        double c0 = col[i];
+        a0 += SQ ? c0 * c0 : c0 * yy[i];
+    }
+    double sum = block_sum<LSQ_NT>(a0 + a1, sh);
+    if (threadIdx.x == 0) part[(size_t)w * n + j] = sum;
+}
+// window count for a dense m x n matrix (0: one block per column is fine)
+static inline int lsq_dense_t_windows(const lsq_ctx *c, int m, int n) {
+    if (n <= 0 || n >= c->num_cus || m < 8192) return 0;
+    int nwin = (4 * c->num_cus + n - 1) / n;
+    nwin = std::min(nwin, std::max(1, m / 2048));
+    return nwin > 1 ? nwin : 0;
+}
+
 // Per-window column sums -> d_bpart[w*n + j] (first pass of the window-blocked J'*y)
 struct EpiPart {
     static constexpr bool REDUCE = false;
@@ -894,6 +928,14 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
         if (grid > 0)
             hipLaunchKernelGGL((k_dense_n<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m,
                                J->n, x, epi, nb);
+    } else if (const int nwin = lsq_dense_t_windows(c, J->m, J->n)) {
+        LSQ_TRY(lsq_dense_part(J, nwin));
+        const int wrows = ((J->m + nwin - 1) / nwin + 3) / 4 * 4;
+        hipLaunchKernelGGL((k_dense_t_win<false>), dim3(nwin * J->n), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
+                           wrows, J->d_dpart, epi.done);
+        int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
+        int grid = cap((long long)nb + epi.extra_blocks);
+        hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dpart, J->n, nwin, epi, nb);
     } else {
         int grid = cap((long long)J->n + epi.extra_blocks);
         if (grid > 0)

@@ -223,8 +223,9 @@ def test_empty_and_tiny_sparse(ctx):
     assert lsq.mul_(lsq.DeviceVector(ctx, 1), J, lsq.DeviceVector(ctx, 1, [3.0])).get()[0] == 6.0
 
 
-@pytest.mark.parametrize("m,n", [(300, 17), (7, 40), (1025, 129)])
+@pytest.mark.parametrize("m,n", [(300, 17), (7, 40), (1025, 129), (20000, 12), (100001, 3), (8192, 255)])
 def test_dense_products(ctx, m, n):
+    """(the last three shapes take the window-blocked J'y / colsumabs2 of matrices with few columns)"""
     rng = np.random.default_rng(m * n)
     D = rng.standard_normal((m, n))
     J = lsq.DeviceMatrix(ctx, D)
@@ -234,6 +235,10 @@ def test_dense_products(ctx, m, n):
     out = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, lsq.DeviceVector(ctx, m, y), 1.0, 0.0, trans=True).get()
     assert np.allclose(out, D.T @ y, rtol=1e-12, atol=1e-12)
     assert np.allclose(lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get(), (D * D).sum(0), rtol=1e-13)
+    out2 = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, lsq.DeviceVector(ctx, m, y), -1.5, 0.25, trans=True).get()
+    assert np.allclose(out2, -1.5 * D.T @ y + 0.25 * x, rtol=1e-12, atol=1e-12)
+    again = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, lsq.DeviceVector(ctx, m, y), -1.5, 0.25, trans=True).get()
+    assert np.array_equal(out2, again)   # fixed-order window sums
 
 
 def test_blas1(ctx):
