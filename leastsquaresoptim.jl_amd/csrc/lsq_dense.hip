@@ -1174,13 +1174,19 @@ __device__ __forceinline__ void qr_static_for(F &&f) {
         f(std::integral_constant<int, N - 1>{});
     }
 }
-template <int NT, int RPT, int K, int S>
+//
+// TSQR = true (tall and thin operands, n <= K): every workgroup is on its own -- its slab of RPT*NT rows of ALL n
+// columns and of b sits in registers, the K rounds factor the slab locally (pivot rows = the slab's first rows, no
+// exchange), and the only thing written is the slab's n x n triangle and the first n entries of its Q'b, stacked
+// for the next level (tsq_S: (slabs*n) x n, tsq_r): ONE pass over the matrix.
+template <int NT, int RPT, int K, int S, bool TSQR = false>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live pivots, <= K */, double *__restrict__ tau,
                  double *__restrict__ beta_out, double *__restrict__ scale_out, int G /* groups = target columns (>= 1) */,
                  unsigned long long *__restrict__ xslot, unsigned long long epoch,
                  int *__restrict__ err, double *__restrict__ Pn /* side panel: column (col - c0) * M */, int c0,
-                 double *__restrict__ rhs_col /* last panel: the right-hand side rides along as target column "cend" */) {
+                 double *__restrict__ rhs_col /* last panel: the right-hand side rides along as target column "cend" */,
+                 double *__restrict__ tsq_S = nullptr, int tsq_ld = 0, double *__restrict__ tsq_r = nullptr) {
     constexpr int NW = NT / 64;
     constexpr int NS = 2 * (K + 1);
     __shared__ double sh[NW][NS];
@@ -1188,7 +1194,10 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     __shared__ double sat[NS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int g = (int)blockIdx.x, sidx = 0;
-    if (S > 1 && S < 64) {           // members 8 apart: one XCD; 8 * S workgroups must be resident together
+    if (TSQR) {                      // one workgroup per slab, a single "group" whose target is b
+        g = 0;
+        sidx = (int)blockIdx.x;
+    } else if (S > 1 && S < 64) {           // members 8 apart: one XCD; 8 * S workgroups must be resident together
         const int kq = (int)blockIdx.x >> 3;
         sidx = kq % S;
         g = (kq / S) * 8 + ((int)blockIdx.x & 7);
@@ -1225,12 +1234,14 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rj, tb, q * NT * 8, 0);
         a[q] = __builtin_bit_cast(double, w);
     }
+    double mybeta = 0.0;   // (TSQR)
     // (rounds as instantiations, not as a loop: the unroller gives up on a body of this size for K >= 6 and the
     // register arrays would land in scratch)
     auto round = [&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
-        const bool live = r < kk;                   // (uniform; a dead round of a ragged last launch is a no-op)
-        const int c = i + r;                        // pivot column == pivot row of this round
+        if (r >= kk) return;                        // (uniform over the whole grid: a dead round of a ragged launch)
+        const bool live = true;
+        const int c = (TSQR ? i + sidx * (RPT * NT) : i) + r;   // pivot row of this round (TSQR: of this slab)
         // sm: [0] v'v  [1] alpha  then per later column x (pivots r+1.., target): v'x and x(c).  The even entries are
         // sums over all rows; the odd ones are single elements of row c, all owned by ONE thread (slab 0, thread r:
         // only element 0 of a thread can sit at or above the pivot row) which hands them out directly
@@ -1274,7 +1285,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
 #pragma unroll
         for (int e = 0; e < NS; e += 2)
             if (e < NSr) sm[e] = row_allsum((lane & 15) < NW ? sh[lane & 15][e] : 0.0);
-        if (S == 1) {
+        if (S == 1 || TSQR) {
 #pragma unroll
             for (int e = 1; e < NS; e += 2)
                 if (e < NSr) sm[e] = sat[e];
@@ -1332,7 +1343,9 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
             sc = 1.0 / (alpha - beta);
         }
         if (!live) ti = 0.0;
-        if (live && g == 0 && sidx == 0 && tid == 0) { tau[c] = ti; beta_out[c] = beta; scale_out[c] = sc; }
+        if (TSQR) {
+            if (tid == r) mybeta = beta;            // R(r, r) of this slab, kept by the owner of the slab's row r
+        } else if (live && g == 0 && sidx == 0 && tid == 0) { tau[c] = ti; beta_out[c] = beta; scale_out[c] = sc; }
         if (ti != 0.0) {
             double tw[K + 1];
 #pragma unroll
@@ -1356,6 +1369,18 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         }
     };
     qr_static_for<K>(round);
+    if (TSQR) {
+        // rows 0 .. kk-1 of the slab: R(r, x) = element 0 of thread r in column x (x > r), beta on the diagonal, zeros
+        // before it; and entry r of the slab's Q'b
+        if (tid < kk) {
+            const size_t row = (size_t)sidx * kk + tid;
+#pragma unroll
+            for (int x = 0; x < K; ++x)
+                if (x < kk) tsq_S[(size_t)x * tsq_ld + row] = x < tid ? 0.0 : (x == tid ? mybeta : pv[x][0]);
+            tsq_r[row] = a[0];
+        }
+        return;
+    }
     if (g == 0) {
         // pivot columns 1 .. kk-1 are final (unscaled) now.  They go to the SIDE panel, not in place: other groups
         // may not have fetched them yet (a launch can be larger than what the device holds at once), and
@@ -2363,6 +2388,7 @@ struct Qr2Work {
     unsigned long long epoch = 0;
     int *d_err = nullptr;                  //   set when a slab wait gave up
     double *Pn = nullptr;                  // stage 1: side panel (M x 64) for the later pivot columns of a launch
+    double *tsS = nullptr, *tsr = nullptr; // TSQR level 0: stacked slab triangles ((slabs*n) x n) and Q'b entries
     int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
     int kslices = 0, M = 0, n = 0;
 };
@@ -2371,7 +2397,7 @@ static void qr2_free(void *p) {
     if (!q) return;
     hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
     hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
-    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn);
+    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn); hipFree(q->tsS); hipFree(q->tsr);
     if (q->h_fro) hipHostFree(q->h_fro);
     delete q;
 }
@@ -2387,7 +2413,46 @@ static bool qr2_applies(int M, int n) {
 
 // factors [A | b] (s->d_qr, s->d_qu) and leaves R2, pivots (jp) and Q'b for k_qrcp_solve(phase 0) in the
 // stage-2 buffers; returns them through the out parameters
+static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, double **R_out, double **rhs_out);
+// tall and thin operands (n <= 32, many rows): level 0 of a TSQR -- one pass over the matrix, every workgroup
+// factors its own slab in registers -- then the stacked triangles go through the regular panel machinery
+static int qr2_tsqr_slab_rows(int n) {   // (K + 1) * RPT doubles of registers per thread, K = n rounded up
+    return 256 * (n <= 8 ? 8 : n <= 12 ? 6 : n <= 16 ? 4 : n <= 24 ? 3 : 2);
+}
+static bool qr2_tsqr_applies(int M, int n) {
+    if (getenv("LSQ_QR_NO_TSQR") || n > 32 || n < 2) return false;
+    return getenv("LSQ_QR_TSQR") ? M >= 2 * qr2_tsqr_slab_rows(n) : M >= 32768;
+}
+static int qr2_workspace(lsq_solver *s, int M, int n);
+
 static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_out) {
+    lsq_ctx *c = s->ctx;
+    LSQ_TRY(qr2_workspace(s, M, n));
+    Qr2Work *q = (Qr2Work *)s->qr2;
+    if (qr2_tsqr_applies(M, n)) {
+        const int L = qr2_tsqr_slab_rows(n), S = lsq_div_up(M, L), Ms = S * n;
+        if (!q->tsS) {
+            LSQ_HIP(hipMalloc(&q->tsS, ((size_t)Ms * n + 32768) * sizeof(double)));
+            LSQ_HIP(hipMalloc(&q->tsr, ((size_t)Ms + 32768) * sizeof(double)));
+        }
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(S), dim3(256), 0, c->stream, s->d_qr, M, n, 0, n, q->tau1, q->lazy, q->lazy + n, 1,
+                               q->xslot, ++q->epoch, q->d_err, q->Pn, 0, s->d_qu, q->tsS, Ms, q->tsr);
+        };
+        if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, true>);
+        else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, true>);
+        else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, true>);
+        else if (n <= 20) go(k_qr1_step_multi<256, 3, 20, 1, true>);
+        else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, true>);
+        else if (n <= 28) go(k_qr1_step_multi<256, 2, 28, 1, true>);
+        else go(k_qr1_step_multi<256, 2, 32, 1, true>);
+        LSQ_HIP(hipGetLastError());
+        return qr2_factor_core(s, q->tsS, q->tsr, Ms, n, R_out, rhs_out);
+    }
+    return qr2_factor_core(s, s->d_qr, s->d_qu, M, n, R_out, rhs_out);
+}
+
+static int qr2_workspace(lsq_solver *s, int M, int n) {
     lsq_ctx *c = s->ctx;
     Qr2Work *q = (Qr2Work *)s->qr2;
     if (!q || q->M != M || q->n != n) {
@@ -2418,7 +2483,13 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
         s->qr2 = q;
         s->qr2_free = qr2_free;
     }
-    double *A = s->d_qr, *rhs = s->d_qu;
+    return LSQ_OK;
+}
+
+// the factorisation proper on [A | rhs] (A: M rows, column stride M); the workspace was sized for at least M rows
+static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, double **R_out, double **rhs_out) {
+    lsq_ctx *c = s->ctx;
+    Qr2Work *q = (Qr2Work *)s->qr2;
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
         bool lazy = false;
@@ -2444,7 +2515,8 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
                 const int kk = std::min(K, cend - i), G = std::max(1, cend - i - kk + (ride ? 1 : 0));
                 const int grid = S >= 64 ? G * S : S > 1 ? 8 * S * ((G + 7) / 8) : G;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), 0, c->stream, A, M, cend, i, kk, q->tau1, q->lazy, q->lazy + n, G,
-                                   q->xslot, ++q->epoch, q->d_err, q->Pn, c0, ride ? rhs : (double *)nullptr);
+                                   q->xslot, ++q->epoch, q->d_err, q->Pn, c0, ride ? rhs : (double *)nullptr,
+                                   (double *)nullptr, 0, (double *)nullptr);
             }
             lazy = true;
             side_k = K;
