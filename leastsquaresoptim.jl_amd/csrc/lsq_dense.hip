@@ -2531,9 +2531,9 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
         else if (coop && prow > 4 * 8 * 256 && prow <= 8 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 8>, 256, 4, 8);
         else if (coop && prow > 8 * 8 * 256 && prow <= 8 * 10 * 256) steps_multi(k_qr1_step_multi<256, 10, 4, 8>, 256, 4, 8);
         // tall operands: more slabs (the exchange of a round grows with S; there are few columns to pay it)
-        else if (coop && prow > 8 * 10 * 256 && prow <= 16 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 16>, 256, 4, 16);
-        else if (coop && prow > 16 * 8 * 256 && prow <= 64 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 64>, 256, 4, 64);
-        else if (coop && prow > 64 * 8 * 256 && prow <= 64 * 32 * 256) steps_multi(k_qr1_step_multi<256, 32, 2, 64>, 256, 2, 64);
+        else if (coop && prow > 8 * 10 * 256 && prow <= 8 * 16 * 256) steps_multi(k_qr1_step_multi<256, 16, 4, 8>, 256, 4, 8);
+        else if (coop && prow > 8 * 16 * 256 && prow <= 32 * 16 * 256) steps_multi(k_qr1_step_multi<256, 16, 4, 32>, 256, 4, 32);
+        else if (coop && prow > 32 * 16 * 256 && prow <= 64 * 32 * 256) steps_multi(k_qr1_step_multi<256, 32, 2, 64>, 256, 2, 64);
         else if (coop && prow > 64 * 32 * 256 && prow <= 256 * 32 * 256) steps_multi(k_qr1_step_multi<256, 32, 2, 256>, 256, 2, 256);
         else if (coop && prow > 8 * 256 && prow <= 2 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 2>, 256, 4, 2);
         else if (want_multi && prow <= 8 * 512) steps_multi(k_qr1_step_multi<512, 8, 4, 1>, 512, 4, 1);
