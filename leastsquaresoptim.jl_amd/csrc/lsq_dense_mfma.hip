@@ -123,7 +123,15 @@ k_syrk_reduce(const double *__restrict__ W, int n, int kslices, const double *__
         const int gi = bi * MT + row, gj = bj * MT + col;
         if (gi < n && gj < n && gi <= gj) {
             double s = 0.0;
-            for (int sl = 0; sl < kslices; ++sl) s += W[((size_t)sl * ntiles + tile) * (MT * MT) + e];  // fixed order
+            int sl = 0;
+            for (; sl + 8 <= kslices; sl += 8) {     // eight loads in flight, added in slice order (fixed order)
+                double t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t8[u] = W[((size_t)(sl + u) * ntiles + tile) * (MT * MT) + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t8[u];
+            }
+            for (; sl < kslices; ++sl) s += W[((size_t)sl * ntiles + tile) * (MT * MT) + e];
             if (gi == gj && damp) s += damp[gi];
             C[(size_t)gj * n + gi] = s;
         }
@@ -583,6 +591,72 @@ k_chol_trsv(const double *__restrict__ U, int n, double *__restrict__ b) {
     }
 }
 
+// J'J for FEW columns (n <= 32) and many rows: the 64 x 64 MFMA tile would compute 4096 products per row for
+// n(n+1)/2 useful ones, so here a workgroup streams a window of rows through LDS (32 rows at a time) and every
+// thread owns up to three (i, j) pairs of the upper triangle; per-window partial sums land in W[window][pair]
+// and k_syrk_small_reduce adds the windows in index order (+ damp on the diagonal).  Memory-bound: one pass over J.
+constexpr int SS_ROWS = 64;
+constexpr int SS_MAXN = 32;
+constexpr int SS_PPT = (SS_MAXN * (SS_MAXN + 1) / 2 + 255) / 256;   // pairs per thread (3)
+__global__ void __launch_bounds__(256)
+k_syrk_small(const double *__restrict__ A, int m, int n, int wrows, double *__restrict__ W) {
+    __shared__ double sA[SS_ROWS][SS_MAXN + 1];
+    const int tid = threadIdx.x;
+    const int npairs = n * (n + 1) / 2;
+    int pi[SS_PPT], pj[SS_PPT];
+#pragma unroll
+    for (int q = 0; q < SS_PPT; ++q) {       // pair index -> (i <= j), column-major upper triangle: p = j(j+1)/2 + i
+        const int p = tid + q * 256;
+        int j = 0;
+        while ((j + 1) * (j + 2) / 2 <= p && j + 1 < n) ++j;
+        pj[q] = j;
+        pi[q] = min(p - j * (j + 1) / 2, j);
+    }
+    double acc[SS_PPT] = {0.0, 0.0, 0.0};
+    const int r0 = blockIdx.x * wrows, r1 = min(m, r0 + wrows);
+    for (int rb = r0; rb < r1; rb += SS_ROWS) {
+        for (int e = tid; e < SS_ROWS * n; e += 256) {
+            const int r = e % SS_ROWS, cidx = e / SS_ROWS;          // (rows contiguous in memory: coalesced per column)
+            sA[r][cidx] = rb + r < r1 ? A[(size_t)cidx * m + rb + r] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SS_PPT; ++q) {
+            if (tid + q * 256 < npairs) {
+                double a = acc[q];
+#pragma unroll 8
+                for (int r = 0; r < SS_ROWS; ++r) a += sA[r][pi[q]] * sA[r][pj[q]];
+                acc[q] = a;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < SS_PPT; ++q)
+        if (tid + q * 256 < npairs) W[(size_t)blockIdx.x * npairs + tid + q * 256] = acc[q];
+}
+__global__ void __launch_bounds__(256)
+k_syrk_small_reduce(const double *__restrict__ W, int n, int nwin, const double *__restrict__ damp, double *__restrict__ C) {
+    const int npairs = n * (n + 1) / 2;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npairs) return;
+    int j = 0;
+    while ((j + 1) * (j + 2) / 2 <= p) ++j;
+    const int i = p - j * (j + 1) / 2;
+    double s0 = 0.0;
+    int w = 0;
+    for (; w + 8 <= nwin; w += 8) {           // eight loads in flight, added in window order
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = W[(size_t)(w + u) * npairs + p];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s0 += t[u];
+    }
+    for (; w < nwin; ++w) s0 += W[(size_t)w * npairs + p];
+    if (i == j && damp) s0 += damp[i];
+    C[(size_t)j * n + i] = s0;
+}
+
 // largest diagonal entry of the n x n matrix C (one workgroup): the reference point of the full-rank certificate
 __global__ void __launch_bounds__(256)
 k_diag_max(const double *__restrict__ C, int n, double *__restrict__ out) {
@@ -608,9 +682,25 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         s->work_elems = need;
     }
     LSQ_HIP(hipMemsetAsync(s->d_info, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices), dim3(256), 0, c->stream, J->d_dense, m, m, n, 0, kslices,
-                       s->d_T, (double *)nullptr, 0);
-    hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
+    if (n <= SS_MAXN && m >= 16384 && !getenv("LSQ_SYRK_MFMA")) {
+        // few columns, many rows: the pair kernel (one pass over J, no 64 x 64 tile of mostly padding)
+        const int nwin = std::max(1, std::min(2 * c->num_cus, m / 1024));
+        const int wrows = ((m + nwin - 1) / nwin + SS_ROWS - 1) / SS_ROWS * SS_ROWS;
+        const int npairs = n * (n + 1) / 2;
+        const size_t need2 = (size_t)nwin * npairs;
+        if (s->work_elems < need2) {
+            hipFree(s->d_T);
+            LSQ_HIP(hipMalloc(&s->d_T, need2 * sizeof(double)));
+            s->work_elems = need2;
+        }
+        const int nw = (m + wrows - 1) / wrows;
+        hipLaunchKernelGGL(k_syrk_small, dim3(nw), dim3(256), 0, c->stream, J->d_dense, m, n, wrows, s->d_T);
+        hipLaunchKernelGGL(k_syrk_small_reduce, dim3((npairs + 255) / 256), dim3(256), 0, c->stream, s->d_T, n, nw, d_damp, s->d_chol);
+    } else {
+        hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices), dim3(256), 0, c->stream, J->d_dense, m, m, n, 0, kslices,
+                           s->d_T, (double *)nullptr, 0);
+        hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
+    }
     if (d_dmax) hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);
     // parking space for the factored diagonal blocks (k_chol_panel16): the tail of the SYRK slice buffer is free by now
     bool merged = false;
