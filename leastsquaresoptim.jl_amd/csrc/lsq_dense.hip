@@ -1179,7 +1179,9 @@ __device__ __forceinline__ void qr_static_for(F &&f) {
 // columns and of b sits in registers, the K rounds factor the slab locally (pivot rows = the slab's first rows, no
 // exchange), and the only thing written is the slab's n x n triangle and the first n entries of its Q'b, stacked
 // for the next level (tsq_S: (slabs*n) x n, tsq_r): ONE pass over the matrix.
-template <int NT, int RPT, int K, int S, bool TSQR = false>
+// TSQR = 2: the same with one WAVEFRONT per slab (64*RPT rows): the reductions are wave reductions, the row-c elements
+// come from their owner lane by v_readlane -- no LDS, no barrier anywhere in the rounds.
+template <int NT, int RPT, int K, int S, int TSQR = 0>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live pivots, <= K */, double *__restrict__ tau,
                  double *__restrict__ beta_out, double *__restrict__ scale_out, int G /* groups = target columns (>= 1) */,
@@ -1193,10 +1195,11 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     __shared__ double sx[S][NS];
     __shared__ double sat[NS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int QS = TSQR == 2 ? 64 : NT;      // rows between two elements of a thread
     int g = (int)blockIdx.x, sidx = 0;
-    if (TSQR) {                      // one workgroup per slab, a single "group" whose target is b
+    if (TSQR) {                      // one workgroup (or wavefront) per slab, a single "group" whose target is b
         g = 0;
-        sidx = (int)blockIdx.x;
+        sidx = TSQR == 2 ? (int)blockIdx.x * NW + wv : (int)blockIdx.x;
     } else if (S > 1 && S < 64) {           // members 8 apart: one XCD; 8 * S workgroups must be resident together
         const int kq = (int)blockIdx.x >> 3;
         sidx = kq % S;
@@ -1213,7 +1216,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     // ONE shared 32-bit VGPR offset + a scalar offset; rows beyond M read as zero and their stores are dropped by
     // the bounds check, and a dead column (ragged last launch, no target) gets an empty descriptor
     typedef unsigned v2u_qr __attribute__((ext_vector_type(2)));
-    const int t = i + sidx * (RPT * NT) + tid;    // row of element 0
+    const int t = i + sidx * (RPT * QS) + (TSQR == 2 ? lane : tid);    // row of element 0
     const unsigned tb = (unsigned)t * 8u;
     const unsigned colbytes = (unsigned)M * 8u;
     double pv[K][RPT], a[RPT];
@@ -1223,7 +1226,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         rp[r] = __builtin_amdgcn_make_buffer_rsrc(A + (size_t)(i + (r < kk ? r : 0)) * M, 0, r < kk ? colbytes : 0u, 0x00020000);
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rp[r], tb, q * NT * 8, 0);
+            const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rp[r], tb, q * QS * 8, 0);
             pv[r][q] = __builtin_bit_cast(double, w);
         }
     }
@@ -1231,7 +1234,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         __builtin_amdgcn_make_buffer_rsrc(is_rhs ? rhs_col : A + (size_t)(has_col ? j : i) * M, 0, has_col ? colbytes : 0u, 0x00020000);
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rj, tb, q * NT * 8, 0);
+        const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rj, tb, q * QS * 8, 0);
         a[q] = __builtin_bit_cast(double, w);
     }
     double mybeta = 0.0;   // (TSQR)
@@ -1241,7 +1244,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         constexpr int r = decltype(rc)::value;
         if (r >= kk) return;                        // (uniform over the whole grid: a dead round of a ragged launch)
         const bool live = true;
-        const int c = (TSQR ? i + sidx * (RPT * NT) : i) + r;   // pivot row of this round (TSQR: of this slab)
+        const int c = (TSQR ? i + sidx * (RPT * QS) : i) + r;   // pivot row of this round (TSQR: of this slab)
         // sm: [0] v'v  [1] alpha  then per later column x (pivots r+1.., target): v'x and x(c).  The even entries are
         // sums over all rows; the odd ones are single elements of row c, all owned by ONE thread (slab 0, thread r:
         // only element 0 of a thread can sit at or above the pivot row) which hands them out directly
@@ -1267,6 +1270,14 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
 #pragma unroll
         for (int e = 0; e < NS; e += 2)
             if (e < NSr) sm[e] = wave_allsum(sm[e]);
+        if constexpr (TSQR == 2) {
+            // wave slab: the sums are complete; the row-c elements sit in lane r
+            sm[1] = readlane_f64(pv[r][0], r);
+#pragma unroll
+            for (int x = 0; x < K; ++x)
+                if (x > r) sm[2 * (x - r) + 1] = readlane_f64(pv[x][0], r);
+            sm[2 * (K - r) + 1] = readlane_f64(a[0], r);
+        } else {
         __syncthreads();                             // (the previous round's readers of sh, sx and sat are done)
         if (lane == 0) {
 #pragma unroll
@@ -1285,7 +1296,9 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
 #pragma unroll
         for (int e = 0; e < NS; e += 2)
             if (e < NSr) sm[e] = row_allsum((lane & 15) < NW ? sh[lane & 15][e] : 0.0);
-        if (S == 1 || TSQR) {
+        }
+        if constexpr (TSQR == 2) {
+        } else if (S == 1 || TSQR) {
 #pragma unroll
             for (int e = 1; e < NS; e += 2)
                 if (e < NSr) sm[e] = sat[e];
@@ -1344,7 +1357,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         }
         if (!live) ti = 0.0;
         if (TSQR) {
-            if (tid == r) mybeta = beta;            // R(r, r) of this slab, kept by the owner of the slab's row r
+            if ((TSQR == 2 ? lane : tid) == r) mybeta = beta;   // R(r, r) of this slab, kept by the owner of the slab's row r
         } else if (live && g == 0 && sidx == 0 && tid == 0) { tau[c] = ti; beta_out[c] = beta; scale_out[c] = sc; }
         if (ti != 0.0) {
             double tw[K + 1];
@@ -1372,11 +1385,12 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     if (TSQR) {
         // rows 0 .. kk-1 of the slab: R(r, x) = element 0 of thread r in column x (x > r), beta on the diagonal, zeros
         // before it; and entry r of the slab's Q'b
-        if (tid < kk) {
-            const size_t row = (size_t)sidx * kk + tid;
+        const int own = TSQR == 2 ? lane : tid;
+        if (own < kk && sidx < G) {                  // (G: number of slabs; a workgroup's last wavefronts may have none)
+            const size_t row = (size_t)sidx * kk + own;
 #pragma unroll
             for (int x = 0; x < K; ++x)
-                if (x < kk) tsq_S[(size_t)x * tsq_ld + row] = x < tid ? 0.0 : (x == tid ? mybeta : pv[x][0]);
+                if (x < kk) tsq_S[(size_t)x * tsq_ld + row] = x < own ? 0.0 : (x == own ? mybeta : pv[x][0]);
             tsq_r[row] = a[0];
         }
         return;
@@ -2388,7 +2402,7 @@ struct Qr2Work {
     unsigned long long epoch = 0;
     int *d_err = nullptr;                  //   set when a slab wait gave up
     double *Pn = nullptr;                  // stage 1: side panel (M x 64) for the later pivot columns of a launch
-    double *tsS = nullptr, *tsr = nullptr; // TSQR level 0: stacked slab triangles ((slabs*n) x n) and Q'b entries
+    double *tsS[2] = {nullptr, nullptr}, *tsr[2] = {nullptr, nullptr};   // TSQR levels (ping-pong): stacked slab triangles ((slabs*n) x n) and Q'b entries
     int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
     int kslices = 0, M = 0, n = 0;
 };
@@ -2397,7 +2411,7 @@ static void qr2_free(void *p) {
     if (!q) return;
     hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
     hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
-    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn); hipFree(q->tsS); hipFree(q->tsr);
+    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn); hipFree(q->tsS[0]); hipFree(q->tsS[1]); hipFree(q->tsr[0]); hipFree(q->tsr[1]);
     if (q->h_fro) hipHostFree(q->h_fro);
     delete q;
 }
@@ -2416,7 +2430,7 @@ static bool qr2_applies(int M, int n) {
 static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, double **R_out, double **rhs_out);
 // tall and thin operands (n <= 32, many rows): level 0 of a TSQR -- one pass over the matrix, every workgroup
 // factors its own slab in registers -- then the stacked triangles go through the regular panel machinery
-static int qr2_tsqr_slab_rows(int n) {   // (K + 1) * RPT doubles of registers per thread, K = n rounded up
+static int qr2_tsqr_slab_rows(int n) {   // rows of a 256-thread slab ((K + 1) * RPT doubles of registers per thread); a wave slab is a quarter
     return 256 * (n <= 8 ? 8 : n <= 12 ? 6 : n <= 16 ? 4 : n <= 24 ? 3 : 2);
 }
 static bool qr2_tsqr_applies(int M, int n) {
@@ -2430,24 +2444,43 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
     LSQ_TRY(qr2_workspace(s, M, n));
     Qr2Work *q = (Qr2Work *)s->qr2;
     if (qr2_tsqr_applies(M, n)) {
-        const int L = qr2_tsqr_slab_rows(n), S = lsq_div_up(M, L), Ms = S * n;
-        if (!q->tsS) {
-            LSQ_HIP(hipMalloc(&q->tsS, ((size_t)Ms * n + 32768) * sizeof(double)));
-            LSQ_HIP(hipMalloc(&q->tsr, ((size_t)Ms + 32768) * sizeof(double)));
+        // levels of wave slabs (64 * RPT rows each) until the stack is short enough for the panel machinery
+        const bool block_slabs = getenv("LSQ_QR_TSQR_BLOCK") != nullptr;
+        const int L = block_slabs ? qr2_tsqr_slab_rows(n) : qr2_tsqr_slab_rows(n) / 4;
+        double *Acur = s->d_qr, *bcur = s->d_qu;
+        int Mcur = M;
+        for (int level = 0; level < 6 && qr2_tsqr_applies(Mcur, n); ++level) {
+            const int S = lsq_div_up(Mcur, L), Ms = S * n;
+            if (!q->tsS[0]) {
+                for (int u = 0; u < 2; ++u) {
+                    LSQ_HIP(hipMalloc(&q->tsS[u], ((size_t)Ms * n + 32768) * sizeof(double)));
+                    LSQ_HIP(hipMalloc(&q->tsr[u], ((size_t)Ms + 32768) * sizeof(double)));
+                }
+            }
+            double *So = q->tsS[level & 1], *ro = q->tsr[level & 1];
+            auto go = [&](auto kern, int slabs_per_block) {
+                hipLaunchKernelGGL(kern, dim3(lsq_div_up(S, slabs_per_block)), dim3(256), 0, c->stream, Acur, Mcur, n, 0, n, q->tau1,
+                                   q->lazy, q->lazy + n, S, q->xslot, ++q->epoch, q->d_err, q->Pn, 0, bcur, So, Ms, ro);
+            };
+            if (block_slabs) {
+                if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, 1>, 1);
+                else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, 1>, 1);
+                else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, 1>, 1);
+                else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, 1>, 1);
+                else go(k_qr1_step_multi<256, 2, 32, 1, 1>, 1);
+            } else {
+                if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, 2>, 4);
+                else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, 2>, 4);
+                else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, 2>, 4);
+                else if (n <= 20) go(k_qr1_step_multi<256, 3, 20, 1, 2>, 4);
+                else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, 2>, 4);
+                else if (n <= 28) go(k_qr1_step_multi<256, 2, 28, 1, 2>, 4);
+                else go(k_qr1_step_multi<256, 2, 32, 1, 2>, 4);
+            }
+            Acur = So; bcur = ro; Mcur = Ms;
         }
-        auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(S), dim3(256), 0, c->stream, s->d_qr, M, n, 0, n, q->tau1, q->lazy, q->lazy + n, 1,
-                               q->xslot, ++q->epoch, q->d_err, q->Pn, 0, s->d_qu, q->tsS, Ms, q->tsr);
-        };
-        if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, true>);
-        else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, true>);
-        else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, true>);
-        else if (n <= 20) go(k_qr1_step_multi<256, 3, 20, 1, true>);
-        else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, true>);
-        else if (n <= 28) go(k_qr1_step_multi<256, 2, 28, 1, true>);
-        else go(k_qr1_step_multi<256, 2, 32, 1, true>);
         LSQ_HIP(hipGetLastError());
-        return qr2_factor_core(s, q->tsS, q->tsr, Ms, n, R_out, rhs_out);
+        return qr2_factor_core(s, Acur, bcur, Mcur, n, R_out, rhs_out);
     }
     return qr2_factor_core(s, s->d_qr, s->d_qu, M, n, R_out, rhs_out);
 }

@@ -461,18 +461,21 @@ def test_ldiv_qr_panel_variants(ctx, m, coop, monkeypatch):
         assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12), (m, coop, pivot, "second solve")
 
 
-@pytest.mark.parametrize("tsqr", ["default", "off"])
+@pytest.mark.parametrize("tsqr", ["default", "block", "off"])
 @pytest.mark.parametrize("m,n", [(30000, 20), (100000, 20), (300000, 12), (1200000, 8), (2200000, 6), (50000, 70),
                                  (40000, 31), (33000, 2), (70000, 17), (90000, 25)])
 def test_ldiv_qr_tall_thin(ctx, m, n, tsqr, monkeypatch):
     """Tall, thin operands (the usual shape of a fitting problem: many residuals, few parameters).  Default: from
-    32768 rows and n <= 32 a TSQR level (every workgroup factors its own slab of rows in registers, the stacked
-    triangles go through the panel machinery) -- one pass over the matrix.  LSQ_QR_NO_TSQR=1 (and n > 32, or
+    32768 rows and n <= 32 TSQR levels (every wavefront factors its own slab of rows in registers, without LDS or
+    barriers; levels repeat until the stacked triangles are short enough for the panel machinery) -- one pass
+    over the matrix.  LSQ_QR_NO_TSQR=1 (and n > 32, or
     fewer rows): 16 / 64 / 256 row slabs per column with the generalised exchange, the right-hand side riding
     through the last panel's steps as one more target column.  Oracle = the reference's pivoted-QR solve;
     repeated solve bit-identical (fixed-order reductions and exchanges)."""
     if tsqr == "off":
         monkeypatch.setenv("LSQ_QR_NO_TSQR", "1")
+    if tsqr == "block":
+        monkeypatch.setenv("LSQ_QR_TSQR_BLOCK", "1")   # one workgroup (not one wavefront) per slab
     rng = np.random.default_rng(m + n)
     A = rng.standard_normal((m, n)) / np.sqrt(m)
     y = rng.standard_normal(m)
