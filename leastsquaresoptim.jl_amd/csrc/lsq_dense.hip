@@ -14,7 +14,9 @@
 
 int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax);
 int lsq_cholesky_blocked_solve(lsq_solver *s, int n, double *d_x);
-int lsq_tri_inv_fro2(lsq_solver *s, const double *U, int n, double *fro2_inv);  // lsq_dense_mfma.hip
+int lsq_tri_inv_fro2(lsq_solver *s, const double *U, int n, double *fro2_inv);
+void lsq_tri_pipe_err_copy(lsq_solver *s, int *h_dst);
+void lsq_tri_pipe_disable(lsq_solver *s);  // lsq_dense_mfma.hip
 
 // ---------------------------------------------------------------------------------------------
 // generic dense products
@@ -851,7 +853,13 @@ static bool chol_certified(lsq_solver *s, lsq_mat *J, const double *d_y, double 
     *rc = LSQ_OK;
     auto fail = [&](int code) { *rc = code; return true; };
     if (lsq_cholesky_blocked(s, J, nullptr, nullptr, s->d_work) != LSQ_OK) return fail(LSQ_EHIP);
+    // the solves run before the decision is known (discarded if the certificate refuses): the one synchronisation
+    // below then also shows whether a wait of the pipelined solves gave up
+    if (lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x) != LSQ_OK) return fail(LSQ_EHIP);   // mul!(x, J', y)
+    if (lsq_cholesky_blocked_solve(s, n, d_x) != LSQ_OK) return fail(LSQ_EHIP);
     double fro2 = 0.0;
+    int perr = 0;
+    lsq_tri_pipe_err_copy(s, &perr);
     if (lsq_tri_inv_fro2(s, s->d_chol, n, &fro2) != LSQ_OK) return fail(LSQ_EHIP);   // (synchronises the stream)
     int info = 0;
     double dmax = 0.0;
@@ -861,8 +869,11 @@ static bool chol_certified(lsq_solver *s, lsq_mat *J, const double *d_y, double 
     const bool ok = info == 0 && std::isfinite(fro2) && fro2 > 0.0 && std::isfinite(dmax) &&
                     1.0 / fro2 > 16.0 * n * DBL_EPSILON * dmax;
     if (!ok) return false;
-    if (lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x) != LSQ_OK) return fail(LSQ_EHIP);   // mul!(x, J', y)
-    if (lsq_cholesky_blocked_solve(s, n, d_x) != LSQ_OK) return fail(LSQ_EHIP);
+    if (perr) {
+        lsq_tri_pipe_disable(s);
+        if (lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x) != LSQ_OK) return fail(LSQ_EHIP);
+        if (lsq_cholesky_blocked_solve(s, n, d_x) != LSQ_OK) return fail(LSQ_EHIP);
+    }
     s->last_chol_path = 3;
     return true;
 }
@@ -887,12 +898,18 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
         LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
         LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr));
         s->last_chol_path = 2;
-        int info = 0;
+        int info = 0, perr = 0;
         LSQ_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        lsq_tri_pipe_err_copy(s, &perr);
         LSQ_HIP(hipStreamSynchronize(c->stream));
         if (info != 0) {
             lsq_set_error("PosDefException: matrix is not positive definite; Cholesky failed at %d", info);
             return LSQ_ENOTPD;
+        }
+        if (perr) {                               // (the factor is intact: only the two solves are repeated)
+            lsq_tri_pipe_disable(s);
+            LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));
+            LSQ_TRY(lsq_cholesky_blocked_solve(s, n, d_x));
         }
     } else if (blocked && !d_damp && !getenv("LSQ_NO_MFMA") && !getenv("LSQ_CHOL_ALWAYS_PIVOT") &&
                chol_certified(s, J, d_y, d_x, &rc_cert)) {
@@ -2401,6 +2418,7 @@ struct Qr2Work {
     unsigned long long *xslot = nullptr;   // stage 1, slab exchange: [64 groups][8 slabs][8 rounds][18 sums][2 words]
     unsigned long long epoch = 0;
     int *d_err = nullptr;                  //   set when a slab wait gave up
+    bool no_exchange = false;              //   ... after which this solver uses neither slabs nor the pipelined solve
     double *Pn = nullptr;                  // stage 1: side panel (M x 64) for the later pivot columns of a launch
     double *tsS[2] = {nullptr, nullptr}, *tsr[2] = {nullptr, nullptr};   // TSQR levels (ping-pong): stacked slab triangles ((slabs*n) x n) and Q'b entries
     int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
@@ -2558,7 +2576,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
         const int prow = M - c0;
         // slabs (S > 1) need every CU of an unpartitioned device; LSQ_QR1_COOP=0 keeps one workgroup per column
         const char *cv = getenv("LSQ_QR1_COOP");
-        const int coop = !want_multi || c->num_cus < 256 ? 0 : cv ? atoi(cv) : 1;
+        const int coop = !want_multi || c->num_cus < 256 || q->no_exchange ? 0 : cv ? atoi(cv) : 1;
         if (getenv("LSQ_QR1_LOOP")) steps(k_qr1_step);
         else if (coop && prow > 2 * 8 * 256 && prow <= 4 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 4>, 256, 4, 4);
         else if (coop && prow > 4 * 8 * 256 && prow <= 8 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 8>, 256, 4, 8);
@@ -2630,10 +2648,16 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
 
 // true when ||R||_F ||inv(R)||_F certifies that xGELSY would keep all n columns (see k_tri_diaginv); X = inv(R)
 // is left in q->Xinv.  One small device-to-host copy: the caller picks its launch sequence from the answer.
-static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double rcond, bool *certified) {
+// The certified solve (pipelined back-substitution with the inverted diagonal blocks) is launched BEFORE the copy that
+// carries the decision, so the same synchronisation also tells whether one of the in-kernel exchanges gave up
+// (*timed_out: the caller repeats the solve without them; the result of this attempt is discarded).
+static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double rcond, bool *certified, const double *rhs2,
+                                 int *jp, double *d_x, bool *solved, bool *timed_out) {
     lsq_ctx *c = s->ctx;
     Qr2Work *q = (Qr2Work *)s->qr2;
     *certified = false;
+    *solved = false;
+    *timed_out = false;
     constexpr int FRO_BLOCKS = 256;
     if (!q->Xinv) {
         LSQ_HIP(hipMalloc(&q->Xinv, ((size_t)n * n + 8) * sizeof(double)));
@@ -2649,14 +2673,30 @@ static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double 
         hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, R2, q->Xinv, q->T2, n, sb, 1);
     }
     hipLaunchKernelGGL(k_tri_fro, dim3(FRO_BLOCKS), dim3(256), 0, c->stream, R2, q->Xinv, n, q->fro);
+    if (lsq_div_up(n, 64) <= 256 && !q->no_exchange && !getenv("LSQ_QR_SUBST_SOLVE")) {   // speculative: used if certified
+        if (!q->bslot) {
+            LSQ_HIP(hipMalloc(&q->bslot, (size_t)256 * 64 * 2 * sizeof(unsigned long long)));
+            LSQ_ZERO(q->bslot, 0, (size_t)256 * 64 * 2 * sizeof(unsigned long long));
+        }
+        hipLaunchKernelGGL(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
+        hipLaunchKernelGGL(k_tri_bsolve, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, q->Xinv, n, (size_t)64 * n + 64, n,
+                           rhs2, d_x, q->bslot, ++q->epoch, q->d_err);
+        *solved = true;
+    }
+    if (!q->no_exchange && getenv("LSQ_TEST_EXCHANGE_TIMEOUT")) {   // test hook: pretend a wait gave up
+        static const int one = 1;
+        LSQ_HIP(hipMemcpyAsync(q->d_err, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
     LSQ_HIP(hipMemcpyAsync(q->h_fro, q->fro, 2 * FRO_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipMemcpyAsync(q->h_fro + 2 * FRO_BLOCKS, q->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     if (*(const int *)(q->h_fro + 2 * FRO_BLOCKS) != 0) {
+        // a bounded wait of an in-kernel exchange gave up (workgroups not dispatched in index order, or the device
+        // shared with other work): this solver stops using them
         LSQ_ZERO(q->d_err, 0, sizeof(int));
-        lsq_set_error("qr: a slab exchange of the panel factorisation timed out (workgroups of a group not co-resident?); "
-                      "set LSQ_QR1_COOP=0");
-        return LSQ_EHIP;
+        q->no_exchange = true;
+        *timed_out = true;
+        return LSQ_OK;
     }
     double fr = 0.0, fx = 0.0;
     for (int b = 0; b < FRO_BLOCKS; ++b) { fr += q->h_fro[2 * b]; fx += q->h_fro[2 * b + 1]; }
@@ -2684,7 +2724,7 @@ static void tripipe_free(void *p) {
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
     lsq_ctx *c = s->ctx;
     const int nblk = lsq_div_up(n, 64);
-    if (nblk > 256 || getenv("LSQ_CHOL_SUBST_SOLVE")) return LSQ_EARG;
+    if (nblk > 256 || s->pipe_off || getenv("LSQ_CHOL_SUBST_SOLVE")) return LSQ_EARG;
     TriPipe *t = (TriPipe *)s->tripipe;
     if (!t || t->n != n) {
         if (t) tripipe_free(t);
@@ -2709,8 +2749,27 @@ int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
                        t->epoch, t->d_err);
     hipLaunchKernelGGL(k_tri_bsolve, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, t->z, d_bx, t->slot_b,
                        t->epoch, t->d_err);
+    if (getenv("LSQ_TEST_EXCHANGE_TIMEOUT")) {   // test hook: pretend a wait gave up (and spoil the result it would have spoilt)
+        static const int one = 1;
+        LSQ_HIP(hipMemcpyAsync(t->d_err, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        LSQ_HIP(hipMemsetAsync(d_bx, 0xff, (size_t)n * sizeof(double), c->stream));
+    }
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
+}
+
+// did a wait of the pipelined solves give up?  lsq_tri_pipe_err_copy enqueues the copy of the flag next to the caller's own
+// status copy (one synchronisation for both); lsq_tri_pipe_disable acts on it: the solver stops using the pipelined
+// solves and the caller repeats them with the single-workgroup kernel.
+void lsq_tri_pipe_err_copy(lsq_solver *s, int *h_dst) {
+    TriPipe *t = (TriPipe *)s->tripipe;
+    *h_dst = 0;
+    if (t && !s->pipe_off) (void)hipMemcpyAsync(h_dst, t->d_err, sizeof(int), hipMemcpyDeviceToHost, s->ctx->stream);
+}
+void lsq_tri_pipe_disable(lsq_solver *s) {
+    TriPipe *t = (TriPipe *)s->tripipe;
+    if (t) (void)hipMemsetAsync(t->d_err, 0, sizeof(int), s->ctx->stream);
+    s->pipe_off = 1;
 }
 
 // sum of squares of inv(U) for the n x n upper triangle U (explicit inverse: k_tri_diaginv + k_tri_level levels);
@@ -2754,7 +2813,8 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
     }
     const int M = d_damp ? m + n : m;
     const int lu = d_damp ? M : std::max(m, n);
-    if (n > 0 && M > 0) {
+    if (n > 0 && M > 0)
+    for (int attempt = 0; attempt < 2; ++attempt) {     // (a second pass only after an in-kernel exchange timed out)
         long long tot = (long long)M * n;
         int grid = (int)std::min<long long>((tot + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
         hipLaunchKernelGGL(k_stack, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, m, n, d_damp, s->d_qr);
@@ -2770,23 +2830,23 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
             int *jp = (int *)s->d_tau;
             Qr2Work *q = (Qr2Work *)s->qr2;
             bool have_rank = false;
-            bool full_rank = false;
-            if (!getenv("LSQ_QR_ALWAYS_PIVOT")) LSQ_TRY(qr2_certify_full_rank(s, R2, n, (double)mn * DBL_EPSILON, &full_rank));
+            bool full_rank = false, solved = false, timed_out = false;
+            if (!getenv("LSQ_QR_ALWAYS_PIVOT"))
+                LSQ_TRY(qr2_certify_full_rank(s, R2, n, (double)mn * DBL_EPSILON, &full_rank, rhs2, jp, d_x, &solved, &timed_out));
+            if (timed_out) {
+                if (attempt == 0) continue;      // once more from the stacked operand, without in-kernel exchanges
+                lsq_set_error("qr: an in-kernel exchange timed out twice");
+                return LSQ_EHIP;
+            }
             if (full_rank) {
                 // rank = n is certain: the unpivoted triangle gives the same (unique) solution, jp = identity
-                hipLaunchKernelGGL(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
-                if (lsq_div_up(n, 64) <= 256 && !getenv("LSQ_QR_SUBST_SOLVE")) {
-                    if (!q->bslot) {
-                        LSQ_HIP(hipMalloc(&q->bslot, (size_t)256 * 64 * 2 * sizeof(unsigned long long)));
-                        LSQ_ZERO(q->bslot, 0, (size_t)256 * 64 * 2 * sizeof(unsigned long long));
-                    }
-                    hipLaunchKernelGGL(k_tri_bsolve, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, q->Xinv, n,
-                                       (size_t)64 * n + 64, n, rhs2, d_x,
-                                       q->bslot, ++q->epoch, q->d_err);
-                } else if (n <= QRK_MAXN)
-                    hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
-                else
-                    hipLaunchKernelGGL(k_tri_matvec, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, q->Xinv, n, rhs2, d_x);
+                if (!solved) {
+                    hipLaunchKernelGGL(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
+                    if (n <= QRK_MAXN)
+                        hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
+                    else
+                        hipLaunchKernelGGL(k_tri_matvec, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, q->Xinv, n, rhs2, d_x);
+                }
                 LSQ_HIP(hipGetLastError());
                 s->last_rank = -1;
                 s->last_qr_path = 3;
@@ -2859,6 +2919,7 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
                                s->d_work, (int *)s->d_tau, s->d_T, (double)mn * DBL_EPSILON, s->d_info, 3);
         }
         LSQ_HIP(hipGetLastError());
+        break;
     }
     s->last_rank = -1;  // fetched lazily by lsq_solver_info
     if (nmul) *nmul = 1;

@@ -58,6 +58,7 @@ struct lsq_solver {
     void (*tripipe_free)(void *) = nullptr;
     double *tri_X = nullptr, *tri_T = nullptr, *tri_fro = nullptr, *tri_hfro = nullptr;   // explicit inverse of the Cholesky factor (Dogleg certificate)
     int last_chol_path = 0;         // lsq_solver_chol_path
+    int pipe_off = 0;               // a wait of the pipelined triangular solves gave up once: single-workgroup solves from then on
 };
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx);
 

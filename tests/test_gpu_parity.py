@@ -531,6 +531,37 @@ def test_dense_solves_are_repeatable(ctx, m, n, rank, solver, monkeypatch):
             monkeypatch.delenv(env)
 
 
+def test_dense_exchange_timeout_falls_back(ctx, monkeypatch):
+    """The in-kernel exchanges (row slabs of the QR panel steps, pipelined block solves) wait with a bound; when a wait
+    gives up, the same synchronisation that carries the solver's decision reports it and the solve is repeated
+    without exchanges -- from then on for that solver.  LSQ_TEST_EXCHANGE_TIMEOUT makes the library pretend (and
+    spoil the result the way a real timeout would): answers must still be the oracle's."""
+    monkeypatch.setenv("LSQ_TEST_EXCHANGE_TIMEOUT", "1")
+    rng = np.random.default_rng(99)
+    m, n = 9000, 200                       # slabs in the panel steps, 4 blocks in the solves
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    xr, rk, *_ = O.qr_solve(A, y)
+    sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+    for _ in range(2):                     # first solve: timeout + retry; second: exchanges already off
+        sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+        assert sv.info()["qr_rank"] == rk == n
+        assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
+    for for_lm in (True, False):
+        svc = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=for_lm)
+        for _ in range(2):
+            if for_lm:
+                svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+                xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y, damp)[1]
+            else:
+                svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+                xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y)[1]
+            assert np.allclose(dxo.get(), xc, rtol=1e-9, atol=1e-12), for_lm
+
+
 @pytest.mark.parametrize("cond,certified", [(1e2, True), (1e6, True), (1e11, True), (1e12, False)])
 def test_ldiv_qr_certificate_decision(ctx, cond, certified, monkeypatch):
     """The full-rank certificate (||R||_F ||inv(R)||_F * rcond * 16 <= 1) may only skip the pivoted sweep when
