@@ -194,15 +194,33 @@ struct lsq_mat {
 // ---------------------------------------------------------------------------------------------
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// Wave reductions on the DPP network (row rotations inside the 16-lane rows, then the four row results through
+// v_readlane) instead of six rounds through the LDS crossbar (ds_bpermute): every lane ends up with the result, in
+// a fixed association -- ((r0 + r1) + (r2 + r3)) over rows, rotation pairs inside a row -- so all lanes, all waves
+// and all kernels agree bit for bit on the same inputs.
+template <int CTRL>
+__device__ __forceinline__ double lsq_dpp_mov_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lsq_readlane_f64(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;  // lane 0 holds the sum
+    v += lsq_dpp_mov_f64<0x128>(v);   // row_ror:8
+    v += lsq_dpp_mov_f64<0x124>(v);   // row_ror:4
+    v += lsq_dpp_mov_f64<0x122>(v);   // row_ror:2
+    v += lsq_dpp_mov_f64<0x121>(v);   // row_ror:1
+    return (lsq_readlane_f64(v, 0) + lsq_readlane_f64(v, 16)) + (lsq_readlane_f64(v, 32) + lsq_readlane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
+    v = fmax(v, lsq_dpp_mov_f64<0x128>(v));
+    v = fmax(v, lsq_dpp_mov_f64<0x124>(v));
+    v = fmax(v, lsq_dpp_mov_f64<0x122>(v));
+    v = fmax(v, lsq_dpp_mov_f64<0x121>(v));
+    return fmax(fmax(lsq_readlane_f64(v, 0), lsq_readlane_f64(v, 16)), fmax(lsq_readlane_f64(v, 32), lsq_readlane_f64(v, 48)));
 }
 
 // Sum over the block in a fixed order (deterministic); result valid in thread 0.
