@@ -1141,30 +1141,18 @@ k_qr1_step_lazy(double *__restrict__ A, int M, int cend, int i, double *__restri
     if (tid == 0) cj[i] = aji - tw;
 }
 
-// DPP all-reductions (no LDS round trips): after row_allsum every lane of a 16-lane row holds the row's sum
-// (rotations pair the same operands in every lane, so the lanes agree bit for bit); wave_allsum adds the four
-// row sums in a fixed order.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
+// DPP all-reductions (no LDS round trips; helpers of lsq_common.h): after row_allsum every lane of a 16-lane row holds
+// the row's sum (rotations pair the same operands in every lane, so the lanes agree bit for bit); wave_allsum = wave_sum
+// adds the four row sums in a fixed order.
 __device__ __forceinline__ double row_allsum(double x) {
-    x += dpp_mov_f64<0x128>(x);   // row_ror:8
-    x += dpp_mov_f64<0x124>(x);   // row_ror:4
-    x += dpp_mov_f64<0x122>(x);   // row_ror:2
-    x += dpp_mov_f64<0x121>(x);   // row_ror:1
+    x += lsq_dpp_mov_f64<0x128>(x);   // row_ror:8
+    x += lsq_dpp_mov_f64<0x124>(x);   // row_ror:4
+    x += lsq_dpp_mov_f64<0x122>(x);   // row_ror:2
+    x += lsq_dpp_mov_f64<0x121>(x);   // row_ror:1
     return x;
 }
-__device__ __forceinline__ double readlane_f64(double x, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-}
-__device__ __forceinline__ double wave_allsum(double x) {
-    x = row_allsum(x);
-    return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
-}
+__device__ __forceinline__ double readlane_f64(double x, int l) { return lsq_readlane_f64(x, l); }
+__device__ __forceinline__ double wave_allsum(double x) { return wave_sum(x); }
 
 // K lazy reflectors per launch.  A launch's fixed cost (dispatch + the fetch of the columns) dominates a step,
 // so one launch carries the K pivot columns i .. i+K-1 through K reduction rounds: every workgroup fetches
