@@ -2500,7 +2500,7 @@ static int qr2_workspace(lsq_solver *s, int M, int n) {
         q->M = M; q->n = n;
         const int ncolsB = Q2_NB + n + 1;
         const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
-        q->kslices = std::max(1, std::min(64, (2 * c->num_cus + ntile - 1) / ntile));
+        q->kslices = std::max(1, std::min(64, (4 * c->num_cus + ntile - 1) / ntile));   // (4 workgroups per CU: their barriers and LDS phases interleave)
         LSQ_HIP(hipMalloc(&q->Vb, ((size_t)M * Q2_NB + 64) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->Wp, (size_t)q->kslices * ntile * Q2_NB * Q2_NB * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->W, (size_t)ntile * Q2_NB * Q2_NB * sizeof(double)));

@@ -673,7 +673,10 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     lsq_ctx *c = s->ctx;
     const int m = J->m, n = J->n;
     const int nt = (n + MT - 1) / MT, ntiles = nt * (nt + 1) / 2;
-    int kslices = std::max(1, std::min(512, (2 * c->num_cus + ntiles - 1) / ntiles));   // (few tiles, many rows: slices fill the chip)
+    // split-K slices: enough workgroups for ~6 per CU when there are many tiles (their barriers and LDS phases interleave:
+    // 42 TFLOP/s at 16384 x 2048), ~2 per CU when the slice reduction would otherwise dominate (4096 x 512)
+    const int occ = ntiles >= 128 ? 6 : 2;
+    int kslices = std::max(1, std::min(512, (occ * c->num_cus + ntiles - 1) / ntiles));
     kslices = std::min(kslices, std::max(1, m / (4 * KC)));
     const size_t need = (size_t)kslices * ntiles * MT * MT;
     if (s->work_elems < need) {
