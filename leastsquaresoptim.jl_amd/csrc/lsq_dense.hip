@@ -1633,6 +1633,7 @@ k_qr1_tw_mfma(const double *__restrict__ W, int ncolsB, const double *__restrict
         for (int e = tid; e < npair * sz * sz; e += 256) {
             const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
             double acc = 0.0;
+#pragma unroll 8
             for (int k = cc; k < sz; ++k) acc += Y[(ob + r) * LS + oa + k] * X[(oa + k) * LS + oa + cc];
             Tm[(pr * sz + r) * 33 + cc] = acc;     // (two pairs of 16 rows or one of 32: 32 x 32 in all)
         }
@@ -1641,6 +1642,7 @@ k_qr1_tw_mfma(const double *__restrict__ W, int ncolsB, const double *__restrict
         for (int e = tid; e < npair * sz * sz; e += 256) {
             const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
             double acc = 0.0;
+#pragma unroll 8
             for (int k = 0; k <= r; ++k) acc += X[(ob + r) * LS + ob + k] * Tm[(pr * sz + k) * 33 + cc];
             X[(ob + r) * LS + oa + cc] = -acc;
         }
@@ -2112,6 +2114,7 @@ k_tri_diaginv(const double *__restrict__ R, int n, double *__restrict__ X, int l
         for (int e = tid; e < npair * sz * sz; e += 256) {
             const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
             double acc = 0.0;
+#pragma unroll 8
             for (int k = 0; k <= cc; ++k) acc += sR[(oa + r) * LS + ob + k] * sX[(ob + k) * LS + ob + cc];
             Tm[(pr * sz + r) * 33 + cc] = acc;
         }
@@ -2120,6 +2123,7 @@ k_tri_diaginv(const double *__restrict__ R, int n, double *__restrict__ X, int l
         for (int e = tid; e < npair * sz * sz; e += 256) {
             const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
             double acc = 0.0;
+#pragma unroll 8
             for (int k = r; k < sz; ++k) acc += sX[(oa + r) * LS + oa + k] * Tm[(pr * sz + k) * 33 + cc];
             sX[(oa + r) * LS + ob + cc] = -acc;
         }
