@@ -531,6 +531,44 @@ def test_dense_solves_are_repeatable(ctx, m, n, rank, solver, monkeypatch):
             monkeypatch.delenv(env)
 
 
+def test_dense_shape_sweep(ctx):
+    """The dense launch sequence depends on the shape in many ways (one-workgroup / two-stage / TSQR levels, 1-256
+    row slabs, ragged panels, pair kernel vs MFMA tiles for J'J): shapes around every threshold, all four
+    solver variants, against LAPACK through numpy (full-rank operands: the solution is unique, so any
+    stable method is the oracle here; tools/dense_fuzz.py is the long version)."""
+    rng = np.random.default_rng(2026)
+    ms = [16, 17, 63, 65, 129, 257, 1000, 2047, 2049, 4097, 8193, 16385, 20481, 32769, 50000, 131073]
+    ns = [1, 2, 3, 8, 9, 13, 15, 16, 17, 21, 25, 29, 32, 33, 63, 64, 65, 100, 129, 200]
+    shapes = set()
+    while len(shapes) < 70:
+        n = int(rng.choice(ns))
+        m = max(int(rng.choice(ms)), n + int(rng.integers(0, 40)))
+        if m * n <= 6e6:
+            shapes.add((m, n))
+    for m, n in sorted(shapes):
+        A = rng.standard_normal((m, n)) / np.sqrt(m)
+        y = rng.standard_normal(m)
+        damp = rng.random(n) + 0.05
+        J = lsq.DeviceMatrix(ctx, A)
+        x = lsq.DeviceVector(ctx, n)
+        ref0 = np.linalg.lstsq(A, y, rcond=None)[0]
+        refd = np.linalg.solve(A.T @ A + np.diag(damp), A.T @ y)
+        cond = np.linalg.cond(A) if m * n <= 2e5 else 10.0
+        for solver in (lsq.QR(), lsq.Cholesky()):
+            for for_lm in (False, True):
+                sv = lsq.AllocatedSolver(J, solver, for_lm=for_lm)
+                if for_lm:
+                    sv.ldiv_(x, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+                else:
+                    sv.ldiv_(x, lsq.DeviceVector(ctx, m, y))
+                ref = refd if for_lm else ref0
+                tol = 1e-9 * max(1.0, cond * cond if (isinstance(solver, lsq.Cholesky) and not for_lm) else cond)
+                err = np.linalg.norm(x.get() - ref) / np.linalg.norm(ref)
+                assert np.isfinite(err) and err <= tol, (m, n, type(solver).__name__, for_lm, err, sv.info())
+                sv.free()
+        J.free()
+
+
 def test_dense_exchange_timeout_falls_back(ctx, monkeypatch):
     """The in-kernel exchanges (row slabs of the QR panel steps, pipelined block solves) wait with a bound; when a wait
     gives up, the same synchronisation that carries the solver's decision reports it and the solve is repeated
