@@ -1863,6 +1863,17 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
     // the columns standing at this block's positions are fetched right away (the norms are indexed by POSITION,
     // so the pivot search needs no indirection); only a column sitting at the pivot's position has to be
     // fetched again -- that slot works on the column the exchange brings there
+    // every column is reached through a buffer descriptor (uniform base, n*8 bytes; an absent column gets an empty one):
+    // the fetches are unconditional -- rows beyond n read as zero, their stores are dropped -- instead of one exec-masked
+    // branch per element
+    typedef unsigned v2u_q2 __attribute__((ext_vector_type(2)));
+    const unsigned tb = (unsigned)(i + 1 + tid) * 8u, ib = (unsigned)i * 8u, colbytes = (unsigned)n * 8u;
+    auto col_rsrc = [&](const double *base, bool present) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, present ? colbytes : 0u, 0x00020000);
+    };
+    auto ld = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+    };
     double a[Q2S_CPB][Q2S_RPT], cji[Q2S_CPB];
     int own[Q2S_CPB];
 #pragma unroll
@@ -1870,14 +1881,14 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
         const int item = (int)blockIdx.x * Q2S_CPB + c;
         own[c] = -1;                                            // -1: nothing, -2: rhs
         const double *cg = nullptr;
-        if (!is_ice && item < npos) { own[c] = colat_in[i + 1 + item]; cg = R + (size_t)own[c] * n; }
-        else if (!is_ice && item == npos) { own[c] = -2; cg = rhs; }
+        if (!is_ice && item < npos) {
+            own[c] = __builtin_amdgcn_readfirstlane(colat_in[i + 1 + item]);
+            cg = R + (size_t)own[c] * n;
+        } else if (!is_ice && item == npos) { own[c] = -2; cg = rhs; }
+        const __amdgpu_buffer_rsrc_t rc = col_rsrc(cg ? cg : R, cg != nullptr);
 #pragma unroll
-        for (int q = 0; q < Q2S_RPT; ++q) {
-            const int k = i + 1 + tid + q * Q2S_NT;
-            a[c][q] = (cg && k < n) ? cg[k] : 0.0;
-        }
-        cji[c] = cg ? cg[i] : 0.0;
+        for (int q = 0; q < Q2S_RPT; ++q) a[c][q] = ld(rc, tb, q * Q2S_NT * 8);
+        cji[c] = ld(rc, ib, 0);
     }
     // (a) first maximum of the norms over positions i..n-1
     double best = -1.0;
@@ -1898,30 +1909,27 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
     for (int w = 1; w < 4; ++w)
         if (s_best[w] > best || (s_best[w] == best && s_bpos[w] < bpos)) { best = s_best[w]; bpos = s_bpos[w]; }
     const int ppos = bpos < n ? bpos : i;
-    const int pcol = colat_in[ppos], icol = colat_in[i];
+    const int pcol = __builtin_amdgcn_readfirstlane(colat_in[ppos]), icol = __builtin_amdgcn_readfirstlane(colat_in[i]);
     // (b) reflector of the pivot column on rows i..n-1
     const double *cp = R + (size_t)pcol * n;
+    const __amdgpu_buffer_rsrc_t rp = col_rsrc(cp, true);
     double v[Q2S_RPT];
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < Q2S_RPT; ++q) {
-        const int k = i + 1 + tid + q * Q2S_NT;
-        v[q] = k < n ? cp[k] : 0.0;
+        v[q] = ld(rp, tb, q * Q2S_NT * 8);
         acc += v[q] * v[q];
     }
-    const double alpha = cp[i];
+    const double alpha = ld(rp, ib, 0);
 #pragma unroll
     for (int c = 0; c < Q2S_CPB; ++c) {
         const int item = (int)blockIdx.x * Q2S_CPB + c;
         if (own[c] >= 0 && i + 1 + item == ppos) {   // this position receives the displaced column
             own[c] = icol;
-            const double *co = R + (size_t)icol * n;
+            const __amdgpu_buffer_rsrc_t ro = col_rsrc(R + (size_t)icol * n, true);
 #pragma unroll
-            for (int q = 0; q < Q2S_RPT; ++q) {
-                const int k = i + 1 + tid + q * Q2S_NT;
-                a[c][q] = k < n ? co[k] : 0.0;
-            }
-            cji[c] = co[i];
+            for (int q = 0; q < Q2S_RPT; ++q) a[c][q] = ld(ro, tb, q * Q2S_NT * 8);
+            cji[c] = ld(ro, ib, 0);
         }
     }
     const double xn = sqrt(blk_sum_256(acc, sh));
@@ -1994,11 +2002,11 @@ k_qr2_step(double *__restrict__ R, int n, int i, double *__restrict__ rhs, const
             const double wt = (((shv[0][c] + shv[1][c]) + shv[2][c]) + shv[3][c]) + cji[c];      // v_i = 1
             const double tw = ti * wt;
             double *cj = own[c] == -2 ? rhs : R + (size_t)own[c] * n;
+            const __amdgpu_buffer_rsrc_t rj = col_rsrc(cj, true);
 #pragma unroll
             for (int q = 0; q < Q2S_RPT; ++q) {
-                const int k = i + 1 + tid + q * Q2S_NT;
                 a[c][q] -= v[q] * tw;
-                if (k < n) cj[k] = a[c][q];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_q2, a[c][q]), rj, tb, q * Q2S_NT * 8, 0);
             }
             cji[c] -= tw;
             if (tid == 0) cj[i] = cji[c];
