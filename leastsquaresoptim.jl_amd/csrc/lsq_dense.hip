@@ -948,15 +948,19 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two-stage column-pivoted QR for tall problems: the pivoted sweep of dgeqp3 streams
-// the whole trailing matrix once per column (C3: 2.6e11 bytes).  Stage 1 is an UNPIVOTED blocked
-// Householder QR of [A | b] (64-column panels; inside a panel one launch per column touches only
-// the panel; the trailing matrix is updated once per panel with the compact-WY form on the fp64
-// MFMA units: W = V'[V | A2 | b] (split-K, deterministic reduce), T from the Gram block (dlarft),
-// A2 -= V (T'W)).  Stage 2 runs the pivoted sweep (k_qr_pivot / k_qr_apply, the dlaqp2 recurrence) on
-// the n x n triangle R with Q1'b riding along: A P = Q1 (R P) = Q1 Q2 R2, so R2, the pivots and
-// Q2'Q1'b are what ldiv!(::QRPivoted, b) needs; the rank decision (dlaic1, rcond) and the
-// minimum-norm completion then run unchanged (k_qrcp_solve, phase 0).
+// Two-stage column-pivoted QR: the pivoted sweep of dgeqp3 streams the whole trailing matrix once
+// per column (C3: 2.6e11 bytes).  Stage 1 is an UNPIVOTED blocked Householder QR of [A | b]:
+//   * 64-column panels; the panel steps carry K pivot columns per launch in registers (k_qr1_step_multi: lazy
+//     reflectors, 1-256 row slabs per column with an in-kernel exchange, TSQR levels for tall thin operands; the older
+//     per-column kernels k_qr1_step / _reg / _lazy remain selectable for A/B runs);
+//   * per panel the trailing matrix is updated once with the compact-WY form on the fp64 MFMA units:
+//     W = V'[V | A2 | b] (k_qr1_vtb: split-K, deterministic reduce), T'W through an explicit T' built in LDS from the
+//     Gram block (k_qr1_tw_mfma), A2 -= V (T'W) (k_qr1_update); in the last panel b rides through the steps instead.
+// Then either the FULL-RANK CERTIFICATE (qr2_certify_full_rank: explicit inverse of the triangle, Frobenius bound on
+// cond_2 -- xGELSY's rank decision is provably n, the unpivoted triangle gives the solution: k_tri_bsolve), or stage 2:
+// the pivoted sweep (k_qr2_step, the dlaqp2 recurrence with lazy column exchanges) on the n x n triangle R with Q1'b
+// riding along: A P = Q1 (R P) = Q1 Q2 R2, so R2, the pivots and Q2'Q1'b are what ldiv!(::QRPivoted, b) needs; the rank
+// decision (dlaic1, rcond) and the minimum-norm completion then run unchanged (k_qrcp_solve, phase 0).
 // ---------------------------------------------------------------------------------------------
 typedef double v4d_qr __attribute__((ext_vector_type(4)));
 constexpr int Q2_NB = 64;     // panel width
