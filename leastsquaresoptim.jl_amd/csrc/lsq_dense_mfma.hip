@@ -1,6 +1,7 @@
-// Dense normal-equation path at C2 scale (dense_cholesky.jl:43-59): fp64-MFMA SYRK for J'J,
-// blocked right-looking Cholesky (64-wide panels: diagonal block factored in LDS, row panel by
-// forward substitution, trailing update on the MFMA kernel again) and blocked triangular solves.
+// Dense normal-equation path (dense_cholesky.jl:29-59): fp64-MFMA SYRK for J'J (k_syrk_mfma; the pair kernel
+// k_syrk_small when there are few columns and many rows), blocked right-looking Cholesky (64-wide panels, diagonal
+// block and row panel in one launch: k_chol_panel16; trailing update on the MFMA kernel again) and the two
+// triangular solves pipelined over the 64-blocks (lsq_tri_chol_solve in lsq_dense.hip; k_chol_trsv as fallback).
 //
 // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16), one f64 of A and of B per lane
 //   A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
