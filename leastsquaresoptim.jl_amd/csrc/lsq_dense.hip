@@ -2467,8 +2467,7 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
     Qr2Work *q = (Qr2Work *)s->qr2;
     if (qr2_tsqr_applies(M, n)) {
         // levels of wave slabs (64 * RPT rows each) until the stack is short enough for the panel machinery
-        const bool block_slabs = getenv("LSQ_QR_TSQR_BLOCK") != nullptr;
-        const int L = block_slabs ? qr2_tsqr_slab_rows(n) : qr2_tsqr_slab_rows(n) / 4;
+        const int L = qr2_tsqr_slab_rows(n) / 4;
         double *Acur = s->d_qr, *bcur = s->d_qu;
         int Mcur = M;
         for (int level = 0; level < 6 && qr2_tsqr_applies(Mcur, n); ++level) {
@@ -2484,21 +2483,13 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
                 hipLaunchKernelGGL(kern, dim3(lsq_div_up(S, slabs_per_block)), dim3(256), 0, c->stream, Acur, Mcur, n, 0, n, q->tau1,
                                    q->lazy, q->lazy + n, S, q->xslot, ++q->epoch, q->d_err, q->Pn, 0, bcur, So, Ms, ro);
             };
-            if (block_slabs) {
-                if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, 1>, 1);
-                else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, 1>, 1);
-                else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, 1>, 1);
-                else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, 1>, 1);
-                else go(k_qr1_step_multi<256, 2, 32, 1, 1>, 1);
-            } else {
-                if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, 2>, 4);
-                else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, 2>, 4);
-                else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, 2>, 4);
-                else if (n <= 20) go(k_qr1_step_multi<256, 3, 20, 1, 2>, 4);
-                else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, 2>, 4);
-                else if (n <= 28) go(k_qr1_step_multi<256, 2, 28, 1, 2>, 4);
-                else go(k_qr1_step_multi<256, 2, 32, 1, 2>, 4);
-            }
+            if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, 2>, 4);
+            else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, 2>, 4);
+            else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, 2>, 4);
+            else if (n <= 20) go(k_qr1_step_multi<256, 3, 20, 1, 2>, 4);
+            else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, 2>, 4);
+            else if (n <= 28) go(k_qr1_step_multi<256, 2, 28, 1, 2>, 4);
+            else go(k_qr1_step_multi<256, 2, 32, 1, 2>, 4);
             Acur = So; bcur = ro; Mcur = Ms;
         }
         LSQ_HIP(hipGetLastError());
