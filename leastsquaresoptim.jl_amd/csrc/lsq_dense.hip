@@ -1184,12 +1184,12 @@ __device__ __forceinline__ void qr_static_for(F &&f) {
     }
 }
 //
-// TSQR = true (tall and thin operands, n <= K): every workgroup is on its own -- its slab of RPT*NT rows of ALL n
+// TSQR = 1 (tall and thin operands, n <= K; kept for reference, not instantiated): every workgroup is on its own -- its slab of RPT*NT rows of ALL n
 // columns and of b sits in registers, the K rounds factor the slab locally (pivot rows = the slab's first rows, no
 // exchange), and the only thing written is the slab's n x n triangle and the first n entries of its Q'b, stacked
 // for the next level (tsq_S: (slabs*n) x n, tsq_r): ONE pass over the matrix.
-// TSQR = 2: the same with one WAVEFRONT per slab (64*RPT rows): the reductions are wave reductions, the row-c elements
-// come from their owner lane by v_readlane -- no LDS, no barrier anywhere in the rounds.
+// TSQR = 2 (the one in use): the same with one WAVEFRONT per slab (64*RPT rows): the reductions are wave reductions, the
+// row-c elements come from their owner lane by v_readlane -- no LDS, no barrier anywhere in the rounds.
 template <int NT, int RPT, int K, int S, int TSQR = 0>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live pivots, <= K */, double *__restrict__ tau,
