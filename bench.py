@@ -207,12 +207,19 @@ def main():
     except Exception:
         pass
 
+    # (the headline measurement is complete at this point: a failure in the reported-alongside legs must not lose it)
     cpu = None
     if not a.no_cpu and a.cpu_steps > 0 and world == 1:   # reported at N = 1 only
-        cpu = cpu_baseline(a, pr, inputs)
+        try:
+            cpu = cpu_baseline(a, pr, inputs)
+        except Exception as e:   # noqa: BLE001
+            cpu = {"value": None, "unit": "LM outer iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
     dense = None
     if not a.no_cpu and world == 1 and not a.no_dense:
-        dense = dense_secondary(ctx, lsq)
+        try:
+            dense = dense_secondary(ctx, lsq)
+        except Exception as e:   # noqa: BLE001
+            dense = {"error": repr(e)}
 
     value = a.steps * world / dt
     out = {"metric": "lm_lsmr_outer_iterations_per_sec", "value": value, "unit": "LM outer iterations/s",
