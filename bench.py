@@ -12,11 +12,11 @@ trajectory: with the reference's default tolerances it converges in 6 iterations
 8th every further step is rejected (no g!, one inner iteration) -- timing those would inflate
 the rate.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]         (N > 1: spawns N ranks under torch.distributed.run itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, the J*v product inside LSMR
-(k_seg_stream<EpiU>): algorithmic bytes per launch (12*nnz + 4*(m+1) + 8*n + 16*m
+(k_sell_rows<EpiU>): algorithmic bytes per launch (12*nnz + 4*(m+1) + 8*n + 16*m
 = 140.08 MB, plus 24*n for the fused damping rows) / average launch duration measured with HIP
 events on the library's stream inside the timed region.  `cpu_baseline` is the oracle (scalar C
 port, 1 thread) timed on this box's host on a bounded sample of the same workload.
@@ -46,11 +46,44 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=96, help="outer iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the secondary dense-path timings (C2/C3 ldiv!)")
-    return ap.parse_args()
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="how many times the K-step timed region is repeated (value = median region)")
+    ap.add_argument("--exchange", choices=("nccl", "gloo"), default=os.environ.get("LSQ_EXCHANGE_BACKEND", "nccl"),
+                    help="backend of the per-outer-iteration ||r|| exchange of sharded runs (nccl = RCCL over xGMI)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch-path check without a GPU: spawn the ranks, build the process group (gloo), run the "
+                         "exchange protocol on made-up scalars and print the JSON line with value = null")
+    # ranks started by spawn_ranks() get the original command line through the environment: torchrun's own argparse
+    # would try to abbreviation-match script options such as --m against its own (--master-addr, --max-restarts, ...)
+    argv = json.loads(os.environ["LSQ_BENCH_ARGV"]) if "LSQ_BENCH_ARGV" in os.environ else None
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside a torchrun environment: re-execute under torch.distributed.run with one
+    rank per GPU (what the driver's own multi-GPU command line does).  Does not return."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    os.environ["LSQ_BENCH_ARGV"] = json.dumps(sys.argv[1:])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)                      # re-executes under torch.distributed.run; never returns
     # Exactly ONE line on stdout: native libraries (RCCL's version banner, rocm notices) also write to fd 1,
     # so everything but the final JSON line is sent to stderr.
     sys.stdout.flush()
@@ -59,31 +92,34 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
+    if a.dry_run:
+        return dry_run(a, rank, world, real_stdout)
     import torch  # plumbing only: device selection, barrier, RCCL all-reduce
     dist = None
     # LSQ_BENCH_FORCE_EXCHANGE=1 (diagnostic): run the sharded protocol with its RCCL exchange even on one rank
     force_x = world == 1 and os.environ.get("LSQ_BENCH_FORCE_EXCHANGE") == "1"
     if force_x:
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+    exchange_backend, rccl_ranks = None, 0
     if world > 1 or force_x:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        # the per-iteration scalar exchange (80 bytes of host values) goes over a CPU group: an RCCL kernel
-        # would compete for CUs with the persistent one-workgroup-per-CU product kernels (measured with
-        # LSQ_BENCH_FORCE_EXCHANGE=1: 2370 -> 2190 it/s); RCCL stays the backend of barrier / reductions of
-        # device data.  LSQ_EXCHANGE_BACKEND=nccl switches back.
-        xgroup, xdev = None, "cuda"
-        if os.environ.get("LSQ_EXCHANGE_BACKEND", "gloo") == "gloo":
+        rccl_ranks = dist.get_world_size()          # size of the nccl (= RCCL) group that carries the exchange
+        # The per-outer-iteration exchange {sum ssr, max |g|, all-converged} is ONE RCCL all-reduce over xGMI
+        # (north_star).  --exchange gloo / LSQ_EXCHANGE_BACKEND=gloo is an opt-in A/B (the payload is 80
+        # bytes of host scalars, and an RCCL kernel has to find a CU next to the persistent product kernels).
+        xgroup, xdev, exchange_backend = None, "cuda", "nccl"
+        if a.exchange == "gloo":
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the container hostname may not resolve
-            try:
-                xgroup, xdev = dist.new_group(backend="gloo"), "cpu"
-            except Exception as e:   # no CPU backend: fall back to RCCL for the scalars too
-                print("bench: gloo group unavailable (%s); scalar exchange over RCCL" % e, file=sys.stderr)
-                xgroup, xdev = None, "cuda"
+            xgroup, xdev, exchange_backend = dist.new_group(backend="gloo"), "cpu", "gloo"
+        print("bench: rank %d/%d on cuda:%d, exchange backend %s" % (rank, world, local_rank, exchange_backend),
+              file=sys.stderr)
     else:
         torch.cuda.set_device(local_rank)
     import numpy as np
@@ -107,12 +143,9 @@ def main():
 
     LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
 
-    def run(iters, prof=False):
+    def run(iters):
         """`iters` outer iterations as solves of --iters-per-solve from x0 = 0; returns
         (iterations done, inner iterations, last result)."""
-        if prof:
-            L.lsq_prof_select(ctx.h, prof)      # bits 0-7: kernel mask; bits 8+: time every k-th launch
-            L.lsq_prof_begin(ctx.h, 8192)
         done = inner = 0
         r = None
         while done < iters:
@@ -134,18 +167,30 @@ def main():
 
     if a.warmup > 0:
         run(a.warmup)
-    barrier()
-    t0 = time.perf_counter()
+    # The timed region is EXACTLY K steps between barrier + synchronize; it is repeated --repeats times (each
+    # repeat bracketed the same way) and `value` comes from the MEDIAN region, so the headline is not one sample
+    # of a few milliseconds.  Every third J*v launch of every region carries its own start/stop events.
     stride = int(os.environ.get("LSQ_BENCH_PROF_STRIDE", "3"))
-    steps_done, inner_local, r = run(a.steps, prof=1 | (stride << 8))   # timed region: every 3rd J*v launch carries events
-    barrier()
-    dt = time.perf_counter() - t0
+    L.lsq_prof_select(ctx.h, 1 | (stride << 8))     # bits 0-7: kernel mask; bits 8+: time every k-th launch
+    L.lsq_prof_begin(ctx.h, 1 << 16)
+    region_s, inner_local, r = [], 0, None
+    reps = max(1, a.repeats)
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        steps_done, inner_rep, r = run(a.steps)
+        barrier()
+        region_s.append(time.perf_counter() - t0)
+        inner_local += inner_rep
+        assert steps_done == a.steps, (steps_done, a.steps)
     avg = (C.c_double * 2)()
     cnt = (C.c_int * 2)()
     L.lsq_prof_end(ctx.h, avg, cnt)
     # the J'u kernel is timed in a separate (untimed) pass of one solve: every instrumented launch
     # costs a few microseconds of pipeline gaps, which the timed region should not pay twice
-    run(a.iters_per_solve, prof=2)
+    L.lsq_prof_select(ctx.h, 2)
+    L.lsq_prof_begin(ctx.h, 8192)
+    run(a.iters_per_solve)
     avg2 = (C.c_double * 2)()
     cnt2 = (C.c_int * 2)()
     L.lsq_prof_end(ctx.h, avg2, cnt2)
@@ -154,15 +199,17 @@ def main():
     ev_ovh = C.c_double(0.0)   # what an EMPTY event pair measures on this stream (marker overhead)
     L.lsq_prof_overhead(ctx.h, 50, C.byref(ev_ovh))
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor(region_s, dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)       # every region: the slowest rank's time
+        region_s = [float(v) for v in tt.tolist()]
         it = torch.tensor([float(inner_local)], dtype=torch.float64, device="cuda")
         dist.all_reduce(it)
         inner_total = float(it.item())
     else:
         inner_total = float(inner_local)
-    assert steps_done == a.steps, (steps_done, a.steps)
+    srt = sorted(region_s)
+    dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    inner_total /= reps                                  # per region
 
     # generic J*v (y <- J x + y) timed back-to-back with HIP events, for reference
     xv = lsq.DeviceVector(ctx, n, np.random.default_rng(0).standard_normal(n))
@@ -198,14 +245,16 @@ def main():
             "generic_jtu_ms": ms_t.value, "generic_jtu_GBps": bytes_jtu / (ms_t.value * 1e-3) / 1e9}
 
     # HBM traffic of that kernel comes from rocprofv3 PMC passes (it cannot be read inside this
-    # process): the committed measurement for exactly this workload, if present
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-        if tr["config"] == {"m": m, "n": n, "nnz": nnz}:
-            roof["traffic"] = tr["hbm_bytes_per_launch"]
-            roof["traffic_source"] = tr["source"]
-    except Exception:
-        pass
+    # process): the committed measurement for exactly this workload, newest round first
+    for rnd in ("r02", "r01"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))
+            if tr["config"] == {"m": m, "n": n, "nnz": nnz}:
+                roof["traffic"] = tr["hbm_bytes_per_launch"]
+                roof["traffic_source"] = tr["source"]
+                break
+        except Exception:
+            pass
 
     # (the headline measurement is complete at this point: a failure in the reported-alongside legs must not lose it)
     cpu = None
@@ -226,9 +275,12 @@ def main():
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
+           "repeats": reps, "region_ms": {"median": dt * 1e3, "min": srt[0] * 1e3, "max": srt[-1] * 1e3},
+           "value_min": a.steps * world / srt[-1], "value_max": a.steps * world / srt[0],
            "config": {"workload": "C4: sparse CSC %dx%d, nnz=%d (%.3g%%), LevenbergMarquardt(LSMR()), tanh model, "
                                   "1 problem per GPU" % (m, n, nnz, 100.0 * nnz / (m * n)),
                       "m": m, "n": n, "nnz": nnz, "seed": lsq.synthetic.BASE_SEED, "problems": world,
+                      "exchange_backend": exchange_backend, "rccl_ranks": rccl_ranks,
                       "lsmr_inner_iterations_total": inner_total,
                       "lsmr_inner_per_outer": inner_total / (a.steps * world),
                       "lsmr_inner_iterations_per_sec": inner_total / dt, "iters_per_solve": a.iters_per_solve,
@@ -239,6 +291,44 @@ def main():
         dist.destroy_process_group()
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + "\n").encode())   # fd 1 stays on stderr: RCCL prints its banner at exit
+
+
+def dry_run(a, rank, world, real_stdout):
+    """--dry-run: everything about the launch EXCEPT the hot path (there is no CPU implementation of it): rank
+    bookkeeping, process group, the sharded runs' exchange protocol (sharding.py) on made-up scalars over gloo,
+    max-over-ranks of a timed region, ONE JSON line from rank 0 with value = null.  What the CPU test suite uses to
+    check that `bench.py --gpus N` really runs N ranks."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from lsq_amd import sharding
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo")
+        cb = sharding.make_allreduce_callback(dist, rank, world, "cpu")
+        t0 = time.perf_counter()
+        seen = []
+        for it in range(a.steps):
+            vals = (C.c_double * 3)(1.0 + rank, float(it), 1.0 if it == a.steps - 1 else 0.0)
+            assert cb(vals, 3, None) == 0
+            seen.append((vals[0], vals[1], vals[2]))
+        sharding.drain_all()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ranks = dist.get_world_size()
+        assert seen[-1] == (world * (world + 1) / 2.0, float(a.steps - 1), 1.0), seen[-1]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks = 1
+    if rank == 0:
+        out = {"metric": "lm_lsmr_outer_iterations_per_sec", "value": None, "unit": "LM outer iterations/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True,
+               "config": {"workload": "dry run: launch path only, no hot-path work", "problems": world,
+                          "exchange_backend": "gloo", "rccl_ranks": 0, "process_group_ranks": ranks}}
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 def dense_secondary(ctx, lsq):

@@ -28,7 +28,8 @@ typedef enum {
     LSQ_EBOUNDS = 5,    /* "Initial guess must be within bounds" (levenberg_marquardt.jl:51) */
     LSQ_EHIP = 6,       /* a HIP runtime call failed */
     LSQ_EARG = 7,       /* invalid argument (e.g. QR on a sparse Jacobian, types.jl:115-117) */
-    LSQ_ECALLBACK = 8   /* a user callback reported failure */
+    LSQ_ECALLBACK = 8,  /* a user callback reported failure */
+    LSQ_ERCCL = 9       /* sharded run: the exchange reported that a peer rank left its loop with an error */
 } lsq_status;
 
 typedef struct lsq_ctx lsq_ctx;       /* one per device/stream; not thread-safe */
@@ -163,7 +164,11 @@ typedef int (*lsq_g_callback)(lsq_mat *J, const double *d_x, void *user);
  * look-ahead window is full), so the exchange overlaps the device; it never acts on the result
  * ("all converged" cannot hold while it is not converged itself), which lets an implementation
  * return the previous exchange's values to such a rank and leave the new one in flight
- * (leastsquaresoptim.jl_amd/sharding.py does; bench.py carries it over a CPU process group). */
+ * (leastsquaresoptim.jl_amd/sharding.py does; bench.py carries it over the RCCL process group).
+ * Error protocol: a rank that leaves its loop with an error calls the hook one last time with
+ * converged_local = -1; an implementation reports "some rank has left" to the others either by returning 2
+ * or by setting the returned third value to -1 -- the loop then returns LSQ_ERCCL instead of entering another
+ * collective that the departed rank will never join. */
 typedef int (*lsq_allreduce_callback)(double *h_vals, int count, void *user);
 
 typedef struct {
@@ -193,6 +198,7 @@ typedef struct {
     int bad_index;              /* for LSQ_ENONFINITE */
     double seconds;             /* wall time of the loop (host clock, includes syncs) */
     long long lsmr_iterations;  /* total inner iterations */
+    double ssr0;                /* sum(abs2, f(x0)): state 0 of the reference's trace (levenberg_marquardt.jl:70) */
 } lsq_result;
 
 void lsq_options_default(lsq_options *opt);

@@ -2,7 +2,7 @@
 (include/lsqhip.h) of hand-written gfx950 HIP kernels.  Import as `lsq_amd` (root shim)."""
 from . import _lib
 from ._lib import (ArgumentError, DimensionMismatch, HipError, IsFiniteException, LsqError,
-                   PosDefException, RankDeficientException, build, declared_symbols, lib)
+                   PeerAborted, PosDefException, RankDeficientException, build, declared_symbols, lib)
 from .api import (axpy_, box_clip_, clamp_, copyto_, ediv_, fill_, first_nonfinite, rmul_, vsum,
                   AllocatedSolver, Cholesky, Context, DeviceMatrix, DeviceOperator, DeviceVector, Dogleg, LSMR,
                   LeastSquaresProblem, LeastSquaresProblemAllocated, LeastSquaresResult, LevenbergMarquardt, OptimizationState, QR,

@@ -23,7 +23,7 @@ OP_MUL_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void
 OP_COLSUM_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)                  # (d_out, user)
 PRECOND_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)   # (d_P, J, d_damp, user)
 
-OK, EDIM, ENOTPD, ERANK, ENONFINITE, EBOUNDS, EHIP, EARG, ECALLBACK = range(9)
+OK, EDIM, ENOTPD, ERANK, ENONFINITE, EBOUNDS, EHIP, EARG, ECALLBACK, ERCCL = range(10)
 QR, CHOLESKY, LSMR = 0, 1, 2
 DOGLEG, LEVENBERG_MARQUARDT = 0, 1
 
@@ -43,7 +43,7 @@ class Result(C.Structure):
                 ("converged", C.c_int), ("x_converged", C.c_int), ("f_converged", C.c_int),
                 ("g_converged", C.c_int), ("f_calls", C.c_int), ("g_calls", C.c_int),
                 ("mul_calls", C.c_int), ("status", C.c_int), ("bad_index", C.c_int),
-                ("seconds", C.c_double), ("lsmr_iterations", C.c_longlong)]
+                ("seconds", C.c_double), ("lsmr_iterations", C.c_longlong), ("ssr0", C.c_double)]
 
 
 def build(verbose=False):
@@ -183,9 +183,13 @@ class HipError(LsqError):
     pass
 
 
+class PeerAborted(LsqError):
+    """Sharded run: another rank left its loop with an error (LSQ_ERCCL)."""
+
+
 _EXC = {EDIM: DimensionMismatch, ENOTPD: PosDefException, ERANK: RankDeficientException,
         ENONFINITE: IsFiniteException, EBOUNDS: ArgumentError, EHIP: HipError, EARG: ArgumentError,
-        ECALLBACK: LsqError}
+        ECALLBACK: LsqError, ERCCL: PeerAborted}
 
 
 def check(status):

@@ -683,7 +683,8 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
     r.trace = tr
     states = []
     if tracing and tr is not None:
-        # utils.jl:86-131: state 0 is (0, ssr0, Inf); we record the per-iteration states
+        # levenberg_marquardt.jl:70 / dogleg.jl:74: state 0 = (0, ssr(x0), Inf), then one state per iteration
+        states.append(OptimizationState(0, float(res.ssr0), float("inf")))
         for k in range(res.iterations):
             states.append(OptimizationState(k + 1, tr["ssr"][k], tr["gnorm"][k]))
         if show_trace:

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/lsqhip.h"
@@ -66,7 +67,21 @@ struct lsq_ctx {
     int prof_kernels = 3;                // bit k: instrument kernel k (a timed launch costs ~9 us of gaps)
     int prof_stride = 1, prof_tick = 0;  // time every prof_stride-th armed launch
     std::vector<hipEvent_t> prof_ev[2];  // start/stop pairs per kernel id
+    // kernels whose dynamic-LDS limit has been raised on THIS context's device (function attributes may be per device)
+    std::unordered_map<const void *, size_t> lds_cfg;
 };
+
+// raise a kernel's dynamic-LDS limit once per context (= per device)
+static inline int lsq_set_lds(lsq_ctx *c, const void *kern, size_t bytes) {
+    auto it = c->lds_cfg.find(kern);
+    if (it != c->lds_cfg.end() && it->second >= bytes) return LSQ_OK;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return LSQ_EHIP;
+    }
+    c->lds_cfg[kern] = bytes;
+    return LSQ_OK;
+}
 
 // record a start (phase 0) / stop (phase 1) event for kernel `kid` if instrumentation is on
 // phase 0 arms the instrumentation for kernel `kid`: a launch site that supports it (the LDS-staged

@@ -473,7 +473,13 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             continue;
         }
         if (c->idle_hook) lsq_run_idle_hook(c);   // look-ahead window full: the device has work for a while
-        if ((++spins & 0x3ffu) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
+        if ((++spins & 0x3ffu) != 0) continue;
+        const hipError_t sq = hipStreamQuery(c->stream);
+        if (sq != hipSuccess && sq != hipErrorNotReady) {   // launch failure / device fault: the mailbox will never move
+            lsq_set_error("HIP error inside the LSMR iteration: %s", hipGetErrorString(sq));
+            return LSQ_EHIP;
+        }
+        if (sq == hipSuccess) {
             // stream drained: whatever the mailbox shows now is final for the enqueued work
             w = *(volatile unsigned long long *)c->h_mail;
             if ((unsigned)(w >> 41) == epoch && ((w >> 40) & 1ull)) continue;

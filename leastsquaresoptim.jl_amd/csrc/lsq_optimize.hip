@@ -525,10 +525,18 @@ static int check_start(const double *hx, int n, const lsq_options *o) {
 }
 
 // One global exchange per outer iteration for sharded problems.
+// Callback protocol (include/lsqhip.h, lsq_options.allreduce): vals = {ssr, maxabs_gr, converged}; converged < 0 on
+// the way in announces "this rank is leaving with an error"; converged < 0 on the way out (or return code 2) says
+// that some rank did -- every rank then leaves its loop with LSQ_ERCCL instead of waiting in a collective forever.
 static int global_exchange(const lsq_options *o, double *ssr, double *gnorm, int *all_converged) {
     if (!o->allreduce) return LSQ_OK;
     double v[3] = {*ssr, *gnorm, (double)*all_converged};
-    if (o->allreduce(v, 3, o->allreduce_user) != 0) {
+    const int rc = o->allreduce(v, 3, o->allreduce_user);
+    if (rc == 2 || (rc == 0 && v[2] < -0.5)) {
+        lsq_set_error("sharded run: a peer rank left its loop with an error");
+        return LSQ_ERCCL;
+    }
+    if (rc != 0) {
         lsq_set_error("allreduce callback failed");
         return LSQ_ECALLBACK;
     }
@@ -537,6 +545,22 @@ static int global_exchange(const lsq_options *o, double *ssr, double *gnorm, int
     *all_converged = v[2] > 0.5 ? 1 : 0;
     return LSQ_OK;
 }
+
+// Every exit of a sharded loop: the idle hook (which points at a stack object of the loop) is disarmed, and a rank
+// that leaves with an error tells its peers so with one last exchange.
+struct ShardedExit {
+    lsq_ctx *c;
+    const lsq_options *o;
+    int finish(int st) {
+        c->idle_hook = nullptr;
+        c->idle_user = nullptr;
+        if (st != LSQ_OK && st != LSQ_ERCCL && o->allreduce) {
+            double v[3] = {0.0, 0.0, -1.0};
+            (void)o->allreduce(v, 3, o->allreduce_user);
+        }
+        return st;
+    }
+};
 
 #define CB(call)                                          \
     do {                                                  \
@@ -569,8 +593,15 @@ struct IterateGuard {
     }
 };
 
+static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x_user, double *fcur_user,
+                            lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r);
 static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x_user, double *fcur_user,
                        lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
+    ShardedExit ex{c, o};
+    return ex.finish(optimize_lm_loop(c, sv, b, J, x_user, fcur_user, f, g, user, o, r));
+}
+static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x_user, double *fcur_user,
+                            lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
     const int m = J->m, n = J->n;
     double *x = x_user, *fcur = fcur_user, *xt = b.xt, *ftrial = b.ftrial;
     IterateGuard guard{c, x, fcur, x_user, fcur_user, m, n};
@@ -582,6 +613,7 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
     f_calls++;
     double ssr;
     LSQ_TRY(lsq_sumsq(c, m, fcur, &ssr));
+    r->ssr0 = ssr;
     double maxabs_gr = INFINITY;
     bool need_jac = true;
     int iter = 0, nonfinite_at = -1;
@@ -704,6 +736,9 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
             nonfinite_at = trial_nonfinite;
         } else {
             hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, xt, b.dx, x);  // :135
+            // a non-finite trial component stays non-finite through (x - dx) + dx: the reference's
+            // check_isfinite(x) at the top of the next iteration then throws (utils.jl:70-75)
+            nonfinite_at = trial_nonfinite;
             delta = std::max(delta / decrease_factor, MIN_DELTA);
             decrease_factor *= 2.0;
         }
@@ -723,8 +758,15 @@ static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, d
 // ---------------------------------------------------------------------------------------------
 // dogleg.jl:41-203
 // ---------------------------------------------------------------------------------------------
+static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x, double *fcur,
+                                lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r);
 static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x, double *fcur,
                            lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
+    ShardedExit ex{c, o};
+    return ex.finish(optimize_dogleg_loop(c, sv, b, J, x, fcur, f, g, user, o, r));
+}
+static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x, double *fcur,
+                                lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
     const int m = J->m, n = J->n;
     double delta = o->delta > 0 ? o->delta : 1.0;
     bool reuse = false, converged = false;
@@ -734,6 +776,7 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
     f_calls++;
     double ssr;
     LSQ_TRY(lsq_sumsq(c, m, fcur, &ssr));
+    r->ssr0 = ssr;
     double maxabs_gr = INFINITY;
     int iter = 0, nonfinite_at = -1;
     LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
@@ -861,6 +904,7 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
         } else {
             reuse = true;
             hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.xt, b.dx, x);
+            nonfinite_at = trial_nonfinite;   // (x - dx) + dx keeps a non-finite component non-finite (see optimize_lm)
         }
         if (rho < DECREASE_THRESHOLD) delta = std::max(MIN_DELTA, delta * 0.5);           // :193-197
         else if (rho > INCREASE_THRESHOLD) delta = std::max(delta, 3.0 * wnorm_dx);
@@ -1108,11 +1152,9 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         }
         J->csc_fresh = !lazy_csc;
         const size_t lds = (size_t)J->n * sizeof(double);
-        static thread_local bool attr = false;
-        if (lds_ok && !attr) {
-            hipFuncSetAttribute((const void *)k_scale_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 12000 * 8);
-            hipFuncSetAttribute((const void *)k_scale_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 12000 * 8);
-            attr = true;
+        if (lds_ok) {
+            LSQ_TRY(lsq_set_lds(c, (const void *)k_scale_lds<true>, 12000 * 8));
+            LSQ_TRY(lsq_set_lds(c, (const void *)k_scale_lds<false>, 12000 * 8));
         }
         hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
         if (J->nnz > 0) {

@@ -697,19 +697,12 @@ struct EpiGradSq {
 };
 
 bool lsq_can_fuse_grad_colsum(const lsq_mat *J) {
-    static thread_local int ok = -1;  // 160 KiB of dynamic LDS: yl + products + squares
+    // 160 KiB of dynamic LDS: yl + products + squares
     if (J->kind == LSQ_MAT_CSC && J->scols.active && !lsq_small_mat(J)) return true;
     if (J->kind != LSQ_MAT_CSC || J->nwin <= 1 || J->bcsc.plan != LSQ_PLAN_LDSWIN || lsq_small_mat(J)) return false;
-    if (ok < 0) {
-        const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + 2 * LSQ_BIG_WINDOW) * sizeof(double);
-        bool a = hipFuncSetAttribute((const void *)k_bcsc_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds) == hipSuccess;
-        bool b = hipFuncSetAttribute((const void *)k_bcsc_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds) == hipSuccess;
-        (void)hipGetLastError();
-        ok = a && b;
-    }
-    return ok == 1;
+    const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + 2 * LSQ_BIG_WINDOW) * sizeof(double);
+    return lsq_set_lds(J->ctx, (const void *)k_bcsc_lds<true, true>, lds) == LSQ_OK &&
+           lsq_set_lds(J->ctx, (const void *)k_bcsc_lds<false, true>, lds) == LSQ_OK;
 }
 
 int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {

@@ -592,12 +592,7 @@ static inline int launch_segs(lsq_ctx *ctx, const LsqSegs &segs, const double *x
             const size_t lds = (size_t)(nxpad + LSQ_BIG_WINDOW) * sizeof(double);
             const bool i16 = segs.d_idx16 != nullptr;
             auto kern = i16 ? k_seg_stream_lds<Epi, true> : k_seg_stream_lds<Epi, false>;
-            static thread_local const void *configured[2] = {nullptr, nullptr};
-            if (configured[i16] != (const void *)kern) {
-                LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)((LSQ_LDS_X_MAX + LSQ_BIG_WINDOW) * sizeof(double))));
-                configured[i16] = (const void *)kern;
-            }
+            LSQ_TRY(lsq_set_lds(ctx, (const void *)kern, (LSQ_LDS_X_MAX + LSQ_BIG_WINDOW) * sizeof(double)));
             int grid = std::max(1, std::min(segs.nbig, ctx->num_cus));
             hipEvent_t e0, e1;
             if (lsq_prof_take(ctx, &e0, &e1))
@@ -807,12 +802,7 @@ static inline int launch_sell_rows(lsq_mat *J, const double *val, const double *
     const int nxpad = (J->n + 1) & ~1;
     const size_t lds = (size_t)(nxpad + LSQ_SELL_ROWS_MAX) * sizeof(double);
     auto kern = k_sell_rows<Epi>;
-    static thread_local size_t configured = 0;
-    if (configured < lds) {
-        LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((LSQ_LDS_X_MAX + LSQ_SELL_ROWS_MAX) * sizeof(double))));
-        configured = (LSQ_LDS_X_MAX + LSQ_SELL_ROWS_MAX) * sizeof(double);
-    }
+    LSQ_TRY(lsq_set_lds(c, (const void *)kern, (LSQ_LDS_X_MAX + LSQ_SELL_ROWS_MAX) * sizeof(double)));
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
     hipEvent_t e0, e1;
     if (lsq_prof_take(c, &e0, &e1))
@@ -832,11 +822,7 @@ static inline int launch_sell_cols(lsq_mat *J, const double *y, const int *done)
     const LsqSell &S = J->scols;
     const size_t lds = (size_t)(LSQ_SELL_GROWS_MAX + (SQ ? 2 : 1) * LSQ_SELL_CCOLS_MAX) * sizeof(double);
     auto kern = k_sell_cols<SQ>;
-    static thread_local bool configured = false;
-    if (!configured) {
-        LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
     hipEvent_t e0, e1;
     if (lsq_prof_take(c, &e0, &e1))
@@ -890,14 +876,10 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
         if (J->nwin > 1) {
             LSQ_TRY(lsq_ensure_csr(J));
             if (J->bcsc.plan == LSQ_PLAN_LDSWIN) {
-                static thread_local bool configured[2] = {false, false};
                 const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + LSQ_BIG_WINDOW) * sizeof(double);
                 const bool i16 = J->bcsc.d_idx16 != nullptr;
                 auto kern = i16 ? k_bcsc_lds<true, false> : k_bcsc_lds<false, false>;
-                if (!configured[i16]) {
-                    LSQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    configured[i16] = true;
-                }
+                LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
                 int g2 = std::max(1, std::min(J->bcsc.nwin, c->num_cus));
                 hipEvent_t e0, e1;
                 if (lsq_prof_take(c, &e0, &e1))

@@ -223,7 +223,14 @@ int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, dou
     volatile unsigned long long *hw = (volatile unsigned long long *)(c->h_slots + LSQ_NSLOTS);
     unsigned long long spins = 0;
     while (*hw != seq) {
-        if ((++spins & 0xfffffu) == 0 && hipStreamQuery(c->stream) == hipSuccess && *hw != seq) {
+        if ((++spins & 0xfffffu) != 0) continue;
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipErrorNotReady) continue;
+        if (q != hipSuccess) {   // launch failure / device fault: the word will never arrive
+            lsq_set_error("HIP error while waiting for the iteration's scalars: %s", hipGetErrorString(q));
+            return LSQ_EHIP;
+        }
+        if (*hw != seq) {
             // stream drained but the word is not visible (should not happen with coherent host memory)
             LSQ_HIP(hipMemcpy(c->h_slots + first, c->d_slots + first, count * sizeof(double), hipMemcpyDeviceToHost));
             break;
@@ -286,9 +293,11 @@ __global__ void __launch_bounds__(LSQ_NT) k_box_clip(int n, double *__restrict__
                                                       const double *__restrict__ hi) {
     for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n;
          i += (long long)gridDim.x * LSQ_NT) {
+        // Julia's min / max propagate NaN from EITHER argument (fmin / fmax drop it): a NaN step component must stay
+        // NaN so that the trial point is non-finite, as in the reference (levenberg_marquardt.jl:89-98)
         double d = dx[i];
-        if (lo) d = fmin(d, x[i] - lo[i]);
-        if (hi) d = fmax(d, x[i] - hi[i]);
+        if (lo) { const double a = x[i] - lo[i]; d = (d != d || a != a) ? d + a : (d < a ? d : a); }
+        if (hi) { const double a = x[i] - hi[i]; d = (d != d || a != a) ? d + a : (d > a ? d : a); }
         dx[i] = d;
     }
 }

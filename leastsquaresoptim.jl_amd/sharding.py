@@ -1,30 +1,38 @@
 """The one global exchange of sharded runs: independent problems, one per rank, and a
 single all-reduce per OUTER iteration carrying {sum of ssr, max of gradient norms, all-converged}.
 
-A mixed sum/max/min reduction is packed into ONE SUM all-reduce of world+2 doubles: slot 0 = ssr,
-slot 1 = converged count, slot 2+rank = this rank's gradient norm (zeros elsewhere), so every rank
-recovers the max locally.  Backend `nccl` is RCCL over xGMI on MI355X; `gloo` is used by the CPU
-tests.  The payload is 8*(world+2) bytes: latency-only, never inside the LSMR loop.
+A mixed sum/max/min reduction is packed into ONE SUM all-reduce of world+3 doubles: slot 0 = ssr,
+slot 1 = converged count, slot 2 = count of ranks that are LEAVING WITH AN ERROR, slot 3+rank = this
+rank's gradient norm (zeros elsewhere), so every rank recovers the max locally.  Backend `nccl` is RCCL
+over xGMI on MI355X; `gloo` is used by the CPU tests.  The payload is 8*(world+3) bytes: latency-only,
+never inside the LSMR loop.
+
+Error protocol (include/lsqhip.h): the loop calls the hook a last time with converged = -1 when it leaves
+with an error; every rank that sees a non-zero abort count gets return code 2 (-> LSQ_ERCCL) and issues
+no further collective, so all ranks issue the same number of all-reduces and nobody waits forever.
 """
 import sys
 
 from . import _lib
 
 
+NSLOT = 3   # ssr, converged count, abort count; then one gradient-norm slot per rank
+
+
 def exchange(dist, rank, world, ssr, gnorm, converged, buf, host=None):
-    """Returns (sum ssr, max gnorm, all converged).  `buf` is a float64 tensor of world+2 elements on
+    """Returns (sum ssr, max gnorm, all converged).  `buf` is a float64 tensor of world+NSLOT elements on
     the backend's device; `host` an optional (pinned) staging tensor of the same shape."""
     import torch
     if host is None:
-        host = torch.zeros(world + 2, dtype=torch.float64)
+        host = torch.zeros(world + NSLOT, dtype=torch.float64)
     host.zero_()
     host[0] = ssr
     host[1] = 1.0 if converged else 0.0
-    host[2 + rank] = gnorm
+    host[NSLOT + rank] = gnorm
     buf.copy_(host)
     dist.all_reduce(buf)
     host.copy_(buf)
-    return float(host[0]), float(host[2:].max()), bool(float(host[1]) >= world - 0.5)
+    return float(host[0]), float(host[NSLOT:].max()), bool(float(host[1]) >= world - 0.5)
 
 
 _DRAINS = []
@@ -53,8 +61,8 @@ def make_allreduce_callback(dist, rank, world, device, group=None):
     The staging buffers are written through numpy views (no tensor indexing ops)."""
     import torch
     on_gpu = str(device).startswith("cuda")
-    bufs = [torch.zeros(world + 2, dtype=torch.float64, device=device) for _ in range(2)]
-    hosts = [torch.zeros(world + 2, dtype=torch.float64) for _ in range(2)]
+    bufs = [torch.zeros(world + NSLOT, dtype=torch.float64, device=device) for _ in range(2)]
+    hosts = [torch.zeros(world + NSLOT, dtype=torch.float64) for _ in range(2)]
     if on_gpu:
         hosts = [h.pin_memory() for h in hosts]
     views = [h.numpy() for h in hosts]   # share memory with the (pinned) staging tensors
@@ -68,32 +76,42 @@ def make_allreduce_callback(dist, rank, world, device, group=None):
         else:
             hosts[k].copy_(bufs[k])
         hv = views[k]
-        return float(hv[0]), float(hv[2:].max()), 1.0 if hv[1] >= world - 0.5 else 0.0
+        if hv[2] > 0.5:
+            state["aborted"] = True
+        return float(hv[0]), float(hv[NSLOT:].max()), 1.0 if hv[1] >= world - 0.5 else 0.0
 
     def _cb(vals, count, _user):
         try:
+            if state.get("aborted"):
+                return 2
             k = state["slot"]
             prev, pk = state["work"], k ^ 1
+            # the exchange left in flight an iteration ago is complete by now: look at it BEFORE issuing the next
+            # one, so that a rank that learns of an abort issues no further collective
+            if prev is not None:
+                state["last"] = _finish(prev, pk)
+                state["work"] = None
+                if state.get("aborted"):
+                    return 2
+            leaving = vals[2] < -0.5
             conv = vals[2] > 0.5
             hv = views[k]
             hv[:] = 0.0
-            hv[0] = vals[0]
+            hv[0] = 0.0 if leaving else vals[0]
             hv[1] = 1.0 if conv else 0.0
-            hv[2 + rank] = vals[1]
+            hv[2] = 1.0 if leaving else 0.0
+            hv[NSLOT + rank] = 0.0 if leaving else vals[1]
             bufs[k].copy_(hosts[k], non_blocking=True)
             work = dist.all_reduce(bufs[k], async_op=True, group=group)
-            if conv or state.get("last") is None:
-                if prev is not None:
-                    _finish(prev, pk)            # drain the exchange left in flight while active
-                res = _finish(work, k)
-                state["work"] = None
+            if leaving or conv or state.get("last") is None:
+                res = _finish(work, k)           # frozen / leaving / first call: synchronous
             else:
-                if prev is not None:
-                    state["last"] = _finish(prev, pk)
-                res = state["last"]
+                res = state["last"]              # active rank: this iteration's exchange stays in flight
                 state["work"] = work
             state["last"] = res
             state["slot"] = k ^ 1
+            if state.get("aborted"):
+                return 0 if leaving else 2
             vals[0], vals[1], vals[2] = res
             return 0
         except Exception as e:  # pragma: no cover
@@ -102,7 +120,7 @@ def make_allreduce_callback(dist, rank, world, device, group=None):
 
     def _drain():
         if state["work"] is not None:
-            _finish(state["work"], state["slot"] ^ 1)
+            state["last"] = _finish(state["work"], state["slot"] ^ 1)
             state["work"] = None
 
     _DRAINS.append(_drain)

@@ -852,10 +852,17 @@ static int check_bounds(const double *x, int n, const double *lo, const double *
 
 static void apply_box(double *dx, const double *x, int n, const double *lo, const double *hi) {
     /* levenberg_marquardt.jl:89-98, dogleg.jl:148-160: the STEP is clipped, x_new = x - dx */
+    /* Julia's min / max return NaN when EITHER argument is NaN */
     if (lo)
-        for (int i = 0; i < n; ++i) dx[i] = dx[i] < x[i] - lo[i] ? dx[i] : x[i] - lo[i];
+        for (int i = 0; i < n; ++i) {
+            double a = x[i] - lo[i];
+            dx[i] = (isnan(dx[i]) || isnan(a)) ? dx[i] + a : (dx[i] < a ? dx[i] : a);
+        }
     if (hi)
-        for (int i = 0; i < n; ++i) dx[i] = dx[i] > x[i] - hi[i] ? dx[i] : x[i] - hi[i];
+        for (int i = 0; i < n; ++i) {
+            double a = x[i] - hi[i];
+            dx[i] = (isnan(dx[i]) || isnan(a)) ? dx[i] + a : (dx[i] > a ? dx[i] : a);
+        }
 }
 
 static void record(const orc_options *o, int it, int n, double ssr, double g, double delta,

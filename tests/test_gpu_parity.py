@@ -1043,6 +1043,43 @@ def test_nonfinite_raises():
     assert e.value.indices == [0]
 
 
+@pytest.mark.parametrize("opt", ["dogleg", "lm"])
+@pytest.mark.parametrize("sol", ["qr", "lsmr"])
+@pytest.mark.parametrize("bounded", [False, True])
+def test_nan_in_jacobian_at_a_later_iteration_raises(opt, sol, bounded):
+    """check_isfinite(x) on the REJECTED-step path (utils.jl:70-75, levenberg_marquardt.jl:135, dogleg.jl:189): a
+    Jacobian that turns NaN at its 2nd evaluation gives a NaN step, the step is rejected (rho = NaN), the restored
+    x = (x - dx) + dx is NaN, and the next iteration throws IsFiniteException -- the same index as the oracle.  With
+    bounds the NaN step must survive the box clipping (Julia's min / max propagate NaN; fmin / fmax would not)."""
+    name, f, g0, x0 = P.wood()
+    calls = {"n": 0}
+
+    def g(Jm, x):
+        g0(Jm, x)
+        calls["n"] += 1
+        if calls["n"] >= 2:
+            Jm[1, 2] = np.nan
+
+    kw = dict(lower=[-10.0] * 4, upper=[10.0] * 4) if bounded else {}
+    J0 = np.zeros((4, 4))
+    if sol == "lsmr":
+        J = sp.csc_matrix(np.ones((4, 4)))
+        gg = lambda Jm, x: (g(J0, x), Jm.data.__setitem__(slice(None), J0.reshape(-1, order="F")))
+    else:
+        J, gg = J0.copy(), g
+    nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(4), f_=f, g_=gg, J=J)
+    with pytest.raises(lsq.IsFiniteException) as e:
+        lsq.optimize_(nls, OPT[opt][0](SOL[sol][0]()), iterations=50, **kw)
+    # the oracle on the same problem
+    calls["n"] = 0
+    Jo = O.Mat(dense=np.zeros((4, 4))) if sol == "qr" else O.Mat(csc=P.full_csc_pattern(4, 4) + (np.zeros(16),))
+    go = lambda Jv, x: (g(J0, x), Jv.__setitem__(slice(None), J0.reshape(-1, order="F")))
+    ro = O.optimize(OPT[opt][1], SOL[sol][1], Jo, x0, f, go, iterations=50,
+                    lower=kw.get("lower"), upper=kw.get("upper"))
+    assert ro.status == O.ENONFINITE
+    assert e.value.indices == [ro.bad_index]
+
+
 # --------------------------------------------------------------- synthetic model (bench family)
 @pytest.mark.parametrize("sparse,opt,sol,big", [(True, "lm", "lsmr", False), (False, "lm", "cholesky", False),
                                                 (False, "dogleg", "qr", False), (True, "dogleg", "lsmr", False),

@@ -29,7 +29,7 @@ def _init(rank, world, port):
 
 def _worker_exchange(rank, world, port, q):
     _init(rank, world, port)
-    buf = torch.zeros(world + 2, dtype=torch.float64)
+    buf = torch.zeros(world + lsq.sharding.NSLOT, dtype=torch.float64)
     out = []
     # rank r contributes ssr = r+1, gnorm = 10*(r+1); only rank 0 has converged in round 0
     out.append(lsq.sharding.exchange(dist, rank, world, rank + 1.0, 10.0 * (rank + 1), rank == 0, buf))
@@ -48,6 +48,19 @@ def _worker_exchange(rank, world, port, q):
         assert cb2(vals, 3, None) == 0
         seq.append((vals[0], vals[1], vals[2]))
     out.append(seq)
+    # error protocol: rank 1 leaves with an error (converged = -1) at its 3rd call; rank 0 (active, one exchange in
+    # flight) learns of it at its 4th call BEFORE issuing another collective: both ranks issue exactly 3 all-reduces
+    cb3 = lsq.sharding.make_allreduce_callback(dist, rank, world, "cpu")
+    rcs = []
+    for it in range(5):
+        leaving = rank == 1 and it == 2
+        vals = (C.c_double * 3)(1.0, 1.0, -1.0 if leaving else 0.0)
+        rcs.append(cb3(vals, 3, None))
+        if leaving or rcs[-1] == 2:
+            break
+    out.append(rcs)
+    lsq.sharding.drain_all()
+    dist.barrier()
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -69,6 +82,8 @@ def test_exchange_gloo_world2():
         assert res[r][2] == (6.0, 3.0, 1.0)
         # sums over ranks {0,1}: iteration it contributes 20*it + 1, max gnorm it + 1
         assert res[r][3] == [(1.0, 1.0, 0.0), (1.0, 1.0, 0.0), (21.0, 2.0, 0.0), (61.0, 4.0, 1.0)]
+    assert res[1][4] == [0, 0, 0]            # the leaving rank: its last call succeeds
+    assert res[0][4] == [0, 0, 0, 2]         # its peer: told at the next call, no further collective
 
 
 def _worker_lm(rank, world, port, q):
@@ -109,3 +124,83 @@ def test_two_ranks_lm_with_exchange():
     assert it0 == it1 == max(alone0, alone1) + 1 or it0 == it1 == max(alone0, alone1)
     assert d0 == 0.0 and d1 == 0.0                      # local trajectories untouched
     assert ssr0 == pytest.approx(s0 + s1, rel=1e-12) and ssr1 == pytest.approx(ssr0, rel=1e-15)
+
+
+def _worker_lm_rccl(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    ctx = lsq.Context(0)
+    pr = lsq.synthetic.TanhProblem(6000, 60, sparse=True, per_col=100, seed=12, ctx=ctx)
+    pr.reset()
+    cb = lsq.sharding.make_allreduce_callback(dist, rank, world, "cuda")     # default group = the nccl (RCCL) group
+    r = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, iterations=60, allreduce=cb)
+    lsq.sharding.drain_all()
+    pr.reset()
+    r1 = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, iterations=60)
+    q.put((dist.get_backend(), dist.get_world_size(), r.iterations, r.converged, r.ssr, r1.iterations, r1.ssr,
+           float(np.max(np.abs(r.minimizer - r1.minimizer)))))
+    pr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_lm_with_rccl_exchange_world1():
+    """The exchange callback over the `nccl` (= RCCL) backend on real hardware: a one-rank group (a GPU box has one
+    device), the same code path bench.py's sharded runs take by default.  The run must equal the unsharded run."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_lm_rccl, args=(0, 1, port, q))
+    p.start()
+    backend, ws, it, conv, ssr, it1, ssr1, d = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and ws == 1
+    assert conv and it in (it1, it1 + 1)      # the frozen-rank protocol may add the iteration that sees "all converged"
+    assert d == 0.0 and ssr == pytest.approx(ssr1, rel=1e-15)
+
+
+def _bench_line(args, env=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=e, timeout=timeout,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                         # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must itself start 2 ranks (round-1 bug: --gpus was
+    parsed and ignored).  --dry-run = the launch path only (no CPU implementation of the hot path exists)."""
+    j = _bench_line(["--gpus", "2", "--steps", "6", "--dry-run", "--m", "4000", "--n", "40"])
+    assert j["n_gpus"] == 2 and j["config"]["process_group_ranks"] == 2 and j["config"]["problems"] == 2
+    assert j["dry_run"] is True and j["value"] is None
+
+
+def test_bench_rejects_mismatched_world():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=e,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode != 0 and b"WORLD_SIZE=1" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_forced_exchange_runs_on_rccl():
+    """bench.py's sharded protocol with its default exchange backend on hardware (one rank: LSQ_BENCH_FORCE_EXCHANGE)."""
+    j = _bench_line(["--steps", "8", "--warmup", "8", "--repeats", "3", "--m", "20000", "--n", "200", "--per-col", "100",
+                     "--no-cpu"], env={"LSQ_BENCH_FORCE_EXCHANGE": "1"})
+    assert j["n_gpus"] == 1 and j["config"]["exchange_backend"] == "nccl" and j["config"]["rccl_ranks"] == 1
+    assert j["value"] > 0 and j["repeats"] == 3 and j["region_ms"]["min"] <= j["region_ms"]["median"] <= j["region_ms"]["max"]
