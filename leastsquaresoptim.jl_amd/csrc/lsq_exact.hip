@@ -275,7 +275,12 @@ k_lsmr_exact(ExactMat M, const double *__restrict__ y, const double *__restrict_
     auto norm_u = [&]() {  // DampenedVector norm (il:72) / norm(u)
         if (tid == 0) {
             double sy = seq_sumsq(u, m);
-            s_a = damped ? sqrt(sy + seq_sumsq(ux, n)) : sqrt(sy);
+            if (damped) {   // sqrt(norm(y)^2 + norm(x)^2), literally (il:72)
+                const double ny = sqrt(sy), nx = sqrt(seq_sumsq(ux, n));
+                s_a = sqrt(ny * ny + nx * nx);
+            } else {
+                s_a = sqrt(sy);
+            }
         }
         __syncthreads();
         double r = s_a;

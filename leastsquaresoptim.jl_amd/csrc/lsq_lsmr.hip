@@ -113,7 +113,14 @@ struct EpiU {
 };
 
 // ---- K2: v~ <- P (J'u~ + d ux~)/beta - beta v ; publishes the block partials of sum(v~^2) -------
-// beta = sqrt(sum u~^2) is formed by every block from K1's partials (lsmr.jl:119, il:72).
+// norm(::DampenedVector) exactly as the reference writes it: sqrt(norm(y)^2 + norm(x)^2), iterative_lsmr.jl:72 -- the
+// square of a square root is not the sum it came from, so this is NOT sqrt(sum y^2 + sum x^2) in the last bit.
+__device__ __forceinline__ double dampened_norm(double sumsq_y, double sumsq_x) {
+    const double ny = sqrt(sumsq_y), nx = sqrt(sumsq_x);
+    return sqrt(ny * ny + nx * nx);
+}
+
+// beta = norm(u~) is formed by every block from K1's partials (lsmr.jl:119, il:72).
 struct EpiV {
     static constexpr bool REDUCE = true;
     using defer = void;
@@ -137,8 +144,7 @@ struct EpiV {
     __device__ void block_prepare() {
         double b2, bx, unused;
         ordered_sum256x3(pu, npu, px, npx, nullptr, nullptr, b2, bx, unused);
-        if (px) b2 += bx;                           // DampenedVector norm, iterative_lsmr.jl:72
-        beta = sqrt(b2);
+        beta = dg ? dampened_norm(b2, px ? bx : 0.0) : sqrt(b2);   // (px null in the setup pass: u~x == 0)
         beta_zero = !(beta > 0.0);
         inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;   // lsmr.jl:120-121 rmul!(u, inv(beta))
         first = st->first;
@@ -171,10 +177,9 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
     if (st->done) return;
     double beta2, betax2, alpha2;
     ordered_sum256x3(pu, npu, px_in, npx_in, pv, npv, beta2, betax2, alpha2);
-    if (px_in) beta2 += betax2;                           // (null in the setup pass: u~x == 0)
     if (threadIdx.x == 0) {
         ns = *st;
-        const double beta = sqrt(beta2);
+        const double beta = dg ? dampened_norm(beta2, px_in ? betax2 : 0.0) : sqrt(beta2);   // (px_in null in the setup pass)
         ns.beta = beta;
         ns.beta_zero = !(beta > 0.0);
         if (!ns.beta_zero) {
@@ -292,7 +297,7 @@ k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp
             *npu = 1;
         }
     }
-    const double beta = sqrt(beta2);
+    const double beta = damp ? dampened_norm(beta2, 0.0) : sqrt(beta2);   // u_x = 0 (zerosvector, il:246)
     const bool beta_zero = !(beta > 0.0);
     const double inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
     double acc = 0.0;

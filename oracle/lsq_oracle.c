@@ -11,7 +11,17 @@
  * published LAPACK algorithms: dpotf2, dpstf2, dlaqp2/dlarfg/dlarf (dgeqp3 semantics),
  * dorm2r, dlaic1, dlatrz/dlarz (dtzrzf), dormr3 (dormrz), and the rank-revealing
  * minimum-norm solve of LinearAlgebra.ldiv!(::QRPivoted, b) (the xGELSY algorithm with
- * rcond = min(m,n)*eps).  Summation is in plain index order.
+ * rcond = min(m,n)*eps).
+ *
+ * SUMMATION ORDER.  By default (mode 0) every sum is taken in plain index order.  That is a
+ * guess where the reference hands the sum to Julia's stdlib: `sum(abs2, .)` / `sum(.)` are
+ * Base.mapreduce (pairwise above 1024 elements, an @simd loop below, i.e. reassociated into
+ * 4 / 8 / 16 lanes depending on the CPU), `norm` is BLAS nrm2 from 32 elements up (OpenBLAS on
+ * x86-64: extended-precision accumulation), dense `mul!` is BLAS gemv (SIMD dot products).
+ * orc_set_sum_mode() switches those sites -- and only those: loops the reference writes out
+ * itself (wdot, utils.jl:165-172; the SparseArrays products) stay sequential -- to other
+ * plausible orders, so that tests can tell which results do NOT depend on the guess
+ * (tests/golden/count_stable.json).
  */
 #include "lsq_oracle.h"
 
@@ -28,12 +38,148 @@
 #define DECREASE_THRESHOLD 0.25 /* dogleg.jl:38 */
 #define INCREASE_THRESHOLD 0.75 /* dogleg.jl:39 */
 
-static double sumsq(const double *x, int n) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += x[i] * x[i];
-    return s;
+/* ------------------------------------------------------------------------------------------
+ * Summation-order model of the stdlib reductions (see the header comment).
+ *   0  sequential (default)
+ *   1  Base.mapreduce without SIMD: v = t0 + t1, then sequential; pairwise halves above 1024
+ *   2/3/4  Base.mapreduce with its @simd loop vectorised into 4 / 8 / 16 lanes (lane j takes the
+ *      elements 2+j, 2+j+L, ...; lanes combined by halving; scalar remainder added last);
+ *      BLAS-backed sites (nrm2 from 32 elements, dense gemv 'T' dots) use the same lanes
+ *   5  as 4, but nrm2 accumulates in long double (OpenBLAS's x87 dnrm2 kernel on x86-64)
+ *   6  NOT a model of the reference: 64 lanes + halving tree at EVERY reduction, including the ones the
+ *      reference writes as sequential loops (wdot, the sparse products) -- the class of orders the
+ *      wavefront reductions of the HIP fast path use.  Separates "differs from the oracle because the
+ *      run is round-off chaotic" from "differs because something is wrong".
+ * ---------------------------------------------------------------------------------------- */
+static int g_sum_mode = 0;
+static unsigned long long g_rng = 0; /* modes >= 100: every reduction adds its terms in a random order (seed = mode) */
+void orc_set_sum_mode(int mode) {
+    g_sum_mode = mode;
+    g_rng = 0x9E3779B97F4A7C15ull * (unsigned long long)(mode + 1);
 }
-static double nrm2(const double *x, int n) { return sqrt(sumsq(x, n)); }
+static int everywhere(void) { return g_sum_mode == 6 || g_sum_mode >= 100; } /* also the reference's own loops */
+/* modes >= 1000: index order, but the result of every reduction is moved by one rounding error (factor 1 +- 2^-53 at
+ * random): the effect of ANY algebraically equivalent reformulation around the sums (1/beta folded into the next
+ * product, fused epilogues, ...), which is what the HIP fast path does on top of reordering. */
+static int noisy(void) { return g_sum_mode >= 1000; }
+static unsigned long long rng_next(void) {
+    g_rng ^= g_rng << 13; g_rng ^= g_rng >> 7; g_rng ^= g_rng << 17;
+    return g_rng;
+}
+int orc_get_sum_mode(void) { return g_sum_mode; }
+static int mode_lanes(void) {
+    switch (g_sum_mode) {
+    case 2: return 4;
+    case 3: return 8;
+    case 4: case 5: return 16;
+    case 6: return 64;
+    default: return g_sum_mode >= 100 ? 64 : 1;
+    }
+}
+/* sum of t[first..last) in L lanes + sequential remainder, starting from v in lane 0 */
+static double lanes_sum(double v, const double *t, int n, int L) {
+    if (noisy()) {
+        for (int i = 0; i < n; ++i) v += t[i];
+        return v * ((rng_next() & 1ull) ? 1.0 + DBL_EPSILON / 2 * 2 : 1.0 - DBL_EPSILON / 2);
+    }
+    if (g_sum_mode >= 100) { /* random order */
+        double *p = malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+        memcpy(p, t, (size_t)n * sizeof(double));
+        for (int i = n - 1; i > 0; --i) {
+            int j = (int)(rng_next() % (unsigned long long)(i + 1));
+            double tmp = p[i]; p[i] = p[j]; p[j] = tmp;
+        }
+        for (int i = 0; i < n; ++i) v += p[i];
+        free(p);
+        return v;
+    }
+    if (L <= 1) {
+        for (int i = 0; i < n; ++i) v += t[i];
+        return v;
+    }
+    double acc[64];
+    int body = (n / L) * L;
+    if (body == 0) {
+        for (int i = 0; i < n; ++i) v += t[i];
+        return v;
+    }
+    acc[0] = v;
+    for (int j = 1; j < L; ++j) acc[j] = 0.0;
+    for (int i = 0; i < body; i += L)
+        for (int j = 0; j < L; ++j) acc[j] += t[i + j];
+    for (int h = L / 2; h >= 1; h /= 2)
+        for (int j = 0; j < h; ++j) acc[j] += acc[j + h];
+    v = acc[0];
+    for (int i = body; i < n; ++i) v += t[i];
+    return v;
+}
+/* Base.mapreduce_impl(identity, +, t, 1, n, 1024) */
+static double mapreduce_sum(const double *t, int n) {
+    if (n == 0) return 0.0;
+    if (n == 1) return t[0];
+    if (n < 1024) return lanes_sum(t[0] + t[1], t + 2, n - 2, mode_lanes());
+    int mid = (n - 1) / 2 + 1; /* imid = ifirst + (ilast - ifirst) >> 1, first half = ifirst..imid */
+    return mapreduce_sum(t, mid) + mapreduce_sum(t + mid, n - mid);
+}
+static double *scratch(int n) {
+    static double *buf = NULL;
+    static int cap = 0;
+    if (n > cap) {
+        free(buf);
+        cap = n + 1024;
+        buf = malloc((size_t)cap * sizeof(double));
+    }
+    return buf;
+}
+/* sum(x) as Julia's `sum` (levenberg_marquardt.jl:84) */
+static double sum_stdlib(const double *x, int n) {
+    if (g_sum_mode == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += x[i];
+        return s;
+    }
+    return mapreduce_sum(x, n);
+}
+/* sum(abs2, x): levenberg_marquardt.jl:60,111,117; dogleg.jl:68,111,168,174; utils.jl:141,148 */
+static double sumsq(const double *x, int n) {
+    if (g_sum_mode == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += x[i] * x[i];
+        return s;
+    }
+    double *t = scratch(n);
+    for (int i = 0; i < n; ++i) t[i] = x[i] * x[i];
+    return mapreduce_sum(t, n);
+}
+/* dot product as a BLAS kernel forms it (dense gemv 'T', syrk) */
+static double dot_blas(const double *a, const double *b, int n) {
+    int L = mode_lanes();
+    if (L <= 1) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += a[i] * b[i];
+        return s;
+    }
+    double *t = scratch(n);
+    for (int i = 0; i < n; ++i) t[i] = a[i] * b[i];
+    return lanes_sum(0.0, t, n, L);
+}
+/* norm(x): LinearAlgebra.norm2 = generic_norm2 below 32 elements (a sequential sum of squares when no
+ * scaling is needed), BLAS nrm2 from 32 elements up [stdlib].  lsmr.jl:74,119,123,206. */
+static double nrm2(const double *x, int n) {
+    if (g_sum_mode == 0 || n < 32) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += x[i] * x[i];
+        return sqrt(s);
+    }
+    if (g_sum_mode == 5) {
+        long double s = 0.0L;
+        for (int i = 0; i < n; ++i) s += (long double)x[i] * (long double)x[i];
+        return (double)sqrtl(s);
+    }
+    double *t = scratch(n);
+    for (int i = 0; i < n; ++i) t[i] = x[i] * x[i];
+    return sqrt(lanes_sum(0.0, t, n, mode_lanes()));
+}
 static void scal(double *x, int n, double a) {
     for (int i = 0; i < n; ++i) x[i] *= a;
 }
@@ -53,11 +199,7 @@ void orc_colsumabs2(double *v, const orc_mat *A) {
     if (A->kind == ORC_DENSE) {
         for (int j = 0; j < A->n; ++j) v[j] = sumsq(A->val + (size_t)j * A->m, A->m);
     } else {
-        for (int j = 0; j < A->n; ++j) {
-            double s = 0.0;
-            for (int k = A->colptr[j]; k < A->colptr[j + 1]; ++k) s += A->val[k] * A->val[k];
-            v[j] = s;
-        }
+        for (int j = 0; j < A->n; ++j) v[j] = sumsq(A->val + A->colptr[j], A->colptr[j + 1] - A->colptr[j]);
     }
 }
 
@@ -90,6 +232,25 @@ static void scale_or_fill(double *y, int n, double beta) {
  * dogleg.jl:109,171, iterative_lsmr.jl:32,91.  Dense: gemv 'N' as column axpys. */
 void orc_mul(double *y, const orc_mat *A, const double *x, double alpha, double beta) {
     scale_or_fill(y, A->m, beta);
+    if (everywhere()) { /* every row's products summed as a 64-lane tree, then added to beta*y */
+        int m = A->m, n = A->n;
+        double *rows = calloc((size_t)m * (n > 0 ? n : 1), sizeof(double));
+        int *cnt = calloc(m > 0 ? m : 1, sizeof(int));
+        for (int j = 0; j < n; ++j) {
+            double ax = x[j] * alpha;
+            if (A->kind == ORC_DENSE) {
+                for (int i = 0; i < m; ++i) rows[(size_t)i * n + cnt[i]++] = A->val[(size_t)j * m + i] * ax;
+            } else {
+                for (int k = A->colptr[j]; k < A->colptr[j + 1]; ++k) {
+                    int i = A->rowval[k];
+                    rows[(size_t)i * n + cnt[i]++] = A->val[k] * ax;
+                }
+            }
+        }
+        for (int i = 0; i < m; ++i) y[i] += lanes_sum(0.0, rows + (size_t)i * n, cnt[i], 64);
+        free(rows); free(cnt);
+        return;
+    }
     if (A->kind == ORC_DENSE) {
         for (int j = 0; j < A->n; ++j) {
             double ax = x[j] * alpha;
@@ -111,14 +272,20 @@ void orc_mulT(double *x, const orc_mat *A, const double *y, double alpha, double
     if (A->kind == ORC_DENSE) {
         for (int j = 0; j < A->n; ++j) {
             const double *col = A->val + (size_t)j * A->m;
-            double t = 0.0;
-            for (int i = 0; i < A->m; ++i) t += col[i] * y[i];
+            double t = dot_blas(col, y, A->m);
             x[j] += t * alpha;
         }
     } else {
         for (int j = 0; j < A->n; ++j) {
             double t = 0.0;
-            for (int k = A->colptr[j]; k < A->colptr[j + 1]; ++k) t += A->val[k] * y[A->rowval[k]];
+            if (everywhere()) {
+                int len = A->colptr[j + 1] - A->colptr[j];
+                double *tb = scratch(len);
+                for (int k = 0; k < len; ++k) tb[k] = A->val[A->colptr[j] + k] * y[A->rowval[A->colptr[j] + k]];
+                t = lanes_sum(0.0, tb, len, 64);
+            } else {
+                for (int k = A->colptr[j]; k < A->colptr[j + 1]; ++k) t += A->val[k] * y[A->rowval[k]];
+            }
             x[j] += t * alpha;
         }
     }
@@ -126,6 +293,11 @@ void orc_mulT(double *x, const orc_mat *A, const double *y, double alpha, double
 
 /* utils.jl:165-176 */
 double orc_wdot(const double *x, const double *y, const double *w, int n) {
+    if (everywhere()) {
+        double *tb = scratch(n);
+        for (int i = 0; i < n; ++i) tb[i] = w[i] * x[i] * y[i];
+        return lanes_sum(0.0, tb, n, 64);
+    }
     double out = 0.0;
     for (int i = 0; i < n; ++i) out += w[i] * x[i] * y[i];
     return out;
@@ -203,6 +375,13 @@ static void op_mulT(const lsmr_op *op, double *b, const double *ay, const double
     for (int i = 0; i < n; ++i) b[i] += alpha * t2[i];           /* :49 axpy! */
 }
 
+/* norm(::DampenedVector) = sqrt(norm(y)^2 + norm(x)^2), iterative_lsmr.jl:72 -- literally: the square of a
+ * square root is not the sum it came from (the round-1 oracle formed sqrt(sum y^2 + sum x^2)). */
+static double dampened_norm(const double *y, int m, const double *x, int n) {
+    double ny = nrm2(y, m), nx = nrm2(x, n);
+    return sqrt(ny * ny + nx * nx);
+}
+
 /* lsmr.jl:53-238.  lambda == 0 for every caller.  Returns iter (mvps = 2*iter, :236). */
 int orc_lsmr(double *x, const orc_mat *J, const double *diag, const double *P, double *by,
              double atol, double btol, double conlim, int maxiter, int *istop_out,
@@ -219,7 +398,7 @@ int orc_lsmr(double *x, const orc_mat *J, const double *diag, const double *P, d
 
     op_mul(&op, by, bx, x, -1.0, 1.0);                           /* :73 u = b - A x */
     double *uy = by, *ux = bx;
-    double beta = diag ? sqrt(sumsq(uy, m) + sumsq(ux, n)) : nrm2(uy, m); /* :74, il:72 */
+    double beta = diag ? dampened_norm(uy, m, ux, n) : nrm2(uy, m);  /* :74, il:72 */
     if (beta > 0) {
         double ib = 1.0 / beta;
         scal(uy, m, ib);
@@ -244,7 +423,7 @@ int orc_lsmr(double *x, const orc_mat *J, const double *diag, const double *P, d
         while (iter < maxiter) {
             iter += 1;
             op_mul(&op, uy, ux, v, 1.0, -alpha);                 /* :118 */
-            beta = diag ? sqrt(sumsq(uy, m) + sumsq(ux, n)) : nrm2(uy, m);
+            beta = diag ? dampened_norm(uy, m, ux, n) : nrm2(uy, m);
             if (beta > 0) {
                 double ib = 1.0 / beta;
                 scal(uy, m, ib);
@@ -374,8 +553,7 @@ static void normal_matrix(double *C, const orc_mat *J) { /* mul!(cholm, J', J) :
     for (int j = 0; j < n; ++j)
         for (int i = 0; i <= j; ++i) {
             const double *a = J->val + (size_t)i * m, *b = J->val + (size_t)j * m;
-            double s = 0.0;
-            for (int k = 0; k < m; ++k) s += a[k] * b[k];
+            double s = dot_blas(a, b, m);
             C[(size_t)j * n + i] = s;
             C[(size_t)i * n + j] = s;
         }
@@ -913,9 +1091,7 @@ static int optimize_lm(int solver, orc_mat *J, double *x, double *fcur, orc_f_cb
         if (bad >= 0) { st = ORC_ENONFINITE; r->bad_index = bad; iter--; break; }
         if (need_jac) { g(J->val, x, ud); g_calls++; need_jac = 0; }
         orc_colsumabs2(dtd, J);                                             /* :82 */
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += dtd[i];
-        double mean = s / n;                                                /* :84 */
+        double mean = sum_stdlib(dtd, n) / n;                               /* :84 */
         double lo = MIN_DIAGONAL * mean, hi = MAX_DIAGONAL * mean;
         for (int i = 0; i < n; ++i) dtd[i] = dtd[i] > hi ? hi : (dtd[i] < lo ? lo : dtd[i]);
         scal(dtd, n, 1.0 / delta);                                          /* :86 */

@@ -76,6 +76,11 @@ typedef struct {
     int bad_index;           /* first non-finite index for ORC_ENONFINITE */
 } orc_result;
 
+/* summation-order model of the stdlib reductions (lsq_oracle.c header): 0 = index order (default), 1 = mapreduce
+ * without SIMD, 2/3/4 = 4/8/16 SIMD lanes, 5 = 16 lanes + extended-precision nrm2.  Process-global. */
+void orc_set_sum_mode(int mode);
+int orc_get_sum_mode(void);
+
 /* --- kernels (utils.jl, SparseArrays/BLAS semantics) --- */
 void orc_colsumabs2(double *v, const orc_mat *A);
 void orc_rowsumabs2(double *v, const orc_mat *A);

@@ -75,6 +75,20 @@ def lib():
     return _LIB
 
 
+def set_sum_mode(mode):
+    """Summation-order model of the stdlib reductions (see lsq_oracle.c): 0 = index order (default)."""
+    lib().orc_set_sum_mode(int(mode))
+
+
+SUM_MODES = {0: "index order", 1: "mapreduce, no SIMD", 2: "4 SIMD lanes", 3: "8 SIMD lanes", 4: "16 SIMD lanes",
+             5: "16 SIMD lanes + extended-precision nrm2"}
+# mode 6 (64-lane trees at EVERY reduction, sparse products and wdot included) is not a model of the reference but of
+# the class of orders the HIP fast path uses; see lsq_oracle.c
+FAST_PATH_MODE = 6
+RANDOM_ORDER_MODES = list(range(100, 116))       # every reduction adds its terms in a random order
+ROUNDING_NOISE_MODES = list(range(1000, 1032))    # index order, every reduction result moved by one rounding error
+
+
 def _dp(a):
     return None if a is None else a.ctypes.data_as(c_dp)
 

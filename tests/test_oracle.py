@@ -317,3 +317,113 @@ def test_golden_trajectories():
         assert (r.f_calls, r.g_calls, r.mul_calls) == (rec["f_calls"], rec["g_calls"], rec["mul_calls"])
         assert r.converged == rec["converged"]
         assert np.allclose(r.minimizer, rec["x"], rtol=1e-9, atol=1e-11)
+
+
+# ------------------------------------------------- reference-held numeric vectors: NIST StRD certified values
+# The ONLY numbers in the reference's repository that pin results beyond `ssr <= 1e-3`: the certified parameter
+# values of the 16 NIST StRD problems in test/nonlinearfitting.jl (restated as data in tests/golden/nist.json).
+# The reference runs Dogleg(QR()) and LevenbergMarquardt(QR()) from every column of `parameters` with
+# x_tol = 1e-50, f_tol = 1e-36, g_tol = 1e-50 and PRINTS how many land within 1e-3 of the certified values (it only
+# asserts !isnan).  The starts below are NIST's "start 1" of the higher-difficulty problems, from which these
+# optimizers are known not to reach the certified minimum; everywhere else the certified values must be hit.
+NIST_KNOWN_MISSES = {("MGH09", "dogleg", 0), ("BoxBOD", "lm", 0), ("MGH10", "dogleg", 0), ("MGH10", "lm", 0)}
+NIST_KW = dict(x_tol=1e-50, f_tol=1e-36, g_tol=1e-50, iterations=1000)      # nonlinearfitting.jl:1465
+
+
+@pytest.mark.parametrize("opt", ["dogleg", "lm"])
+@pytest.mark.parametrize("jac", ["central", "analytic"])
+def test_nist_certified_values(opt, jac):
+    import nist
+    hits = total = 0
+    for p in nist.problems():
+        for si, start in enumerate(p.starts):
+            J = O.Mat(dense=np.zeros((p.m, p.n)))
+            g = p.g_flat if jac == "analytic" else nist.central_difference_g(p.f, p.m, p.n)
+            r = O.optimize(O.DOGLEG if opt == "dogleg" else O.LM, O.QR, J, start, p.f, g, trace=False, **NIST_KW)
+            assert r.status == O.OK and not np.isnan(np.mean(r.minimizer)), (p.name, si)      # the reference's assert
+            ok = np.linalg.norm(r.minimizer - p.certified) <= 1e-3                            # the reference's count
+            total += 1
+            hits += ok
+            if (p.name, opt, si) not in NIST_KNOWN_MISSES:
+                assert ok, (p.name, opt, jac, si, r.minimizer, p.certified)
+    assert total == 33 and hits >= total - 2, (hits, total)
+
+
+def test_nist_fixture_is_consistent():
+    """The fixture's own arithmetic: residual sum of squares at the certified parameters equals NIST's certified
+    value for the problems whose value is common knowledge (the fixture would fail this if columns were swapped or a
+    model mistranslated)."""
+    import nist
+    rss = {"Misra1a": 1.2455138894e-01, "Thurber": 5.6427082397e+03, "MGH09": 3.0750560385e-04,
+           "Lanczos3": 1.6117193594e-08, "BoxBOD": 1.1680088766e+03, "Eckerle4": 1.4635887487e-03}
+    for p in nist.problems():
+        out = np.zeros(p.m)
+        p.f(out, p.certified)
+        if p.name in rss:
+            assert np.sum(out ** 2) == pytest.approx(rss[p.name], rel=1e-9), p.name
+        # analytic Jacobian vs central differences at the certified point
+        Ja, Jf = np.zeros((p.m, p.n), order="F"), np.zeros((p.m, p.n), order="F")
+        p.g(Ja, p.certified)
+        nist.central_difference_g(p.f, p.m, p.n)(Jf.reshape(-1, order="F"), p.certified)
+        assert np.max(np.abs(Ja - Jf)) <= 1e-5 * max(1.0, np.max(np.abs(Ja))), p.name
+
+
+# ------------------------------------------------- what the summation-order guess does and does not decide
+def test_count_stable_set_reproduces():
+    """tests/golden/count_stable.json (tests/golden/make_count_stable.py): the runs of the MINPACK grid whose counts,
+    accept patterns and inner counts are the same under EVERY summation-order model of the stdlib reductions
+    (orc_set_sum_mode 0..5).  For those the oracle's counts do not depend on how Julia associates its sums; for the
+    others they are one valid outcome among several (and the reference's own outcome pin still holds in every mode)."""
+    with open(os.path.join(GOLDEN, "count_stable.json")) as fh:
+        cs = json.load(fh)
+    with open(os.path.join(GOLDEN, "minpack_oracle.json")) as fh:
+        gold = {(r["problem"], r["optimizer"], r["solver"], r["sparse"]): r for r in json.load(fh)["runs"]}
+    names = {"dogleg": O.DOGLEG, "lm": O.LM, "qr": O.QR, "cholesky": O.CHOLESKY, "lsmr": O.LSMR}
+    probs = {P.label(p): p for p in P.minpack_all()}
+    assert cs["total"] == 162 and cs["stable"] >= 140
+    try:
+        for rec in cs["runs"]:
+            key = (rec["problem"], rec["optimizer"], rec["solver"], rec["sparse"])
+            g = gold[key]
+            for mode in (0, 2, 3, 4, 5):
+                O.set_sum_mode(mode)
+                r = run(probs[rec["problem"]], names[rec["optimizer"]], names[rec["solver"]], rec["sparse"], trace=False)
+                assert r.ssr <= 1e-3, (key, mode)                  # test/nonlinearsolvers.jl:532 holds whatever the order
+                same = (r.iterations, r.f_calls, r.g_calls, r.mul_calls) == \
+                       (g["iterations"], g["f_calls"], g["g_calls"], g["mul_calls"])
+                if rec["stable"]:
+                    assert same, (key, mode)
+                elif mode in rec["modes_with_other_counts"]:
+                    assert not same, (key, mode)
+        # the robust flag (random orders + last-bit perturbations of every reduction): spot-checked on two draws
+        assert 100 <= sum(r["robust"] for r in cs["runs"]) <= cs["stable"]
+        for rec in cs["runs"]:
+            if not rec["robust"]:
+                continue
+            key = (rec["problem"], rec["optimizer"], rec["solver"], rec["sparse"])
+            g = gold[key]
+            for mode in (O.FAST_PATH_MODE, O.RANDOM_ORDER_MODES[3], O.ROUNDING_NOISE_MODES[7]):
+                O.set_sum_mode(mode)
+                r = run(probs[rec["problem"]], names[rec["optimizer"]], names[rec["solver"]], rec["sparse"], trace=False)
+                assert (r.iterations, r.f_calls, r.g_calls, r.mul_calls) == \
+                       (g["iterations"], g["f_calls"], g["g_calls"], g["mul_calls"]), (key, mode)
+    finally:
+        O.set_sum_mode(0)
+
+
+def test_sum_modes_are_reorderings():
+    """Every mode computes the same sums up to round-off (they are re-associations, not different formulas)."""
+    rng = np.random.default_rng(5)
+    A = O.Mat(dense=rng.standard_normal((300, 40)))
+    y = rng.standard_normal(300)
+    try:
+        ref = None
+        for mode in sorted(O.SUM_MODES):
+            O.set_sum_mode(mode)
+            cur = (O.colsumabs2(A), O.mulT(A, y), O.lsmr(A, y, diag=np.full(40, 0.3))["x"])
+            if ref is None:
+                ref = cur
+            for a, b in zip(ref, cur):
+                assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(a)))
+    finally:
+        O.set_sum_mode(0)
