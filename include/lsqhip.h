@@ -145,6 +145,10 @@ int lsq_solver_info(const lsq_solver *s, int *lsmr_iter, int *lsmr_istop, int *q
  * 2 blocked unpivoted QR + pivoted sweep on R,  3 blocked unpivoted QR + full-rank certificate
  * (||R||_F ||inv(R)||_F * rcond * 16 <= 1 proves xGELSY's rank = n; no pivoting needed) */
 int lsq_solver_qr_path(const lsq_solver *s, int *path);
+/* how the 64-column panels of the last blocked QR were factored: 0 no blocked factorisation yet, 1 column-by-column
+ * Householder steps (k_qr1_step_multi), 2 CholeskyQR2 + basis-kernel block reflector (lsq_qr_cholqr.hip; falls back to 1
+ * for the whole solve when a panel is too ill-conditioned for it) */
+int lsq_solver_qr_panel(const lsq_solver *s, int *kind);
 /* the same for Cholesky() (dense_cholesky.jl:29-59):  0 none yet, 1 one-workgroup kernel (dpotf2 / pivoted dpstf2),
  * 2 blocked unpivoted factorisation (LM: J'J + damp),  3 blocked unpivoted factorisation + full-rank certificate
  * (Dogleg: 1 / ||inv(U)||_F^2 > 16 n eps max diag proves that cholesky!(.., Val(true)) would not stop early) */

@@ -123,6 +123,7 @@ def lib():
         "lsq_ldiv_damped": (i, [vp, vp, vp, vp, vp, c_ip]),
         "lsq_solver_info": (i, [vp, c_ip, c_ip, c_ip]),
         "lsq_solver_qr_path": (i, [vp, c_ip]),
+        "lsq_solver_qr_panel": (i, [vp, c_ip]),
         "lsq_solver_chol_path": (i, [vp, c_ip]),
         "lsq_options_default": (None, [C.POINTER(Options)]),
         "lsq_optimize": (i, [vp, i, i, vp, vp, vp, F_CALLBACK, G_CALLBACK, vp, C.POINTER(Options),

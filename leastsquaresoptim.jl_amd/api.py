@@ -433,7 +433,10 @@ class AllocatedSolver:
         check(lib().lsq_solver_qr_path(self.h, C.byref(path)))
         cpath = C.c_int(0)
         check(lib().lsq_solver_chol_path(self.h, C.byref(cpath)))
+        panel = C.c_int(0)
+        check(lib().lsq_solver_qr_panel(self.h, C.byref(panel)))
         return dict(lsmr_iter=it.value, lsmr_istop=st.value, qr_rank=rk.value,
+                    qr_panel={0: None, 1: "householder-steps", 2: "cholqr2"}[panel.value],
                     qr_path={0: None, 1: "one-stage", 2: "two-stage-pivoted", 3: "two-stage-certified"}[path.value],
                     chol_path={0: None, 1: "one-workgroup", 2: "blocked", 3: "blocked-certified"}[cpath.value])
 

@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 
+#include "lsq_qr_cholqr.h"
 #include "lsq_solver.h"
 #include "lsq_spmv.h"
 
@@ -1334,7 +1335,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
                     unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
                     int spins = 0;
                     while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
-                        if (++spins > QR1_SPIN_LIMIT) { *err = 1; break; }
+                        if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); break; }
                         __builtin_amdgcn_s_sleep(1);
                         w0 = __hip_atomic_load(f, RLX_AGENT);
                         w1 = __hip_atomic_load(f + 1, RLX_AGENT);
@@ -2313,7 +2314,7 @@ k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int ldx
             unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
             int spins = 0;
             while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
-                if (++spins > QR1_SPIN_LIMIT) { *err = 1; break; }
+                if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); break; }
                 __builtin_amdgcn_s_sleep(1);
                 w0 = __hip_atomic_load(f, RLX_AGENT);
                 w1 = __hip_atomic_load(f + 1, RLX_AGENT);
@@ -2370,7 +2371,7 @@ k_tri_fsolve_t(const double *__restrict__ U, const double *__restrict__ X, int l
             unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
             int spins = 0;
             while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
-                if (++spins > QR1_SPIN_LIMIT) { *err = 1; break; }
+                if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); break; }
                 __builtin_amdgcn_s_sleep(1);
                 w0 = __hip_atomic_load(f, RLX_AGENT);
                 w1 = __hip_atomic_load(f + 1, RLX_AGENT);
@@ -2427,6 +2428,9 @@ struct Qr2Work {
     double *tsS[2] = {nullptr, nullptr}, *tsr[2] = {nullptr, nullptr};   // TSQR levels (ping-pong): stacked slab triangles ((slabs*n) x n) and Q'b entries
     int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
     int kslices = 0, M = 0, n = 0;
+    CqrWork cq;               // stage 1: CholeskyQR2 panel (lsq_qr_cholqr.hip)
+    bool no_cholqr = false;   //   ... off for this solver after a breakdown (ill-conditioned / rank-deficient panels)
+    bool cholqr_used = false; //   the current factorisation took it at least once
 };
 static void qr2_free(void *p) {
     Qr2Work *q = (Qr2Work *)p;
@@ -2435,6 +2439,7 @@ static void qr2_free(void *p) {
     hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
     hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn); hipFree(q->tsS[0]); hipFree(q->tsS[1]); hipFree(q->tsr[0]); hipFree(q->tsr[1]);
     if (q->h_fro) hipHostFree(q->h_fro);
+    lsq_cqr_free(&q->cq);
     delete q;
 }
 
@@ -2536,8 +2541,35 @@ static int qr2_workspace(lsq_solver *s, int M, int n) {
 static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, double **R_out, double **rhs_out) {
     lsq_ctx *c = s->ctx;
     Qr2Work *q = (Qr2Work *)s->qr2;
+    // CholeskyQR2 panels (lsq_qr_cholqr.hip) need the error word to travel back with the certificate's copy
+    const bool cq_ok = !q->no_cholqr && !getenv("LSQ_QR1_NO_CHOLQR") && !getenv("LSQ_QR_ALWAYS_PIVOT");
+    q->cholqr_used = false;
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
+        if (cq_ok && nb == Q2_NB && M - c0 >= 256) {
+            // panel: two Gram / Cholesky passes, no column-by-column chain; block reflector in basis-kernel form
+            if (!q->cq.ready) LSQ_TRY(lsq_cqr_alloc(c, &q->cq, q->M));
+            q->cholqr_used = true;
+            const int rows = M - c0, ldv = rows;
+            LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, q->Vb, ldv, q->d_err));
+            const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
+            const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
+            int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
+            hipLaunchKernelGGL(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
+                               q->Wp);
+            {
+                long long tot = (long long)ntile * Q2_NB * Q2_NB;
+                int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
+                hipLaunchKernelGGL(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
+            }
+            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
+            {
+                const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
+                hipLaunchKernelGGL(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M,
+                                   c0, cend, n, rhs, ncols, q->W2);
+            }
+            continue;
+        }
         bool lazy = false;
         int side_k = 0;   // > 0: later pivot columns of a launch sit in the side panel
         // last panel: b rides through the steps as one more target column, so no block update is left to do
@@ -2636,6 +2668,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
         hipLaunchKernelGGL(k_qr1_extract, dim3(g), dim3(256), 0, c->stream, A, M, n, rhs, q->R, q->rhs2);
     }
     LSQ_HIP(hipGetLastError());
+    s->last_qr_panel = q->cholqr_used ? 2 : 1;
     *R_out = q->R;
     *rhs_out = q->rhs2;
     return LSQ_OK;
@@ -2685,11 +2718,13 @@ static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double 
     LSQ_HIP(hipMemcpyAsync(q->h_fro, q->fro, 2 * FRO_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipMemcpyAsync(q->h_fro + 2 * FRO_BLOCKS, q->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
-    if (*(const int *)(q->h_fro + 2 * FRO_BLOCKS) != 0) {
-        // a bounded wait of an in-kernel exchange gave up (workgroups not dispatched in index order, or the device
-        // shared with other work): this solver stops using them
+    if (const int ev = *(const int *)(q->h_fro + 2 * FRO_BLOCKS)) {
+        // bit 0: a bounded wait of an in-kernel exchange gave up (workgroups not dispatched in index order, or the device
+        // shared with other work) -- this solver stops using them;  bit 1: a CholeskyQR2 panel broke down (ill-conditioned
+        // or rank-deficient panel) -- this solver goes back to the column-by-column panel.  Either way: once more.
         LSQ_ZERO(q->d_err, 0, sizeof(int));
-        q->no_exchange = true;
+        if (ev & 1) q->no_exchange = true;
+        if (ev & 2) q->no_cholqr = true;
         *timed_out = true;
         return LSQ_OK;
     }
@@ -2809,7 +2844,7 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
     const int M = d_damp ? m + n : m;
     const int lu = d_damp ? M : std::max(m, n);
     if (n > 0 && M > 0)
-    for (int attempt = 0; attempt < 2; ++attempt) {     // (a second pass only after an in-kernel exchange timed out)
+    for (int attempt = 0; attempt < 3; ++attempt) {     // (again only after an in-kernel exchange timed out / a CholeskyQR2 panel broke down)
         long long tot = (long long)M * n;
         int grid = (int)std::min<long long>((tot + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
         hipLaunchKernelGGL(k_stack, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, m, n, d_damp, s->d_qr);
@@ -2829,8 +2864,8 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
             if (!getenv("LSQ_QR_ALWAYS_PIVOT"))
                 LSQ_TRY(qr2_certify_full_rank(s, R2, n, (double)mn * DBL_EPSILON, &full_rank, rhs2, jp, d_x, &solved, &timed_out));
             if (timed_out) {
-                if (attempt == 0) continue;      // once more from the stacked operand, without in-kernel exchanges
-                lsq_set_error("qr: an in-kernel exchange timed out twice");
+                if (attempt < 2) continue;       // once more from the stacked operand, without what gave up
+                lsq_set_error("qr: the fast paths gave up three times");
                 return LSQ_EHIP;
             }
             if (full_rank) {

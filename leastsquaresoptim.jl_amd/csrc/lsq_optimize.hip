@@ -89,6 +89,11 @@ extern "C" int lsq_solver_set_preconditioner(lsq_solver *s, lsq_precond_callback
     return LSQ_OK;
 }
 
+extern "C" int lsq_solver_qr_panel(const lsq_solver *s, int *kind) {
+    if (!s || !kind) { lsq_set_error("lsq_solver_qr_panel: null argument"); return LSQ_EARG; }
+    *kind = s->last_qr_panel;
+    return LSQ_OK;
+}
 extern "C" int lsq_solver_qr_path(const lsq_solver *s, int *path) {
     if (!s || !path) { lsq_set_error("lsq_solver_qr_path: null argument"); return LSQ_EARG; }
     *path = s->last_qr_path;

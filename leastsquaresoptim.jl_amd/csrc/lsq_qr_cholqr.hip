@@ -1,0 +1,445 @@
+// Communication-avoiding panel of the blocked Householder QR (stage 1 of lsq_qr_solve; dense_qr.jl:30-88 = geqp3 + the
+// xGELSY solve in the reference, restated as unpivoted blocked QR + certificate / pivoted sweep on R, lsq_dense.hip).
+//
+// The BLAS-2 panel (k_qr1_step_multi) is a chain of dependent launches: 16 per 64 columns, 14 us each, 55 % of the C3
+// solve (16384 x 2048).  Here a 64-column panel P (rows x 64) is orthogonalised with TWO passes over it and no
+// column-by-column communication:
+//
+//   pass 1   G1 = P'P (fp64 MFMA, split over 64-row slabs, fixed-order reduce);  R1 = chol(G1);  Q1 = P inv(R1)
+//   pass 2   G2 = Q1'Q1 = I + E;  R2 = chol(G2) -- or, when ||E||_F <= 1e-5, its second-order expansion
+//            R2 = I + X, X = Phi(E) - Phi(Phi(E)'Phi(E)), Phi = strict upper + half the diagonal, with no dependent chain at
+//            all;  Q = Q1 inv(R2)  (CholeskyQR2: ||Q'Q - I|| = O(eps) whenever cond(P) <~ 1e7; beyond that pass 1 breaks
+//            down or ||E|| > 1/2, a device flag is raised and the caller repeats the factorisation with the BLAS-2 panel)
+//
+// and the orthogonal transformation of the block step is taken in the basis-kernel (compact WY) form built from Q itself
+// (Yamamoto; Ballard et al., "Reconstructing Householder vectors from TSQR"):
+//
+//   S = diag(+-1) from the modified LU of Q_top (S_j = -sign of the running diagonal, pivots >= 1 in magnitude),
+//   V = Q - [S; 0],   B = Q_top - S = L U,   Qfull = I - V T V',  T' = -inv(B) S,  Qfull' P = [S R2 R1; 0]
+//
+// so the existing block update applies unchanged:  W = V'[A2 | b] (k_qr1_vtb),  W2 = T'W = inv(B)(A2_top - S Q'[A2|b])
+// (k_cqr_tw, one 64 x 64 x N MFMA product),  A2 -= V W2 (k_qr1_update).  The 64-step LU runs in ONE workgroup on a side
+// stream (k_cqr_top: it needs the top 64 rows only, so it starts as soon as G2 is known and runs beside pass 2 and the
+// V'A2 product), off the critical path for all but the narrowest trailing matrices.  Small-matrix work: lsq_small64.h.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+
+#include "lsq_qr_cholqr.h"
+#include "lsq_small64.h"
+
+constexpr int CQ_RS = 64;                  // rows of the panel per workgroup (256 workgroups at 16384 rows: every CU)
+constexpr int CQ_QST = CQ_RS + 2;          // slab image [col][row], row stride (doubles)
+constexpr int CQ_LDS_DOUBLES = 2 * S64_MAT + S64_TMP + 64 * CQ_QST;
+constexpr size_t CQ_LDS = (size_t)CQ_LDS_DOUBLES * sizeof(double);
+constexpr size_t CQ_LDS_LU = (size_t)(4 * S64_MAT + S64_TMP) * sizeof(double);
+constexpr size_t CQ_LDS_TW = (size_t)(2 * S64_MAT) * sizeof(double);
+#ifdef CQ_TIMING   // phase time stamps of workgroup 0 (tools/micro/cqr_bench.hip only)
+__device__ unsigned long long cq_tbuf[64];
+#define CQ_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) cq_tbuf[k] = wall_clock64(); } while (0)
+#else
+#define CQ_T(k) do { } while (0)
+#endif
+constexpr int CQ_FAIL = 2;                 // bit of the solver's error word (bit 0: an in-kernel exchange timed out)
+
+// 64 x 64 row-major matrix in global memory -> LDS image (stride S64_LS): all 16 loads of a thread in flight at once
+// (one wavefront per SIMD here: a load per loop trip would cost a full memory latency each)
+__device__ __forceinline__ void cq_load64(double *__restrict__ dst, const double *__restrict__ src, int tid) {
+    double t[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t[q] = src[tid + 256 * q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q;
+        dst[(e >> 6) * S64_LS + (e & 63)] = t[q];
+    }
+}
+
+// Gram of the slab image, UPPER 16 x 16 tiles only (10 of 16; the consumers read the upper triangle), 3 / 3 / 2 / 2 tiles
+// per wavefront, K = CQ_RS; partial -> Gp (row-major 64 x 64; the strictly lower tiles stay as allocated: zero)
+__device__ __forceinline__ void cq_slab_gram(const double *__restrict__ Qs, double *__restrict__ Gp, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    const int ij = lane & 15, kq = lane >> 4;
+    const int first = w < 2 ? 3 * w : 6 + 2 * (w - 2), count = w < 2 ? 3 : 2;
+    for (int t = 0; t < count; ++t) {
+        const int id = first + t;                       // 0..9 -> (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+        const int ti = id < 4 ? 0 : id < 7 ? 1 : id < 9 ? 2 : 3;
+        const int tj = id < 4 ? id : id < 7 ? id - 3 : id < 9 ? id - 5 : 3;
+        const double *pa = Qs + (16 * ti + ij) * CQ_QST + kq, *pb = Qs + (16 * tj + ij) * CQ_QST + kq;
+        s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k0 = 0; k0 < CQ_RS; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = pa[k0 + 4 * u]; b[u] = pb[k0 + 4 * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gp[(16 * ti + kq + 4 * r) * 64 + 16 * tj + ij] = acc[r];
+    }
+}
+
+// The 64 x 64 factor of a pass from its reduced Gram matrix G (row-major, upper triangle valid):
+//   on return  M1 = R (upper, zeros below),  M2 = inv(R).
+// PASS 1: R1 = chol(G).   PASS 2: G = Q1'Q1 = I + E -- ||E||_F <= 1e-5: second-order expansion (no dependent chain: two
+// structured MFMA products, the element-wise steps on 16 register-resident entries per thread); larger: Cholesky again;
+// ||E||_F > 1/2: cond(Q1)^2 eps is no longer O(eps) -- *bad is set (as for a Cholesky breakdown).
+template <int PASS>
+__device__ __forceinline__ void cq_factor(const double *__restrict__ G, double *__restrict__ M1, double *__restrict__ M2,
+                                          double *__restrict__ T, int *s_fail, double *s_red, int *bad, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    double g[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[q] = G[tid + 256 * q];         // entry e = tid + 256 q: row e >> 6, column e & 63
+    *bad = 0;
+    bool series = false;
+    if (PASS == 2) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            const double v = g[q] - (r == c ? 1.0 : 0.0);
+            acc += r < c ? 2.0 * v * v : (r == c ? v * v : 0.0);      // (only the upper triangle of G is formed)
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) s_red[wv] = acc;
+        __syncthreads();
+        const double fro2 = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (!(fro2 <= 0.25)) *bad = 1;                                 // (NaN lands here too)
+        series = fro2 <= 1e-10;
+    }
+    if (series) {
+        // X1 = Phi(E);  X2 = X1 - Phi(X1'X1);  inv(R2) = I - X2 + X2 X2;  R2 = I + X2      (Phi: strict upper + half diagonal)
+        double x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            x[q] = r < c ? g[q] : (r == c ? 0.5 * (g[q] - 1.0) : 0.0);
+            M1[r * S64_LS + c] = x[q];
+        }
+        __syncthreads();
+        s64_gemm<true, false, S64_LtU>(M2, M1, M1, 1.0, tid);      // upper tiles of X1'X1
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            const double v = r <= c ? M2[r * S64_LS + c] : 0.0;
+            x[q] -= r < c ? v : (r == c ? 0.5 * v : 0.0);
+        }
+        __syncthreads();                                           // (everyone has read M2 / the product has read M1)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q; M1[(e >> 6) * S64_LS + (e & 63)] = x[q]; }
+        __syncthreads();
+        s64_gemm<false, false, S64_UU>(M2, M1, M1, 1.0, tid);      // X2 X2 (upper; zero tiles below)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            const double d = r == c ? 1.0 : 0.0;
+            M2[r * S64_LS + c] = d - x[q] + M2[r * S64_LS + c];
+            M1[r * S64_LS + c] = d + x[q];
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q; M1[(e >> 6) * S64_LS + (e & 63)] = g[q]; }
+        __syncthreads();
+        if (s64_chol(M1, M2, s_fail, tid)) *bad = 1;
+        s64_chol_inverse(M1, M2, T, tid);
+    }
+}
+
+// rows r0.. of a 64-column block times the upper triangular inv(R) in M2: one 16-row tile per wavefront, K = 64 (zero
+// blocks skipped); the lane's part of the product -> acc[4] (MFMA D layout: column 16 j + (lane & 15), rows (lane >> 4) + 4 r)
+__device__ __forceinline__ void cq_rows_times_inv(const double *__restrict__ P, size_t lda, int nr, const double *__restrict__ M2,
+                                                  s64_v4d acc[4], int lane, int wv) {
+    const int ij = lane & 15, kq = lane >> 4;
+    const int row = wv * 16 + ij;
+    const bool rin = row < nr;
+    const double *prow = P + (rin ? row : 0);
+    double a[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const double v = prow[(size_t)(s * 4 + kq) * lda];
+        a[s] = rin ? v : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (s64_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int k = s * 4 + kq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j >= (s >> 2))       // block (k-tile, j) of an upper triangular matrix is zero for j < k-tile
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], M2[k * S64_LS + 16 * j + ij], acc[j], 0, 0, 0);
+    }
+}
+
+// PASS 0: Gram partials of the raw panel.   PASS 1: R1 = chol(G), Q1 = P inv(R1) in place, Gram partials of Q1.
+// PASS 2: R2 from G2 = Q1'Q1, Q = Q1 inv(R2) -> Vb.      P = A(c0 + [0, rows), c0 + [0, 64)), column-major, ld lda.
+template <int PASS>
+__global__ void __launch_bounds__(256)
+k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__restrict__ G, double *__restrict__ Gp,
+           double *__restrict__ R1g, double *__restrict__ Vb, int ldv, int *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *M1 = sm, *M2 = sm + S64_MAT, *T = sm + 2 * S64_MAT, *Qs = sm + 2 * S64_MAT + S64_TMP;
+    __shared__ int s_fail;
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slab = blockIdx.x, r0 = slab * CQ_RS, nr = min(CQ_RS, rows - r0);
+    double *P = A + (size_t)c0 * lda + c0 + r0;         // element (row, col) at P[col * lda + row]
+    CQ_T(PASS * 16 + 0);
+    if (PASS == 0) {
+        // thread: row (tid & 63), columns (tid >> 6) + 4 q -- 16 loads in flight
+        const int row = tid & (CQ_RS - 1), cq = tid >> 6;
+        const bool rin = row < nr;
+        const double *src = P + (rin ? row : 0);
+        double t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = src[(size_t)(cq + 4 * q) * lda];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Qs[(cq + 4 * q) * CQ_QST + row] = rin ? t[q] : 0.0;
+        __syncthreads();
+        CQ_T(1);
+        cq_slab_gram(Qs, Gp + (size_t)slab * 4096, tid);
+        CQ_T(2);
+        return;
+    }
+    int bad;
+    cq_factor<PASS>(G, M1, M2, T, &s_fail, s_red, &bad, tid);     // every workgroup, identically
+    if (bad && slab == 0 && tid == 0) atomicOr(err, CQ_FAIL);
+    CQ_T(PASS * 16 + 2);
+    if (PASS == 1 && slab == 0)
+        for (int e = tid; e < 4096; e += 256) R1g[e] = M1[(e >> 6) * S64_LS + (e & 63)];
+    // ---- slab product  Qslab = Pslab * inv(R) ------------------------------------------------------------------
+    CQ_T(PASS * 16 + 3);
+    {
+        s64_v4d acc[4];
+        cq_rows_times_inv(P, (size_t)lda, nr, M2, acc, lane, wv);
+        const int ij = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Qs[(16 * j + ij) * CQ_QST + wv * 16 + kq + 4 * r] = acc[j][r];
+    }
+    __syncthreads();
+    CQ_T(PASS * 16 + 4);
+    double *dst = PASS == 1 ? P : Vb + r0;
+    const size_t ldd = PASS == 1 ? (size_t)lda : (size_t)ldv;
+    {
+        const int row = tid & (CQ_RS - 1), cq = tid >> 6;
+        if (row < nr) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dst[(cq + 4 * q) * ldd + row] = Qs[(cq + 4 * q) * CQ_QST + row];
+        }
+    }
+    CQ_T(PASS * 16 + 5);
+    if (PASS == 1) cq_slab_gram(Qs, Gp + (size_t)slab * 4096, tid);
+    CQ_T(PASS * 16 + 6);
+}
+
+// G = sum of the slab partials (fixed order): 64 outputs per workgroup, 16 partial sums per output (one batch of loads
+// per thread for up to 256 slabs), combined in index order
+__global__ void __launch_bounds__(1024) k_cqr_reduce(const double *__restrict__ Gp, int nslab, double *__restrict__ G) {
+    __shared__ double part[16][64];
+    const int tid = threadIdx.x, o = tid & 63, p = tid >> 6;
+    const int e = blockIdx.x * 64 + o;
+    const int per = (nslab + 15) / 16, s0 = p * per, s1 = min(nslab, s0 + per);
+    double acc = 0.0;
+    int s = s0;
+    for (; s + 16 <= s1; s += 16) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = Gp[(size_t)(s + u) * 4096 + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += t[u];
+    }
+    for (; s < s1; ++s) acc += Gp[(size_t)s * 4096 + e];
+    part[p][o] = acc;
+    __syncthreads();
+    if (p == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tot += part[u][o];
+        G[e] = tot;
+    }
+}
+
+// ONE workgroup, on the side stream, beside pass 2 and the caller's V'[A2 | b] product: everything that hangs on the TOP
+// 64 rows only.  It repeats pass 2's factor and forms Q_top = Q1_top inv(R2) itself (so it needs nothing from pass 2),
+// then: modified LU of B = Q_top - S (S on the fly), inv(B) = inv(U) inv(L) and S -> global;
+// R = R2 R1 and the panel's part of the factor, S R, -> A's 64 x 64 triangle.
+__global__ void __launch_bounds__(256)
+k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, double *__restrict__ A, int lda, int c0,
+          double *__restrict__ Binv, double *__restrict__ Sg, int *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *B0 = sm, *B1 = sm + S64_MAT, *B2 = sm + 2 * S64_MAT, *B3 = sm + 3 * S64_MAT, *T = sm + 4 * S64_MAT;
+    __shared__ double sS[64], sR[64], s_red[4];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    CQ_T(48);
+    int bad;
+    cq_factor<2>(G2, B0, B1, T, &s_fail, s_red, &bad, tid);       // B0 = R2, B1 = inv(R2)  (the flag is raised by pass 2)
+    (void)bad; (void)err;
+    cq_load64(B2, R1g, tid);
+    __syncthreads();
+    s64_gemm<false, false, S64_UU>(B3, B0, B2, 1.0, tid);          // B3 = R = R2 R1
+    {   // Q_top (row-major) -> B2
+        const double *P = A + (size_t)c0 * lda + c0;               // Q1's top rows (pass 1 wrote them in place)
+        s64_v4d acc[4];
+        cq_rows_times_inv(P, (size_t)lda, 64, B1, acc, lane, wv);
+        __syncthreads();                                           // (the product above has read B2 = R1)
+        const int ij = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B2[(wv * 16 + kq + 4 * r) * S64_LS + 16 * j + ij] = acc[j][r];
+    }
+    __syncthreads();
+    CQ_T(49);
+    double *M = B2, *Li = B0;
+    s64_lu_modified(M, Li, sS, sR, tid);
+    CQ_T(50);
+    // the panel's part of the factor: rows c0..c0+63 of columns c0..c0+63 <- S R (upper triangle)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, col = e >> 6, row = e & 63;
+        if (row <= col) A[(size_t)(c0 + col) * lda + c0 + row] = sS[row] * B3[row * S64_LS + col];
+    }
+    if (tid < 64) Sg[tid] = sS[tid];
+    __syncthreads();
+    // inv(L) = (inv(L'))': Z = L' (upper, unit diagonal) -> B1, X <- inv(Z) -> B3, diagonal blocks inv(L_kk)' from Li
+    double *Z = B1, *X = B3;
+    for (int e = tid; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        Z[r * S64_LS + c] = r < c ? M[c * S64_LS + r] : (r == c ? 1.0 : 0.0);
+        X[r * S64_LS + c] = ((r >> 4) == (c >> 4)) ? Li[c * S64_LS + r] : 0.0;
+    }
+    __syncthreads();
+    s64_triinv_levels(Z, X, T, tid);           // X = inv(L') = inv(L)'
+    // Uc = clean upper part of M -> B0 (Li is done); inv(U) -> B1 (Z is done)
+    double *Uc = B0, *Xu = B1;
+    for (int e = tid; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        Uc[r * S64_LS + c] = r <= c ? M[r * S64_LS + c] : 0.0;
+    }
+    __syncthreads();
+    s64_diaginv_upper(Uc, Xu, tid);
+    s64_triinv_levels(Uc, Xu, T, tid);
+    CQ_T(51);
+    s64_gemm<false, true, S64_UL>(Binv, Xu, X, 1.0, tid, 64);     // inv(B) = inv(U) inv(L) = Xu * X' -> global (row-major)
+    CQ_T(52);
+}
+
+// W2(:, 64 columns of the workgroup) = inv(B) (A2_top - S W_Q)   [W = V'[V | A2 | b] with V = Q, from k_qr1_vtb + wreduce]
+// B-matrix column cb >= 64 is A(:, cend + cb - 64) or the right-hand side (last column); rows from c0.
+__global__ void __launch_bounds__(256)
+k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Binv, const double *__restrict__ Sg,
+         const double *__restrict__ A, int lda, int c0, int cend, int n, const double *__restrict__ rhs, double *__restrict__ Vb,
+         int ldv, double *__restrict__ W2) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *sBi = sm;                      // inv(B), row-major
+    double *sRh = sm + S64_MAT;            // RHS[k][j]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ncols = ncolsB - 64, j0 = blockIdx.x * 64;
+    cq_load64(sBi, Binv, tid);
+    {
+        double top[16], wq[16];
+        const double sk = Sg[tid & 63];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, j = e >> 6, k = e & 63, col = min(j0 + j, ncols - 1), a = cend + col;
+            top[q] = a < n ? A[(size_t)a * lda + c0 + k] : rhs[c0 + k];
+            wq[q] = W[(size_t)(64 + col) * 64 + k];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, j = e >> 6, k = e & 63;
+            sRh[k * S64_LS + j] = j0 + j < ncols ? top[q] - sk * wq[q] : 0.0;
+        }
+    }
+    if (blockIdx.x == 0 && tid < 64) Vb[(size_t)tid * ldv + tid] -= Sg[tid];     // V = Q - [S; 0] for the update
+    __syncthreads();
+    const int ij = lane & 15, kq = lane >> 4;
+    for (int q = wv; q < 16; q += 4) {
+        const int ti = q >> 2, tj = q & 3;
+        s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = s * 4 + kq;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sBi[(16 * ti + ij) * S64_LS + k], sRh[k * S64_LS + 16 * tj + ij], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + kq + 4 * r, col = j0 + 16 * tj + ij;
+            if (col < ncols) W2[(size_t)col * 64 + row] = acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
+    w->max_slabs = (M + CQ_RS - 1) / CQ_RS;
+    LSQ_HIP(hipMalloc(&w->Gp, (size_t)w->max_slabs * 4096 * sizeof(double)));
+    LSQ_HIP(hipMemset(w->Gp, 0, (size_t)w->max_slabs * 4096 * sizeof(double)));   // (the strictly lower tiles are never written)
+    LSQ_HIP(hipMalloc(&w->G, 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->R1, 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->G2, 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->Binv, 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->S, 64 * sizeof(double)));
+    {   // highest priority: its single workgroup (141 KB of LDS) must get a CU before the caller's V'[A2 | b] grid fills them
+        int lo = 0, hi = 0;
+        LSQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        LSQ_HIP(hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, hi));
+    }
+    LSQ_HIP(hipEventCreateWithFlags(&w->ev_q, hipEventDisableTiming));
+    LSQ_HIP(hipEventCreateWithFlags(&w->ev_lu, hipEventDisableTiming));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_pass<0>, CQ_LDS));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_pass<1>, CQ_LDS));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_pass<2>, CQ_LDS));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_top, CQ_LDS_LU));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_tw, CQ_LDS_TW));
+    w->ready = true;
+    return LSQ_OK;
+}
+
+void lsq_cqr_free(CqrWork *w) {
+    if (!w || !w->ready) return;
+    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->S);
+    hipEventDestroy(w->ev_q); hipEventDestroy(w->ev_lu);
+    hipStreamDestroy(w->side);
+    w->ready = false;
+}
+
+int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err) {
+    const int rows = M - c0, nslab = (rows + CQ_RS - 1) / CQ_RS;
+    hipLaunchKernelGGL(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, c->stream, A, M, c0, rows, (const double *)nullptr, w->Gp,
+                       w->R1, Vb, ldv, d_err);
+    hipLaunchKernelGGL(k_cqr_reduce, dim3(64), dim3(1024), 0, c->stream, (const double *)w->Gp, nslab, w->G);
+    hipLaunchKernelGGL(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, c->stream, A, M, c0, rows, (const double *)w->G, w->Gp,
+                       w->R1, Vb, ldv, d_err);
+    hipLaunchKernelGGL(k_cqr_reduce, dim3(64), dim3(1024), 0, c->stream, (const double *)w->Gp, nslab, w->G2);
+    LSQ_HIP(hipGetLastError());
+    // everything that hangs on the top 64 rows (the 64-step LU among it) runs on the side stream from here on, beside
+    // pass 2 and the caller's V'[A2 | b] product
+    LSQ_HIP(hipEventRecord(w->ev_q, c->stream));
+    LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
+    hipLaunchKernelGGL(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1, A, M, c0,
+                       w->Binv, w->S, d_err);
+    LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
+    hipLaunchKernelGGL(k_cqr_pass<2>, dim3(nslab), dim3(256), CQ_LDS, c->stream, A, M, c0, rows, (const double *)w->G2, w->Gp,
+                       w->R1, Vb, ldv, d_err);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, const double *A, int M, int c0, int cend, int n,
+               const double *rhs, double *Vb, int ldv, double *W2) {
+    LSQ_HIP(hipStreamWaitEvent(c->stream, w->ev_lu, 0));
+    const int ncols = ncolsB - 64;
+    hipLaunchKernelGGL(k_cqr_tw, dim3(std::max(1, (ncols + 63) / 64)), dim3(256), CQ_LDS_TW, c->stream, W, ncolsB,
+                       (const double *)w->Binv, (const double *)w->S, A, M, c0, cend, n, rhs, Vb, ldv, W2);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}

@@ -42,6 +42,7 @@ struct lsq_solver {
     int *d_info = nullptr;
     // --- dense QR (dense_qr.jl:6-28, 50-54) ---
     int last_qr_path = 0;      // lsq_solver_qr_path
+    int last_qr_panel = 0;     // lsq_solver_qr_panel
     double *d_qr = nullptr;    // (m [+n]) * n
     double *d_qu = nullptr;    // max(m,n) or m+n
     double *d_tau = nullptr;

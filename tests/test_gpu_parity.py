@@ -496,6 +496,76 @@ def test_ldiv_qr_tall_thin(ctx, m, n, tsqr, monkeypatch):
     assert np.allclose(dxo.get(), xd, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("for_lm", [False, True])
+def test_qr_cholqr_panel_and_its_fallback(ctx, for_lm):
+    """Stage 1 of the blocked QR factors its 64-column panels by CholeskyQR2 + a basis-kernel block reflector
+    (lsq_qr_cholqr.hip).  (i) On ordinary operands it is the path taken and the solve agrees with LAPACK and with the
+    column-by-column Householder panel (LSQ_QR1_NO_CHOLQR=1) to rounding.  (ii) A panel too ill-conditioned for it (cond
+    1e10: the Gram matrix is numerically singular) raises the device flag; the solve is repeated with the Householder
+    panel and the answer is still the backward-stable one.  (iii) Exactly rank-deficient operands end in the pivoted
+    sweep as before."""
+    rng = np.random.default_rng(11)
+    m, n = 3000, 192
+
+    def solve(A, y, damp=None, env=None):
+        if env:
+            os.environ[env] = "1"
+        try:
+            J = lsq.DeviceMatrix(ctx, A)
+            sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=damp is not None)
+            x = lsq.DeviceVector(ctx, A.shape[1])
+            if damp is None:
+                sv.ldiv_(x, lsq.DeviceVector(ctx, A.shape[0], y))
+            else:
+                sv.ldiv_(x, lsq.DeviceVector(ctx, A.shape[0], y), lsq.DeviceVector(ctx, A.shape[1], damp))
+            out, info = x.get(), sv.info()
+            sv.free()
+            J.free()
+            return out, info
+        finally:
+            if env:
+                del os.environ[env]
+
+    y = rng.standard_normal(m)
+    damp = (rng.random(n) + 0.05) if for_lm else None
+
+    def reference(A):
+        if damp is None:
+            return np.linalg.lstsq(A, y, rcond=None)[0]
+        return np.linalg.lstsq(np.vstack([A, np.diag(np.sqrt(damp))]), np.concatenate([y, np.zeros(n)]), rcond=None)[0]
+
+    # (i) well conditioned
+    A = rng.standard_normal((m, n))
+    x, info = solve(A, y, damp)
+    assert info["qr_panel"] == "cholqr2" and info["qr_path"] == "two-stage-certified"
+    xh, infoh = solve(A, y, damp, env="LSQ_QR1_NO_CHOLQR")
+    assert infoh["qr_panel"] == "householder-steps"
+    ref = reference(A)
+    assert np.linalg.norm(x - ref) <= 1e-12 * np.linalg.norm(ref) and np.linalg.norm(x - xh) <= 1e-12 * np.linalg.norm(ref)
+    # moderately ill conditioned (cond 1e5): still CholeskyQR2 (second pass by Cholesky, not by the expansion)
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A5 = U @ np.diag(np.logspace(0, -5, n)) @ V.T
+    x, info = solve(A5, y, damp)
+    ref = reference(A5)
+    assert info["qr_panel"] == "cholqr2"
+    assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
+    # (ii) cond 1e10: breakdown -> Householder panel, same accuracy as LAPACK's own (cond * eps)
+    A10 = U @ np.diag(np.logspace(0, -10, n)) @ V.T
+    x, info = solve(A10, y, damp)
+    ref = reference(A10)
+    if not for_lm:          # (with damping the stacked operand is well conditioned again: nothing to fall back from)
+        assert info["qr_panel"] == "householder-steps"
+    assert np.linalg.norm(x - ref) <= (1e-4 if not for_lm else 1e-10) * np.linalg.norm(ref)
+    # (iii) rank deficient: minimum-norm solution through the pivoted sweep
+    if not for_lm:
+        Ad = rng.standard_normal((m, 40)) @ rng.standard_normal((40, n))
+        x, info = solve(Ad, y)
+        ref = np.linalg.lstsq(Ad, y, rcond=None)[0]
+        assert info["qr_path"] == "two-stage-pivoted"
+        assert np.linalg.norm(x - ref) <= 1e-8 * np.linalg.norm(ref)
+
+
 @pytest.mark.parametrize("m,n,rank,solver", [(700, 200, 1, "qr"), (3000, 130, 130, "qr"), (9000, 200, 200, "qr"),
                                              (700, 200, 200, "chol"), (3000, 500, 500, "chol")])
 def test_dense_solves_are_repeatable(ctx, m, n, rank, solver, monkeypatch):

@@ -25,7 +25,8 @@ def bench(m, n, solver, for_lm, reps=5):
     xr = x.get()
     if for_lm: ref = np.linalg.solve(A.T @ A + 0.1 * np.eye(n), A.T @ y.get())
     else: ref = np.linalg.lstsq(A, y.get(), rcond=None)[0]
-    print("%-9s %6dx%-5d for_lm=%d  %.3f ms  relerr %.2e" % (type(solver).__name__, m, n, for_lm, dt * 1e3, np.linalg.norm(xr - ref) / np.linalg.norm(ref)), flush=True)
+    inf = sv.info()
+    print("%-9s %6dx%-5d for_lm=%d  %.3f ms  relerr %.2e  %s %s" % (type(solver).__name__, m, n, for_lm, dt * 1e3, np.linalg.norm(xr - ref) / np.linalg.norm(ref), inf.get("qr_path"), inf.get("qr_panel")), flush=True)
 for arg in sys.argv[1:] or ["chol:4096:512:1", "qr:4096:512:0", "qr:4096:512:1"]:
     k, m, n, f = arg.split(":")
     bench(int(m), int(n), lsq.Cholesky() if k == "chol" else lsq.QR(), int(f) == 1, reps=3)
