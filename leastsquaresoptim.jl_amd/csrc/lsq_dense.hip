@@ -2751,9 +2751,9 @@ static void tripipe_free(void *p) {
     hipFree(t->Xd); hipFree(t->z); hipFree(t->slot_f); hipFree(t->slot_b); hipFree(t->d_err);
     delete t;
 }
-int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
-    lsq_ctx *c = s->ctx;
+static int tri_chol_pipe(lsq_solver *s, int n, TriPipe **out) {
     const int nblk = lsq_div_up(n, 64);
+    *out = nullptr;
     if (nblk > 256 || s->pipe_off || getenv("LSQ_CHOL_SUBST_SOLVE")) return LSQ_EARG;
     TriPipe *t = (TriPipe *)s->tripipe;
     if (!t || t->n != n) {
@@ -2773,8 +2773,21 @@ int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
         s->tripipe = t;
         s->tripipe_free = tripipe_free;
     }
+    *out = t;
+    return LSQ_OK;
+}
+double *lsq_tri_chol_diagbuf(lsq_solver *s, int n) {
+    TriPipe *t = nullptr;
+    return tri_chol_pipe(s, n, &t) == LSQ_OK ? t->Xd : nullptr;
+}
+int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
+    lsq_ctx *c = s->ctx;
+    const int nblk = lsq_div_up(n, 64);
+    TriPipe *t = nullptr;
+    if (tri_chol_pipe(s, n, &t) != LSQ_OK) return LSQ_EARG;
     ++t->epoch;
-    hipLaunchKernelGGL(k_tri_diaginv, dim3(nblk), dim3(256), 0, c->stream, U, n, t->Xd, 64, (size_t)4096);
+    if (!s->chol_have_diaginv)     // (the MFMA panel kernel of the blocked factorisation has already left inv(U_kk) in Xd)
+        hipLaunchKernelGGL(k_tri_diaginv, dim3(nblk), dim3(256), 0, c->stream, U, n, t->Xd, 64, (size_t)4096);
     hipLaunchKernelGGL(k_tri_fsolve_t, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, d_bx, t->z, t->slot_f,
                        t->epoch, t->d_err);
     hipLaunchKernelGGL(k_tri_bsolve, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, t->z, d_bx, t->slot_b,

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "lsq_small64.h"
 #include "lsq_solver.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -474,6 +475,62 @@ k_chol_panel16(double *__restrict__ C, int n, int j0, int *__restrict__ info, do
     }
 }
 
+// The same step on the fp64 MFMA unit (lsq_small64.h): the only dependent chains left are the four 16 x 16 diagonal
+// sub-blocks (one wavefront, registers); row panels and trailing tiles of the 64 x 64 block, its explicit inverse
+// W = inv(U11) and the row panel of the big matrix, U12 = W' A12 (one 64 x 64 x 64 product per workgroup), are tile
+// products.  58 us -> ~20 us per step at n = 512.  The inverse also goes to Xd[j0 / 64] (column-major 64 x 64): the
+// pipelined triangular solves need exactly these blocks (k_tri_diaginv is then skipped).
+constexpr size_t CHP_LDS = (size_t)(3 * S64_MAT + S64_TMP) * sizeof(double);
+__global__ void __launch_bounds__(256)
+k_chol_panel_mfma(double *__restrict__ C, int n, int j0, int *__restrict__ info, double *__restrict__ Ds, double *__restrict__ Xd) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *M1 = sm, *M2 = sm + S64_MAT, *M3 = sm + 2 * S64_MAT, *T = sm + 3 * S64_MAT;
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int nb = min(NB, n - j0);
+    if (*info != 0) return;  // an earlier panel failed
+    const int c0 = j0 + nb + blockIdx.x * NB;
+    {   // diagonal block (upper triangle; identity padding past nb) and this workgroup's 64 columns of the row panel
+        double g[16], x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e & 63, cidx = e >> 6;
+            const bool in = r < nb && cidx < nb && r <= cidx;
+            g[q] = in ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
+            x[q] = (r < nb && c0 + cidx < n) ? C[(size_t)(c0 + cidx) * n + j0 + r] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e & 63, cidx = e >> 6;
+            M1[r * S64_LS + cidx] = g[q];
+            M3[r * S64_LS + cidx] = x[q];       // A12 chunk, [k = row of the panel][j = column]
+        }
+    }
+    __syncthreads();
+    const int bad = s64_chol(M1, M2, &s_fail, tid);
+    if (bad) {
+        if (tid == 0 && blockIdx.x == 0) *info = j0 + bad;   // PosDefException position (1-based)
+        return;
+    }
+    s64_chol_inverse(M1, M2, T, tid);           // M2 = inv(U11)
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e & 63, cidx = e >> 6;
+            if (r <= cidx && r < nb && cidx < nb) Ds[(size_t)(j0 / NB) * NB * NB + (size_t)cidx * NB + r] = M1[r * S64_LS + cidx];
+            if (Xd) Xd[(size_t)(j0 / NB) * NB * NB + (size_t)cidx * NB + r] = (r < nb && cidx < nb) ? M2[r * S64_LS + cidx] : 0.0;
+        }
+    }
+    if (c0 >= n) return;   // last panel: nothing to the right
+    __syncthreads();       // (workgroup 0 has parked U11: M1 is free now)
+    s64_gemm<true, false, S64_LF>(M1, M2, M3, 1.0, tid);          // U12 chunk = inv(U11)' A12 chunk
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, r = e & 63, cidx = e >> 6;
+        if (r < nb && c0 + cidx < n) C[(size_t)(c0 + cidx) * n + j0 + r] = M1[r * S64_LS + cidx];
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_chol_diag_restore(double *__restrict__ C, int n, const double *__restrict__ Ds, const int *__restrict__ info) {
     const int j0 = blockIdx.x * NB, nb = min(NB, n - j0);
@@ -709,11 +766,24 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     // parking space for the factored diagonal blocks (k_chol_panel16): the tail of the SYRK slice buffer is free by now
     bool merged = false;
     double *Ds = s->d_Ds;
+    // the MFMA panel kernel leaves the inverted diagonal blocks where the pipelined triangular solves look for them
+    double *Xd = nullptr;
+    s->chol_have_diaginv = false;
+    if (!getenv("LSQ_CHOL_PANEL16") && !getenv("LSQ_CHOL_PER_COLUMN") && !getenv("LSQ_CHOL_TWO_LAUNCH")) {
+        LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_panel_mfma, CHP_LDS));
+        Xd = lsq_tri_chol_diagbuf(s, n);
+        s->chol_have_diaginv = Xd != nullptr;
+    }
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = std::min(NB, n - j0), rest = n - j0 - nb;
         static const bool per_column = getenv("LSQ_CHOL_PER_COLUMN") != nullptr;   // the one-barrier-per-column kernels
         static const bool two_launch = getenv("LSQ_CHOL_TWO_LAUNCH") != nullptr;   // diagonal block and row panel separately
-        if (!per_column && !two_launch) {
+        static const bool old_panel = getenv("LSQ_CHOL_PANEL16") != nullptr;       // the register / substitution panel kernel
+        if (!per_column && !two_launch && !old_panel) {
+            hipLaunchKernelGGL(k_chol_panel_mfma, dim3(std::max(1, (rest + NB - 1) / NB)), dim3(256), CHP_LDS, c->stream, s->d_chol,
+                               n, j0, s->d_info, Ds, Xd);
+            merged = true;
+        } else if (!per_column && !two_launch) {
             hipLaunchKernelGGL(k_chol_panel16, dim3(std::max(1, (rest + NB - 1) / NB)), dim3(256), 0, c->stream, s->d_chol, n, j0,
                                s->d_info, Ds);
             merged = true;

@@ -69,22 +69,33 @@ __device__ __forceinline__ void s64_tile_store(double *__restrict__ M, int r0, i
 // ---- 16 x 16 diagonal block of a Cholesky factorisation G = U'U, ONE wavefront, registers ----------------------
 // lanes 0..15: column c of the block (rows r <= c); lanes 16..31: column c of the identity, which the same row
 // operations turn into inv(U_kk)' (lower triangular).  Writes U_kk (zeros below the diagonal) into M in place and
-// inv(U_kk)' into W at the same position.  Returns non-zero when a pivot is not positive (wave-uniform).
+// inv(U_kk)' into W at the same position.  Returns 0, or 1 + the index (inside the block) of the first pivot that is not
+// positive (wave-uniform).
 __device__ __forceinline__ int s64_chol16(double *__restrict__ M, double *__restrict__ W, int o, int lane) {
     const int c = lane & 15;
     const bool mat = lane < 16, idn = lane >= 16 && lane < 32;
     double u[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) u[r] = mat ? (r <= c ? M[(o + r) * S64_LS + o + c] : 0.0) : ((idn && r == c) ? 1.0 : 0.0);
-    int bad = 0;
+    int bad = 0;                                 // 1 + index of the first pivot that is not positive
+    // software-pipelined: the next pivot's reciprocal square root (a long dependent chain) is issued as soon as row j+1
+    // has its update, and the updates of the other rows fill its latency (one wavefront per SIMD: nothing else would)
+    double ajj = s64_readlane(u[0], 0);
+    double sj = s64_rsqrt(ajj);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const double ajj = s64_readlane(u[j], j);
-        bad |= !(ajj > 0.0);                     // (a non-positive pivot turns the rest into NaN / Inf: reported, not used)
-        const double rowj = u[j] * s64_rsqrt(ajj);   // U[j][c] (c >= j); identity lanes: row j of inv(U)' so far
+        bad = (bad == 0 && !(ajj > 0.0)) ? j + 1 : bad;   // (such a pivot turns the rest into NaN / Inf: reported, not used)
+        const double rowj = u[j] * sj;           // U[j][c] (c >= j); identity lanes: row j of inv(U)' so far
         u[j] = rowj;
+        if (j + 1 < 16) {
+            u[j + 1] = __builtin_fma(-s64_readlane(rowj, j + 1), rowj, u[j + 1]);
+            ajj = s64_readlane(u[j + 1], j + 1);
+            sj = s64_rsqrt(ajj);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = j + 1; i < 16; ++i) u[i] = __builtin_fma(-s64_readlane(rowj, i), rowj, u[i]);   // U[j][i] * U[j][c]
+        for (int i = j + 2; i < 16; ++i) u[i] = __builtin_fma(-s64_readlane(rowj, i), rowj, u[i]);   // U[j][i] * U[j][c]
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (mat) {
 #pragma unroll
@@ -97,8 +108,8 @@ __device__ __forceinline__ int s64_chol16(double *__restrict__ M, double *__rest
 }
 
 // ---- Cholesky G = U'U of a 64 x 64 matrix (upper triangle of M is read), in place: M <- U (zeros below) --------------
-// W receives the four inv(U_kk)' diagonal blocks (the other entries of W are not touched).  Returns non-zero (uniform)
-// when G is not positive definite; M then holds finite garbage.  `fail` is an LDS int.
+// W receives the four inv(U_kk)' diagonal blocks (the other entries of W are not touched).  Returns 0, or (uniform)
+// 1 + the index of the first pivot that is not positive -- M then holds garbage.  `fail` is an LDS int.
 __device__ __forceinline__ int s64_chol(double *__restrict__ M, double *__restrict__ W, int *fail, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
     if (tid == 0) *fail = 0;
@@ -107,7 +118,7 @@ __device__ __forceinline__ int s64_chol(double *__restrict__ M, double *__restri
         const int o = kb * 16;
         if (wv == 0) {
             const int bad = s64_chol16(M, W, o, lane);
-            if (bad && lane == 0) *fail = 1;
+            if (bad && lane == 0 && *fail == 0) *fail = o + bad;
         }
         __syncthreads();
         const int nt = 3 - kb;                   // tiles to the right
@@ -321,8 +332,9 @@ __device__ __forceinline__ void s64_lu_modified(double *__restrict__ M, double *
 //   S64_LtU    op(A) lower (e.g. X' for an upper X), op(B) upper: C = A'A-like, only tiles ti <= tj are formed and nothing
 //              else is written (the caller reads the upper triangle); k-tiles 0..ti                               (20 of 64)
 //   S64_UL     op(A) upper, op(B) lower: full result, k-tiles max(ti, tj)..3                                       (30 of 64)
+//   S64_LF     op(A) lower, op(B) full: k-tiles 0..ti                                                                (40 of 64)
 // ldc: row stride of C (S64_LS for an LDS matrix, 64 for a row-major matrix in global memory).
-enum { S64_FULL = 0, S64_UU = 1, S64_LtU = 2, S64_UL = 3 };
+enum { S64_FULL = 0, S64_UU = 1, S64_LtU = 2, S64_UL = 3, S64_LF = 4 };
 template <bool TA, bool TB, int SHAPE = S64_FULL>
 __device__ __forceinline__ void s64_gemm(double *__restrict__ C, const double *__restrict__ A, const double *__restrict__ B,
                                          double sgn, int tid, int ldc = S64_LS) {
@@ -330,12 +342,14 @@ __device__ __forceinline__ void s64_gemm(double *__restrict__ C, const double *_
     const int ij = lane & 15, kq = lane >> 4;
     for (int q = wv; q < 16; q += 4) {
         // tiles are dealt so that the four wavefronts get equal work for the triangular shapes (ti + tj pairs)
-        const int ti = q >> 2, tj = (SHAPE == S64_FULL || SHAPE == S64_UL) ? (q & 3) : ((q & 3) + ti) & 3;
+        const int ti = (SHAPE == S64_LF) ? ((q >> 2) + (q & 3)) & 3 : q >> 2;      // (S64_LF: rows dealt round-robin: equal work)
+        const int tj = (SHAPE == S64_FULL || SHAPE == S64_UL || SHAPE == S64_LF) ? (q & 3) : ((q & 3) + ti) & 3;
         int k0 = 0, k1 = 4;
         bool live = true;
         if (SHAPE == S64_UU) { live = ti <= tj; k0 = ti; k1 = tj + 1; }
         if (SHAPE == S64_LtU) { live = ti <= tj; k1 = ti + 1; }
         if (SHAPE == S64_UL) { k0 = ti > tj ? ti : tj; }
+        if (SHAPE == S64_LF) { k1 = ti + 1; }
         s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
         if (live) {
             for (int kt = k0; kt < k1; ++kt) {

@@ -60,8 +60,11 @@ struct lsq_solver {
     double *tri_X = nullptr, *tri_T = nullptr, *tri_fro = nullptr, *tri_hfro = nullptr;   // explicit inverse of the Cholesky factor (Dogleg certificate)
     int last_chol_path = 0;         // lsq_solver_chol_path
     int pipe_off = 0;               // a wait of the pipelined triangular solves gave up once: single-workgroup solves from then on
+    bool chol_have_diaginv = false; // the last blocked factorisation left inv(U_kk) in the solve pipeline's buffer
 };
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx);
+// buffer of the inverted 64 x 64 diagonal blocks of the pipelined solves (allocates the pipeline; nullptr when it is off)
+double *lsq_tri_chol_diagbuf(lsq_solver *s, int n);
 
 #ifdef __HIPCC__
 // the scalar recurrence of one iteration (lsmr.jl:127-196, :205), on a private copy of the state
