@@ -67,6 +67,7 @@ struct lsq_ctx {
     int prof_kernels = 3;                // bit k: instrument kernel k (a timed launch costs ~9 us of gaps)
     int prof_stride = 1, prof_tick = 0;  // time every prof_stride-th armed launch
     std::vector<hipEvent_t> prof_ev[2];  // start/stop pairs per kernel id
+    std::vector<hipEvent_t> prof_pool;   // events created by lsq_prof_begin, so that a timed launch creates nothing
     // kernels whose dynamic-LDS limit has been raised on THIS context's device (function attributes may be per device)
     std::unordered_map<const void *, size_t> lds_cfg;
 };
@@ -103,8 +104,13 @@ static inline void lsq_prof_mark(lsq_ctx *c, int kid, int phase) {
 // used by launch sites: returns true and fills start/stop when the launch should be timed
 static inline bool lsq_prof_take(lsq_ctx *c, hipEvent_t *start, hipEvent_t *stop) {
     if (c->prof_max <= 0 || c->prof_pending < 0) return false;
-    if (hipEventCreate(start) != hipSuccess) return false;
-    if (hipEventCreate(stop) != hipSuccess) { hipEventDestroy(*start); return false; }
+    if (c->prof_pool.size() >= 2) {          // (hipEventCreate costs microseconds of host time: not inside the solve)
+        *start = c->prof_pool.back(); c->prof_pool.pop_back();
+        *stop = c->prof_pool.back(); c->prof_pool.pop_back();
+    } else {
+        if (hipEventCreate(start) != hipSuccess) return false;
+        if (hipEventCreate(stop) != hipSuccess) { hipEventDestroy(*start); return false; }
+    }
     auto &v = c->prof_ev[c->prof_pending];
     v.push_back(*start);
     v.push_back(*stop);

@@ -174,11 +174,20 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
               double *__restrict__ t, double *partials, unsigned *counter) {
     __shared__ double sh[LSQ_NT / 64];
     __shared__ LsmrState ns;   // this iteration's state, computed from the committed one
-    if (st->done) return;
+    // This kernel is a chain of memory latencies (it moves 0.5 MB): everything that does not depend on the scalars is
+    // fetched up front, together -- the thread's vector elements, the committed state (one coalesced load into LDS; it
+    // also carries the `done` flag of a finished solve) and, inside ordered_sum256x3, counts and partials -- so that one
+    // round trip is paid instead of five.
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * LSQ_NT + tid, jc = j0 < n ? j0 : n - 1;
+    const double e_v = v[jc], e_h = h[jc], e_hb = hbar[jc], e_x = x[jc];
+    const double e_P = P ? P[jc] : 1.0, e_dg = dg ? dg[jc] : 0.0, e_ux = dg ? ux[jc] : 0.0;
+    static_assert(sizeof(LsmrState) % 8 == 0 && sizeof(LsmrState) / 8 <= LSQ_NT, "state copy: one 8-byte word per thread");
+    if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)&ns)[tid] = ((const unsigned long long *)st)[tid];
     double beta2, betax2, alpha2;
-    ordered_sum256x3(pu, npu, px_in, npx_in, pv, npv, beta2, betax2, alpha2);
+    ordered_sum256x3(pu, npu, px_in, npx_in, pv, npv, beta2, betax2, alpha2);   // (its barriers also publish ns)
+    if (ns.done) return;
     if (threadIdx.x == 0) {
-        ns = *st;
         const double beta = dg ? dampened_norm(beta2, px_in ? betax2 : 0.0) : sqrt(beta2);   // (px_in null in the setup pass)
         ns.beta = beta;
         ns.beta_zero = !(beta > 0.0);
@@ -209,8 +218,10 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
     const bool first = ns.first;
     const double vs = ns.vscale, c1 = ns.c1, c2 = ns.c2, c3 = ns.c3, cu = ns.cu;
     double acc = 0.0, accx = 0.0;
-    for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT) {
-        double vj = v[j] * vs;                       // lsmr.jl:78,124 rmul!(v, inv(alpha))
+    for (int j = j0; j < n; j += gridDim.x * LSQ_NT) {
+        const bool pf = j == j0;                     // first trip: the prefetched elements
+        const double Pj = P ? (pf ? e_P : P[j]) : 1.0;
+        double vj = (pf ? e_v : v[j]) * vs;          // lsmr.jl:78,124 rmul!(v, inv(alpha))
         v[j] = vj;
         if (first) {                                 // :89-90, iterative_lsmr.jl:183,242
             h[j] = vj;
@@ -218,20 +229,21 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
             x[j] = 0.0;
             xout[j] = 0.0;
         } else {
-            double hb = hbar[j] * c1 + h[j];         // :152-153
+            const double hj = pf ? e_h : h[j];
+            double hb = (pf ? e_hb : hbar[j]) * c1 + hj;   // :152-153
             hbar[j] = hb;
-            double xj = x[j] + c2 * hb;              // :154
+            double xj = (pf ? e_x : x[j]) + c2 * hb;       // :154
             x[j] = xj;
-            h[j] = h[j] * c3 + vj;                   // :155-156
+            h[j] = hj * c3 + vj;                     // :155-156
             acc += xj * xj;
             // the caller's x always holds P.*x of the newest iterate (iterative_lsmr.jl:195-196,
             // 256-257), so no launch is needed once the stopping rule fires
-            xout[j] = P ? xj * P[j] : xj;
+            xout[j] = P ? xj * Pj : xj;
         }
-        const double tj = P ? vj * P[j] : vj;        // iterative_lsmr.jl:31 ldiv!(tmp, P, a)
+        const double tj = P ? vj * Pj : vj;          // iterative_lsmr.jl:31 ldiv!(tmp, P, a)
         t[j] = tj;
         if (dg) {   // damped rows of the NEXT u (iterative_lsmr.jl:92): u~x <- d.*t - cu*u~x
-            double un = tj * dg[j] - cu * ux[j];
+            double un = tj * (pf ? e_dg : dg[j]) - cu * (pf ? e_ux : ux[j]);
             ux[j] = un;
             accx += un * un;
         }

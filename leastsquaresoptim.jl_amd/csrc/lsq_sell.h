@@ -97,25 +97,30 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
                                                           int nx, int nxpad, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sh[LSQ_BIG_NT / 64];
-    if (epi.done && *epi.done) return;   // launches queued behind a finished solve stop here
-    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
-    if constexpr (EpiHasPrepare<Epi>::value) epi.prepare();
     double *xl = smem;            // nxpad doubles
     double *yw = smem + nxpad;    // LSQ_SELL_ROWS_MAX doubles
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the gather vector is fetched FIRST, together with the `done` flag of a finished solve and the epilogue's scalars:
+    // one memory latency at the head of the kernel instead of three in a row
+    constexpr int XR = (LSQ_LDS_X_MAX + LSQ_BIG_NT - 1) / LSQ_BIG_NT;
+    double xr[XR];
+#pragma unroll
+    for (int q = 0; q < XR; ++q) xr[q] = x[min(tid + q * LSQ_BIG_NT, nx - 1)];
+    const int dflag = epi.done ? *epi.done : 0;
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
+    if constexpr (EpiHasPrepare<Epi>::value) epi.prepare();
+#pragma unroll
+    for (int q = 0; q < XR; ++q)
+        if (tid + q * LSQ_BIG_NT < nx) xl[tid + q * LSQ_BIG_NT] = xr[q];
+    if (dflag) return;   // launches queued behind a finished solve stop here
     constexpr int Q = LSQ_SELL_ROWS_MAX / LSQ_BIG_NT;
     double racc = 0.0;
-    bool staged = false;
     for (int w = blockIdx.x; w < S.nblocks; w += gridDim.x) {
         const int base = w * wrows, rows = min(wrows, m - base);
         double pre[Q];
         if constexpr (EpiHasPre<Epi>::value) {   // epilogue inputs of this window: in flight during the stream
 #pragma unroll
             for (int q = 0; q < Q; ++q) pre[q] = epi.pre(base + min(tid + q * LSQ_BIG_NT, rows - 1));
-        }
-        if (!staged) {
-            for (int i = tid; i < nx; i += LSQ_BIG_NT) xl[i] = x[i];
-            staged = true;
         }
         __syncthreads();   // x staged / the previous window's epilogue is done with yw
         const int s0 = S.wslice[w], s1 = S.wslice[w + 1];
@@ -151,24 +156,31 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, in
                                                           const double *__restrict__ y, double *__restrict__ part,
                                                           const int *done) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (done && *done) return;
     double *yl = smem;                          // LSQ_SELL_GROWS_MAX doubles
     double *ow = smem + LSQ_SELL_GROWS_MAX;     // LSQ_SELL_CCOLS_MAX doubles (+ the same again for SQ)
     double *ow2 = ow + LSQ_SELL_CCOLS_MAX;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int YR = LSQ_SELL_GROWS_MAX / LSQ_BIG_NT;
+    // window of y -> LDS, all loads of a thread issued before the first use
+    auto stage_y = [&](int b) {
+        const int gw = b / ncb, gbase = gw * grows, rows = min(grows, m - gbase);
+        double yr[YR];
+#pragma unroll
+        for (int j = 0; j < YR; ++j) yr[j] = y[gbase + min(tid + j * LSQ_BIG_NT, rows - 1)];
+#pragma unroll
+        for (int j = 0; j < YR; ++j)
+            if (tid + j * LSQ_BIG_NT < grows) yl[tid + j * LSQ_BIG_NT] = (tid + j * LSQ_BIG_NT < rows) ? yr[j] : 0.0;
+    };
+    // the first window is fetched together with the `done` flag of a finished solve (one latency, not two in a row)
+    const int dflag = done ? *done : 0;
+    if ((int)blockIdx.x < S.nblocks) stage_y(blockIdx.x);
+    if (dflag) return;
     for (int b = blockIdx.x; b < S.nblocks; b += gridDim.x) {
         const int gw = b / ncb, cb = b - gw * ncb;
-        const int gbase = gw * grows, rows = min(grows, m - gbase);
         const int cbase = cb * ccols, cols = min(ccols, n - cbase);
-        {   // window of y -> LDS, all loads of a thread issued before the first use
-            constexpr int YR = LSQ_SELL_GROWS_MAX / LSQ_BIG_NT;
-            double yr[YR];
-#pragma unroll
-            for (int j = 0; j < YR; ++j) yr[j] = y[gbase + min(tid + j * LSQ_BIG_NT, rows - 1)];
+        if (b != (int)blockIdx.x) {
             __syncthreads();   // the previous block's output pass is done with ow / yl
-#pragma unroll
-            for (int j = 0; j < YR; ++j)
-                if (tid + j * LSQ_BIG_NT < grows) yl[tid + j * LSQ_BIG_NT] = (tid + j * LSQ_BIG_NT < rows) ? yr[j] : 0.0;
+            stage_y(b);
         }
         __syncthreads();
         const int s0 = S.wslice[b], s1 = S.wslice[b + 1];

@@ -97,11 +97,15 @@ __device__ __forceinline__ void ordered_sum256x3(const double *pa, const int *na
     __shared__ double s_tot3[3];
     const int tid = threadIdx.x;
     if (tid < 256) {
+        // the counts and the first 256 entries of every array are fetched TOGETHER (the arrays hold at least 256 entries;
+        // entries past the count are dropped afterwards): one memory round trip instead of two on a latency-bound path.
+        // Same sums, bit for bit: 0.0 + pa[tid] == pa[tid] for the non-negative partials summed here.
+        const double a0 = pa ? pa[tid] : 0.0, b0 = pb ? pb[tid] : 0.0, c0 = pc ? pc[tid] : 0.0;
         const int ca = pa ? *na : 0, cb = pb ? *nb : 0, cc = pc ? *nc : 0;
-        double a = 0.0, b = 0.0, c = 0.0;
-        for (int i = tid; i < ca; i += 256) a += pa[i];
-        for (int i = tid; i < cb; i += 256) b += pb[i];
-        for (int i = tid; i < cc; i += 256) c += pc[i];
+        double a = tid < ca ? a0 : 0.0, b = tid < cb ? b0 : 0.0, c = tid < cc ? c0 : 0.0;
+        for (int i = tid + 256; i < ca; i += 256) a += pa[i];
+        for (int i = tid + 256; i < cb; i += 256) b += pb[i];
+        for (int i = tid + 256; i < cc; i += 256) c += pc[i];
         a = wave_sum(a);
         b = wave_sum(b);
         c = wave_sum(c);
@@ -752,10 +756,19 @@ __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ p
                                                      int ncolblocks) {
     __shared__ double sh[LSQ_NT / 64];
     __shared__ double grp[LSQ_CMB_GROUPS][LSQ_CMB_COLS + 1];
-    if (epi.done && *epi.done) return;
-    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     const int nwork = ncolblocks + epi.extra_blocks;
     const int cidx = threadIdx.x % LSQ_CMB_COLS, g = threadIdx.x / LSQ_CMB_COLS;
+    // latency-bound (10 MB over 313 workgroups): the `done` flag of a finished solve and the first eight window partials of
+    // this thread are fetched BEFORE the epilogue's prologue (which waits for the previous kernel's partial sums)
+    const int dflag = epi.done ? *epi.done : 0;
+    double t0[8];
+    const bool pre0 = (int)blockIdx.x < ncolblocks && (int)blockIdx.x * LSQ_CMB_COLS + cidx < n && g + 7 * LSQ_CMB_GROUPS < nwin;
+    if (pre0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t0[q] = part[(size_t)(g + q * LSQ_CMB_GROUPS) * n + blockIdx.x * LSQ_CMB_COLS + cidx];
+    }
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
+    if (dflag) return;   // launches queued behind a finished solve stop here
     double racc = 0.0;
     for (int b = blockIdx.x; b < nwork; b += gridDim.x) {
         if (b >= ncolblocks) {
@@ -766,6 +779,11 @@ __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ p
         double acc = 0.0;
         if (j < n) {
             int w = g;
+            if (pre0 && b == (int)blockIdx.x) {       // (same additions in the same order)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += t0[q];
+                w += 8 * LSQ_CMB_GROUPS;
+            }
             for (; w + 7 * LSQ_CMB_GROUPS < nwin; w += 8 * LSQ_CMB_GROUPS) {
                 double t[8];
 #pragma unroll

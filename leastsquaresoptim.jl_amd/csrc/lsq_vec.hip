@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <algorithm>
+
 #include "lsq_common.h"
 
 static thread_local char g_err[512] = "";
@@ -70,6 +72,7 @@ extern "C" int lsq_ctx_destroy(lsq_ctx *c) {
     hipFree(c->d_partials);
     hipFree(c->d_counters);
     hipHostFree((void *)c->h_mail);
+    for (hipEvent_t e : c->prof_pool) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return LSQ_OK;
@@ -81,6 +84,13 @@ extern "C" int lsq_prof_begin(lsq_ctx *c, int max_samples) {
         c->prof_ev[k].clear();
     }
     c->prof_max = max_samples;
+    // the events of the samples to come (bounded: a pool beyond a few thousand pairs is created on demand instead)
+    const size_t want = 2 * (size_t)std::min(max_samples, 4096);
+    while (c->prof_pool.size() < want) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        c->prof_pool.push_back(e);
+    }
     return LSQ_OK;
 }
 
