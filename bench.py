@@ -19,7 +19,8 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, the J*v pro
 (k_sell_rows<EpiU>): algorithmic bytes per launch (12*nnz + 4*(m+1) + 8*n + 16*m
 = 140.08 MB, plus 24*n for the fused damping rows) / average launch duration measured with HIP
 events on the library's stream inside the timed region.  `cpu_baseline` is the oracle (scalar C
-port, 1 thread) timed on this box's host on a bounded sample of the same workload.
+port, 1 thread) timed on this box's host on a bounded sample of the same workload, with an OpenMP
+all-cores variant of the same path beside it (`cpu_baseline.all_cores`).
 """
 import argparse
 import ctypes as C
@@ -331,10 +332,14 @@ def dry_run(a, rank, world, real_stdout):
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
+MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense fp64 matrix peak
+
+
 def dense_secondary(ctx, lsq):
     """BASELINE.json's secondary figures: time per ldiv! of the dense solvers at the C2 / C3 sizes,
-    measured after the timed region on fresh N(0,1)/sqrt(m) matrices, next to the host's LAPACK (numpy/scipy, all threads)
-    on the same operands.  Not part of `value`."""
+    measured after the timed region on fresh N(0,1)/sqrt(m) matrices, next to the host's LAPACK (numpy/scipy, all threads,
+    warmed, median of 3) on the same operands, with the useful flops of SURVEY 8d against the fp64 MFMA peak.  Not part of
+    `value`."""
     import numpy as np
     out = {}
     rng = np.random.default_rng(lsq.synthetic.BASE_SEED)
@@ -346,31 +351,54 @@ def dense_secondary(ctx, lsq):
         y = lsq.DeviceVector(ctx, m, yh)
         x = lsq.DeviceVector(ctx, n)
         sv = lsq.AllocatedSolver(J, solver, for_lm=for_lm)
+        dmp = lsq.DeviceVector(ctx, n, np.full(n, 0.1)) if for_lm else None
 
         def go():
             if for_lm:
-                sv.ldiv_(x, y, lsq.DeviceVector(ctx, n, np.full(n, 0.1)))
+                dmp.set(np.full(n, 0.1))
+                sv.ldiv_(x, y, dmp)
             else:
                 sv.ldiv_(x, y)
             ctx.sync()
         go()
+        go()
         times = []
-        for _ in range(5):          # median of 5: one stray host/runtime hiccup must not colour the figure
+        for _ in range(9):          # median of 9: one stray host/runtime hiccup must not colour the figure
             t0 = time.perf_counter()
             go()
             times.append((time.perf_counter() - t0) * 1e3)
         gpu_ms = sorted(times)[len(times) // 2]
-        t0 = time.perf_counter()
-        if for_lm:
-            ref = np.linalg.solve(A.T @ A + 0.1 * np.eye(n), A.T @ yh)
-        else:   # the reference's algorithm: dgeqp3 + Q'b + triangular solve (full rank here)
-            import scipy.linalg as sla
+
+        def host():
+            if for_lm:
+                return np.linalg.solve(A.T @ A + 0.1 * np.eye(n), A.T @ yh)
+            import scipy.linalg as sla   # the reference's algorithm: dgeqp3 + Q'b + triangular solve (full rank here)
             Q, R, piv = sla.qr(A, mode="economic", pivoting=True)
-            ref = np.empty(n)
-            ref[piv] = sla.solve_triangular(R, Q.T @ yh)
-        cpu_ms = (time.perf_counter() - t0) * 1e3
+            r = np.empty(n)
+            r[piv] = sla.solve_triangular(R, Q.T @ yh)
+            return r
+        reps = 3 if for_lm else 1      # (dgeqp3 at C3 takes seconds: one warm-up, one timed run)
+        ref = host()
+        ht = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ref = host()
+            ht.append((time.perf_counter() - t0) * 1e3)
+        cpu_ms = sorted(ht)[len(ht) // 2]
         err = float(np.linalg.norm(x.get() - ref) / np.linalg.norm(ref))
-        out[name] = {"ldiv_ms": gpu_ms, "host_lapack_ms": cpu_ms, "rel_err_vs_host_lapack": err}
+        if for_lm:    # J'J m n (n+1) + Cholesky n^3/3 + J'y 2mn + two triangular solves 2 n^2
+            flops, dom = m * n * (n + 1) + n ** 3 / 3 + 2 * m * n + 2 * n * n, "k_syrk_mfma (J'J), k_chol_panel_mfma"
+        else:         # Householder QR 2mn^2 - 2n^3/3 (+ Q'b riding along)
+            flops, dom = 2 * m * n * n - 2 * n ** 3 / 3 + 4 * m * n, "k_qr1_vtb / k_qr1_update (block reflector), k_cqr_pass (panel)"
+        tf = flops / (gpu_ms * 1e-3) / 1e12
+        info = sv.info()
+        out[name] = {"ldiv_ms": gpu_ms, "ldiv_ms_min": min(times), "host_lapack_ms": cpu_ms, "host_lapack_runs": reps,
+                     "rel_err_vs_host_lapack": err,
+                     "roofline": {"bound": "mfma", "useful_flops": flops, "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS, "dominant_kernels": dom,
+                                  "note": "whole ldiv! (factorisation + solve) over the useful flops of SURVEY 8d; per-kernel "
+                                          "split and MFMA counters: profiles/r02/dense_kernel_summary.md"},
+                     "path": {k: info.get(k) for k in ("qr_path", "qr_panel", "chol_path")}}
         J.free()
     # time per OUTER iteration of the dense tanh problems (f!, g! and the trust-region bookkeeping included)
     for name, m, n, opt, sol in (("c2_lm_cholesky_4096x512", 4096, 512, lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.CHOLESKY),
@@ -393,7 +421,10 @@ def dense_secondary(ctx, lsq):
 
 
 def cpu_baseline(a, pr, inputs):
-    """The oracle (scalar C port of the reference, 1 thread) on the SAME inputs, bounded sample."""
+    """The oracle (scalar C port of the reference, 1 thread -- the reference's sparse products and vector loops ARE serial,
+    SURVEY 8d) on the SAME inputs and schedule, bounded sample, one warm-up solve first.  Next to it, labelled, the
+    "generous CPU" figure BASELINE.md promises: the same algorithm restructured for all host cores with OpenMP
+    (oracle/lsq_oracle_omp.c: CSR mirror for J*v, both copies written by g!, parallel reductions)."""
     import numpy as np
     from oracle import oracle as O
     m, n = a.m, a.n
@@ -401,14 +432,19 @@ def cpu_baseline(a, pr, inputs):
     A = O.Mat(csc=(m, n, colptr, rowval, nzval))
     J = O.Mat(csc=(m, n, colptr, rowval, np.zeros_like(nzval)))
     f, g, ud, keep = O.tanh_model(A, pr.b)
+
+    def solves(total):
+        done = inner = 0
+        while done < total:  # same schedule as the GPU: solves of --iters-per-solve from x0 = 0
+            k = min(a.iters_per_solve, total - done)
+            ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=k, x_tol=0.0, f_tol=0.0,
+                            g_tol=0.0, trace=True, trace_x=False)
+            done += k
+            inner += int(ro.trace["inner"].sum()) // 2
+        return inner
+    solves(min(a.iters_per_solve, a.cpu_steps))          # warm-up (page faults, caches)
     t0 = time.perf_counter()
-    done = inner = 0
-    while done < a.cpu_steps:  # same schedule as the GPU: solves of --iters-per-solve from x0 = 0
-        k = min(a.iters_per_solve, a.cpu_steps - done)
-        ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=k, x_tol=0.0, f_tol=0.0,
-                        g_tol=0.0, trace=True, trace_x=False)
-        done += k
-        inner += int(ro.trace["inner"].sum()) // 2
+    inner = solves(a.cpu_steps)
     dt = time.perf_counter() - t0
     # CPU J*v bandwidth on the same matrix (algorithmic bytes, same formula)
     x = np.random.default_rng(0).standard_normal(n)
@@ -418,11 +454,31 @@ def cpu_baseline(a, pr, inputs):
         O.mul(A, x, 1.0, 1.0, np.zeros(m))
     t_mv = (time.perf_counter() - t1) / reps
     nnz = len(nzval)
-    return {"value": a.cpu_steps / dt, "unit": "LM outer iterations/s", "cores": 1, "kind": "port",
-            "sample": "%d LM outer iterations (%d LSMR inner; solves of %d iterations from x0=0) of the same C4 "
-                      "problem with oracle/lsq_oracle.c, 1 thread, %.1f s" % (a.cpu_steps, inner, a.iters_per_solve, dt),
-            "lsmr_inner_iterations_per_sec": inner / dt, "host_cores_available": os.cpu_count(),
-            "jv_GBps": (12 * nnz + 4 * (m + 1) + 8 * n + 16 * m) / t_mv / 1e9}
+    out = {"value": a.cpu_steps / dt, "unit": "LM outer iterations/s", "cores": 1, "kind": "port",
+           "sample": "%d LM outer iterations (%d LSMR inner; solves of %d iterations from x0=0) of the same C4 "
+                     "problem with oracle/lsq_oracle.c, 1 thread, after one warm-up solve, %.1f s"
+                     % (a.cpu_steps, inner, a.iters_per_solve, dt),
+           "lsmr_inner_iterations_per_sec": inner / dt, "host_cores_available": os.cpu_count(),
+           "jv_GBps": (12 * nnz + 4 * (m + 1) + 8 * n + 16 * m) / t_mv / 1e9}
+    try:   # the all-cores figure (a restructured, OpenMP-parallel port: labelled, not the reference's serial path)
+        b = np.ascontiguousarray(pr.b, dtype=np.float64)
+        k = a.iters_per_solve
+        O.lm_lsmr_omp(m, n, colptr, rowval, nzval, b, np.zeros(n), k)          # warm-up (also builds nothing persistent)
+        nsolve = max(1, min(24, a.cpu_steps // k))
+        t0 = time.perf_counter()
+        inner_o, thr = 0, 0
+        for _ in range(nsolve):
+            _x, _ssr, it_o, thr = O.lm_lsmr_omp(m, n, colptr, rowval, nzval, b, np.zeros(n), k)
+            inner_o += it_o
+        dto = time.perf_counter() - t0
+        out["all_cores"] = {"value": nsolve * k / dto, "unit": "LM outer iterations/s", "cores": int(thr), "kind": "port (OpenMP)",
+                            "sample": "%d LM outer iterations (%d LSMR inner) of the same C4 problem with "
+                                      "oracle/lsq_oracle_omp.c on %d threads, %.1f s (each solve includes its own CSR build)"
+                                      % (nsolve * k, inner_o, thr, dto),
+                            "lsmr_inner_iterations_per_sec": inner_o / dto}
+    except Exception as e:   # noqa: BLE001
+        out["all_cores"] = {"value": None, "sample": "failed: %r" % (e,)}
+    return out
 
 
 if __name__ == "__main__":

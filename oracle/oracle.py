@@ -313,3 +313,29 @@ def tanh_model(A, b):
     f = C.cast(L.orc_tanh_f, F_CB)
     g = C.cast(L.orc_tanh_g, G_CB)
     return f, g, C.cast(C.pointer(md), C.c_void_p), (md, t, b, A)
+
+
+_OMP = None
+
+
+def lm_lsmr_omp(m, n, colptr, rowval, nzval, b, x0, iterations, threads=0):
+    """The all-cores OpenMP variant of the LM+LSMR path on the sparse tanh model (oracle/lsq_oracle_omp.c): `iterations`
+    outer iterations with zero tolerances from x0.  Returns (x, ssr, inner iterations, threads used).  A measurement
+    baseline (bench.py), not a parity oracle: its reductions are OpenMP reductions."""
+    global _OMP
+    if _OMP is None:
+        path = os.path.join(_HERE, "liblsq_oracle_omp.so")
+        if not os.path.exists(path):
+            build()
+        _OMP = C.CDLL(path)
+        _OMP.orc_omp_lm_lsmr.argtypes = [C.c_int, C.c_int, c_ip, c_ip, c_dp, c_dp, c_dp, C.c_int, C.c_int,
+                                         C.POINTER(C.c_longlong), c_dp]
+    colptr = np.ascontiguousarray(colptr, dtype=np.int32)
+    rowval = np.ascontiguousarray(rowval, dtype=np.int32)
+    nzval, b = f64(nzval), f64(b)
+    x = f64(x0).copy()
+    inner, ssr = C.c_longlong(0), C.c_double(0)
+    _OMP.orc_omp_lm_lsmr(m, n, _ip(colptr), _ip(rowval), _dp(nzval), _dp(b), _dp(x), iterations, threads, C.byref(inner),
+                         C.byref(ssr))
+    used = _OMP.orc_omp_max_threads() if threads <= 0 else threads
+    return x, ssr.value, inner.value, used

@@ -427,3 +427,24 @@ def test_sum_modes_are_reorderings():
                 assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(a)))
     finally:
         O.set_sum_mode(0)
+
+
+def test_openmp_variant_agrees_with_the_oracle():
+    """oracle/lsq_oracle_omp.c (bench.py's all-cores CPU figure) is the same LM + LSMR algorithm with parallel loops:
+    same inner iteration counts, same ssr, iterates to round-off of the reordered reductions."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    m, n, pc = 6000, 60, 40
+    rowval = np.concatenate([np.sort(rng.choice(m, pc, replace=False)) for _ in range(n)]).astype(np.int32)
+    colptr = (np.arange(n + 1) * pc).astype(np.int32)
+    A = rng.standard_normal(n * pc) / np.sqrt(pc)
+    S = sp.csc_matrix((A, rowval, colptr), shape=(m, n))
+    b = S @ np.tanh(rng.uniform(-1, 1, n)) + 1e-3 * rng.standard_normal(m)
+    Am = O.Mat(csc=(m, n, colptr, rowval, A))
+    J = O.Mat(csc=(m, n, colptr, rowval, np.zeros_like(A)))
+    f, g, ud, keep = O.tanh_model(Am, b)
+    ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=8, x_tol=0, f_tol=0, g_tol=0, trace=True, trace_x=False)
+    x, ssr, inner, threads = O.lm_lsmr_omp(m, n, colptr, rowval, A, b, np.zeros(n), 8, threads=2)
+    assert inner == int(ro.trace["inner"].sum()) // 2 and threads == 2
+    assert ssr == pytest.approx(ro.ssr, rel=1e-10)
+    assert np.max(np.abs(x - ro.minimizer)) <= 1e-7
