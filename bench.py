@@ -463,19 +463,24 @@ def cpu_baseline(a, pr, inputs):
     try:   # the all-cores figure (a restructured, OpenMP-parallel port: labelled, not the reference's serial path)
         b = np.ascontiguousarray(pr.b, dtype=np.float64)
         k = a.iters_per_solve
-        O.lm_lsmr_omp(m, n, colptr, rowval, nzval, b, np.zeros(n), k)          # warm-up (also builds nothing persistent)
-        nsolve = max(1, min(24, a.cpu_steps // k))
-        t0 = time.perf_counter()
-        inner_o, thr = 0, 0
-        for _ in range(nsolve):
-            _x, _ssr, it_o, thr = O.lm_lsmr_omp(m, n, colptr, rowval, nzval, b, np.zeros(n), k)
-            inner_o += it_o
-        dto = time.perf_counter() - t0
-        out["all_cores"] = {"value": nsolve * k / dto, "unit": "LM outer iterations/s", "cores": int(thr), "kind": "port (OpenMP)",
-                            "sample": "%d LM outer iterations (%d LSMR inner) of the same C4 problem with "
-                                      "oracle/lsq_oracle_omp.c on %d threads, %.1f s (each solve includes its own CSR build)"
-                                      % (nsolve * k, inner_o, thr, dto),
-                            "lsmr_inner_iterations_per_sec": inner_o / dto}
+        best = None
+        ncpu = os.cpu_count() or 1
+        for thr in sorted({t for t in (16, 32, 64, ncpu // 2, ncpu) if 1 < t <= ncpu}):
+            op = O.OmpProblem(m, n, colptr, rowval, nzval, b, threads=thr)     # (layout build: not timed, as on the GPU)
+            try:
+                op.run(np.zeros(n), k)                                          # warm-up
+                nsolve = 3
+                t0 = time.perf_counter()
+                inner_o = sum(op.run(np.zeros(n), k)[2] for _ in range(nsolve))
+                dto = time.perf_counter() - t0
+            finally:
+                op.close()
+            rec = {"value": nsolve * k / dto, "cores": thr, "lsmr_inner_iterations_per_sec": inner_o / dto,
+                   "sample": "%d LM outer iterations (%d LSMR inner) of the same C4 problem with oracle/lsq_oracle_omp.c on %d "
+                             "threads (OMP_PROC_BIND=close, first-touch placement), %.1f s" % (nsolve * k, inner_o, thr, dto)}
+            if best is None or rec["value"] > best["value"]:
+                best = rec
+        out["all_cores"] = dict(best, unit="LM outer iterations/s", kind="port (OpenMP, best thread count of those tried)")
     except Exception as e:   # noqa: BLE001
         out["all_cores"] = {"value": None, "sample": "failed: %r" % (e,)}
     return out

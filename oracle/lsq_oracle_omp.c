@@ -194,39 +194,93 @@ static int lsmr_damped(omp_prob *p, const double *y, double *damp, double *x, do
     return iter;
 }
 
-/* `iterations` LM outer iterations with tolerances 0 (bench.py's schedule) from x (overwritten with the iterate).
- * Returns 0; *inner_total = LSMR iterations, *ssr_out = final sum of squares.  threads <= 0: all cores. */
-int orc_omp_lm_lsmr(int m, int n, const int *colptr, const int *rowval, const double *Aval, const double *b, double *x,
-                    int iterations, int threads, long long *inner_total, double *ssr_out) {
-    if (threads > 0) omp_set_num_threads(threads);
+/* ---- handle: CSR mirror and every work array built ONCE, pages first-touched by the threads that will stream them ---- */
+typedef struct {
     omp_prob p;
-    memset(&p, 0, sizeof(p));
-    p.m = m; p.n = n; p.nnz = colptr[n]; p.colptr = colptr; p.rowval = rowval; p.A = Aval; p.b = b;
-    const int nnz = p.nnz;
-    p.rowptr = calloc((size_t)m + 1, sizeof(int));
-    p.colidx = malloc((size_t)nnz * sizeof(int));
-    p.Acsr = malloc((size_t)nnz * sizeof(double));
-    p.Jcsc = malloc((size_t)nnz * sizeof(double));
-    p.Jcsr = malloc((size_t)nnz * sizeof(double));
-    p.s = malloc((size_t)n * sizeof(double));
-    for (int k = 0; k < nnz; ++k) p.rowptr[rowval[k] + 1]++;
-    for (int i = 0; i < m; ++i) p.rowptr[i + 1] += p.rowptr[i];
-    {
+    double *fcur, *ftrial, *u, *dx, *dtd, *ux, *v, *h, *hbar, *P, *tmp;
+    int threads;
+} omp_handle;
+
+static double *palloc(size_t n) {   /* parallel first touch with the static partition of the loops above */
+    double *a = malloc((n > 0 ? n : 1) * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) a[i] = 0.0;
+    return a;
+}
+
+void *orc_omp_create(int m, int n, const int *colptr, const int *rowval, const double *Aval, const double *b, int threads) {
+    if (threads > 0) omp_set_num_threads(threads);
+    omp_handle *H = calloc(1, sizeof(omp_handle));
+    omp_prob *p = &H->p;
+    H->threads = threads > 0 ? threads : omp_get_max_threads();
+    p->m = m; p->n = n; p->nnz = colptr[n]; p->b = b;
+    const int nnz = p->nnz;
+    /* private, first-touched copies of the CSC pattern / values too (columns are split statically over the threads) */
+    int *cp = malloc(((size_t)n + 1) * sizeof(int)), *rv = malloc((size_t)nnz * sizeof(int));
+    double *Ac = malloc((size_t)nnz * sizeof(double));
+    memcpy(cp, colptr, ((size_t)n + 1) * sizeof(int));
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < n; ++j)
+        for (int k = colptr[j]; k < colptr[j + 1]; ++k) { rv[k] = rowval[k]; Ac[k] = Aval[k]; }
+    p->colptr = cp; p->rowval = rv; p->A = Ac;
+    p->rowptr = calloc((size_t)m + 1, sizeof(int));
+    for (int k = 0; k < nnz; ++k) p->rowptr[rowval[k] + 1]++;
+    for (int i = 0; i < m; ++i) p->rowptr[i + 1] += p->rowptr[i];
+    int *ci = malloc((size_t)nnz * sizeof(int));
+    double *Ar = malloc((size_t)nnz * sizeof(double));
+    {   /* serial fill into scratch, then a parallel copy so that every row's entries live near the thread that owns the row */
         int *fill = malloc((size_t)m * sizeof(int));
-        memcpy(fill, p.rowptr, (size_t)m * sizeof(int));
+        memcpy(fill, p->rowptr, (size_t)m * sizeof(int));
+        int *ci0 = malloc((size_t)nnz * sizeof(int));
+        double *Ar0 = malloc((size_t)nnz * sizeof(double));
         for (int j = 0; j < n; ++j)
             for (int k = colptr[j]; k < colptr[j + 1]; ++k) {
                 const int q = fill[rowval[k]]++;
-                p.colidx[q] = j;
-                p.Acsr[q] = Aval[k];
+                ci0[q] = j;
+                Ar0[q] = Aval[k];
             }
-        free(fill);
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < m; ++i)
+            for (int k = p->rowptr[i]; k < p->rowptr[i + 1]; ++k) { ci[k] = ci0[k]; Ar[k] = Ar0[k]; }
+        free(fill); free(ci0); free(Ar0);
     }
-    double *fcur = malloc((size_t)m * sizeof(double)), *ftrial = malloc((size_t)m * sizeof(double));
-    double *u = malloc((size_t)m * sizeof(double));
-    double *dx = calloc(n, sizeof(double)), *dtd = calloc(n, sizeof(double)), *ux = calloc(n, sizeof(double));
-    double *v = calloc(n, sizeof(double)), *h = calloc(n, sizeof(double)), *hbar = calloc(n, sizeof(double));
-    double *P = calloc(n, sizeof(double)), *tmp = calloc(n, sizeof(double));
+    p->colidx = ci; p->Acsr = Ar;
+    p->Jcsc = malloc((size_t)nnz * sizeof(double));
+    p->Jcsr = malloc((size_t)nnz * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < n; ++j)
+        for (int k = cp[j]; k < cp[j + 1]; ++k) p->Jcsc[k] = 0.0;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; ++i)
+        for (int k = p->rowptr[i]; k < p->rowptr[i + 1]; ++k) p->Jcsr[k] = 0.0;
+    p->s = palloc(n);
+    H->fcur = palloc(m); H->ftrial = palloc(m); H->u = palloc(m);
+    H->dx = palloc(n); H->dtd = palloc(n); H->ux = palloc(n); H->v = palloc(n); H->h = palloc(n); H->hbar = palloc(n);
+    H->P = palloc(n); H->tmp = palloc(n);
+    return H;
+}
+
+void orc_omp_destroy(void *hh) {
+    omp_handle *H = hh;
+    if (!H) return;
+    omp_prob *p = &H->p;
+    free((void *)p->colptr); free((void *)p->rowval); free((void *)p->A);
+    free(p->rowptr); free(p->colidx); free(p->Acsr); free(p->Jcsc); free(p->Jcsr); free(p->s);
+    free(H->fcur); free(H->ftrial); free(H->u); free(H->dx); free(H->dtd); free(H->ux); free(H->v); free(H->h); free(H->hbar);
+    free(H->P); free(H->tmp);
+    free(H);
+}
+
+/* `iterations` LM outer iterations with tolerances 0 (bench.py's schedule) from x (overwritten with the iterate).
+ * Returns 0; *inner_total = LSMR iterations, *ssr_out = final sum of squares. */
+int orc_omp_run(void *hh, double *x, int iterations, long long *inner_total, double *ssr_out) {
+    omp_handle *H = hh;
+    omp_prob p = H->p;
+    const int m = p.m, n = p.n;
+    const int *colptr = p.colptr;
+    omp_set_num_threads(H->threads);
+    double *fcur = H->fcur, *ftrial = H->ftrial, *u = H->u, *dx = H->dx, *dtd = H->dtd, *ux = H->ux, *v = H->v, *h = H->h,
+           *hbar = H->hbar, *P = H->P, *tmp = H->tmp;
     double delta = 10.0, decrease_factor = 2.0, maxabs_gr = 0.0;
     model_f(&p, x, fcur);
     double ssr = psumsq(fcur, m);
@@ -267,7 +321,7 @@ int orc_omp_lm_lsmr(int m, int n, const int *colptr, const int *rowval, const do
         const double pr = fabs(ssr - pred);
         const double rho = pr > 0 ? (ssr - trial_ssr) / pr : 0.0;
         if (rho > 1e-3) {
-            memcpy(fcur, ftrial, (size_t)m * sizeof(double));
+            double *t = fcur; fcur = ftrial; ftrial = t;
             ssr = trial_ssr;
             const double q = 1.0 - (2.0 * rho - 1.0) * (2.0 * rho - 1.0) * (2.0 * rho - 1.0);
             const double dn = delta / (1.0 / 3.0 > q ? 1.0 / 3.0 : q);
@@ -282,11 +336,10 @@ int orc_omp_lm_lsmr(int m, int n, const int *colptr, const int *rowval, const do
             decrease_factor *= 2.0;
         }
     }
+    H->fcur = fcur; H->ftrial = ftrial;
     if (inner_total) *inner_total = inner;
     if (ssr_out) *ssr_out = ssr;
     (void)maxabs_gr;
-    free(p.rowptr); free(p.colidx); free(p.Acsr); free(p.Jcsc); free(p.Jcsr); free(p.s);
-    free(fcur); free(ftrial); free(u); free(dx); free(dtd); free(ux); free(v); free(h); free(hbar); free(P); free(tmp);
     return 0;
 }
 int orc_omp_max_threads(void) { return omp_get_max_threads(); }

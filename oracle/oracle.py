@@ -318,24 +318,53 @@ def tanh_model(A, b):
 _OMP = None
 
 
-def lm_lsmr_omp(m, n, colptr, rowval, nzval, b, x0, iterations, threads=0):
-    """The all-cores OpenMP variant of the LM+LSMR path on the sparse tanh model (oracle/lsq_oracle_omp.c): `iterations`
-    outer iterations with zero tolerances from x0.  Returns (x, ssr, inner iterations, threads used).  A measurement
-    baseline (bench.py), not a parity oracle: its reductions are OpenMP reductions."""
+def _omp():
     global _OMP
     if _OMP is None:
+        # (thread placement must be decided before the OpenMP runtime starts)
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
         path = os.path.join(_HERE, "liblsq_oracle_omp.so")
         if not os.path.exists(path):
             build()
         _OMP = C.CDLL(path)
-        _OMP.orc_omp_lm_lsmr.argtypes = [C.c_int, C.c_int, c_ip, c_ip, c_dp, c_dp, c_dp, C.c_int, C.c_int,
-                                         C.POINTER(C.c_longlong), c_dp]
-    colptr = np.ascontiguousarray(colptr, dtype=np.int32)
-    rowval = np.ascontiguousarray(rowval, dtype=np.int32)
-    nzval, b = f64(nzval), f64(b)
-    x = f64(x0).copy()
-    inner, ssr = C.c_longlong(0), C.c_double(0)
-    _OMP.orc_omp_lm_lsmr(m, n, _ip(colptr), _ip(rowval), _dp(nzval), _dp(b), _dp(x), iterations, threads, C.byref(inner),
-                         C.byref(ssr))
-    used = _OMP.orc_omp_max_threads() if threads <= 0 else threads
-    return x, ssr.value, inner.value, used
+        _OMP.orc_omp_create.restype = C.c_void_p
+        _OMP.orc_omp_create.argtypes = [C.c_int, C.c_int, c_ip, c_ip, c_dp, c_dp, C.c_int]
+        _OMP.orc_omp_run.argtypes = [C.c_void_p, c_dp, C.c_int, C.POINTER(C.c_longlong), c_dp]
+        _OMP.orc_omp_destroy.argtypes = [C.c_void_p]
+    return _OMP
+
+
+class OmpProblem:
+    """The all-cores OpenMP variant of the LM+LSMR path on the sparse tanh model (oracle/lsq_oracle_omp.c): CSR mirror and
+    work arrays built once (first-touched in parallel), then `run(x0, iterations)` = that many outer iterations with zero
+    tolerances.  A measurement baseline (bench.py), not a parity oracle: its reductions are OpenMP reductions."""
+
+    def __init__(self, m, n, colptr, rowval, nzval, b, threads=0):
+        L = _omp()
+        self._keep = (np.ascontiguousarray(colptr, dtype=np.int32), np.ascontiguousarray(rowval, dtype=np.int32),
+                      f64(nzval), f64(b))
+        self.n = n
+        self.threads = threads if threads > 0 else L.orc_omp_max_threads()
+        self.h = L.orc_omp_create(m, n, _ip(self._keep[0]), _ip(self._keep[1]), _dp(self._keep[2]), _dp(self._keep[3]), threads)
+
+    def run(self, x0, iterations):
+        x = f64(x0).copy()
+        inner, ssr = C.c_longlong(0), C.c_double(0)
+        _omp().orc_omp_run(self.h, _dp(x), iterations, C.byref(inner), C.byref(ssr))
+        return x, ssr.value, inner.value
+
+    def close(self):
+        if self.h:
+            _omp().orc_omp_destroy(self.h)
+            self.h = None
+
+
+def lm_lsmr_omp(m, n, colptr, rowval, nzval, b, x0, iterations, threads=0):
+    """One-shot form: returns (x, ssr, inner iterations, threads used)."""
+    pr = OmpProblem(m, n, colptr, rowval, nzval, b, threads)
+    try:
+        x, ssr, inner = pr.run(x0, iterations)
+        return x, ssr, inner, pr.threads
+    finally:
+        pr.close()
