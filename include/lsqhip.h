@@ -53,6 +53,10 @@ int lsq_free(lsq_ctx *ctx, void *d_ptr);
 int lsq_h2d(lsq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int lsq_d2h(lsq_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int lsq_d2d(lsq_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* page-locked host memory: what a host-side g! should write the Jacobian values into, so that the upload after every
+ * g!(J, x) (levenberg_marquardt.jl:77-81: 80 MB at C4) runs at the PCIe rate, asynchronously (lsq_mat_set_values_async) */
+int lsq_host_alloc(lsq_ctx *ctx, size_t bytes, void **h_out);
+int lsq_host_free(lsq_ctx *ctx, void *h_ptr);
 
 /* ---- Jacobian handles ---- */
 /* Dense m x n, column-major, device-owned (the `J::Matrix` of types.jl:36). */
@@ -65,6 +69,13 @@ int lsq_mat_size(const lsq_mat *J, int *m, int *n, long long *nnz);
 /* Upload values after a host-side g!(J, x): dense m*n column-major, or nzval in CSC order. */
 int lsq_mat_set_values(lsq_mat *J, const double *h_values);
 int lsq_mat_get_values(const lsq_mat *J, double *h_values);
+/* The same upload without blocking the host: the copy is queued on the context's copy stream (the compute stream keeps
+ * running whatever was queued before) and every later use of J on the compute stream waits for it on the DEVICE.
+ * h_values must be page-locked (lsq_host_alloc) and must not be written again before lsq_mat_upload_wait(J) returns
+ * (or the next call that reads results back has returned).  Pageable memory is accepted and falls back to the
+ * synchronous path. */
+int lsq_mat_set_values_async(lsq_mat *J, const double *h_pinned_values);
+int lsq_mat_upload_wait(lsq_mat *J);
 /* Device pointer to the values a device-side g! writes (dense buffer / CSC nzval) ... */
 double *lsq_mat_values(lsq_mat *J);
 /* ... after which the CSR mirror must be refreshed (no-op for dense). */
@@ -101,6 +112,8 @@ int lsq_copy(lsq_ctx *ctx, int n, const double *d_x, double *d_y);              
 int lsq_fill(lsq_ctx *ctx, int n, double a, double *d_x);                          /* fill!   */
 int lsq_sumsq(lsq_ctx *ctx, int n, const double *d_x, double *h_out);              /* sum(abs2, x) */
 int lsq_sum(lsq_ctx *ctx, int n, const double *d_x, double *h_out);                /* sum(x)  */
+int lsq_dot(lsq_ctx *ctx, int n, const double *d_x, const double *d_y, double *h_out);   /* dot(x, y) */
+int lsq_emul(lsq_ctx *ctx, int n, const double *d_x, const double *d_y, double *d_out);  /* map!(*, out, x, y): iterative_lsmr.jl:121 */
 int lsq_nrm2(lsq_ctx *ctx, int n, const double *d_x, double *h_out);               /* norm(x) */
 int lsq_wdot(lsq_ctx *ctx, int n, const double *d_x, const double *d_y, const double *d_w,
              double *h_out);                                                       /* utils.jl:165-175 */

@@ -4,7 +4,7 @@ from . import _lib
 from ._lib import (ArgumentError, DimensionMismatch, HipError, IsFiniteException, LsqError,
                    PeerAborted, PosDefException, RankDeficientException, build, declared_symbols, lib)
 from .api import (axpy_, box_clip_, clamp_, copyto_, ediv_, fill_, first_nonfinite, rmul_, vsum,
-                  AllocatedSolver, Cholesky, Context, DeviceMatrix, DeviceOperator, DeviceVector, Dogleg, LSMR,
+                  AllocatedSolver, Cholesky, Context, PinnedBuffer, DeviceMatrix, DeviceOperator, DeviceVector, Dogleg, LSMR,
                   LeastSquaresProblem, LeastSquaresProblemAllocated, LeastSquaresResult, LevenbergMarquardt, OptimizationState, QR,
                   colsumabs2_, rowsumabs2_, converged, default_context, default_optimizer, default_solver,
                   maxabs, maxabs_projected_gradient, mul_, norm, optimize, optimize_, set_exact, sumsq, wdot,

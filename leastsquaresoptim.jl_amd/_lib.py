@@ -96,6 +96,12 @@ def lib():
         "lsq_mat_size": (i, [vp, c_ip, c_ip, C.POINTER(C.c_longlong)]),
         "lsq_mat_set_values": (i, [vp, c_dp]),
         "lsq_mat_get_values": (i, [vp, c_dp]),
+        "lsq_mat_set_values_async": (i, [vp, c_dp]),
+        "lsq_mat_upload_wait": (i, [vp]),
+        "lsq_host_alloc": (i, [vp, sz, pvp]),
+        "lsq_host_free": (i, [vp, vp]),
+        "lsq_dot": (i, [vp, i, vp, vp, c_dp]),
+        "lsq_emul": (i, [vp, i, vp, vp, vp]),
         "lsq_mat_values": (vp, [vp]),
         "lsq_mat_refresh": (i, [vp]),
         "lsq_mul": (i, [vp, i, d, vp, d, vp]),

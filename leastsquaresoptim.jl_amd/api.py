@@ -191,6 +191,31 @@ def _ptr(v):
     return None if v is None else v.ptr
 
 
+class PinnedBuffer:
+    """Page-locked host memory (lsq_host_alloc) as a float64 numpy array: what a host-side g! should write the Jacobian
+    values into, so that the upload after every g!(J, x) runs asynchronously at the PCIe rate
+    (DeviceMatrix.set_values_async).  `array` is only valid until free()."""
+
+    def __init__(self, ctx, n):
+        self.ctx, self.n = ctx, int(n)
+        p = C.c_void_p()
+        check(lib().lsq_host_alloc(ctx.h, max(self.n, 1) * 8, C.byref(p)))
+        self.ptr = p
+        self.array = np.ctypeslib.as_array(C.cast(p, _lib.c_dp), shape=(max(self.n, 1),))[:self.n]
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().lsq_host_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceMatrix:
     """Jacobian handle: dense column-major or CSC (+ CSR mirror) -- `HipDense` / `HipCSC`."""
 
@@ -226,6 +251,16 @@ class DeviceMatrix:
         if v.size != self.nnz:
             raise DimensionMismatch(_lib.EDIM, "expected %d values, got %d" % (self.nnz, v.size))
         check(lib().lsq_mat_set_values(self.h, v.ctypes.data_as(_lib.c_dp)))
+
+    def set_values_async(self, pinned):
+        """Upload from a PinnedBuffer without blocking the host (lsq_mat_set_values_async): later uses of J wait for the
+        copy on the device; the buffer must not be rewritten before upload_wait() (or a call that reads results back)."""
+        if pinned.n != self.nnz:
+            raise DimensionMismatch(_lib.EDIM, "expected %d values, got %d" % (self.nnz, pinned.n))
+        check(lib().lsq_mat_set_values_async(self.h, C.cast(pinned.ptr, _lib.c_dp)))
+
+    def upload_wait(self):
+        check(lib().lsq_mat_upload_wait(self.h))
 
     def values(self):
         out = np.empty(self.nnz)
@@ -631,6 +666,22 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
     L = lib()
     xh, yh = np.zeros(n), np.zeros(m)
     err = []
+    # Host-side g!: the Jacobian values live in PAGE-LOCKED memory for the duration of the solve -- g! writes them there
+    # directly (a sparse J gets its .data rebound to the pinned array, a dense J is handed over as a pinned column-major
+    # view) and the upload after every g!(J, x) is asynchronous (lsq_mat_set_values_async): no staging copy, no blocked
+    # host, PCIe rate instead of the pageable-copy rate.  SURVEY 8f-1; levenberg_marquardt.jl:77-81 is where the upload sits.
+    stage = None
+    J_user = nls.J
+    if not is_op:
+        stage = allocated._stage if allocated is not None and allocated._stage is not None else PinnedBuffer(ctx, Jd.nnz)
+        if Jd.sparse:
+            np.copyto(stage.array, nls.J.data)
+            data_user = nls.J.data
+            nls.J.data = stage.array
+            J_for_g = nls.J
+        else:
+            J_for_g = stage.array.reshape((m, n), order="F")
+            np.copyto(J_for_g, nls.J)
 
     def fcb(d_out, d_x, _):
         try:
@@ -645,12 +696,15 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
     def gcb(Jh, d_x, _):
         try:
             check(L.lsq_d2h(ctx.h, xh.ctypes.data_as(C.c_void_p), d_x, n * 8))
-            nls.g_(nls.J, xh)
-            if is_op:   # g! updated the operator's own state; nothing to upload
+            if is_op:   # g! updates the operator's own state; nothing to upload
+                nls.g_(nls.J, xh)
                 return 0
-            vals = nls.J.data if Jd.sparse else nls.J.reshape(-1, order="F")
-            vals = np.ascontiguousarray(vals, dtype=np.float64)
-            check(L.lsq_h2d(ctx.h, L.lsq_mat_values(Jh), vals.ctypes.data_as(C.c_void_p), vals.size * 8))
+            Jd.upload_wait()            # (the previous upload has long finished; g! is about to overwrite its source)
+            nls.g_(J_for_g, xh)
+            if Jd.sparse and nls.J.data is not stage.array:     # g! replaced J.data instead of writing into it
+                np.copyto(stage.array, nls.J.data)
+                nls.J.data = stage.array
+            Jd.set_values_async(stage)
             return 0
         except Exception as e:
             err.append(e)
@@ -661,8 +715,19 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
     pc = None
     if getattr(solver, "preconditioner", None) is not None:
         pc = _precond_trampoline(solver.preconditioner, ctx, Jd)
-    st, res, tr = _run_native(ctx, optimizer.kind, solver.kind, Jd, dx, dy, F, G, None, x_tol, f_tol,
-                              g_tol, iterations, delta, lower, upper, tracing, n, preconditioner=pc)
+    try:
+        st, res, tr = _run_native(ctx, optimizer.kind, solver.kind, Jd, dx, dy, F, G, None, x_tol, f_tol,
+                                  g_tol, iterations, delta, lower, upper, tracing, n, preconditioner=pc)
+    finally:
+        if stage is not None:       # hand the values back in ordinary memory before the pinned buffer can go away
+            Jd.upload_wait()
+            if Jd.sparse:
+                data_user[:] = stage.array
+                nls.J.data = data_user
+            else:
+                np.copyto(J_user, J_for_g)
+            if allocated is None or allocated._stage is None:
+                stage.free()
     if err:
         raise err[0]
     if st == _lib.ENONFINITE:
@@ -718,11 +783,16 @@ class LeastSquaresProblemAllocated:
         self._Jd = nls.J if isinstance(nls.J, DeviceOperator) else DeviceMatrix(self.ctx, nls.J)
         self._dx = DeviceVector(self.ctx, len(nls.x), nls.x)
         self._dy = DeviceVector(self.ctx, len(nls.y), nls.y)
+        # the page-locked staging buffer of the Jacobian uploads is part of the allocated problem too
+        self._stage = None if isinstance(self._Jd, DeviceOperator) else PinnedBuffer(self.ctx, self._Jd.nnz)
 
     def free(self):
         if self._Jd is not None and not isinstance(self._Jd, DeviceOperator):
             self._Jd.free()
         self._Jd = None
+        if getattr(self, "_stage", None) is not None:
+            self._stage.free()
+            self._stage = None
 
 
 def optimize(f, x, optimizer, autodiff="central", **kwargs):

@@ -70,6 +70,9 @@ struct lsq_ctx {
     std::vector<hipEvent_t> prof_pool;   // events created by lsq_prof_begin, so that a timed launch creates nothing
     // kernels whose dynamic-LDS limit has been raised on THIS context's device (function attributes may be per device)
     std::unordered_map<const void *, size_t> lds_cfg;
+    // uploads that overlap compute (lsq_mat_set_values_async): created on first use
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;
 };
 
 // raise a kernel's dynamic-LDS limit once per context (= per device)
@@ -178,6 +181,7 @@ struct lsq_mat {
     int *d_map = nullptr;  // csr position -> csc position
     bool csr_fresh = false;
     bool csc_fresh = true;  // false: a device g! wrote the mirrors only (see lsq_ensure_csc)
+    bool upload_pending = false;   // lsq_mat_set_values_async: the host buffer is still being read
     // Row-window-blocked CSC for J'*y when the gathered m-vector outgrows an XCD's L2 (4 MiB):
     // rows are cut into `nwin` windows; segment (w, j) holds column j's entries with rows in
     // window w, so all gathers of a window hit a <= 1 MiB slice of y that stays L2-resident on

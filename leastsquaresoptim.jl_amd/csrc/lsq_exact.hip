@@ -177,7 +177,7 @@ __global__ void k_seq_reduce(int mode, int n, const double *x, const double *y, 
     for (int i = 0; i < n; ++i) {
         if (mode == 0) acc += x[i];
         else if (mode == 1) acc += x[i] * x[i];
-        else if (mode == 2) acc += w[i] * x[i] * y[i];
+        else if (mode == 2) acc += w ? w[i] * x[i] * y[i] : x[i] * y[i];   // wdot (utils.jl:165-172) / dot
         else { double r = x[i] + -1.0 * y[i]; acc += r * r; }   // axpy!(-1, fcur, fpredict) then abs2
     }
     *out = acc;

@@ -619,6 +619,39 @@ extern "C" int lsq_mat_set_values(lsq_mat *J, const double *h) {
     return lsq_mat_refresh(J);
 }
 
+extern "C" int lsq_mat_set_values_async(lsq_mat *J, const double *h) {
+    if (J->kind == LSQ_MAT_OP) {
+        lsq_set_error("a matrix-free operator has no stored values");
+        return LSQ_EARG;
+    }
+    lsq_ctx *c = J->ctx;
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, h) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (!pinned) return lsq_mat_set_values(J, h);     // pageable memory cannot be copied asynchronously
+    if (!c->copy_stream) {
+        LSQ_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        LSQ_HIP(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
+    }
+    double *dst = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
+    // the copy may overwrite the staging copy only after the compute stream is done reading it (a mirror refresh of the
+    // previous upload), and the compute stream may touch J again only after the copy: two device-side waits, no host wait
+    LSQ_HIP(hipEventRecord(c->copy_done, c->stream));
+    LSQ_HIP(hipStreamWaitEvent(c->copy_stream, c->copy_done, 0));
+    if (J->nnz) LSQ_HIP(hipMemcpyAsync(dst, h, J->nnz * sizeof(double), hipMemcpyHostToDevice, c->copy_stream));
+    LSQ_HIP(hipEventRecord(c->copy_done, c->copy_stream));
+    LSQ_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    J->upload_pending = true;
+    return lsq_mat_refresh(J);     // (device work only: the mirrors are rebuilt behind the copy)
+}
+
+extern "C" int lsq_mat_upload_wait(lsq_mat *J) {
+    if (!J->upload_pending) return LSQ_OK;
+    LSQ_HIP(hipEventSynchronize(J->ctx->copy_done));
+    J->upload_pending = false;
+    return LSQ_OK;
+}
+
 extern "C" int lsq_mat_get_values(const lsq_mat *J, double *h) {
     if (J->kind == LSQ_MAT_OP) {
         lsq_set_error("a matrix-free operator has no stored values");

@@ -73,6 +73,8 @@ extern "C" int lsq_ctx_destroy(lsq_ctx *c) {
     hipFree(c->d_counters);
     hipHostFree((void *)c->h_mail);
     for (hipEvent_t e : c->prof_pool) hipEventDestroy(e);
+    if (c->copy_done) hipEventDestroy(c->copy_done);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return LSQ_OK;
@@ -162,6 +164,18 @@ extern "C" int lsq_free(lsq_ctx *c, void *p) {
     if (!p) return LSQ_OK;
     LSQ_HIP(hipStreamSynchronize(c->stream));
     LSQ_HIP(hipFree(p));
+    return LSQ_OK;
+}
+extern "C" int lsq_host_alloc(lsq_ctx *c, size_t bytes, void **out) {
+    LSQ_HIP(hipSetDevice(c->device));
+    LSQ_HIP(hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));
+    return LSQ_OK;
+}
+extern "C" int lsq_host_free(lsq_ctx *c, void *p) {
+    if (!p) return LSQ_OK;
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) LSQ_HIP(hipStreamSynchronize(c->copy_stream));
+    LSQ_HIP(hipHostFree(p));
     return LSQ_OK;
 }
 extern "C" int lsq_h2d(lsq_ctx *c, void *dst, const void *src, size_t bytes) {
@@ -325,7 +339,7 @@ k_reduce(int n, const double *__restrict__ x, const double *__restrict__ y,
         double v = x[i];
         if (MODE == 0) acc += v;
         if (MODE == 1) acc += v * v;
-        if (MODE == 2) acc += w[i] * v * y[i];
+        if (MODE == 2) acc += w ? w[i] * v * y[i] : v * y[i];   // wdot / dot
         if (MODE == 3) {  // maximum(abs, x); a NaN is reported as +inf (both fail every "<= tol")
             double a = fabs(v);
             if (isnan(a)) a = INFINITY;
@@ -387,6 +401,13 @@ extern "C" int lsq_clamp(lsq_ctx *c, int n, double lo, double hi, double *x) {
     LSQ_LAUNCH_EW(k_clamp, n, n, lo, hi, x);
     return LSQ_OK;
 }
+__global__ void __launch_bounds__(LSQ_NT) k_emul(int n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ o) {
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < n; i += (long long)gridDim.x * LSQ_NT) o[i] = x[i] * y[i];
+}
+extern "C" int lsq_emul(lsq_ctx *c, int n, const double *x, const double *y, double *o) {
+    LSQ_LAUNCH_EW(k_emul, n, n, x, y, o);
+    return LSQ_OK;
+}
 extern "C" int lsq_ediv(lsq_ctx *c, int n, const double *x, const double *y, double *o) {
     LSQ_LAUNCH_EW(k_ediv, n, n, x, y, o);
     return LSQ_OK;
@@ -427,6 +448,9 @@ extern "C" int lsq_nrm2(lsq_ctx *c, int n, const double *x, double *h) {
     LSQ_TRY(reduce_to_host<1>(c, n, x, nullptr, nullptr, nullptr, nullptr, h));
     *h = sqrt(*h);
     return LSQ_OK;
+}
+extern "C" int lsq_dot(lsq_ctx *c, int n, const double *x, const double *y, double *h) {
+    return reduce_to_host<2>(c, n, x, y, nullptr, nullptr, nullptr, h);
 }
 extern "C" int lsq_wdot(lsq_ctx *c, int n, const double *x, const double *y, const double *w, double *h) {
     return reduce_to_host<2>(c, n, x, y, w, nullptr, nullptr, h);

@@ -1164,6 +1164,48 @@ def test_nan_in_jacobian_at_a_later_iteration_raises(opt, sol, bounded):
     assert e.value.indices == [ro.bad_index]
 
 
+def test_host_side_g_with_pinned_async_upload(ctx):
+    """a HOST-side g! (numpy writes nonzeros(J), as the reference's sparse g! does,
+    test/nonlinearleastsquares.jl:47-86) -- the values go up through page-locked memory with lsq_mat_set_values_async
+    after every accepted step.  Same problem as the device-side model: same iteration / call counts, same iterates."""
+    m, n, pc = 300000, 2000, 600
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=7, ctx=ctx)
+    pr.reset()
+    rd = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, iterations=12)
+    A, colptr, rowval, b = pr.A, pr.colptr, pr.rowval, pr.b
+    pr.close()
+    S = sp.csc_matrix((A, rowval, colptr), shape=(m, n))
+    cols = np.repeat(np.arange(n), np.diff(colptr))
+
+    def f_(out, x):
+        out[:] = S @ np.tanh(x) - b
+
+    def g_(J, x):
+        np.multiply(A, (1.0 - np.tanh(x) ** 2)[cols], out=J.data)
+
+    J = sp.csc_matrix((np.zeros_like(A), rowval, colptr), shape=(m, n))
+    data_before = J.data
+    nls = lsq.LeastSquaresProblem(x=np.zeros(n), y=np.zeros(m), f_=f_, g_=g_, J=J)
+    rh = lsq.optimize_(nls, lsq.LevenbergMarquardt(lsq.LSMR()), iterations=12, ctx=ctx)
+    assert (rh.iterations, rh.f_calls, rh.g_calls, rh.mul_calls) == (rd.iterations, rd.f_calls, rd.g_calls, rd.mul_calls)
+    assert rh.converged == rd.converged and rh.ssr == pytest.approx(rd.ssr, rel=1e-9)
+    assert np.max(np.abs(rh.minimizer - rd.minimizer)) <= 1e-8
+    # the Jacobian handed back lives in ordinary memory again and holds g!(x_last accepted)
+    assert nls.J.data is data_before and np.all(np.isfinite(nls.J.data)) and np.any(nls.J.data != 0.0)
+    # the pieces on their own: pinned upload == blocking upload
+    Jd = lsq.DeviceMatrix(ctx, S)
+    pin = lsq.PinnedBuffer(ctx, len(A))
+    pin.array[:] = 2.0 * A
+    Jd.set_values_async(pin)
+    Jd.upload_wait()
+    assert np.array_equal(Jd.values(), 2.0 * A)
+    xv = lsq.DeviceVector(ctx, n, np.ones(n))
+    out = lsq.mul_(lsq.DeviceVector(ctx, m), Jd, xv, 1.0, 0.0).get()
+    assert np.max(np.abs(out - 2.0 * (S @ np.ones(n)))) <= 1e-10
+    pin.free()
+    Jd.free()
+
+
 # --------------------------------------------------------------- reference-held vectors: NIST StRD
 NIST_KNOWN_MISSES = {("MGH09", "dogleg", 0), ("BoxBOD", "lm", 0), ("MGH10", "dogleg", 0), ("MGH10", "lm", 0)}
 
