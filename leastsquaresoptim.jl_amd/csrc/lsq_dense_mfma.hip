@@ -1,6 +1,6 @@
 // Dense normal-equation path (dense_cholesky.jl:29-59): fp64-MFMA SYRK for J'J (k_syrk_mfma; the pair kernel
 // k_syrk_small when there are few columns and many rows), blocked right-looking Cholesky (64-wide panels, diagonal
-// block and row panel in one launch: k_chol_panel16; trailing update on the MFMA kernel again) and the two
+// block and row panel in one launch: k_chol_panel_mfma; trailing update on the MFMA kernel again) and the two
 // triangular solves pipelined over the 64-blocks (lsq_tri_chol_solve in lsq_dense.hip; k_chol_trsv as fallback).
 //
 // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16), one f64 of A and of B per lane
@@ -141,341 +141,14 @@ k_syrk_reduce(const double *__restrict__ W, int n, int kslices, const double *__
 }
 
 // ---------------------------------------------------------------------------------------------
-// blocked Cholesky, step j0: every workgroup factors the NB x NB diagonal block in LDS (cheap and
-// saves a launch); workgroup 0 writes it back; each workgroup then turns 256 columns of the row
-// panel A(j0:j0+NB, j0+NB:n) into U12 = U11^{-T} A12 by forward substitution (one column per
-// thread, the 64 unknowns in registers, U11 broadcast from LDS).
+// blocked Cholesky, step j0: every workgroup factors the NB x NB diagonal block in LDS (cheap and saves a launch) while
+// the loads of its own 64 columns of the row panel A(j0:j0+NB, j0+NB:n) are in flight, then turns them into
+// U12 = U11^{-T} A12.  The factored diagonal block is NOT written in place (a workgroup that starts late would read it
+// as input): workgroup 0 parks it in Ds[j0 / 64] and k_chol_diag_restore moves all blocks back after the last panel.
+// (Round 1 did this with register / substitution kernels -- k_chol_diag16, k_chol_trsm16, k_chol_panel16: 58 us per step.)
 // ---------------------------------------------------------------------------------------------
 constexpr int NB = 64;
-// (a) diagonal block: one workgroup, right-looking potf2 on the upper triangle held in LDS
-__global__ void __launch_bounds__(256)
-k_chol_diag(double *__restrict__ C, int n, int j0, int *__restrict__ info) {
-    __shared__ double U[NB][NB + 1];
-    __shared__ double R[NB][NB + 1];
-    __shared__ int s_fail;
-    const int tid = threadIdx.x;
-    const int nb = min(NB, n - j0);
-    if (*info != 0) return;  // an earlier panel failed
-    if (tid == 0) s_fail = 0;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    // One barrier per column: every thread reads the pivot a_jj itself; the trailing update uses
-    // the UNSCALED pivot row, U[i][k] -= U[j][i]*U[j][k]/a_jj, while the scaled row U[j][k]/sqrt(a_jj)
-    // is written to a separate image R (so nobody reads a value that is being rewritten).
-    for (int j = 0; j < nb; ++j) {
-        const double ajj = U[j][j];
-        if (ajj <= 0.0 || isnan(ajj)) {   // uniform: every thread sees the same pivot
-            if (tid == 0) s_fail = j + 1;
-            break;
-        }
-        const double inv = 1.0 / ajj;
-        const double root = sqrt(ajj);
-        if (tid < nb - j) R[j][j + tid] = (tid == 0) ? root : U[j][j + tid] / root;
-        {   // 16 x 16 thread grid over the trailing block, 4 x 4 entries per thread: all LDS reads
-            // are issued before the first use (one latency per column instead of sixteen)
-            const int ti = j + 1 + (tid >> 4), tk = j + 1 + (tid & 15);
-            double ui[4], uk[4], v[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                ui[a] = (ti + 16 * a < nb) ? U[j][ti + 16 * a] * inv : 0.0;
-                uk[a] = (tk + 16 * a < nb) ? U[j][tk + 16 * a] : 0.0;
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int i = ti + 16 * a, k = tk + 16 * b;
-                    v[a][b] = (i < nb && k < nb && i <= k) ? U[i][k] : 0.0;
-                }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int i = ti + 16 * a, k = tk + 16 * b;
-                    if (i < nb && k < nb && i <= k) U[i][k] = v[a][b] - ui[a] * uk[b];
-                }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (s_fail) {
-        if (tid == 0) *info = j0 + s_fail;   // PosDefException position (1-based)
-        return;
-    }
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int r = e % nb, cidx = e / nb;
-        if (r <= cidx) C[(size_t)(j0 + cidx) * n + j0 + r] = R[r][cidx];
-    }
-}
-
-// (a2) the same factorisation with 16-column sub-panels: the 16 x 16 diagonal sub-block is factored by ONE
-// wavefront in registers (lane = column, shuffles hand the pivot row around: 16 short unrolled steps),
-// its row panel by one thread per column, the trailing block by all threads -- 3 barriers per 16
-// columns instead of 16.  The working copy stays UNSCALED (pivot row j is applied as (U[j][i]/a_jj)*U[j][k],
-// in pivot order) and is divided by sqrt(a_jj) only at the end: every entry sees exactly the operations
-// of k_chol_diag in the same order, so the result is bit-identical.
-// broadcast of one lane's double through SGPRs (v_readlane): lane index known at compile time after unrolling,
-// far shorter latency than the LDS-crossbar shuffle on the dependent chain of a factorisation
-__device__ __forceinline__ double lane_bcast(double x, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-}
-constexpr int SB = 16;
-__global__ void __launch_bounds__(256)
-k_chol_diag16(double *__restrict__ C, int n, int j0, int *__restrict__ info) {
-    __shared__ double U[NB][NB + 1];
-    __shared__ double s_inv[NB], s_root[NB];
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int nb = min(NB, n - j0);
-    if (*info != 0) return;  // an earlier panel failed
-    if (tid == 0) s_fail = 0;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    for (int s0 = 0; s0 < NB; s0 += SB) {
-        // (1) 16 x 16 diagonal sub-block, one wavefront, registers
-        if (tid < 64) {
-            double u[SB];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) u[r] = (lane < SB && r <= lane) ? U[s0 + r][s0 + lane] : 0.0;
-            int fail = 0;
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const double ajj = __shfl(u[j], j, 64);
-                if (!fail && s0 + j < nb && (ajj <= 0.0 || isnan(ajj))) fail = s0 + j + 1;
-                const double inv = 1.0 / ajj;
-                if (lane == 0) { s_inv[s0 + j] = inv; s_root[s0 + j] = sqrt(ajj); }
-                const double rowj = u[j];
-#pragma unroll
-                for (int i = j + 1; i < SB; ++i) {
-                    const double uji = __shfl(rowj, i, 64) * inv;
-                    if (lane >= i) u[i] -= uji * rowj;
-                }
-            }
-            if (lane < SB) {
-#pragma unroll
-                for (int r = 0; r < SB; ++r)
-                    if (r <= lane) U[s0 + r][s0 + lane] = u[r];
-            }
-            if (fail && lane == 0) s_fail = fail;
-        }
-        __syncthreads();
-        if (s_fail) break;
-        const int rem = NB - s0 - SB;   // columns to the right of the sub-block
-        // (2) row panel of the sub-block: column c, pivots in order
-        if (tid < rem) {
-            const int cidx = s0 + SB + tid;
-            double x[SB];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) x[r] = U[s0 + r][cidx];
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const double inv = s_inv[s0 + j];
-#pragma unroll
-                for (int r = j + 1; r < SB; ++r) x[r] -= (U[s0 + j][s0 + r] * inv) * x[j];
-            }
-#pragma unroll
-            for (int r = 0; r < SB; ++r) U[s0 + r][cidx] = x[r];
-        }
-        __syncthreads();
-        // (3) trailing block: U[i][k] -= (U[j][i]/a_jj) * U[j][k], j over the sub-panel in order
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int i = s0 + SB + e / rem, k = s0 + SB + e % rem;
-            if (i <= k) {
-                double v = U[i][k];
-#pragma unroll
-                for (int j = 0; j < SB; ++j) v -= (U[s0 + j][i] * s_inv[s0 + j]) * U[s0 + j][k];
-                U[i][k] = v;
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (s_fail) {
-        if (tid == 0) *info = j0 + s_fail;   // PosDefException position (1-based)
-        return;
-    }
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int r = e % nb, cidx = e / nb;
-        if (r <= cidx) C[(size_t)(j0 + cidx) * n + j0 + r] = (r == cidx) ? s_root[r] : U[r][cidx] / s_root[r];
-    }
-}
-
-// (b2) row panel with 16-row sub-steps: same operations per entry, in the same order, as k_chol_trsm
-// (X[q][c] -= U[r][q] * x_r for r ascending), 2 barriers per 16 rows instead of 2 per row.
-__global__ void __launch_bounds__(256)
-k_chol_trsm16(double *__restrict__ C, int n, int j0, const int *__restrict__ info) {
-    __shared__ double U[NB][NB + 1];
-    __shared__ double X[NB][NB + 1];
-    const int tid = threadIdx.x;
-    const int nb = min(NB, n - j0);
-    if (*info != 0) return;
-    const int c0 = j0 + nb + blockIdx.x * NB;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
-        X[r][cidx] = (r < nb && c0 + cidx < n) ? C[(size_t)(c0 + cidx) * n + j0 + r] : 0.0;
-    }
-    __syncthreads();
-    const int cc = tid & 63, qg = tid >> 6;
-    for (int s0 = 0; s0 < NB; s0 += SB) {
-        if (tid < 64) {   // rows s0..s0+15 of column cc, forward substitution in registers
-            double x[SB];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) x[r] = X[s0 + r][cc];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) {
-                x[r] = x[r] / U[s0 + r][s0 + r];
-#pragma unroll
-                for (int q = r + 1; q < SB; ++q) x[q] -= U[s0 + r][s0 + q] * x[r];
-            }
-#pragma unroll
-            for (int r = 0; r < SB; ++r) X[s0 + r][cc] = x[r];
-        }
-        __syncthreads();
-        for (int q = s0 + SB + qg; q < NB; q += 4) {   // rows below: subtract the 16 solved rows, r ascending
-            double v = X[q][cc];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) v -= U[s0 + r][q] * X[s0 + r][cc];
-            X[q][cc] = v;
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        if (r < nb && c0 + cidx < n) C[(size_t)(c0 + cidx) * n + j0 + r] = X[r][cidx];
-    }
-}
-
-// (a2)+(b2) in ONE launch per panel: every workgroup factors the diagonal block itself (identical arithmetic, the
-// block is 32 KB) while the loads of its own 64 columns of the row panel are in flight, then runs the row-panel
-// substitution against the factor it holds in LDS -- one dependent launch and one reload of the block less per
-// panel.  The factored diagonal block is NOT written in place (a workgroup that starts late would read it as
-// input): workgroup 0 parks it in Ds[j0 / 64] and k_chol_diag_restore moves all blocks back after the last panel.
-__global__ void __launch_bounds__(256)
-k_chol_panel16(double *__restrict__ C, int n, int j0, int *__restrict__ info, double *__restrict__ Ds) {
-    __shared__ double U[NB][NB + 1];
-    __shared__ double X[NB][NB + 1];
-    __shared__ double s_inv[NB], s_root[NB];
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int nb = min(NB, n - j0);
-    if (*info != 0) return;  // an earlier panel failed
-    if (tid == 0) s_fail = 0;
-    const int c0 = j0 + nb + blockIdx.x * NB;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
-        X[r][cidx] = (r < nb && c0 + cidx < n) ? C[(size_t)(c0 + cidx) * n + j0 + r] : 0.0;
-    }
-    __syncthreads();
-    for (int s0 = 0; s0 < NB; s0 += SB) {
-        if (tid < 64) {
-            double u[SB];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) u[r] = (lane < SB && r <= lane) ? U[s0 + r][s0 + lane] : 0.0;
-            int fail = 0;
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const double ajj = lane_bcast(u[j], j);
-                if (!fail && s0 + j < nb && (ajj <= 0.0 || isnan(ajj))) fail = s0 + j + 1;
-                const double inv = 1.0 / ajj;
-                if (lane == 0) { s_inv[s0 + j] = inv; s_root[s0 + j] = sqrt(ajj); }
-                const double rowj = u[j];
-#pragma unroll
-                for (int i = j + 1; i < SB; ++i) {
-                    const double uji = lane_bcast(rowj, i) * inv;
-                    if (lane >= i) u[i] -= uji * rowj;
-                }
-            }
-            if (lane < SB) {
-#pragma unroll
-                for (int r = 0; r < SB; ++r)
-                    if (r <= lane) U[s0 + r][s0 + lane] = u[r];
-            }
-            if (fail && lane == 0) s_fail = fail;
-        }
-        __syncthreads();
-        if (s_fail) break;
-        const int rem = NB - s0 - SB;
-        if (tid < rem) {
-            const int cidx = s0 + SB + tid;
-            double x[SB];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) x[r] = U[s0 + r][cidx];
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                const double inv = s_inv[s0 + j];
-#pragma unroll
-                for (int r = j + 1; r < SB; ++r) x[r] -= (U[s0 + j][s0 + r] * inv) * x[j];
-            }
-#pragma unroll
-            for (int r = 0; r < SB; ++r) U[s0 + r][cidx] = x[r];
-        }
-        __syncthreads();
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int i = s0 + SB + e / rem, k = s0 + SB + e % rem;
-            if (i <= k) {
-                double v = U[i][k];
-#pragma unroll
-                for (int j = 0; j < SB; ++j) v -= (U[s0 + j][i] * s_inv[s0 + j]) * U[s0 + j][k];
-                U[i][k] = v;
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (s_fail) {
-        if (tid == 0 && blockIdx.x == 0) *info = j0 + s_fail;   // PosDefException position (1-based)
-        return;
-    }
-    // the factor as k_chol_diag16 stores it (same values), kept in LDS for the row panel
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        if (r <= cidx) {
-            const double v = (r == cidx) ? s_root[r] : U[r][cidx] / s_root[r];
-            U[r][cidx] = v;
-            if (blockIdx.x == 0 && r < nb && cidx < nb) Ds[(size_t)(j0 / NB) * NB * NB + (size_t)cidx * NB + r] = v;
-        }
-    }
-    __syncthreads();
-    if (c0 >= n) return;   // last panel: nothing to the right
-    const int cc = tid & 63, qg = tid >> 6;
-    for (int s0 = 0; s0 < NB; s0 += SB) {
-        if (tid < 64) {   // rows s0..s0+15 of column cc, forward substitution in registers
-            double x[SB];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) x[r] = X[s0 + r][cc];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) {
-                x[r] = x[r] / U[s0 + r][s0 + r];
-#pragma unroll
-                for (int q = r + 1; q < SB; ++q) x[q] -= U[s0 + r][s0 + q] * x[r];
-            }
-#pragma unroll
-            for (int r = 0; r < SB; ++r) X[s0 + r][cc] = x[r];
-        }
-        __syncthreads();
-        for (int q = s0 + SB + qg; q < NB; q += 4) {   // rows below: subtract the 16 solved rows, r ascending
-            double v = X[q][cc];
-#pragma unroll
-            for (int r = 0; r < SB; ++r) v -= U[s0 + r][q] * X[s0 + r][cc];
-            X[q][cc] = v;
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        if (r < nb && c0 + cidx < n) C[(size_t)(c0 + cidx) * n + j0 + r] = X[r][cidx];
-    }
-}
-
-// The same step on the fp64 MFMA unit (lsq_small64.h): the only dependent chains left are the four 16 x 16 diagonal
+// On the fp64 MFMA unit (lsq_small64.h): the only dependent chains left are the four 16 x 16 diagonal
 // sub-blocks (one wavefront, registers); row panels and trailing tiles of the 64 x 64 block, its explicit inverse
 // W = inv(U11) and the row panel of the big matrix, U12 = W' A12 (one 64 x 64 x 64 product per workgroup), are tile
 // products.  58 us -> ~20 us per step at n = 512.  The inverse also goes to Xd[j0 / 64] (column-major 64 x 64): the
@@ -539,37 +212,6 @@ k_chol_diag_restore(double *__restrict__ C, int n, const double *__restrict__ Ds
     for (int e = threadIdx.x; e < NB * NB; e += 256) {
         const int r = e % NB, cidx = e / NB;
         if (r <= cidx && cidx < nb) C[(size_t)(j0 + cidx) * n + j0 + r] = Ds[(size_t)blockIdx.x * NB * NB + (size_t)cidx * NB + r];
-    }
-}
-
-// (b) row panel: U12 = U11^{-T} A12.  A workgroup owns 64 columns of A12; the 64 x 64 chunk X and
-// U11 live in LDS; row r of X is finished and its multiples subtracted from the rows below, one
-// barrier per row (thread = (column, row group)).
-__global__ void __launch_bounds__(256)
-k_chol_trsm(double *__restrict__ C, int n, int j0, const int *__restrict__ info) {
-    __shared__ double U[NB][NB + 1];
-    __shared__ double X[NB][NB + 1];
-    const int tid = threadIdx.x;
-    const int nb = min(NB, n - j0);
-    if (*info != 0) return;
-    const int c0 = j0 + nb + blockIdx.x * NB;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        U[r][cidx] = (r < nb && cidx < nb && r <= cidx) ? C[(size_t)(j0 + cidx) * n + j0 + r] : (r == cidx ? 1.0 : 0.0);
-        X[r][cidx] = (r < nb && c0 + cidx < n) ? C[(size_t)(c0 + cidx) * n + j0 + r] : 0.0;
-    }
-    __syncthreads();
-    const int cc = tid & 63, qg = tid >> 6;
-    for (int r = 0; r < nb; ++r) {
-        const double xr = X[r][cc] / U[r][r];
-        __syncthreads();                       // everyone has read row r before it is overwritten
-        if (qg == 0) X[r][cc] = xr;
-        for (int q = r + 1 + qg; q < nb; q += 4) X[q][cc] -= U[r][q] * xr;
-        __syncthreads();
-    }
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e % NB, cidx = e / NB;
-        if (r < nb && c0 + cidx < n) C[(size_t)(c0 + cidx) * n + j0 + r] = X[r][cidx];
     }
 }
 
@@ -743,7 +385,7 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         s->work_elems = need;
     }
     LSQ_HIP(hipMemsetAsync(s->d_info, 0, sizeof(int), c->stream));
-    if (n <= SS_MAXN && m >= 16384 && !getenv("LSQ_SYRK_MFMA")) {
+    if (n <= SS_MAXN && m >= 16384) {
         // few columns, many rows: the pair kernel (one pass over J, no 64 x 64 tile of mostly padding)
         const int nwin = std::max(1, std::min(2 * c->num_cus, m / 1024));
         const int wrows = ((m + nwin - 1) / nwin + SS_ROWS - 1) / SS_ROWS * SS_ROWS;
@@ -763,37 +405,20 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
     }
     if (d_dmax) hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);
-    // parking space for the factored diagonal blocks (k_chol_panel16): the tail of the SYRK slice buffer is free by now
+    // parking space for the factored diagonal blocks (k_chol_panel_mfma)
     bool merged = false;
     double *Ds = s->d_Ds;
     // the MFMA panel kernel leaves the inverted diagonal blocks where the pipelined triangular solves look for them
     double *Xd = nullptr;
     s->chol_have_diaginv = false;
-    if (!getenv("LSQ_CHOL_PANEL16") && !getenv("LSQ_CHOL_PER_COLUMN") && !getenv("LSQ_CHOL_TWO_LAUNCH")) {
-        LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_panel_mfma, CHP_LDS));
-        Xd = lsq_tri_chol_diagbuf(s, n);
-        s->chol_have_diaginv = Xd != nullptr;
-    }
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_panel_mfma, CHP_LDS));
+    Xd = lsq_tri_chol_diagbuf(s, n);
+    s->chol_have_diaginv = Xd != nullptr;
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = std::min(NB, n - j0), rest = n - j0 - nb;
-        static const bool per_column = getenv("LSQ_CHOL_PER_COLUMN") != nullptr;   // the one-barrier-per-column kernels
-        static const bool two_launch = getenv("LSQ_CHOL_TWO_LAUNCH") != nullptr;   // diagonal block and row panel separately
-        static const bool old_panel = getenv("LSQ_CHOL_PANEL16") != nullptr;       // the register / substitution panel kernel
-        if (!per_column && !two_launch && !old_panel) {
-            hipLaunchKernelGGL(k_chol_panel_mfma, dim3(std::max(1, (rest + NB - 1) / NB)), dim3(256), CHP_LDS, c->stream, s->d_chol,
-                               n, j0, s->d_info, Ds, Xd);
-            merged = true;
-        } else if (!per_column && !two_launch) {
-            hipLaunchKernelGGL(k_chol_panel16, dim3(std::max(1, (rest + NB - 1) / NB)), dim3(256), 0, c->stream, s->d_chol, n, j0,
-                               s->d_info, Ds);
-            merged = true;
-        } else {
-            hipLaunchKernelGGL(per_column ? k_chol_diag : k_chol_diag16, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, j0,
-                               s->d_info);
-            if (rest > 0)
-                hipLaunchKernelGGL(per_column ? k_chol_trsm : k_chol_trsm16, dim3((rest + NB - 1) / NB), dim3(256), 0, c->stream,
-                                   s->d_chol, n, j0, (const int *)s->d_info);
-        }
+        hipLaunchKernelGGL(k_chol_panel_mfma, dim3(std::max(1, (rest + NB - 1) / NB)), dim3(256), CHP_LDS, c->stream, s->d_chol,
+                           n, j0, s->d_info, Ds, Xd);
+        merged = true;
         if (rest > 0) {
             const int nt2 = (rest + MT - 1) / MT;
             // A22 -= U12' U12 : "A" = rows j0..j0+nb of chol (lda n), columns from j0+nb

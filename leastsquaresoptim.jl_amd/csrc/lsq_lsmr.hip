@@ -364,8 +364,6 @@ void lsq_lsmr_free(lsq_solver *s) {
 static inline int nvec_grid(const lsq_ctx *c, int n) {
     int g = lsq_div_up(n > 0 ? n : 1, LSQ_NT);
     int cap = c->num_cus * 4;
-    static const int forced = getenv("LSQ_UPDATE_GRID") ? atoi(getenv("LSQ_UPDATE_GRID")) : 0;
-    if (forced > 0) return forced < g ? forced : g;
     return g > cap ? cap : g;
 }
 

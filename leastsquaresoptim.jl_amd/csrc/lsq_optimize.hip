@@ -1176,13 +1176,8 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         }
         if (have_cols) {
             if (lds_ok && ccol) {
-                static const bool nt_cols = getenv("LSQ_SCALE_COLS_NT") != nullptr;
-                if (nt_cols)
-                    hipLaunchKernelGGL(k_scale_lds<true>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
-                                       ccol, md->d_Ab, md->d_t, J->n, cval);
-                else
-                    hipLaunchKernelGGL(k_scale_lds<false>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
-                                       ccol, md->d_Ab, md->d_t, J->n, cval);
+                hipLaunchKernelGGL(k_scale_lds<false>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
+                                   ccol, md->d_Ab, md->d_t, J->n, cval);
             } else if (J->scols.active) {
                 // n > 65535: no 16-bit columns; rebuild the sliced columns from the CSC copy instead
                 if (lazy_csc) return 1;

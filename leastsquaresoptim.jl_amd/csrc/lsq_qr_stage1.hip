@@ -1,0 +1,960 @@
+// Stage 1 of the two-stage QR (lsq_qr.hip: dense_qr.jl:30-88): UNPIVOTED blocked Householder QR of [A | b] with 64-column
+// panels -- CholeskyQR2 panels (lsq_qr_cholqr.hip) with the column-by-column Householder steps (k_qr1_step_multi) as the
+// fallback for ill-conditioned panels and narrow / short operands, TSQR levels for tall-and-thin operands -- and the
+// compact-WY block update on the fp64 MFMA unit (k_qr1_vtb, k_qr1_tw_mfma, k_qr1_update).
+#include <type_traits>
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include <cstdlib>
+
+#include "lsq_qr_work.h"
+#include "lsq_spmv.h"
+
+// ---------------------------------------------------------------------------------------------
+// Two-stage column-pivoted QR: the pivoted sweep of dgeqp3 streams the whole trailing matrix once
+// per column (C3: 2.6e11 bytes).  Stage 1 is an UNPIVOTED blocked Householder QR of [A | b]:
+//   * 64-column panels; the panel steps carry K pivot columns per launch in registers (k_qr1_step_multi: lazy
+//     reflectors, 1-256 row slabs per column with an in-kernel exchange, TSQR levels for tall thin operands; the older
+//     per-column kernels k_qr1_step / _reg / _lazy remain selectable for A/B runs);
+//   * per panel the trailing matrix is updated once with the compact-WY form on the fp64 MFMA units:
+//     W = V'[V | A2 | b] (k_qr1_vtb: split-K, deterministic reduce), T'W through an explicit T' built in LDS from the
+//     Gram block (k_qr1_tw_mfma), A2 -= V (T'W) (k_qr1_update); in the last panel b rides through the steps instead.
+// Then either the FULL-RANK CERTIFICATE (qr2_certify_full_rank: explicit inverse of the triangle, Frobenius bound on
+// cond_2 -- xGELSY's rank decision is provably n, the unpivoted triangle gives the solution: k_tri_bsolve), or stage 2:
+// the pivoted sweep (k_qr2_step, the dlaqp2 recurrence with lazy column exchanges) on the n x n triangle R with Q1'b
+// riding along: A P = Q1 (R P) = Q1 Q2 R2, so R2, the pivots and Q2'Q1'b are what ldiv!(::QRPivoted, b) needs; the rank
+// decision (dlaic1, rcond) and the minimum-norm completion then run unchanged (k_qrcp_solve, phase 0).
+// ---------------------------------------------------------------------------------------------
+
+// One column step inside a panel [c0, cend).  first: only the reflector of column c0.  Otherwise
+// block b applies H_i to column j = i+1+b of the panel; the block of j == i+1 then forms H_{i+1}
+// from the column it has just updated (dlarfg), so a step is ONE launch.
+__global__ void __launch_bounds__(QR_NT)
+k_qr1_step(double *__restrict__ A, int M, int cend, int i, int first, double *__restrict__ tau) {
+    __shared__ double sh[QR_NT / 64];
+    __shared__ double s_w;
+    const int tid = threadIdx.x;
+    const int j = first ? i : i + 1 + blockIdx.x;
+    if (j >= cend) return;
+    double *cj = A + (size_t)j * M;
+    if (!first) {
+        const double *ci = A + (size_t)i * M;
+        const double ti = tau[i];
+        if (ti != 0.0) {
+            double w = 0.0;
+            for (int k = i + 1 + tid; k < M; k += QR_NT) w += ci[k] * cj[k];
+            w = blk_sum_qr(w, sh);
+            if (tid == 0) s_w = ti * (w + cj[i]);   // v_i(i) = 1
+            __syncthreads();
+            const double tw = s_w;
+            for (int k = i + 1 + tid; k < M; k += QR_NT) cj[k] -= ci[k] * tw;
+            if (tid == 0) cj[i] -= tw;
+            __syncthreads();
+        }
+        if (j != i + 1) return;
+    }
+    // reflector of column j on rows j..M-1 (dlarfg)
+    double acc = 0.0;
+    for (int k = j + 1 + tid; k < M; k += QR_NT) acc += cj[k] * cj[k];
+    const double xn = sqrt(blk_sum_qr(acc, sh));
+    __shared__ double s_tau, s_scale;
+    if (tid == 0) {
+        const double alpha = j < M ? cj[j] : 0.0;
+        if (xn == 0.0 || j >= M) { s_tau = 0.0; s_scale = 0.0; }
+        else {
+            const double beta = -copysign(hypot(alpha, xn), alpha);
+            s_tau = (beta - alpha) / beta;
+            s_scale = 1.0 / (alpha - beta);
+            cj[j] = beta;
+        }
+        tau[j] = s_tau;
+    }
+    __syncthreads();
+    if (s_tau != 0.0) {
+        const double sc = s_scale;
+        for (int k = j + 1 + tid; k < M; k += QR_NT) cj[k] *= sc;
+    }
+}
+
+// DPP all-reductions (no LDS round trips; helpers of lsq_common.h): after row_allsum every lane of a 16-lane row holds
+// the row's sum (rotations pair the same operands in every lane, so the lanes agree bit for bit); wave_allsum = wave_sum
+// adds the four row sums in a fixed order.
+__device__ __forceinline__ double row_allsum(double x) {
+    x += lsq_dpp_mov_f64<0x128>(x);   // row_ror:8
+    x += lsq_dpp_mov_f64<0x124>(x);   // row_ror:4
+    x += lsq_dpp_mov_f64<0x122>(x);   // row_ror:2
+    x += lsq_dpp_mov_f64<0x121>(x);   // row_ror:1
+    return x;
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) { return lsq_readlane_f64(x, l); }
+__device__ __forceinline__ double wave_allsum(double x) { return wave_sum(x); }
+
+// K lazy reflectors per launch.  A launch's fixed cost (dispatch + the fetch of the columns) dominates a step,
+// so one launch carries the K pivot columns i .. i+K-1 through K reduction rounds: every workgroup fetches
+// the K pivot columns and its own target column i+K+blockIdx.x, and in round r forms H_{i+r} from pivot
+// column r -- left UNSCALED by the round that finished it ("lazy" reflectors: sum v^2 and v'a share ONE block reduction; beta,
+// tau and the scale 1/(alpha - beta) go to side arrays, the V materialisation applies the scale) -- and applies it to the later
+// pivot columns and to the target, all in
+// registers.  The pivot columns are updated redundantly by every workgroup (identical arithmetic); workgroup
+// 0 stores them and the side arrays.  Thread rows start at row i so that the pivot element of every round is
+// an ordinary masked element: "alpha" and the row-(i+r) entries of the other columns come out of the same
+// block reduction as the dot products (sums with a single non-zero term are exact).
+//
+// S > 1: the rows of a column are cut into S slabs of RPT*NT rows, one workgroup each -- S times more CUs
+// stream the panel, a workgroup holds 1/S of a column per array (so K can be larger), and the S workgroups of
+// a target column ("group") add their partial sums through memory once per round: each publishes its NS
+// partials with agent-scope stores, then picks up all S sets (its own included, so every member adds the
+// same values in the same order) and goes on.  The members of a group sit at block
+// indices 8 apart -- the same XCD under the round-robin dispatch -- and a launch never has more workgroups
+// than the device holds at once (host side), so the members of a group are always co-resident; the wait is
+// bounded anyway and reports through *err instead of hanging.
+template <int N, class F>
+__device__ __forceinline__ void qr_static_for(F &&f) {
+    if constexpr (N > 0) {
+        qr_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+//
+// TSQR = 1 (tall and thin operands, n <= K; kept for reference, not instantiated): every workgroup is on its own -- its slab of RPT*NT rows of ALL n
+// columns and of b sits in registers, the K rounds factor the slab locally (pivot rows = the slab's first rows, no
+// exchange), and the only thing written is the slab's n x n triangle and the first n entries of its Q'b, stacked
+// for the next level (tsq_S: (slabs*n) x n, tsq_r): ONE pass over the matrix.
+// TSQR = 2 (the one in use): the same with one WAVEFRONT per slab (64*RPT rows): the reductions are wave reductions, the
+// row-c elements come from their owner lane by v_readlane -- no LDS, no barrier anywhere in the rounds.
+template <int NT, int RPT, int K, int S, int TSQR = 0>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live pivots, <= K */, double *__restrict__ tau,
+                 double *__restrict__ beta_out, double *__restrict__ scale_out, int G /* groups = target columns (>= 1) */,
+                 unsigned long long *__restrict__ xslot, unsigned long long epoch,
+                 int *__restrict__ err, double *__restrict__ Pn /* side panel: column (col - c0) * M */, int c0,
+                 double *__restrict__ rhs_col /* last panel: the right-hand side rides along as target column "cend" */,
+                 double *__restrict__ tsq_S = nullptr, int tsq_ld = 0, double *__restrict__ tsq_r = nullptr) {
+    constexpr int NW = NT / 64;
+    constexpr int NS = 2 * (K + 1);
+    __shared__ double sh[NW][NS];
+    __shared__ double sx[S][NS];
+    __shared__ double sat[NS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int QS = TSQR == 2 ? 64 : NT;      // rows between two elements of a thread
+    int g = (int)blockIdx.x, sidx = 0;
+    if (TSQR) {                      // one workgroup (or wavefront) per slab, a single "group" whose target is b
+        g = 0;
+        sidx = TSQR == 2 ? (int)blockIdx.x * NW + wv : (int)blockIdx.x;
+    } else if (S > 1 && S < 64) {           // members 8 apart: one XCD; 8 * S workgroups must be resident together
+        const int kq = (int)blockIdx.x >> 3;
+        sidx = kq % S;
+        g = (kq / S) * 8 + ((int)blockIdx.x & 7);
+        if (g >= G) return;
+    } else if (S >= 64) {            // members consecutive (all XCDs): a group spans S <= 256 indices (the device holds 512)
+        g = (int)blockIdx.x / S;
+        sidx = (int)blockIdx.x % S;
+    }
+    const int j = i + kk + g;
+    const bool is_rhs = rhs_col != nullptr && j == cend;
+    const bool has_col = j < cend || is_rhs;
+    // one buffer descriptor per column (scalar base, byte count M*8): every fetch and store is descriptor +
+    // ONE shared 32-bit VGPR offset + a scalar offset; rows beyond M read as zero and their stores are dropped by
+    // the bounds check, and a dead column (ragged last launch, no target) gets an empty descriptor
+    typedef unsigned v2u_qr __attribute__((ext_vector_type(2)));
+    const int t = i + sidx * (RPT * QS) + (TSQR == 2 ? lane : tid);    // row of element 0
+    const unsigned tb = (unsigned)t * 8u;
+    const unsigned colbytes = (unsigned)M * 8u;
+    double pv[K][RPT], a[RPT];
+    __amdgpu_buffer_rsrc_t rp[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        rp[r] = __builtin_amdgcn_make_buffer_rsrc(A + (size_t)(i + (r < kk ? r : 0)) * M, 0, r < kk ? colbytes : 0u, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rp[r], tb, q * QS * 8, 0);
+            pv[r][q] = __builtin_bit_cast(double, w);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rj =
+        __builtin_amdgcn_make_buffer_rsrc(is_rhs ? rhs_col : A + (size_t)(has_col ? j : i) * M, 0, has_col ? colbytes : 0u, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const v2u_qr w = __builtin_amdgcn_raw_buffer_load_b64(rj, tb, q * QS * 8, 0);
+        a[q] = __builtin_bit_cast(double, w);
+    }
+    double mybeta = 0.0;   // (TSQR)
+    // (rounds as instantiations, not as a loop: the unroller gives up on a body of this size for K >= 6 and the
+    // register arrays would land in scratch)
+    auto round = [&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        if (r >= kk) return;                        // (uniform over the whole grid: a dead round of a ragged launch)
+        const bool live = true;
+        const int c = (TSQR ? i + sidx * (RPT * QS) : i) + r;   // pivot row of this round (TSQR: of this slab)
+        // sm: [0] v'v  [1] alpha  then per later column x (pivots r+1.., target): v'x and x(c).  The even entries are
+        // sums over all rows; the odd ones are single elements of row c, all owned by ONE thread (slab 0, thread r:
+        // only element 0 of a thread can sit at or above the pivot row) which hands them out directly
+        double sm[NS];
+        constexpr int NSr = 2 * (K - r) + 2;
+        {
+            const double v = t > c ? pv[r][0] : 0.0;
+            sm[0] = v * v;
+#pragma unroll
+            for (int x = 0; x < K; ++x)       // (constant trip counts: the unroller must not depend on r)
+                if (x > r) sm[2 * (x - r)] = v * pv[x][0];
+            sm[2 * (K - r)] = v * a[0];
+        }
+#pragma unroll
+        for (int q = 1; q < RPT; ++q) {
+            const double v = pv[r][q];
+            sm[0] = __builtin_fma(v, v, sm[0]);
+#pragma unroll
+            for (int x = 0; x < K; ++x)
+                if (x > r) sm[2 * (x - r)] = __builtin_fma(v, pv[x][q], sm[2 * (x - r)]);
+            sm[2 * (K - r)] = __builtin_fma(v, a[q], sm[2 * (K - r)]);
+        }
+#pragma unroll
+        for (int e = 0; e < NS; e += 2)
+            if (e < NSr) sm[e] = wave_allsum(sm[e]);
+        if constexpr (TSQR == 2) {
+            // wave slab: the sums are complete; the row-c elements sit in lane r
+            sm[1] = readlane_f64(pv[r][0], r);
+#pragma unroll
+            for (int x = 0; x < K; ++x)
+                if (x > r) sm[2 * (x - r) + 1] = readlane_f64(pv[x][0], r);
+            sm[2 * (K - r) + 1] = readlane_f64(a[0], r);
+        } else {
+        __syncthreads();                             // (the previous round's readers of sh, sx and sat are done)
+        if (lane == 0) {
+#pragma unroll
+            for (int e = 0; e < NS; e += 2)
+                if (e < NSr) sh[wv][e] = sm[e];
+        }
+        if (t == c) {                                // the owner of row c (slab 0, thread r)
+            sat[1] = pv[r][0];
+#pragma unroll
+            for (int x = 0; x < K; ++x)
+                if (x > r) sat[2 * (x - r) + 1] = pv[x][0];
+            sat[2 * (K - r) + 1] = a[0];
+        }
+        __syncthreads();
+        static_assert(NW <= 16, "one 16-lane row sums the wave partials");
+#pragma unroll
+        for (int e = 0; e < NS; e += 2)
+            if (e < NSr) sm[e] = row_allsum((lane & 15) < NW ? sh[lane & 15][e] : 0.0);
+        }
+        if constexpr (TSQR == 2) {
+        } else if (S == 1 || TSQR) {
+#pragma unroll
+            for (int e = 1; e < NS; e += 2)
+                if (e < NSr) sm[e] = sat[e];
+        } else {
+            // flag-in-data exchange (the low-latency protocol of the collectives libraries): every 64-bit word
+            // carries 32 bits of payload and the 32-bit epoch, so a reader that sees the epoch has the payload --
+            // one store and one load on the critical path, no fences, no separate flag.  Sums: every slab publishes
+            // its partial; row-c elements: slab 0 alone publishes them.
+            const unsigned ep = (unsigned)epoch;
+            if (tid < NSr && ((tid & 1) == 0 || sidx == 0)) {
+                double val = 0.0;
+#pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    if (e < NSr && tid == e) val = (e & 1) ? sat[e] : sm[e];
+                unsigned long long *mine = xslot + ((((size_t)g * S + sidx) * K + r) * NS + tid) * 2;
+                const unsigned long long hi = (unsigned long long)ep << 32;
+                __hip_atomic_store(mine, hi | (unsigned)__double2loint(val), RLX_AGENT);
+                __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(val), RLX_AGENT);
+            }
+            for (int idx = tid; idx < S * NS; idx += NT) {
+                const int sp = idx / NS, e = idx % NS;
+                if (e < NSr && ((e & 1) == 0 || sp == 0)) {
+                    const unsigned long long *f = xslot + ((((size_t)g * S + sp) * K + r) * NS + e) * 2;
+                    unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+                    int spins = 0;
+                    while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
+                        if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        w0 = __hip_atomic_load(f, RLX_AGENT);
+                        w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+                    }
+                    sx[sp][e] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                if (e < NSr) {
+                    if (e & 1) sm[e] = sx[0][e];
+                    else {
+                        double tot = 0.0;
+#pragma unroll 8
+                        for (int sp = 0; sp < S; ++sp) tot += sx[sp][e];   // (fixed order: every member gets the same bits)
+                        sm[e] = tot;
+                    }
+                }
+            }
+        }
+        const double alpha = sm[1];
+        double ti = 0.0, beta = alpha, sc = 0.0;
+        if (sm[0] != 0.0) {
+            // (sum v^2 is already formed unscaled, so dlapy2's overflow guard has nothing left to protect)
+            beta = -copysign(sqrt(__builtin_fma(alpha, alpha, sm[0])), alpha);
+            ti = (beta - alpha) / beta;
+            sc = 1.0 / (alpha - beta);
+        }
+        if (!live) ti = 0.0;
+        if (TSQR) {
+            if ((TSQR == 2 ? lane : tid) == r) mybeta = beta;   // R(r, r) of this slab, kept by the owner of the slab's row r
+        } else if (live && g == 0 && sidx == 0 && tid == 0) { tau[c] = ti; beta_out[c] = beta; scale_out[c] = sc; }
+        if (ti != 0.0) {
+            double tw[K + 1];
+#pragma unroll
+            for (int x = 0; x <= K; ++x)
+                if (x > r) tw[x] = ti * (sc * sm[2 * (x - r)] + sm[2 * (x - r) + 1]);
+            {
+                const double vs = t > c ? pv[r][0] * sc : (t == c ? 1.0 : 0.0);
+#pragma unroll
+                for (int x = 0; x < K; ++x)
+                    if (x > r) pv[x][0] -= vs * tw[x];
+                a[0] -= vs * tw[K];
+            }
+#pragma unroll
+            for (int q = 1; q < RPT; ++q) {
+                const double vs = pv[r][q] * sc;
+#pragma unroll
+                for (int x = 0; x < K; ++x)
+                    if (x > r) pv[x][q] = __builtin_fma(-vs, tw[x], pv[x][q]);
+                a[q] = __builtin_fma(-vs, tw[K], a[q]);
+            }
+        }
+    };
+    qr_static_for<K>(round);
+    if (TSQR) {
+        // rows 0 .. kk-1 of the slab: R(r, x) = element 0 of thread r in column x (x > r), beta on the diagonal, zeros
+        // before it; and entry r of the slab's Q'b
+        const int own = TSQR == 2 ? lane : tid;
+        if (own < kk && sidx < G) {                  // (G: number of slabs; a workgroup's last wavefronts may have none)
+            const size_t row = (size_t)sidx * kk + own;
+#pragma unroll
+            for (int x = 0; x < K; ++x)
+                if (x < kk) tsq_S[(size_t)x * tsq_ld + row] = x < own ? 0.0 : (x == own ? mybeta : pv[x][0]);
+            tsq_r[row] = a[0];
+        }
+        return;
+    }
+    if (g == 0) {
+        // pivot columns 1 .. kk-1 are final (unscaled) now.  They go to the SIDE panel, not in place: other groups
+        // may not have fetched them yet (a launch can be larger than what the device holds at once), and
+        // nobody but k_qr1_vbuf needs them again -- it moves them back while it builds V
+#pragma unroll
+        for (int r = 1; r < K; ++r) {
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(Pn + (size_t)(i + (r < kk ? r : 0) - c0) * M, 0, r < kk ? colbytes : 0u, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_qr, pv[r][q]), rs, tb, q * NT * 8, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_qr, a[q]), rj, tb, q * NT * 8, 0);
+}
+
+// V (unit lower trapezoid of the panel, zeros above, zero columns beyond nb) -> Vb[row - c0][col], ld = ldv
+__global__ void __launch_bounds__(256)
+k_qr1_vbuf(double *__restrict__ A, int M, int c0, int nb, double *__restrict__ Vb, int ldv,
+           const double *__restrict__ beta, const double *__restrict__ scale /* lazy reflectors: column c0+c is stored
+           unscaled and its R(c,c) = beta is put on the diagonal here, once nobody reads the old pivot element */,
+           const double *__restrict__ Pn, int K /* k_qr1_step_multi: the later pivot columns of a launch (c % K != 0)
+           were left in the side panel from the launch's first pivot row on; they return to A here */) {
+    const int rows = M - c0;
+    const long long tot = (long long)rows * Q2_NB;
+    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e % rows), cidx = (int)(e / rows);
+        double v = 0.0;
+        if (cidx < nb) {
+            double *pa = A + (size_t)(c0 + cidx) * M + c0 + r;
+            if (Pn && cidx % K != 0 && r >= cidx / K * K) *pa = Pn[(size_t)cidx * M + c0 + r];
+            if (r > cidx) v = *pa * (scale ? scale[c0 + cidx] : 1.0);
+            else if (r == cidx) {
+                v = 1.0;
+                if (beta) *pa = beta[c0 + cidx];
+            }
+        }
+        Vb[(size_t)cidx * ldv + r] = v;
+    }
+}
+
+// last panel, right-hand side already transformed by the steps: nobody needs V any more, only the panel's part of R --
+// the rows c0 .. c0+nb-1 of the side-panel columns go back to A and beta goes on the diagonal
+__global__ void __launch_bounds__(256)
+k_qr1_fin(double *__restrict__ A, int M, int c0, int nb, const double *__restrict__ beta, const double *__restrict__ Pn, int K) {
+    for (int e = threadIdx.x; e < Q2_NB * Q2_NB; e += 256) {
+        const int r = e % Q2_NB, cidx = e / Q2_NB;
+        if (cidx >= nb || r > cidx || c0 + r >= M) continue;
+        double *pa = A + (size_t)(c0 + cidx) * M + c0 + r;
+        if (r == cidx) *pa = beta[c0 + cidx];
+        else if (Pn && cidx % K != 0 && r >= cidx / K * K) *pa = Pn[(size_t)cidx * M + c0 + r];
+    }
+}
+
+// column cb of the virtual matrix B = [V | A(:, cend:n) | b] restricted to rows c0..M-1
+__device__ __forceinline__ const double *q2_bcol(const double *Vb, int ldv, const double *A, int M, int c0, int cend, int n,
+                                                 const double *rhs, int cb) {
+    if (cb < Q2_NB) return Vb + (size_t)cb * ldv;
+    const int a = cend + (cb - Q2_NB);
+    return (a < n ? A + (size_t)a * M : rhs) + c0;
+}
+
+// Wp[slice][tile][64 x 64] = V(rows of the slice)' * B(rows of the slice, 64 columns of tile)   (fp64 MFMA)
+__global__ void __launch_bounds__(256)
+k_qr1_vtb(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, int M, int c0, int cend, int n,
+          const double *__restrict__ rhs, int ncolsB, int kslices, double *__restrict__ Wp) {
+    __shared__ double sA[Q2_NB * Q2_KS];
+    __shared__ double sB[Q2_NB * Q2_KS];
+    const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
+    const int tile = blockIdx.x % ntile, slice = blockIdx.x / ntile;
+    const int rows = M - c0;
+    const int kper = ((rows + kslices - 1) / kslices + Q2_KC - 1) / Q2_KC * Q2_KC;
+    const int kb = slice * kper, ke = min(rows, kb + kper);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    v4d_qr acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d_qr){0.0, 0.0, 0.0, 0.0};
+    const int lc = tid >> 2, lk = (tid & 3) * 8;
+    const int cb = tile * Q2_NB + lc;
+    const double *pbcol = cb < ncolsB ? q2_bcol(Vb, ldv, A, M, c0, cend, n, rhs, cb) : nullptr;
+    const double *pacol = Vb + (size_t)lc * ldv;
+    // the next 32-row slab is fetched into registers while the MFMAs of the current one run
+    double ra[8], rb[8];
+    const double *pb = pbcol ? pbcol : Vb;     // (a dummy column for tiles past the last one: fetched, then zeroed)
+    const bool bok = pbcol != nullptr;
+    auto fetch = [&](int k0) {
+        if (k0 + Q2_KC <= ke) {                // full slab: unconditional fetches, nothing to branch on
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                ra[q] = pacol[k0 + lk + q];
+                const double y = pb[k0 + lk + q];
+                rb[q] = bok ? y : 0.0;
+            }
+        } else {                               // the ragged last slab: clamped addresses, zeroed by selection
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + lk + q, ks = min(k, ke - 1);
+                const double x = pacol[ks], y = pb[ks];
+                ra[q] = k < ke ? x : 0.0;
+                rb[q] = (k < ke && bok) ? y : 0.0;
+            }
+        }
+    };
+    if (kb < ke) fetch(kb);
+    for (int k0 = kb; k0 < ke; k0 += Q2_KC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sA[lc * Q2_KS + lk + q] = ra[q];
+            sB[lc * Q2_KS + lk + q] = rb[q];
+        }
+        __syncthreads();
+        if (k0 + Q2_KC < ke) fetch(k0 + Q2_KC);
+#pragma unroll
+        for (int kk = 0; kk < Q2_KC; kk += 4) {
+            const int ko = kk + (lane >> 4);
+            const double a0 = sA[(wr + (lane & 15)) * Q2_KS + ko];
+            const double a1 = sA[(wr + 16 + (lane & 15)) * Q2_KS + ko];
+            const double b0 = sB[(wc + (lane & 15)) * Q2_KS + ko];
+            const double b1 = sB[(wc + 16 + (lane & 15)) * Q2_KS + ko];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double *out = Wp + ((size_t)slice * ntile + tile) * (Q2_NB * Q2_NB);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + a * 16 + (lane >> 4) + 4 * r;   // index into V's columns
+                const int col = wc + b * 16 + (lane & 15);           // index into the tile's B columns
+                out[(size_t)col * Q2_NB + row] = acc[a][b][r];
+            }
+}
+
+// W[cb][0:64] = sum over slices (fixed order)
+__global__ void __launch_bounds__(256)
+k_qr1_wreduce(const double *__restrict__ Wp, int ncolsB, int kslices, double *__restrict__ W) {
+    const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
+    const long long tot = (long long)ntile * Q2_NB * Q2_NB;
+    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        double s = 0.0;
+        for (int sl = 0; sl < kslices; ++sl) s += Wp[(size_t)sl * tot + e];
+        W[e] = s;   // layout [tile][col][row] == [cb][row]
+    }
+}
+
+// W2 = T' W for the columns of A2 and b without forming T: for H_0 ... H_{nb-1} = I - V T V' the inverse
+// of T is the upper triangle of the Gram block G = V'V with 1/tau on the diagonal (tau_j = 2 / v_j'v_j),
+// so T' W = W2 solves the unit-structured lower-triangular system
+//      W2[j] = tau_j * (W[j] - sum_{k<j} G[j][k] W2[k])
+// (tau_j = 0, i.e. H_j = I, gives W2[j] = 0 as dlarft's zero column does).
+// The 64-step recurrence is taken off the critical path: it reads
+//      (I + D N) x = D w,      D = diag(tau), N = strict lower triangle of G
+// so T' = inv(I + D N) D, the inverse of a UNIT lower-triangular matrix (no divisions; tau_j = 0 gives a zero row
+// as before).  Every workgroup builds it in LDS -- 16 x 16 diagonal blocks by substitution (one thread per
+// column, 120 dependent FMAs instead of 2016), then two levels of  X_BA = -X_BB (Y_BA X_AA)  -- and multiplies
+// its 64 columns of W by it on the MFMA units.  One launch, ~10 us instead of 54.
+__global__ void __launch_bounds__(256)
+k_qr1_tw_mfma(const double *__restrict__ W, int ncolsB, const double *__restrict__ tau, int c0, int nb,
+              double *__restrict__ W2) {
+    constexpr int LS = Q2_NB + 1;
+    __shared__ double Y[Q2_NB * LS];      // D N (strictly lower)
+    __shared__ double X[Q2_NB * LS];      // inv(I + Y), then T' = X D
+    __shared__ double Tm[32 * 33];        // Y_BA X_AA of the current level
+    __shared__ double st[Q2_NB];
+    __shared__ double sB[Q2_NB * Q2_KS];
+    __shared__ double sA[Q2_NB * Q2_KS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < Q2_NB) st[tid] = tid < nb ? tau[c0 + tid] : 0.0;
+    __syncthreads();
+    for (int e = tid; e < Q2_NB * Q2_NB; e += 256) {
+        const int j = e / Q2_NB, k = e % Q2_NB;
+        Y[j * LS + k] = k < j ? st[j] * W[(size_t)j * Q2_NB + k] : 0.0;    // W[cb = j][row = k] = v_k'v_j
+        X[j * LS + k] = 0.0;
+    }
+    __syncthreads();
+    if (tid < Q2_NB) {                    // 16 x 16 diagonal blocks: column c of inv(I + Y_bb)
+        const int o = (tid >> 4) * 16, cc = tid & 15;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = r == cc ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) acc -= Y[(o + r) * LS + o + k] * x[k];
+            x[r] = r >= cc ? acc : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[(o + r) * LS + o + cc] = x[r];
+    }
+    __syncthreads();
+    for (int sz = 16; sz < Q2_NB; sz *= 2) {
+        const int npair = Q2_NB / (2 * sz);
+        // Tm(pair)[r][c] = sum_k Y[B r][A k] X[A k][A c]   (X_AA lower triangular: k >= c)
+        for (int e = tid; e < npair * sz * sz; e += 256) {
+            const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int k = cc; k < sz; ++k) acc += Y[(ob + r) * LS + oa + k] * X[(oa + k) * LS + oa + cc];
+            Tm[(pr * sz + r) * 33 + cc] = acc;     // (two pairs of 16 rows or one of 32: 32 x 32 in all)
+        }
+        __syncthreads();
+        // X_BA[r][c] = -sum_k X[B r][B k] Tm[k][c]       (X_BB lower triangular: k <= r)
+        for (int e = tid; e < npair * sz * sz; e += 256) {
+            const int pr = e / (sz * sz), r = (e / sz) % sz, cc = e % sz, oa = pr * 2 * sz, ob = oa + sz;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int k = 0; k <= r; ++k) acc += X[(ob + r) * LS + ob + k] * Tm[(pr * sz + k) * 33 + cc];
+            X[(ob + r) * LS + oa + cc] = -acc;
+        }
+        __syncthreads();
+    }
+    // W2(:, 64 columns of this workgroup) = (X D) W(:, columns)
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int ncols = ncolsB - Q2_NB;
+    const int j0 = blockIdx.x * Q2_NB;
+    v4d_qr acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d_qr){0.0, 0.0, 0.0, 0.0};
+    const int lc = tid >> 2, lk = (tid & 3) * 8;
+    const double *wcol = j0 + lc < ncols ? W + (size_t)(Q2_NB + j0 + lc) * Q2_NB : nullptr;
+    for (int k0 = 0; k0 < Q2_NB; k0 += Q2_KC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + lk + q;
+            sA[lc * Q2_KS + lk + q] = X[lc * LS + k] * st[k];       // T'[m = lc][k]
+            sB[lc * Q2_KS + lk + q] = wcol ? wcol[k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < Q2_KC; kk += 4) {
+            const int ko = kk + (lane >> 4);
+            const double a0 = sA[(wr + (lane & 15)) * Q2_KS + ko];
+            const double a1 = sA[(wr + 16 + (lane & 15)) * Q2_KS + ko];
+            const double b0 = sB[(wc + (lane & 15)) * Q2_KS + ko];
+            const double b1 = sB[(wc + 16 + (lane & 15)) * Q2_KS + ko];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr + a * 16 + (lane >> 4) + 4 * r;   // entry of W2's column
+                const int col = j0 + wc + b * 16 + (lane & 15);
+                if (col < ncols) W2[(size_t)col * Q2_NB + row] = acc[a][b][r];
+            }
+}
+
+// A2(rows, 64 columns of tile) -= V(rows, :) * W2(:, columns)      (fp64 MFMA, K = 64)
+constexpr int Q2_UCT = 4;   // column tiles per workgroup of the update: the V tile is staged once for all of them
+__global__ void __launch_bounds__(256)
+k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int M, int c0, int cend, int n,
+             double *__restrict__ rhs, int ncols /* n - cend + 1 */, const double *__restrict__ W2) {
+    constexpr int CS = Q2_NB + 1;             // product image [col][row], padded
+    __shared__ double sV[Q2_NB * Q2_NB];     // [k][row]: row contiguous
+    __shared__ double sW[Q2_NB * CS];        // [col][k] (64 x 64 used); after the MFMAs the product image
+    const int rows = M - c0;
+    const int nrt = (rows + Q2_NB - 1) / Q2_NB;
+    const int rt = blockIdx.x % nrt, cg = blockIdx.x / nrt;
+    const int r0 = rt * Q2_NB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const bool rin = r0 + lane < rows;
+    // V and W2 images are exactly 64 x 64 doubles; bank conflicts are
+    // avoided by rotation instead of padding: V column k is stored rotated by 16*(k&3) rows (the four
+    // k-groups of an MFMA operand read then hit four different 128-byte segments), W2 column j by
+    // 2*(j&15) entries (the 16 columns of an operand read hit 16 different bank pairs)
+    if (r0 + Q2_NB <= rows) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = w + 4 * q;                       // V column k, row r0 + lane
+            sV[k * Q2_NB + ((lane + 16 * (k & 3)) & 63)] = Vb[(size_t)k * ldv + r0 + lane];
+        }
+    } else {
+        for (int e = tid; e < Q2_NB * Q2_NB; e += 256) {
+            const int k = e / Q2_NB, r = e % Q2_NB;        // V column k, row r0 + r
+            sV[k * Q2_NB + ((r + 16 * (k & 3)) & 63)] = (r0 + r < rows) ? Vb[(size_t)k * ldv + r0 + r] : 0.0;
+        }
+    }
+    // tile t+1's operands (the A2 tile, row-contiguous: thread = row, 16 columns each; the W2 tile) are fetched
+    // into registers while tile t is multiplied and written back: latency hidden, read-modify-write coalesced
+    double at[16], wt[16], atn[16];
+    auto fetch = [&](int j0, double *ta, double *tw2) {
+        if (r0 + Q2_NB <= rows && j0 + Q2_NB < ncols) {      // interior tile of A2: unconditional fetches
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                ta[q] = (A + (size_t)(cend + j0 + w * 16 + q) * M + c0 + r0)[lane];
+                const int e = tid + q * 256;
+                tw2[q] = W2[(size_t)j0 * Q2_NB + e];                  // (column j0 + e / 64, entry e % 64)
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cidx = j0 + w * 16 + q;
+                const int ac = cend + cidx;
+                ta[q] = (rin && cidx < ncols) ? ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] : 0.0;
+                const int e = tid + q * 256, cw = e / Q2_NB, kk = e % Q2_NB;     // W2 column j0 + cw, entry kk
+                tw2[q] = (j0 + cw < ncols) ? W2[(size_t)(j0 + cw) * Q2_NB + kk] : 0.0;
+            }
+        }
+    };
+    if (cg * Q2_UCT * Q2_NB < ncols) fetch(cg * Q2_UCT * Q2_NB, at, wt);
+    for (int t = 0; t < Q2_UCT; ++t) {
+        const int j0 = (cg * Q2_UCT + t) * Q2_NB;
+        if (j0 >= ncols) break;                        // (uniform)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + q * 256, cw = e / Q2_NB, kk = e % Q2_NB;
+            sW[cw * Q2_NB + ((kk + 2 * (cw & 15)) & 63)] = wt[q];
+        }
+        __syncthreads();
+        const bool more = t + 1 < Q2_UCT && j0 + Q2_NB < ncols;
+        if (more) fetch(j0 + Q2_NB, atn, wt);
+        v4d_qr acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = (v4d_qr){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < Q2_NB; kk += 4) {
+            const int ko = kk + (lane >> 4);
+            const int rot = 16 * (ko & 3);
+            const int c0w = wc + (lane & 15), c1w = wc + 16 + (lane & 15);
+            const double a0 = sV[ko * Q2_NB + ((wr + (lane & 15) + rot) & 63)];
+            const double a1 = sV[ko * Q2_NB + ((wr + 16 + (lane & 15) + rot) & 63)];
+            const double b0 = sW[c0w * Q2_NB + ((ko + 2 * (c0w & 15)) & 63)];
+            const double b1 = sW[c1w * Q2_NB + ((ko + 2 * (c1w & 15)) & 63)];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();                                 // every wave is done with the W2 image
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wr + a * 16 + (lane >> 4) + 4 * r;
+                    const int cidx = wc + b * 16 + (lane & 15);
+                    sW[cidx * CS + row] = acc[a][b][r];
+                }
+        __syncthreads();
+        if (r0 + Q2_NB <= rows && j0 + Q2_NB < ncols) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cl = w * 16 + q;
+                (A + (size_t)(cend + j0 + cl) * M + c0 + r0)[lane] = at[q] - sW[cl * CS + lane];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cl = w * 16 + q, cidx = j0 + cl;
+                if (rin && cidx < ncols) {
+                    const int ac = cend + cidx;
+                    ((ac < n ? A + (size_t)ac * M : rhs) + c0 + r0)[lane] = at[q] - sW[cl * CS + lane];
+                }
+            }
+        }
+        __syncthreads();                                 // the product image is consumed before the next W2 tile lands
+#pragma unroll
+        for (int q = 0; q < 16; ++q) at[q] = atn[q];
+    }
+}
+
+// R (upper triangle of the factored A, zeros below) and the first n entries of Q1'b -> stage-2 operands
+__global__ void __launch_bounds__(256)
+k_qr1_extract(const double *__restrict__ A, int M, int n, const double *__restrict__ rhs, double *__restrict__ R,
+              double *__restrict__ rhs2) {
+    const long long tot = (long long)n * n;
+    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e % n), cidx = (int)(e / n);
+        R[e] = r <= cidx ? A[(size_t)cidx * M + r] : 0.0;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) rhs2[i] = rhs[i];
+}
+
+static void qr2_free(void *p) {
+    Qr2Work *q = (Qr2Work *)p;
+    if (!q) return;
+    hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
+    hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
+    hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn); hipFree(q->tsS[0]); hipFree(q->tsS[1]); hipFree(q->tsr[0]); hipFree(q->tsr[1]);
+    if (q->h_fro) hipHostFree(q->h_fro);
+    lsq_cqr_free(&q->cq);
+    delete q;
+}
+
+static bool qr2_applies(int M, int n) {
+    const bool off = getenv("LSQ_QR_ONE_STAGE") != nullptr;     // (read per call: the tests flip them)
+    const bool force = getenv("LSQ_QR_TWO_STAGE") != nullptr;
+    if (off || M < n || n < 2) return false;
+    // (measured crossover against the one-workgroup / two-launch pivoted kernels: 20 x 5 0.06 vs 0.13 ms,
+    //  100 x 20 0.24 vs 0.17, 200 x 50 0.78 vs 0.25, 2000 x 400 10.1 vs 1.7)
+    return force || (n >= 16 && (long long)M * n >= 1600) || (n >= 2 && (long long)M * n >= 20000);   // (tall and thin: 100000 x 10 1.2 vs 8.0 ms)
+}
+
+// factors [A | b] (s->d_qr, s->d_qu) and leaves R2, pivots (jp) and Q'b for k_qrcp_solve(phase 0) in the
+// stage-2 buffers; returns them through the out parameters
+static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, double **R_out, double **rhs_out);
+// tall and thin operands (n <= 32, many rows): level 0 of a TSQR -- one pass over the matrix, every workgroup
+// factors its own slab in registers -- then the stacked triangles go through the regular panel machinery
+static int qr2_tsqr_slab_rows(int n) {   // rows of a 256-thread slab ((K + 1) * RPT doubles of registers per thread); a wave slab is a quarter
+    return 256 * (n <= 8 ? 8 : n <= 12 ? 6 : n <= 16 ? 4 : n <= 24 ? 3 : 2);
+}
+static bool qr2_tsqr_applies(int M, int n) {
+    if (getenv("LSQ_QR_NO_TSQR") || n > 32 || n < 2) return false;
+    return M >= 32768;
+}
+static int qr2_workspace(lsq_solver *s, int M, int n);
+
+static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_out) {
+    lsq_ctx *c = s->ctx;
+    LSQ_TRY(qr2_workspace(s, M, n));
+    Qr2Work *q = (Qr2Work *)s->qr2;
+    if (qr2_tsqr_applies(M, n)) {
+        // levels of wave slabs (64 * RPT rows each) until the stack is short enough for the panel machinery
+        const int L = qr2_tsqr_slab_rows(n) / 4;
+        double *Acur = s->d_qr, *bcur = s->d_qu;
+        int Mcur = M;
+        for (int level = 0; level < 6 && qr2_tsqr_applies(Mcur, n); ++level) {
+            const int S = lsq_div_up(Mcur, L), Ms = S * n;
+            if (!q->tsS[0]) {
+                for (int u = 0; u < 2; ++u) {
+                    LSQ_HIP(hipMalloc(&q->tsS[u], ((size_t)Ms * n + 32768) * sizeof(double)));
+                    LSQ_HIP(hipMalloc(&q->tsr[u], ((size_t)Ms + 32768) * sizeof(double)));
+                }
+            }
+            double *So = q->tsS[level & 1], *ro = q->tsr[level & 1];
+            auto go = [&](auto kern, int slabs_per_block) {
+                hipLaunchKernelGGL(kern, dim3(lsq_div_up(S, slabs_per_block)), dim3(256), 0, c->stream, Acur, Mcur, n, 0, n, q->tau1,
+                                   q->lazy, q->lazy + n, S, q->xslot, ++q->epoch, q->d_err, q->Pn, 0, bcur, So, Ms, ro);
+            };
+            if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, 2>, 4);
+            else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, 2>, 4);
+            else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, 2>, 4);
+            else if (n <= 20) go(k_qr1_step_multi<256, 3, 20, 1, 2>, 4);
+            else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, 2>, 4);
+            else if (n <= 28) go(k_qr1_step_multi<256, 2, 28, 1, 2>, 4);
+            else go(k_qr1_step_multi<256, 2, 32, 1, 2>, 4);
+            Acur = So; bcur = ro; Mcur = Ms;
+        }
+        LSQ_HIP(hipGetLastError());
+        return qr2_factor_core(s, Acur, bcur, Mcur, n, R_out, rhs_out);
+    }
+    return qr2_factor_core(s, s->d_qr, s->d_qu, M, n, R_out, rhs_out);
+}
+
+static int qr2_workspace(lsq_solver *s, int M, int n) {
+    lsq_ctx *c = s->ctx;
+    Qr2Work *q = (Qr2Work *)s->qr2;
+    if (!q || q->M != M || q->n != n) {
+        qr2_free(q);
+        q = new Qr2Work();
+        q->M = M; q->n = n;
+        const int ncolsB = Q2_NB + n + 1;
+        const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
+        q->kslices = std::max(1, std::min(64, (4 * c->num_cus + ntile - 1) / ntile));   // (4 workgroups per CU: their barriers and LDS phases interleave)
+        LSQ_HIP(hipMalloc(&q->Vb, ((size_t)M * Q2_NB + 64) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->Wp, (size_t)q->kslices * ntile * Q2_NB * Q2_NB * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->W, (size_t)ntile * Q2_NB * Q2_NB * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->W2, (size_t)ntile * Q2_NB * Q2_NB * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->R, ((size_t)n * n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->rhs2, ((size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->tau1, ((size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->vn, (4 * (size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->ice, (2 * (size_t)n + 8) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->lazy, (2 * (size_t)n + 8) * sizeof(double)));
+        const size_t smax = M > 64 * 32 * 256 ? 256 : M > 8 * 10 * 256 ? 64 : 8;
+        const size_t xs = (size_t)64 * smax * 8 * 18 * 2 * sizeof(unsigned long long);
+        LSQ_HIP(hipMalloc(&q->xslot, xs));
+        LSQ_HIP(hipMalloc(&q->d_err, sizeof(int)));
+        LSQ_HIP(hipMalloc(&q->Pn, ((size_t)M * Q2_NB + 32768) * sizeof(double)));
+        LSQ_ZERO(q->xslot, 0, xs);
+        LSQ_ZERO(q->d_err, 0, sizeof(int));
+        LSQ_HIP(hipMalloc(&q->colat, (2 * (size_t)n + 8) * sizeof(int)));
+        s->qr2 = q;
+        s->qr2_free = qr2_free;
+    }
+    return LSQ_OK;
+}
+
+// the factorisation proper on [A | rhs] (A: M rows, column stride M); the workspace was sized for at least M rows
+static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, double **R_out, double **rhs_out) {
+    lsq_ctx *c = s->ctx;
+    Qr2Work *q = (Qr2Work *)s->qr2;
+    // CholeskyQR2 panels (lsq_qr_cholqr.hip) need the error word to travel back with the certificate's copy
+    const bool cq_ok = !q->no_cholqr && !getenv("LSQ_QR1_NO_CHOLQR") && !getenv("LSQ_QR_ALWAYS_PIVOT");
+    q->cholqr_used = false;
+    for (int c0 = 0; c0 < n; c0 += Q2_NB) {
+        const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
+        if (cq_ok && nb == Q2_NB && M - c0 >= 256) {
+            // panel: two Gram / Cholesky passes, no column-by-column chain; block reflector in basis-kernel form
+            if (!q->cq.ready) LSQ_TRY(lsq_cqr_alloc(c, &q->cq, q->M));
+            q->cholqr_used = true;
+            const int rows = M - c0, ldv = rows;
+            LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, q->Vb, ldv, q->d_err));
+            const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
+            const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
+            int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
+            hipLaunchKernelGGL(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
+                               q->Wp);
+            {
+                long long tot = (long long)ntile * Q2_NB * Q2_NB;
+                int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
+                hipLaunchKernelGGL(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
+            }
+            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
+            {
+                const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
+                hipLaunchKernelGGL(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M,
+                                   c0, cend, n, rhs, ncols, q->W2);
+            }
+            continue;
+        }
+        bool lazy = false;
+        int side_k = 0;   // > 0: later pivot columns of a launch sit in the side panel
+        // last panel: b rides through the steps as one more target column, so no block update is left to do
+        const bool ride = cend == n;
+        bool rode = false;
+        auto steps = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(1), dim3(QR_NT), 0, c->stream, A, M, cend, c0, 1, q->tau1);
+            for (int i = c0; i + 1 < cend; ++i)
+                hipLaunchKernelGGL(kern, dim3(cend - i - 1), dim3(QR_NT), 0, c->stream, A, M, cend, i, 0, q->tau1);
+        };
+        auto steps_multi = [&](auto kern, int nt, int K, int S) {
+            for (int i = c0; i < cend; i += K) {
+                const int kk = std::min(K, cend - i), G = std::max(1, cend - i - kk + (ride ? 1 : 0));
+                const int grid = S >= 64 ? G * S : S > 1 ? 8 * S * ((G + 7) / 8) : G;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), 0, c->stream, A, M, cend, i, kk, q->tau1, q->lazy, q->lazy + n, G,
+                                   q->xslot, ++q->epoch, q->d_err, q->Pn, c0, ride ? rhs : (double *)nullptr,
+                                   (double *)nullptr, 0, (double *)nullptr);
+            }
+            lazy = true;
+            side_k = K;
+            rode = ride;
+        };
+        const int prow = M - c0;
+        // slabs (S > 1) need every CU of an unpartitioned device; LSQ_QR1_COOP=0 keeps one workgroup per column
+        const char *cv = getenv("LSQ_QR1_COOP");
+        const int coop = c->num_cus < 256 || q->no_exchange ? 0 : cv ? atoi(cv) : 1;
+        if (coop && prow > 2 * 8 * 256 && prow <= 4 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 4>, 256, 4, 4);
+        else if (coop && prow > 4 * 8 * 256 && prow <= 8 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 8>, 256, 4, 8);
+        else if (coop && prow > 8 * 8 * 256 && prow <= 8 * 10 * 256) steps_multi(k_qr1_step_multi<256, 10, 4, 8>, 256, 4, 8);
+        // tall operands: more slabs (the exchange of a round grows with S; there are few columns to pay it)
+        else if (coop && prow > 8 * 10 * 256 && prow <= 8 * 16 * 256) steps_multi(k_qr1_step_multi<256, 16, 4, 8>, 256, 4, 8);
+        else if (coop && prow > 8 * 16 * 256 && prow <= 32 * 16 * 256) steps_multi(k_qr1_step_multi<256, 16, 4, 32>, 256, 4, 32);
+        else if (coop && prow > 32 * 16 * 256 && prow <= 64 * 32 * 256) steps_multi(k_qr1_step_multi<256, 32, 2, 64>, 256, 2, 64);
+        else if (coop && prow > 64 * 32 * 256 && prow <= 256 * 32 * 256) steps_multi(k_qr1_step_multi<256, 32, 2, 256>, 256, 2, 256);
+        else if (coop && prow > 8 * 256 && prow <= 2 * 8 * 256) steps_multi(k_qr1_step_multi<256, 8, 4, 2>, 256, 4, 2);
+        else if (prow <= 8 * 512) steps_multi(k_qr1_step_multi<512, 8, 4, 1>, 512, 4, 1);
+        else if (prow <= 8 * 1024) steps_multi(k_qr1_step_multi<512, 16, 4, 1>, 512, 4, 1);
+        else if (prow <= 32 * 512) steps_multi(k_qr1_step_multi<512, 32, 2, 1>, 512, 2, 1);
+        else if (prow <= 40 * 512) steps_multi(k_qr1_step_multi<512, 40, 2, 1>, 512, 2, 1);
+        else steps(k_qr1_step);     // (taller than 20480 rows with the slab exchange off: the plain per-column loop)
+        if (rode) {
+            hipLaunchKernelGGL(k_qr1_fin, dim3(1), dim3(256), 0, c->stream, A, M, c0, nb, (const double *)q->lazy,
+                               side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
+            continue;
+        }
+        // block update of the trailing columns and of b
+        const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
+        const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
+        const int rows = M - c0, ldv = rows;
+        {
+            long long tot = (long long)rows * Q2_NB;
+            int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 8);
+            hipLaunchKernelGGL(k_qr1_vbuf, dim3(g), dim3(256), 0, c->stream, A, M, c0, nb, q->Vb, ldv,
+                               lazy ? (const double *)q->lazy : (const double *)nullptr,
+                               lazy ? (const double *)(q->lazy + n) : (const double *)nullptr,
+                               side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
+        }
+        int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
+        hipLaunchKernelGGL(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
+                           q->Wp);
+        {
+            long long tot = (long long)ntile * Q2_NB * Q2_NB;
+            int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
+            hipLaunchKernelGGL(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
+        }
+        hipLaunchKernelGGL(k_qr1_tw_mfma, dim3(std::max(1, lsq_div_up(ncols, Q2_NB))), dim3(256), 0, c->stream, q->W, ncolsB,
+                               q->tau1, c0, nb, q->W2);
+        {
+            const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
+            hipLaunchKernelGGL(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols,
+                               q->W2);
+        }
+    }
+    {
+        long long tot = (long long)n * n;
+        int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 8);
+        hipLaunchKernelGGL(k_qr1_extract, dim3(g), dim3(256), 0, c->stream, A, M, n, rhs, q->R, q->rhs2);
+    }
+    LSQ_HIP(hipGetLastError());
+    s->last_qr_panel = q->cholqr_used ? 2 : 1;
+    *R_out = q->R;
+    *rhs_out = q->rhs2;
+    return LSQ_OK;
+}
+
+bool lsq_qr2_applies(int M, int n) { return qr2_applies(M, n); }
+int lsq_qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_out) { return qr2_factor(s, M, n, R_out, rhs_out); }

@@ -78,7 +78,7 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
     LSQ_HIP(hipMalloc(&S.d_tiles, tiles.size() * sizeof(int)));
     LSQ_HIP(hipMemcpy(S.d_tiles, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
     // big tiles for the LDS-staged stream kernel (only worth it on large patterns)
-    if (S.plan == LSQ_PLAN_STREAM && group == 0 && S.nnz >= (1 << 20) && !getenv("LSQ_NO_LDS_X")) {
+    if (S.plan == LSQ_PLAN_STREAM && group == 0 && S.nnz >= (1 << 20)) {
         // size the big tiles so that every persistent workgroup (one per CU) gets the same count
         std::vector<int> big;
         long long per_round = (long long)LSQ_BIG_NNZ * c->num_cus;
@@ -97,7 +97,7 @@ static int upload_segs(lsq_ctx *c, LsqSegs &S, const std::vector<int> &ptr, cons
         }
         LSQ_HIP(hipMalloc(&S.d_big, (bm.size() + 4) * sizeof(int)));
         LSQ_HIP(hipMemcpy(S.d_big, bm.data(), bm.size() * sizeof(int), hipMemcpyHostToDevice));
-        if (S.nbig > 0 && S.nx <= 65535 && !getenv("LSQ_NO_IDX16")) {  // 10 B/nnz instead of 12
+        if (S.nbig > 0 && S.nx <= 65535) {  // 10 B/nnz instead of 12
             std::vector<unsigned short> i16(S.nnz + pad, 0);
             for (long long k = 0; k < S.nnz; ++k) i16[k] = (unsigned short)idx[k];
             LSQ_HIP(hipMalloc(&S.d_idx16, i16.size() * sizeof(unsigned short)));
@@ -282,7 +282,7 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
     const bool sell_force = getenv("LSQ_SELL_FORCE") != nullptr;   // tests: sliced layouts on small patterns too
     const bool sell_ok = !getenv("LSQ_NO_SELL") && (sell_force || nnz >= (1 << 20)) && nnz > 0;
     // sliced rows for J*x: the whole gather vector must fit in LDS next to the 4096-row output window
-    if (sell_ok && !getenv("LSQ_NO_SELL_ROWS") && J->csr.plan == LSQ_PLAN_STREAM && n <= LSQ_LDS_X_MAX && n >= 1) {
+    if (sell_ok && J->csr.plan == LSQ_PLAN_STREAM && n <= LSQ_LDS_X_MAX && n >= 1) {
         int per_cu = (m + c->num_cus - 1) / c->num_cus;
         int rounds = (per_cu + LSQ_SELL_ROWS_MAX - 1) / LSQ_SELL_ROWS_MAX;
         int wrows = (m + rounds * c->num_cus - 1) / (rounds * c->num_cus);
@@ -304,7 +304,7 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
         }
     }
     // sliced columns for J'*y: gather windows of <= 8192 rows of y in LDS, <= 5120 output columns per block
-    if (sell_ok && !getenv("LSQ_NO_SELL_COLS") && (sell_force || m > 131072) && n >= 1 && !getenv("LSQ_PLAN_BCSC") && !getenv("LSQ_WINDOW_ROWS")) {
+    if (sell_ok && (sell_force || m > 131072) && n >= 1 && !getenv("LSQ_PLAN_BCSC") && !getenv("LSQ_WINDOW_ROWS")) {
         const int ncb = (n + LSQ_SELL_CCOLS_MAX - 1) / LSQ_SELL_CCOLS_MAX;
         const int ccols = (n + ncb - 1) / ncb;
         const int ngw_min = (m + LSQ_SELL_GROWS_MAX - 1) / LSQ_SELL_GROWS_MAX;
@@ -409,7 +409,7 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
                     LSQ_HIP(hipMemcpy(J->bcsc.d_wtile, wt.data(), wt.size() * sizeof(int), hipMemcpyHostToDevice));
                     J->bcsc.nbig = nb;
                     J->bcsc.plan = LSQ_PLAN_LDSWIN;
-                    if (!getenv("LSQ_NO_IDX16")) {  // in-window row offsets (< 4096) in 16 bits
+                    {  // in-window row offsets (< 4096) in 16 bits
                         std::vector<unsigned short> i16(nnz + 8, 0);
                         for (long long k = 0; k < nnz; ++k) i16[k] = (unsigned short)(bidx[k] % rw);
                         LSQ_HIP(hipMalloc(&J->bcsc.d_idx16, i16.size() * sizeof(unsigned short)));
