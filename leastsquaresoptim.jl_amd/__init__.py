@@ -9,7 +9,7 @@ from .api import (axpy_, box_clip_, clamp_, copyto_, ediv_, fill_, first_nonfini
                   colsumabs2_, rowsumabs2_, converged, default_context, default_optimizer, default_solver,
                   maxabs, maxabs_projected_gradient, mul_, norm, optimize, optimize_, set_exact, sumsq, wdot,
                   wnorm)
-from . import loops, sharding, synthetic
+from . import loops, rowshard, sharding, synthetic
 from .loops import optimize_operator_level
 
 __all__ = [n for n in dir() if not n.startswith("_")]
