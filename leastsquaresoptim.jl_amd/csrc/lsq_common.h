@@ -182,6 +182,10 @@ struct lsq_mat {
     bool csr_fresh = false;
     bool csc_fresh = true;  // false: a device g! wrote the mirrors only (see lsq_ensure_csc)
     bool upload_pending = false;   // lsq_mat_set_values_async: the host buffer is still being read
+    // a device-side g! of the form J = A diag(s) may leave the sliced COLUMN copy unmaterialised: the next pass over it
+    // (gradient + colsumabs2, right after g! in both loops) scales A's entries as it streams them and writes the copy
+    const double *cols_pending_src = nullptr;     // A's values in the sliced-column layout
+    const double *cols_pending_scale = nullptr;   // s (n entries)
     // Row-window-blocked CSC for J'*y when the gathered m-vector outgrows an XCD's L2 (4 MiB):
     // rows are cut into `nwin` windows; segment (w, j) holds column j's entries with rows in
     // window w, so all gathers of a window hit a <= 1 MiB slice of y that stays L2-resident on

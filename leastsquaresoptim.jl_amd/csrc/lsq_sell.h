@@ -40,9 +40,13 @@ struct SellDev {
 };
 
 // all products of one lane's output inside one slice, added in index order
-template <bool SQ>
+// SCALE: the stored values are `vp[..] * sc` (a column-scaled model Jacobian J = A diag(s) whose column copy has not been
+// materialised yet): every value pair is scaled as it is loaded and written to `dp` at the same offset, so that this pass IS
+// the materialisation (the padding entries are zeros in the source and stay zeros).
+template <bool SQ, bool SCALE = false>
 __device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L,
-                                              int len, const double *xl, double &sum, double &sq) {
+                                              int len, const double *xl, double &sum, double &sq, double sc = 1.0,
+                                              double *__restrict__ dp = nullptr) {
     int j = 0;
     for (; j + 8 <= L; j += 8) {   // four 20-byte groups in flight per lane
         double2 a[4];
@@ -51,6 +55,14 @@ __device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, con
         for (int u = 0; u < 4; ++u) {
             a[u] = *reinterpret_cast<const double2 *>(vp + (size_t)(j / 2 + u) * 128);
             c[u] = *reinterpret_cast<const unsigned *>(ip + (size_t)(j / 2 + u) * 128);
+        }
+        if constexpr (SCALE) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u].x *= sc;
+                a[u].y *= sc;
+                *reinterpret_cast<double2 *>(dp + (size_t)(j / 2 + u) * 128) = a[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -73,8 +85,13 @@ __device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, con
         }
     }
     for (; j < L; j += 2) {
-        const double2 a = *reinterpret_cast<const double2 *>(vp + (size_t)(j / 2) * 128);
+        double2 a = *reinterpret_cast<const double2 *>(vp + (size_t)(j / 2) * 128);
         const unsigned c = *reinterpret_cast<const unsigned *>(ip + (size_t)(j / 2) * 128);
+        if constexpr (SCALE) {
+            a.x *= sc;
+            a.y *= sc;
+            *reinterpret_cast<double2 *>(dp + (size_t)(j / 2) * 128) = a;
+        }
         double p0 = a.x * xl[c & 0xffffu], p1 = a.y * xl[c >> 16];
         asm volatile("" : "+v"(p0), "+v"(p1));
         const bool in0 = j < len, in1 = j + 1 < len;
@@ -151,10 +168,13 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
 
 // ---- J'*y: per (gather window, column) partial sums; k_combine adds the windows ----------------
 // block b = gw * ncb + cb; part layout [gw][n] (SQ: [gw][2n] = dots | squares)
-template <bool SQ>
+// SCALE (see sell_lane_sum): S.val is the UNSCALED source, `scale[col]` the column factors, `dval` the layout's own value
+// array, which this pass fills.
+template <bool SQ, bool SCALE = false>
 __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, int ccols, int grows, int m, int n,
                                                           const double *__restrict__ y, double *__restrict__ part,
-                                                          const int *done) {
+                                                          const int *done, const double *__restrict__ scale = nullptr,
+                                                          double *__restrict__ dval = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *yl = smem;                          // LSQ_SELL_GROWS_MAX doubles
     double *ow = smem + LSQ_SELL_GROWS_MAX;     // LSQ_SELL_CCOLS_MAX doubles (+ the same again for SQ)
@@ -187,10 +207,16 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, in
         for (int s = s0 + wv; s < s1; s += LSQ_BIG_NT / 64) {
             const int2 sm = S.smeta[__builtin_amdgcn_readfirstlane(s)];
             const unsigned inf = S.info[(size_t)s * 64 + lane];
-            double sum = 0.0, sq = 0.0;
-            sell_lane_sum<SQ>(S.val + (size_t)sm.x + lane * 2, S.idx16 + (size_t)sm.x + lane * 2, sm.y,
-                              (int)(inf >> LSQ_SELL_POS_BITS), yl, sum, sq);
             const unsigned pos = inf & LSQ_SELL_POS_MASK;
+            double sum = 0.0, sq = 0.0;
+            if constexpr (SCALE) {
+                const double sc = pos != LSQ_SELL_POS_MASK ? scale[cbase + (int)pos] : 0.0;    // (lane = one column of the block)
+                sell_lane_sum<SQ, true>(S.val + (size_t)sm.x + lane * 2, S.idx16 + (size_t)sm.x + lane * 2, sm.y,
+                                        (int)(inf >> LSQ_SELL_POS_BITS), yl, sum, sq, sc, dval + (size_t)sm.x + lane * 2);
+            } else {
+                sell_lane_sum<SQ>(S.val + (size_t)sm.x + lane * 2, S.idx16 + (size_t)sm.x + lane * 2, sm.y,
+                                  (int)(inf >> LSQ_SELL_POS_BITS), yl, sum, sq);
+            }
             if (pos != LSQ_SELL_POS_MASK) {
                 ow[pos] = sum;
                 if constexpr (SQ) ow2[pos] = sq;

@@ -592,6 +592,7 @@ int lsq_ensure_csc(lsq_mat *J) {
 // refreshes every mirror of the user-visible CSC values
 int lsq_ensure_csr(lsq_mat *J) {
     if (J->kind != LSQ_MAT_CSC || J->csr_fresh) return LSQ_OK;
+    J->cols_pending_src = J->cols_pending_scale = nullptr;   // (every mirror is rebuilt from the CSC copy below)
     LSQ_TRY(lsq_mirror_rows(J, J->csc.d_val, J->srows.active ? J->srows.d_val : J->csr.d_val));
     LSQ_TRY(lsq_mirror_cols(J, J->csc.d_val, J->scols.active ? J->scols.d_val : J->bcsc.d_val));
     J->csr_fresh = true;

@@ -833,22 +833,47 @@ static inline int launch_sell_rows(lsq_mat *J, const double *val, const double *
     return LSQ_OK;
 }
 
+// sliced-column copy of a column-scaled Jacobian that was left unmaterialised (lsq_mat::cols_pending_*): plain element-wise
+// materialisation, for consumers other than the fused gradient pass
+static __global__ void __launch_bounds__(LSQ_NT) k_sell_scale_cols(long long count, const unsigned short *__restrict__ col16,
+                                                            const double *__restrict__ src, const double *__restrict__ s,
+                                                            double *__restrict__ dst) {
+    for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < count; k += (long long)gridDim.x * LSQ_NT)
+        dst[k] = src[k] * s[col16[k]];
+}
+
 // first pass of J'*y over the sliced columns: per gather-window partials into J->scols.d_part
 template <bool SQ>
 static inline int launch_sell_cols(lsq_mat *J, const double *y, const int *done) {
     lsq_ctx *c = J->ctx;
     const LsqSell &S = J->scols;
     const size_t lds = (size_t)(LSQ_SELL_GROWS_MAX + (SQ ? 2 : 1) * LSQ_SELL_CCOLS_MAX) * sizeof(double);
+    if (J->cols_pending_src) {
+        const double *src = J->cols_pending_src, *scale = J->cols_pending_scale;
+        J->cols_pending_src = J->cols_pending_scale = nullptr;
+        if (SQ && !done) {   // the gradient + colsumabs2 pass right after g!: it materialises the copy as it goes
+            auto kern = k_sell_cols<SQ, true>;
+            LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
+            const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S, src), S.ncb, S.ccols, S.grows,
+                               J->m, J->n, y, S.d_part, done, scale, S.d_val);
+            LSQ_HIP(hipGetLastError());
+            return LSQ_OK;
+        }
+        const int g = (int)std::min<long long>((S.nstore + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
+        hipLaunchKernelGGL(k_sell_scale_cols, dim3(std::max(1, g)), dim3(LSQ_NT), 0, c->stream, (long long)S.nstore, S.d_col16, src,
+                           scale, S.d_val);
+    }
     auto kern = k_sell_cols<SQ>;
     LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
     hipEvent_t e0, e1;
     if (lsq_prof_take(c, &e0, &e1))
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.ncb, S.ccols,
-                              S.grows, J->m, J->n, y, S.d_part, done);
+                              S.grows, J->m, J->n, y, S.d_part, done, (const double *)nullptr, (double *)nullptr);
     else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.ncb, S.ccols, S.grows,
-                           J->m, J->n, y, S.d_part, done);
+                           J->m, J->n, y, S.d_part, done, (const double *)nullptr, (double *)nullptr);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
