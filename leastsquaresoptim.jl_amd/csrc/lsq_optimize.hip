@@ -396,6 +396,25 @@ static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, i
                        pub);
     return LSQ_OK;
 }
+// f!(out, x) followed by sum(out.^2) -> slot.  When f! is the library's own device-side model on the sliced-row layout the
+// sum rides in the residual kernel's epilogue (no second pass over the m-vector: 8 MB and a launch less per iteration at C4)
+static int model_f(double *out, const double *x, void *user);
+static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done);
+static int f_then_sumsq(lsq_ctx *c, bool exact, lsq_f_callback f, void *user, long long m, double *out, const double *x, int ctr,
+                        double *d_out, LsqSlotPublish pub = LsqSlotPublish()) {
+    if (!exact && f == model_f) {
+        bool fused = false;
+        if (model_f_sumsq(user, out, x, ctr, d_out, pub, &fused) != 0) {
+            lsq_set_error("user callback reported failure");
+            return LSQ_ECALLBACK;
+        }
+        if (fused) return LSQ_OK;
+    } else if (f(out, x, user) != 0) {
+        lsq_set_error("user callback reported failure");
+        return LSQ_ECALLBACK;
+    }
+    return sumsq_to_slot(c, exact, m, out, ctr, d_out, pub);
+}
 // sum((J d - f)^2) -> slot (f may be null: sum((J d)^2))
 static int predicted_to_slot(lsq_ctx *c, bool exact, lsq_mat *J, const double *d, const double *f, double *scratch,
                              int ctr, double *d_out, LsqSlotPublish pub = LsqSlotPublish());
@@ -713,11 +732,10 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             // the predicted residual (:114-117) does not depend on f!(x_trial): formed first, while the
             // row copy of J that the last LSMR iterations streamed is still (partly) in the Infinity Cache
             LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));
-            CB(f(ftrial, xt, user));                                      // :107
-            f_calls++;
-            // the last kernel of the iteration hands the scalars to the host
+            // f!(x_trial) and sum(abs2, ftrial) (:107, :111); the last kernel of the iteration hands the scalars to the host
             LsqSlotPublish pub = lsq_slots_ticket(c, SL_GRAD, 5);
-            LSQ_TRY(sumsq_to_slot(c, exact, m, ftrial, 7, c->d_slots + SL_TRIAL, pub));              // :111
+            LSQ_TRY(f_then_sumsq(c, exact, f, user, m, ftrial, xt, 7, c->d_slots + SL_TRIAL, pub));
+            f_calls++;
             LSQ_HIP(hipGetLastError());
             LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, pub.seq, sl));
         }
@@ -886,9 +904,8 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
         hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
                            lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN);    // :160
         LSQ_HIP(hipGetLastError());
-        CB(f(b.ftrial, b.xt, user));                                      // :164
+        LSQ_TRY(f_then_sumsq(c, exact, f, user, m, b.ftrial, b.xt, 7, c->d_slots + SL_TRIAL));   // :164, :168
         f_calls++;
-        LSQ_TRY(sumsq_to_slot(c, exact, m, b.ftrial, 7, c->d_slots + SL_TRIAL));
         LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));  // :171-174
         mul_calls++;
         double sl[4];
@@ -1022,6 +1039,35 @@ struct EpiResidual {  // out = A t - b
     __device__ void finalize(double) const {}
 };
 
+struct EpiResidualSq {  // out = A t - b, and sum(out.^2) -> slot (+ the iteration's scalars to the host, like EpiPredict)
+    static constexpr bool REDUCE = true;
+    const int *done;
+    int extra_blocks;
+    const double *b;
+    double *out;
+    double *partials;
+    unsigned *counter;
+    double *slot;
+    LsqSlotPublish pub;
+    __device__ void seg(int i, double dot, double &racc) const { seg_pre(i, dot, b[i], racc); }
+    using has_pre = void;
+    __device__ double pre(int i) const { return b[i]; }
+    __device__ void seg_pre(int i, double dot, double bi, double &racc) const {
+        const double v = dot - bi;
+        out[i] = v;
+        racc += v * v;
+    }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double t) const {
+        *slot = t;
+        if (pub.count > 0) {
+            for (int i = 0; i < pub.count; ++i)
+                __hip_atomic_store(pub.dst + i, pub.src + i == slot ? t : pub.src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub.seq_word, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+};
+
 // column scaling of a column-segmented value array (CSC nzval or dense columns)
 __global__ void __launch_bounds__(LSQ_NT)
 k_scale_cols(int n, const int *__restrict__ colptr, int m_dense, const double *__restrict__ A,
@@ -1131,6 +1177,20 @@ static int model_f(double *out, const double *x, void *user) {
         tmp.d_dense = md->d_Acsc;
         if (launch_product(&tmp, 0, md->d_t, e) != LSQ_OK) return 1;
     }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// f! + sum(abs2, out) in one pass (sliced rows only; *done tells whether it applied)
+static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done) {
+    lsq_model *md = (lsq_model *)user;
+    lsq_ctx *c = md->ctx;
+    lsq_mat *J = md->J;
+    *done = false;
+    if (!(J->kind == LSQ_MAT_CSC && J->srows.active)) return model_f(out, x, user);
+    hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+    EpiResidualSq e{nullptr, 0, md->d_b, out, c->d_partials, lsq_ctr(c, ctr), d_out, pub};
+    if (launch_sell_rows(J, md->d_Acsr, md->d_t, e) != LSQ_OK) return 1;
+    *done = true;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
