@@ -1017,6 +1017,10 @@ struct lsq_model {
     double *d_Ab = nullptr;    // A values in J's column-mirror layout (window-blocked CSC or sliced columns)
     double *d_b = nullptr;
     double *d_t = nullptr;     // tanh(x)
+    // J's sliced-row values at the latest trial point, written by the residual pass there (model_f_sumsq); g! at that point
+    // adopts the buffer instead of scaling A again
+    double *d_Jspec = nullptr;
+    const double *spec_x = nullptr;   // device vector the speculative values belong to (null: none)
 };
 
 __global__ void __launch_bounds__(LSQ_NT) k_tanh(int n, const double *__restrict__ x, double *__restrict__ t) {
@@ -1066,6 +1070,16 @@ struct EpiResidualSq {  // out = A t - b, and sum(out.^2) -> slot (+ the iterati
             __hip_atomic_store(pub.seq_word, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+};
+
+struct TanhJacMap {   // J = A diag(1 - t.^2) from the staged t = tanh(x) (same arithmetic as k_sfac + k_scale_lds)
+    static constexpr bool on = true;
+    double *dval;
+    __device__ double f(double t) const { return 1.0 - t * t; }
+};
+struct EpiResidualSqJac : EpiResidualSq {
+    using colmap = TanhJacMap;
+    TanhJacMap cm;
 };
 
 // column scaling of a column-segmented value array (CSC nzval or dense columns)
@@ -1160,10 +1174,16 @@ k_scale_bcsc_thread(int nseg, int n, const int *__restrict__ ptr, const double *
     }
 }
 
+// g!'s LDS-staged scaling of the row layout applies (and with it the speculative variant of the residual pass)
+static bool model_rows_by_lds(const lsq_mat *J) {
+    return J->kind == LSQ_MAT_CSC && J->srows.active && J->srows.d_idx16 && J->n <= 12000 && J->nnz >= (1 << 20);
+}
+
 static int model_f(double *out, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
     lsq_mat *J = md->J;
+    md->spec_x = nullptr;
     hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     EpiResidual e{nullptr, 0, md->d_b, out, nullptr, nullptr};
     if (J->kind == LSQ_MAT_CSC && J->srows.active) {
@@ -1189,7 +1209,21 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
     if (!(J->kind == LSQ_MAT_CSC && J->srows.active)) return model_f(out, x, user);
     hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     EpiResidualSq e{nullptr, 0, md->d_b, out, c->d_partials, lsq_ctr(c, ctr), d_out, pub};
-    if (launch_sell_rows(J, md->d_Acsr, md->d_t, e) != LSQ_OK) return 1;
+    md->spec_x = nullptr;
+    if (model_rows_by_lds(J) && !getenv("LSQ_NO_SPEC_JAC")) {
+        // x is a trial point that becomes the next linearisation point if the step is accepted: the Jacobian's row layout there
+        // costs one extra store stream in this pass (A's entries and t are already in registers / LDS)
+        if (!md->d_Jspec) {
+            const size_t rb = (size_t)(lsq_mirror_rows_len(J) + 1024) * sizeof(double);
+            if (hipMalloc(&md->d_Jspec, rb) != hipSuccess) return 1;
+            if (hipMemsetAsync(md->d_Jspec, 0, rb, c->stream) != hipSuccess) return 1;
+        }
+        EpiResidualSqJac ej{e, TanhJacMap{md->d_Jspec}};
+        if (launch_sell_rows(J, md->d_Acsr, md->d_t, ej) != LSQ_OK) return 1;
+        md->spec_x = x;
+    } else if (launch_sell_rows(J, md->d_Acsr, md->d_t, e) != LSQ_OK) {
+        return 1;
+    }
     *done = true;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -1223,7 +1257,10 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         }
         hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
         if (J->nnz > 0) {
-            if (lds_ok && rcol) {
+            if (md->spec_x == x && md->d_Jspec && J->srows.active) {
+                // the residual pass at this very point already wrote the row layout: adopt its buffer
+                std::swap(J->srows.d_val, md->d_Jspec);
+            } else if (lds_ok && rcol) {
                 hipLaunchKernelGGL(k_scale_lds<true>, dim3(c->num_cus), dim3(1024), lds, c->stream, (rlen + 3) / 4, rcol,
                                    md->d_Acsr, md->d_t, J->n, rval);
             } else if (!J->srows.active) {
@@ -1269,6 +1306,7 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         if (tot > 0)
             hipLaunchKernelGGL(k_scale_dense, dim3(J->n, chunks), dim3(LSQ_NT), 0, c->stream, J->m, md->d_Acsc, x, J->d_dense);
     }
+    md->spec_x = nullptr;
     J->version++;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -1310,7 +1348,7 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
 extern "C" int lsq_model_destroy(lsq_model *md) {
     if (!md) return LSQ_OK;
     hipStreamSynchronize(md->ctx->stream);
-    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_Ab); hipFree(md->d_b); hipFree(md->d_t);
+    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_Ab); hipFree(md->d_b); hipFree(md->d_t); hipFree(md->d_Jspec);
     delete md;
     return LSQ_OK;
 }

@@ -39,72 +39,147 @@ struct SellDev {
     int nblocks;
 };
 
-// all products of one lane's output inside one slice, added in index order
+// CM (a "column map", rows kernel only): besides the dot, every stored value times cm.f(x[col]) is written to `mp` at the same
+// offset -- a second matrix with the same pattern whose column factors are a function of the gathered vector (the model
+// Jacobian A diag(1 - t.^2) while the residual A t - b is being formed).
+struct SellNoColMap {
+    static constexpr bool on = false;
+    __device__ double f(double) const { return 0.0; }
+};
+typedef double sell_d2 __attribute__((ext_vector_type(2)));
+// One batch of U value/index pairs of a lane: ALL loads first (each lane has U 20-byte requests in flight), then the sums.
+// CLAMP: the slice has fewer than U pairs left; the surplus loads re-read the last pair and their products are dropped by the
+// `len` selection, like every padding entry.  (Measured alternatives on C4, J*v launch: skipping the surplus loads behind
+// wave-uniform branches 24.4 us against 23.7 us -- the branches split the batch; a fixed 8-wide first batch 24.5 us -- the
+// surplus gathers and adds are not free either.)
+template <int U>
+struct SellBatch {
+    double2 a[U];
+    unsigned c[U];
+};
+template <int U, bool CLAMP>
+__device__ __forceinline__ void sell_batch_load(SellBatch<U> &B, const double *__restrict__ vp, const unsigned short *__restrict__ ip,
+                                                int p0, int np) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = CLAMP ? min(p0 + u, np - 1) : p0 + u;
+        B.a[u] = *reinterpret_cast<const double2 *>(vp + (size_t)q * 128);
+        B.c[u] = *reinterpret_cast<const unsigned *>(ip + (size_t)q * 128);
+    }
+}
+template <int U, bool CLAMP, bool SQ, bool SCALE, class CM>
+__device__ __forceinline__ void sell_batch_sum(SellBatch<U> &B, int p0, int np, int len, const double *xl, double &sum, double &sq,
+                                               double sc, double *__restrict__ dp, const CM &cm, double *__restrict__ mp) {
+    if constexpr (SCALE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            B.a[u].x *= sc;
+            B.a[u].y *= sc;
+            if (!CLAMP || p0 + u < np) *reinterpret_cast<double2 *>(dp + (size_t)(p0 + u) * 128) = B.a[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        // every operand is fetched and every sum formed unconditionally; padding is dropped by SELECTION (a
+        // conditional add lets the compiler sink the value fetch into an exec-masked block behind a full
+        // s_waitcnt vmcnt(0) inside this loop).  The additions happen in entry order.
+        const double x0 = xl[B.c[u] & 0xffffu], x1 = xl[B.c[u] >> 16];
+        double p0v = B.a[u].x * x0, p1v = B.a[u].y * x1;
+        asm volatile("" : "+v"(p0v), "+v"(p1v));   // (the products exist here, whatever the selections below)
+        if constexpr (CM::on) {
+            if (!CLAMP || p0 + u < np) {
+                sell_d2 o;
+                o.x = B.a[u].x * cm.f(x0);
+                o.y = B.a[u].y * cm.f(x1);
+                __builtin_nontemporal_store(o, reinterpret_cast<sell_d2 *>(mp + (size_t)(p0 + u) * 128));
+            }
+        }
+        const int j = 2 * (p0 + u);
+        const bool in0 = j < len, in1 = j + 1 < len;   // (len <= 2 np: clamped surplus pairs are never selected)
+        const double t0 = sum + p0v;
+        sum = in0 ? t0 : sum;
+        const double t1 = sum + p1v;
+        sum = in1 ? t1 : sum;
+        if constexpr (SQ) {
+            const double q0 = sq + B.a[u].x * B.a[u].x;
+            sq = in0 ? q0 : sq;
+            const double q1 = sq + B.a[u].y * B.a[u].y;
+            sq = in1 ? q1 : sq;
+        }
+    }
+}
+
+// all products of one lane's output inside one slice (L entries per lane, even and wave-uniform; `len` of them real), added in
+// index order.  A slice of the C4 workload holds 4-10 pairs per lane: one batch, one memory round trip (the round-1 loop paid one
+// per 4 pairs plus one per leftover pair, in sequence).
 // SCALE: the stored values are `vp[..] * sc` (a column-scaled model Jacobian J = A diag(s) whose column copy has not been
 // materialised yet): every value pair is scaled as it is loaded and written to `dp` at the same offset, so that this pass IS
 // the materialisation (the padding entries are zeros in the source and stay zeros).
-template <bool SQ, bool SCALE = false>
-__device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L,
-                                              int len, const double *xl, double &sum, double &sq, double sc = 1.0,
-                                              double *__restrict__ dp = nullptr) {
-    int j = 0;
-    for (; j + 8 <= L; j += 8) {   // four 20-byte groups in flight per lane
-        double2 a[4];
-        unsigned c[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] = *reinterpret_cast<const double2 *>(vp + (size_t)(j / 2 + u) * 128);
-            c[u] = *reinterpret_cast<const unsigned *>(ip + (size_t)(j / 2 + u) * 128);
-        }
-        if constexpr (SCALE) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u].x *= sc;
-                a[u].y *= sc;
-                *reinterpret_cast<double2 *>(dp + (size_t)(j / 2 + u) * 128) = a[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            // every operand is fetched and every sum formed unconditionally; padding is dropped by SELECTION (a
-            // conditional add lets the compiler sink the value fetch into an exec-masked block behind a full
-            // s_waitcnt vmcnt(0) inside this loop).  Same additions in the same order as before.
-            double p0 = a[u].x * xl[c[u] & 0xffffu], p1 = a[u].y * xl[c[u] >> 16];
-            asm volatile("" : "+v"(p0), "+v"(p1));   // (the products exist here, whatever the selections below)
-            const bool in0 = j + 2 * u < len, in1 = j + 2 * u + 1 < len;
-            const double t0 = sum + p0;
-            sum = in0 ? t0 : sum;
-            const double t1 = sum + p1;
-            sum = in1 ? t1 : sum;
-            if constexpr (SQ) {
-                const double q0 = sq + a[u].x * a[u].x;
-                sq = in0 ? q0 : sq;
-                const double q1 = sq + a[u].y * a[u].y;
-                sq = in1 ? q1 : sq;
-            }
-        }
+template <bool SQ, bool SCALE = false, class CM = SellNoColMap>
+__device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L, int len,
+                                              const double *xl, double &sum, double &sq, double sc = 1.0,
+                                              double *__restrict__ dp = nullptr, CM cm = CM(), double *__restrict__ mp = nullptr) {
+    const int np = L >> 1;
+    int p0 = 0;
+    for (; p0 + 8 <= np; p0 += 8) {
+        SellBatch<8> B;
+        sell_batch_load<8, false>(B, vp, ip, p0, np);
+        sell_batch_sum<8, false, SQ, SCALE, CM>(B, p0, np, len, xl, sum, sq, sc, dp, cm, mp);
     }
-    for (; j < L; j += 2) {
-        double2 a = *reinterpret_cast<const double2 *>(vp + (size_t)(j / 2) * 128);
-        const unsigned c = *reinterpret_cast<const unsigned *>(ip + (size_t)(j / 2) * 128);
-        if constexpr (SCALE) {
-            a.x *= sc;
-            a.y *= sc;
-            *reinterpret_cast<double2 *>(dp + (size_t)(j / 2) * 128) = a;
-        }
-        double p0 = a.x * xl[c & 0xffffu], p1 = a.y * xl[c >> 16];
-        asm volatile("" : "+v"(p0), "+v"(p1));
-        const bool in0 = j < len, in1 = j + 1 < len;
-        const double t0 = sum + p0;
-        sum = in0 ? t0 : sum;
-        const double t1 = sum + p1;
-        sum = in1 ? t1 : sum;
-        if constexpr (SQ) {
-            const double q0 = sq + a.x * a.x;
-            sq = in0 ? q0 : sq;
-            const double q1 = sq + a.y * a.y;
-            sq = in1 ? q1 : sq;
-        }
+    const int rem = np - p0;
+    if (rem > 4) {
+        SellBatch<8> B;
+        sell_batch_load<8, true>(B, vp, ip, p0, np);
+        sell_batch_sum<8, true, SQ, SCALE, CM>(B, p0, np, len, xl, sum, sq, sc, dp, cm, mp);
+    } else if (rem > 2) {
+        SellBatch<4> B;
+        sell_batch_load<4, true>(B, vp, ip, p0, np);
+        sell_batch_sum<4, true, SQ, SCALE, CM>(B, p0, np, len, xl, sum, sq, sc, dp, cm, mp);
+    } else if (rem > 0) {
+        SellBatch<2> B;
+        sell_batch_load<2, true>(B, vp, ip, p0, np);
+        sell_batch_sum<2, true, SQ, SCALE, CM>(B, p0, np, len, xl, sum, sq, sc, dp, cm, mp);
+    }
+}
+
+// The slices of one wave (s0 + wave, + 16, ...), with the next slice's descriptor requested before the current slice's stream.
+//   `scf(pos)` -> the lane's scale factor (SCALE only), `out(pos, sum, sq)` stores a lane's result, `wdst` the value array the
+//   SCALE / column-map variants fill.
+// Contains the workgroup barrier that separates staging the gather vector from the first gather: the first descriptor is
+// requested before it.  (Requesting TWO slices per wave up front made the J*v launch slower, 29.5 us against 23.7 us: the
+// stream is not short of requests in flight, a CU's miss queue is already full with 16 waves x 5-8 KB.)
+struct SellSliceRef {
+    int2 sm;        // {entry offset, padded entry count}
+    unsigned inf;   // position | true count << 13
+};
+__device__ __forceinline__ SellSliceRef sell_slice_ref(const SellDev &S, int s, int s1, int lane) {
+    SellSliceRef r;
+    r.sm = make_int2(0, 0);
+    r.inf = LSQ_SELL_POS_MASK;
+    if (s < s1) {
+        r.sm = S.smeta[__builtin_amdgcn_readfirstlane(s)];
+        r.inf = S.info[(size_t)s * 64 + lane];
+    }
+    return r;
+}
+template <bool SQ, bool SCALE, class CM, class ScaleF, class Out>
+__device__ __forceinline__ void sell_wave_slices(const SellDev &S, int s0, int s1, int wv, int lane, const double *xl, const CM &cm,
+                                                 double *__restrict__ wdst, ScaleF scf, Out out) {
+    constexpr int NW = LSQ_BIG_NT / 64;
+    int s = s0 + wv;
+    SellSliceRef A = sell_slice_ref(S, s, s1, lane);
+    __syncthreads();
+    for (; s < s1; s += NW) {
+        const SellSliceRef a = A;
+        A = sell_slice_ref(S, s + NW, s1, lane);
+        const size_t oa = (size_t)a.sm.x + lane * 2;
+        const unsigned pos = a.inf & LSQ_SELL_POS_MASK;
+        double sc = 1.0;
+        if constexpr (SCALE) sc = pos != LSQ_SELL_POS_MASK ? scf(pos) : 0.0;
+        double *da = (SCALE || CM::on) ? wdst + oa : nullptr;
+        double sum = 0.0, sq = 0.0;
+        sell_lane_sum<SQ, SCALE, CM>(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), xl, sum, sq, sc, da, cm, da);
+        if (pos != LSQ_SELL_POS_MASK) out(pos, sum, sq);
     }
 }
 
@@ -124,6 +199,8 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
 #pragma unroll
     for (int q = 0; q < XR; ++q) xr[q] = x[min(tid + q * LSQ_BIG_NT, nx - 1)];
     const int dflag = epi.done ? *epi.done : 0;
+    const int wfirst = min((int)blockIdx.x, S.nblocks - 1);
+    const int ws0 = S.wslice[wfirst], ws1 = S.wslice[wfirst + 1];   // (slice range of the first window: same round trip)
     if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     if constexpr (EpiHasPrepare<Epi>::value) epi.prepare();
 #pragma unroll
@@ -134,22 +211,19 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
     double racc = 0.0;
     for (int w = blockIdx.x; w < S.nblocks; w += gridDim.x) {
         const int base = w * wrows, rows = min(wrows, m - base);
+        const int s0 = w == (int)blockIdx.x ? ws0 : S.wslice[w], s1 = w == (int)blockIdx.x ? ws1 : S.wslice[w + 1];
         double pre[Q];
         if constexpr (EpiHasPre<Epi>::value) {   // epilogue inputs of this window: in flight during the stream
 #pragma unroll
             for (int q = 0; q < Q; ++q) pre[q] = epi.pre(base + min(tid + q * LSQ_BIG_NT, rows - 1));
         }
-        __syncthreads();   // x staged / the previous window's epilogue is done with yw
-        const int s0 = S.wslice[w], s1 = S.wslice[w + 1];
-        for (int s = s0 + wv; s < s1; s += LSQ_BIG_NT / 64) {
-            const int2 sm = S.smeta[__builtin_amdgcn_readfirstlane(s)];
-            const unsigned inf = S.info[(size_t)s * 64 + lane];
-            double sum = 0.0, sq = 0.0;
-            sell_lane_sum<false>(S.val + (size_t)sm.x + lane * 2, S.idx16 + (size_t)sm.x + lane * 2, sm.y,
-                                 (int)(inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
-            const unsigned pos = inf & LSQ_SELL_POS_MASK;
-            if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
-        }
+        // (the barrier inside: x staged / the previous window's epilogue is done with yw)
+        if constexpr (EpiHasColMap<Epi>::value)
+            sell_wave_slices<false, false, typename Epi::colmap>(S, s0, s1, wv, lane, xl, epi.cm, epi.cm.dval, [](unsigned) { return 1.0; },
+                                                                 [&](unsigned pos, double sum, double) { yw[pos] = sum; });
+        else
+            sell_wave_slices<false, false, SellNoColMap>(S, s0, s1, wv, lane, xl, SellNoColMap(), nullptr, [](unsigned) { return 1.0; },
+                                                         [&](unsigned pos, double sum, double) { yw[pos] = sum; });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -193,6 +267,8 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, in
     };
     // the first window is fetched together with the `done` flag of a finished solve (one latency, not two in a row)
     const int dflag = done ? *done : 0;
+    const int bfirst = min((int)blockIdx.x, S.nblocks - 1);
+    const int ws0 = S.wslice[bfirst], ws1 = S.wslice[bfirst + 1];
     if ((int)blockIdx.x < S.nblocks) stage_y(blockIdx.x);
     if (dflag) return;
     for (int b = blockIdx.x; b < S.nblocks; b += gridDim.x) {
@@ -202,26 +278,13 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, in
             __syncthreads();   // the previous block's output pass is done with ow / yl
             stage_y(b);
         }
-        __syncthreads();
-        const int s0 = S.wslice[b], s1 = S.wslice[b + 1];
-        for (int s = s0 + wv; s < s1; s += LSQ_BIG_NT / 64) {
-            const int2 sm = S.smeta[__builtin_amdgcn_readfirstlane(s)];
-            const unsigned inf = S.info[(size_t)s * 64 + lane];
-            const unsigned pos = inf & LSQ_SELL_POS_MASK;
-            double sum = 0.0, sq = 0.0;
-            if constexpr (SCALE) {
-                const double sc = pos != LSQ_SELL_POS_MASK ? scale[cbase + (int)pos] : 0.0;    // (lane = one column of the block)
-                sell_lane_sum<SQ, true>(S.val + (size_t)sm.x + lane * 2, S.idx16 + (size_t)sm.x + lane * 2, sm.y,
-                                        (int)(inf >> LSQ_SELL_POS_BITS), yl, sum, sq, sc, dval + (size_t)sm.x + lane * 2);
-            } else {
-                sell_lane_sum<SQ>(S.val + (size_t)sm.x + lane * 2, S.idx16 + (size_t)sm.x + lane * 2, sm.y,
-                                  (int)(inf >> LSQ_SELL_POS_BITS), yl, sum, sq);
-            }
-            if (pos != LSQ_SELL_POS_MASK) {
-                ow[pos] = sum;
-                if constexpr (SQ) ow2[pos] = sq;
-            }
-        }
+        const int s0 = b == (int)blockIdx.x ? ws0 : S.wslice[b], s1 = b == (int)blockIdx.x ? ws1 : S.wslice[b + 1];
+        sell_wave_slices<SQ, SCALE, SellNoColMap>(S, s0, s1, wv, lane, yl, SellNoColMap(), dval,
+                                                  [&](unsigned pos) { return scale[cbase + (int)pos]; },   // (lane = one column)
+                                                  [&](unsigned pos, double sum, double sq) {
+                                                      ow[pos] = sum;
+                                                      if constexpr (SQ) ow2[pos] = sq;
+                                                  });
         __syncthreads();
         double *dst = part + (size_t)gw * (SQ ? 2 : 1) * n + cbase;
         for (int i = tid; i < cols; i += LSQ_BIG_NT) {

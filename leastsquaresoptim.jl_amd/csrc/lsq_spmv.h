@@ -245,6 +245,10 @@ struct EpiHasPrepare : std::false_type {};
 template <class E>
 struct EpiHasPrepare<E, std::void_t<typename E::has_prepare>> : std::true_type {};
 template <class E, class = void>
+struct EpiHasColMap : std::false_type {};   // E::colmap cm: see sell_lane_sum
+template <class E>
+struct EpiHasColMap<E, std::void_t<typename E::colmap>> : std::true_type {};
+template <class E, class = void>
 struct EpiHasPre : std::false_type {};
 template <class E>
 struct EpiHasPre<E, std::void_t<typename E::has_pre>> : std::true_type {};
@@ -835,7 +839,8 @@ static inline int launch_sell_rows(lsq_mat *J, const double *val, const double *
 
 // sliced-column copy of a column-scaled Jacobian that was left unmaterialised (lsq_mat::cols_pending_*): plain element-wise
 // materialisation, for consumers other than the fused gradient pass
-static __global__ void __launch_bounds__(LSQ_NT) k_sell_scale_cols(long long count, const unsigned short *__restrict__ col16,
+template <int = 0>
+__global__ void __launch_bounds__(LSQ_NT) k_sell_scale_cols(long long count, const unsigned short *__restrict__ col16,
                                                             const double *__restrict__ src, const double *__restrict__ s,
                                                             double *__restrict__ dst) {
     for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < count; k += (long long)gridDim.x * LSQ_NT)
@@ -861,7 +866,7 @@ static inline int launch_sell_cols(lsq_mat *J, const double *y, const int *done)
             return LSQ_OK;
         }
         const int g = (int)std::min<long long>((S.nstore + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
-        hipLaunchKernelGGL(k_sell_scale_cols, dim3(std::max(1, g)), dim3(LSQ_NT), 0, c->stream, (long long)S.nstore, S.d_col16, src,
+        hipLaunchKernelGGL(k_sell_scale_cols<0>, dim3(std::max(1, g)), dim3(LSQ_NT), 0, c->stream, (long long)S.nstore, S.d_col16, src,
                            scale, S.d_val);
     }
     auto kern = k_sell_cols<SQ>;

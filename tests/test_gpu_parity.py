@@ -1265,6 +1265,32 @@ def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opt", ["lm", "dogleg"])
+def test_tanh_model_fused_passes_change_nothing(ctx, opt, monkeypatch):
+    """The built-in model fuses around g!: the residual pass at a trial point also writes the Jacobian's row layout
+    there (adopted by g! when the step is accepted) and the sliced-column copy is written by the gradient + colsumabs2
+    pass.  Both are pure re-schedulings: with them switched off (LSQ_NO_SPEC_JAC / LSQ_EAGER_COLS) every iterate has
+    the same bits."""
+    m, n, per_col = 300000, 2000, 600
+    okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
+    xs = []
+    for env in ({}, {"LSQ_NO_SPEC_JAC": "1"}, {"LSQ_NO_SPEC_JAC": "1", "LSQ_EAGER_COLS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=7, ctx=ctx)
+        pr.reset()
+        r = pr.optimize(okind, lsq._lib.LSMR, trace=True, iterations=12)
+        xs.append((r.iterations, r.ssr, np.array(r.trace["x"]), np.array(r.trace["accepted"]) if "accepted" in r.trace else None))
+        pr.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    assert xs[0][0] > 3
+    for other in xs[1:]:
+        assert other[0] == xs[0][0] and other[1] == xs[0][1]
+        assert np.array_equal(other[2], xs[0][2])
+
+
+@pytest.mark.gpu
 def test_device_g_leaves_csc_copy_lazy_but_consistent(ctx):
     """On big sparse problems the built-in device g! writes only the mirrors the products read;
     the CSC-ordered nzval must still read back correctly (rebuilt on demand), and colsumabs2 /
