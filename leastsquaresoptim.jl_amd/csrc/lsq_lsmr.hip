@@ -163,6 +163,65 @@ struct EpiV {
     __device__ void finalize(double) const {}
 };
 
+// alpha, beta and the rotations of one iteration on a private copy of the state (one thread)
+__device__ __forceinline__ void lsmr_scalars(LsmrState &ns, double beta2, double betax2, double alpha2, bool damped, bool have_px) {
+    const double beta = damped ? dampened_norm(beta2, have_px ? betax2 : 0.0) : sqrt(beta2);   // (no px in the setup pass)
+    ns.beta = beta;
+    ns.beta_zero = !(beta > 0.0);
+    if (!ns.beta_zero) {
+        ns.alpha = sqrt(alpha2);                       // lsmr.jl:77,123
+        ns.vscale = ns.alpha > 0.0 ? 1.0 / ns.alpha : 1.0;
+    } else {
+        if (ns.first) ns.alpha = 0.0;
+        ns.vscale = 1.0;                               // v was left untouched (lsmr.jl:120)
+    }
+    const double alpha = ns.alpha;
+    if (ns.first) {                                    // lsmr.jl:82-113
+        ns.zetabar = alpha * beta;
+        ns.alphabar = alpha;
+        ns.rho = 1.0; ns.rhobar = 1.0; ns.cbar = 1.0; ns.sbar = 0.0;
+        ns.betadd = beta; ns.betad = 0.0; ns.rhodold = 1.0; ns.tautildeold = 0.0;
+        ns.thetatilde = 0.0; ns.zeta = 0.0; ns.d = 0.0;
+        ns.normA = -1.0; ns.condA = -1.0; ns.normx = -1.0;
+        ns.normA2 = alpha * alpha;
+        ns.maxrbar = 0.0; ns.minrbar = 1e100;
+        ns.normb = beta; ns.normr = beta; ns.normAr = alpha * beta;
+    } else {
+        lsmr_rotate_inline(ns, alpha, beta);
+    }
+    ns.cu = beta > 0.0 ? alpha / beta : alpha;         // next K1: u~_new = A v - (alpha/beta) u~
+}
+
+// ||x||, the 7 stopping rules and the commit of the new state (one thread of the last block)
+__device__ __forceinline__ void lsmr_commit(LsmrState &s, double total, LsmrState *st, LsqMailbox *mail) {
+    if (s.first) {
+        s.first = 0;
+        if (!(s.normAr != 0.0)) s.done = 1;      // lsmr.jl:115: exit if b = 0 or A'b = 0
+        *st = s;
+        publish(mail, st);
+        return;
+    }
+    s.iter += 1;
+    s.normx = sqrt(total);                       // lsmr.jl:206
+    double test1 = s.normr / s.normb;
+    double test2 = s.normAr / (s.normA * s.normr);
+    double test3 = 1.0 / s.condA;
+    double t1 = test1 / (1.0 + s.normA * s.normx / s.normb);
+    double rtol = s.btol + s.atol * s.normA * s.normx / s.normb;
+    int istop = 0;                               // :224-231, first hit wins
+    if (s.iter >= s.maxiter) istop = 7;
+    else if (1.0 + test3 <= 1.0) istop = 6;
+    else if (1.0 + test2 <= 1.0) istop = 5;
+    else if (1.0 + t1 <= 1.0) istop = 4;
+    else if (test3 <= s.ctol) istop = 3;
+    else if (test2 <= s.atol) istop = 2;
+    else if (test1 <= rtol) istop = 1;
+    s.istop = istop;
+    if (istop) s.done = 1;
+    *st = s;
+    publish(mail, st);
+}
+
 // ---- K3: alpha, rotations (every block, redundantly and identically), n-vector updates, ||x||,
 //          stopping rules and the commit of the new state (last block) --------------------------
 __global__ void __launch_bounds__(LSQ_NT)
@@ -187,33 +246,7 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
     double beta2, betax2, alpha2;
     ordered_sum256x3(pu, npu, px_in, npx_in, pv, npv, beta2, betax2, alpha2);   // (its barriers also publish ns)
     if (ns.done) return;
-    if (threadIdx.x == 0) {
-        const double beta = dg ? dampened_norm(beta2, px_in ? betax2 : 0.0) : sqrt(beta2);   // (px_in null in the setup pass)
-        ns.beta = beta;
-        ns.beta_zero = !(beta > 0.0);
-        if (!ns.beta_zero) {
-            ns.alpha = sqrt(alpha2);                       // lsmr.jl:77,123
-            ns.vscale = ns.alpha > 0.0 ? 1.0 / ns.alpha : 1.0;
-        } else {
-            if (ns.first) ns.alpha = 0.0;
-            ns.vscale = 1.0;                               // v was left untouched (lsmr.jl:120)
-        }
-        const double alpha = ns.alpha;
-        if (ns.first) {                                    // lsmr.jl:82-113
-            ns.zetabar = alpha * beta;
-            ns.alphabar = alpha;
-            ns.rho = 1.0; ns.rhobar = 1.0; ns.cbar = 1.0; ns.sbar = 0.0;
-            ns.betadd = beta; ns.betad = 0.0; ns.rhodold = 1.0; ns.tautildeold = 0.0;
-            ns.thetatilde = 0.0; ns.zeta = 0.0; ns.d = 0.0;
-            ns.normA = -1.0; ns.condA = -1.0; ns.normx = -1.0;
-            ns.normA2 = alpha * alpha;
-            ns.maxrbar = 0.0; ns.minrbar = 1e100;
-            ns.normb = beta; ns.normr = beta; ns.normAr = alpha * beta;
-        } else {
-            lsmr_rotate_inline(ns, alpha, beta);
-        }
-        ns.cu = beta > 0.0 ? alpha / beta : alpha;         // next K1: u~_new = A v - (alpha/beta) u~
-    }
+    if (threadIdx.x == 0) lsmr_scalars(ns, beta2, betax2, alpha2, dg != nullptr, px_in != nullptr);
     __syncthreads();
     const bool first = ns.first;
     const double vs = ns.vscale, c1 = ns.c1, c2 = ns.c2, c3 = ns.c3, cu = ns.cu;
@@ -256,37 +289,13 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
         }
     }
     double bv = block_sum<LSQ_NT>(acc, sh);
-    grid_reduce<LSQ_NT>(bv, partials, counter, gridDim.x, sh, [&](double total) {
-        // last block: every other block is past its prologue, so the state can be committed
-        LsmrState &s = ns;
-        if (s.first) {
-            s.first = 0;
-            if (!(s.normAr != 0.0)) s.done = 1;      // lsmr.jl:115: exit if b = 0 or A'b = 0
-            *st = s;
-            publish(mail, st);
-            return;
-        }
-        s.iter += 1;
-        s.normx = sqrt(total);                       // lsmr.jl:206
-        double test1 = s.normr / s.normb;
-        double test2 = s.normAr / (s.normA * s.normr);
-        double test3 = 1.0 / s.condA;
-        double t1 = test1 / (1.0 + s.normA * s.normx / s.normb);
-        double rtol = s.btol + s.atol * s.normA * s.normx / s.normb;
-        int istop = 0;                               // :224-231, first hit wins
-        if (s.iter >= s.maxiter) istop = 7;
-        else if (1.0 + test3 <= 1.0) istop = 6;
-        else if (1.0 + test2 <= 1.0) istop = 5;
-        else if (1.0 + t1 <= 1.0) istop = 4;
-        else if (test3 <= s.ctol) istop = 3;
-        else if (test2 <= s.atol) istop = 2;
-        else if (test1 <= rtol) istop = 1;
-        s.istop = istop;
-        if (istop) s.done = 1;
-        *st = s;
-        publish(mail, st);
-    });
+    // last block: every other block is past its prologue, so the state can be committed
+    grid_reduce<LSQ_NT>(bv, partials, counter, gridDim.x, sh, [&](double total) { lsmr_commit(ns, total, st, mail); });
 }
+
+// (Measured and dropped in round 2: K2's two passes + K3 as ONE launch for the sliced columns, one resident workgroup per CU
+//  with two grid barriers -- hierarchical tickets + a polled flag, ~2.2 us each -- and v~ kept in registers.  42.7 us against
+//  25.3 + 5.9 + 9.0 us in three launches: the barriers cost what the two launch ramps cost; 2885 vs 2874-2895 LM it/s on C4.)
 
 // ---- setup from the caller's J'y in one launch: P, sqrt(damp), state reset and
 // v~ = P.*(J'y)/beta_1 with the block partials of sum(v~^2)  (k_lsmr_prep + k_lsmr_begin +

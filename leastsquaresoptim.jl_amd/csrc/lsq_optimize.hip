@@ -1016,7 +1016,9 @@ struct lsq_model {
     double *d_Acsr = nullptr;  // A values in J's row-mirror layout (CSR order or sliced rows)
     double *d_Ab = nullptr;    // A values in J's column-mirror layout (window-blocked CSC or sliced columns)
     double *d_b = nullptr;
-    double *d_t = nullptr;     // tanh(x)
+    double *d_t = nullptr;     // tanh(x) of the latest f!
+    double *d_s = nullptr;     // 1 - tanh(x)^2 of the latest g! (its own buffer: a pending column copy still reads it)
+    double *d_sspec = nullptr; // the same at the speculative point
     // J's sliced-row values at the latest trial point, written by the residual pass there (model_f_sumsq); g! at that point
     // adopts the buffer instead of scaling A again
     double *d_Jspec = nullptr;
@@ -1109,6 +1111,14 @@ k_scale_csr(long long nnz, const int *__restrict__ colidx, const double *__restr
             double *__restrict__ out) {
     for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < nnz; k += (long long)gridDim.x * LSQ_NT)
         out[k] = A[k] * sfac[colidx[k]];
+}
+__global__ void __launch_bounds__(LSQ_NT) k_tanh_sfac(int n, const double *__restrict__ x, double *__restrict__ t,
+                                                      double *__restrict__ s) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
+        const double v = tanh(x[i]);
+        t[i] = v;
+        s[i] = 1.0 - v * v;
+    }
 }
 __global__ void __launch_bounds__(LSQ_NT) k_sfac(int n, const double *__restrict__ x, double *__restrict__ s) {
     for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
@@ -1207,7 +1217,6 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
     lsq_mat *J = md->J;
     *done = false;
     if (!(J->kind == LSQ_MAT_CSC && J->srows.active)) return model_f(out, x, user);
-    hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     EpiResidualSq e{nullptr, 0, md->d_b, out, c->d_partials, lsq_ctr(c, ctr), d_out, pub};
     md->spec_x = nullptr;
     if (model_rows_by_lds(J) && !getenv("LSQ_NO_SPEC_JAC")) {
@@ -1218,11 +1227,13 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
             if (hipMalloc(&md->d_Jspec, rb) != hipSuccess) return 1;
             if (hipMemsetAsync(md->d_Jspec, 0, rb, c->stream) != hipSuccess) return 1;
         }
+        hipLaunchKernelGGL(k_tanh_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t, md->d_sspec);
         EpiResidualSqJac ej{e, TanhJacMap{md->d_Jspec}};
         if (launch_sell_rows(J, md->d_Acsr, md->d_t, ej) != LSQ_OK) return 1;
         md->spec_x = x;
-    } else if (launch_sell_rows(J, md->d_Acsr, md->d_t, e) != LSQ_OK) {
-        return 1;
+    } else {
+        hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+        if (launch_sell_rows(J, md->d_Acsr, md->d_t, e) != LSQ_OK) return 1;
     }
     *done = true;
     return hipGetLastError() == hipSuccess ? 0 : 1;
@@ -1255,18 +1266,20 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
             LSQ_TRY(lsq_set_lds(c, (const void *)k_scale_lds<true>, 12000 * 8));
             LSQ_TRY(lsq_set_lds(c, (const void *)k_scale_lds<false>, 12000 * 8));
         }
-        hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+        const bool adopt = md->spec_x == x && md->d_Jspec && J->srows.active && J->nnz > 0;
+        if (adopt) std::swap(md->d_s, md->d_sspec);   // (the factors 1 - tanh(x)^2 came with it)
+        else hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_s);
         if (J->nnz > 0) {
-            if (md->spec_x == x && md->d_Jspec && J->srows.active) {
+            if (adopt) {
                 // the residual pass at this very point already wrote the row layout: adopt its buffer
                 std::swap(J->srows.d_val, md->d_Jspec);
             } else if (lds_ok && rcol) {
                 hipLaunchKernelGGL(k_scale_lds<true>, dim3(c->num_cus), dim3(1024), lds, c->stream, (rlen + 3) / 4, rcol,
-                                   md->d_Acsr, md->d_t, J->n, rval);
+                                   md->d_Acsr, md->d_s, J->n, rval);
             } else if (!J->srows.active) {
                 long long g2 = std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
                 hipLaunchKernelGGL(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
-                                   md->d_Acsr, md->d_t, J->csr.d_val);
+                                   md->d_Acsr, md->d_s, J->csr.d_val);
             } else {
                 return 1;   // (sliced rows always carry 16-bit columns)
             }
@@ -1277,10 +1290,10 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
                 // scales A's entries as it streams them and writes the copy (launch_sell_cols): 106 MB less traffic per
                 // accepted step at C4 than scaling first and streaming the result again
                 J->cols_pending_src = md->d_Ab;
-                J->cols_pending_scale = md->d_t;
+                J->cols_pending_scale = md->d_s;
             } else if (lds_ok && ccol) {
                 hipLaunchKernelGGL(k_scale_lds<false>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
-                                   ccol, md->d_Ab, md->d_t, J->n, cval);
+                                   ccol, md->d_Ab, md->d_s, J->n, cval);
             } else if (J->scols.active) {
                 // n > 65535: no 16-bit columns; rebuild the sliced columns from the CSC copy instead
                 if (lazy_csc) return 1;
@@ -1289,12 +1302,12 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
                 int nsegs = J->bcsc.nseg;
                 int g3 = std::min(lsq_div_up(nsegs, LSQ_NT), c->num_cus * 16);
                 hipLaunchKernelGGL(k_scale_bcsc_thread, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n,
-                                   J->bcsc.d_ptr, md->d_Ab, md->d_t, J->bcsc.d_val);
+                                   J->bcsc.d_ptr, md->d_Ab, md->d_s, J->bcsc.d_val);
             } else {
                 int nsegs = J->bcsc.nseg;
                 int g3 = std::min(lsq_div_up(nsegs, LSQ_NT / 64), c->num_cus * 16);
                 hipLaunchKernelGGL(k_scale_bcsc, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n, J->bcsc.d_ptr,
-                                   md->d_Ab, md->d_t, J->bcsc.d_val);
+                                   md->d_Ab, md->d_s, J->bcsc.d_val);
             }
         }
         J->csr_fresh = true;  // every mirror written directly: no permutation pass needed
@@ -1327,6 +1340,8 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
     LSQ_HIP(hipMalloc(&md->d_b, (size_t)(J->m > 0 ? J->m : 1) * sizeof(double)));
     LSQ_HIP(hipMemcpy(md->d_b, hb, (size_t)J->m * sizeof(double), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&md->d_t, (size_t)(J->n > 0 ? J->n : 1) * sizeof(double)));
+    LSQ_HIP(hipMalloc(&md->d_s, (size_t)(J->n > 0 ? J->n : 1) * sizeof(double)));
+    LSQ_HIP(hipMalloc(&md->d_sspec, (size_t)(J->n > 0 ? J->n : 1) * sizeof(double)));
     if (J->kind == LSQ_MAT_CSC) {
         // A in the layouts the products of J read (same maps as J's own mirrors), permuted once
         const size_t rb = (size_t)(lsq_mirror_rows_len(J) + 1024) * sizeof(double);
@@ -1348,7 +1363,7 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
 extern "C" int lsq_model_destroy(lsq_model *md) {
     if (!md) return LSQ_OK;
     hipStreamSynchronize(md->ctx->stream);
-    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_Ab); hipFree(md->d_b); hipFree(md->d_t); hipFree(md->d_Jspec);
+    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_Ab); hipFree(md->d_b); hipFree(md->d_t); hipFree(md->d_s); hipFree(md->d_sspec); hipFree(md->d_Jspec);
     delete md;
     return LSQ_OK;
 }

@@ -244,39 +244,34 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
 // block b = gw * ncb + cb; part layout [gw][n] (SQ: [gw][2n] = dots | squares)
 // SCALE (see sell_lane_sum): S.val is the UNSCALED source, `scale[col]` the column factors, `dval` the layout's own value
 // array, which this pass fills.
-template <bool SQ, bool SCALE = false>
-__global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, int ccols, int grows, int m, int n,
-                                                          const double *__restrict__ y, double *__restrict__ part,
-                                                          const int *done, const double *__restrict__ scale = nullptr,
-                                                          double *__restrict__ dval = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+// window of y -> LDS, all loads of a thread issued before the first use
+__device__ __forceinline__ void sell_cols_stage_y(int b, int ncb, int grows, int m, const double *__restrict__ y, double *yl, int tid) {
+    constexpr int YR = LSQ_SELL_GROWS_MAX / LSQ_BIG_NT;
+    const int gw = b / ncb, gbase = gw * grows, rows = min(grows, m - gbase);
+    double yr[YR];
+#pragma unroll
+    for (int j = 0; j < YR; ++j) yr[j] = y[gbase + min(tid + j * LSQ_BIG_NT, rows - 1)];
+#pragma unroll
+    for (int j = 0; j < YR; ++j)
+        if (tid + j * LSQ_BIG_NT < grows) yl[tid + j * LSQ_BIG_NT] = (tid + j * LSQ_BIG_NT < rows) ? yr[j] : 0.0;
+}
+// the workgroup's blocks (blockIdx.x, + gridDim.x, ...); the y window of the first one is already on its way to LDS
+// (sell_cols_stage_y) and its slice range is (ws0, ws1)
+template <bool SQ, bool SCALE>
+__device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int ccols, int grows, int m, int n,
+                                               const double *__restrict__ y, double *__restrict__ part,
+                                               const double *__restrict__ scale, double *__restrict__ dval, double *smem, int ws0,
+                                               int ws1) {
     double *yl = smem;                          // LSQ_SELL_GROWS_MAX doubles
     double *ow = smem + LSQ_SELL_GROWS_MAX;     // LSQ_SELL_CCOLS_MAX doubles (+ the same again for SQ)
     double *ow2 = ow + LSQ_SELL_CCOLS_MAX;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int YR = LSQ_SELL_GROWS_MAX / LSQ_BIG_NT;
-    // window of y -> LDS, all loads of a thread issued before the first use
-    auto stage_y = [&](int b) {
-        const int gw = b / ncb, gbase = gw * grows, rows = min(grows, m - gbase);
-        double yr[YR];
-#pragma unroll
-        for (int j = 0; j < YR; ++j) yr[j] = y[gbase + min(tid + j * LSQ_BIG_NT, rows - 1)];
-#pragma unroll
-        for (int j = 0; j < YR; ++j)
-            if (tid + j * LSQ_BIG_NT < grows) yl[tid + j * LSQ_BIG_NT] = (tid + j * LSQ_BIG_NT < rows) ? yr[j] : 0.0;
-    };
-    // the first window is fetched together with the `done` flag of a finished solve (one latency, not two in a row)
-    const int dflag = done ? *done : 0;
-    const int bfirst = min((int)blockIdx.x, S.nblocks - 1);
-    const int ws0 = S.wslice[bfirst], ws1 = S.wslice[bfirst + 1];
-    if ((int)blockIdx.x < S.nblocks) stage_y(blockIdx.x);
-    if (dflag) return;
     for (int b = blockIdx.x; b < S.nblocks; b += gridDim.x) {
         const int gw = b / ncb, cb = b - gw * ncb;
         const int cbase = cb * ccols, cols = min(ccols, n - cbase);
         if (b != (int)blockIdx.x) {
             __syncthreads();   // the previous block's output pass is done with ow / yl
-            stage_y(b);
+            sell_cols_stage_y(b, ncb, grows, m, y, yl, tid);
         }
         const int s0 = b == (int)blockIdx.x ? ws0 : S.wslice[b], s1 = b == (int)blockIdx.x ? ws1 : S.wslice[b + 1];
         sell_wave_slices<SQ, SCALE, SellNoColMap>(S, s0, s1, wv, lane, yl, SellNoColMap(), dval,
@@ -292,4 +287,19 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, in
             if constexpr (SQ) dst[n + i] = ow2[i];
         }
     }
+}
+
+template <bool SQ, bool SCALE = false>
+__global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, int ccols, int grows, int m, int n,
+                                                          const double *__restrict__ y, double *__restrict__ part,
+                                                          const int *done, const double *__restrict__ scale = nullptr,
+                                                          double *__restrict__ dval = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // the first window is fetched together with the `done` flag of a finished solve (one latency, not two in a row)
+    const int dflag = done ? *done : 0;
+    const int bfirst = min((int)blockIdx.x, S.nblocks - 1);
+    const int ws0 = S.wslice[bfirst], ws1 = S.wslice[bfirst + 1];
+    if ((int)blockIdx.x < S.nblocks) sell_cols_stage_y(blockIdx.x, ncb, grows, m, y, smem, threadIdx.x);
+    if (dflag) return;
+    sell_cols_pass<SQ, SCALE>(S, ncb, ccols, grows, m, n, y, part, scale, dval, smem, ws0, ws1);
 }
