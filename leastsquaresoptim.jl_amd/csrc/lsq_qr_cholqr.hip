@@ -31,7 +31,12 @@
 
 constexpr int CQ_RS = 64;                  // rows of the panel per workgroup (256 workgroups at 16384 rows: every CU)
 constexpr int CQ_QST = CQ_RS + 2;          // slab image [col][row], row stride (doubles)
-constexpr int CQ_LDS_DOUBLES = 2 * S64_MAT + S64_TMP + 64 * CQ_QST;
+// pass kernels: inv(R) | R | scratch; the slab image (64 * CQ_QST doubles) lives over R + scratch once the factor is done:
+// 75 KB instead of 109, i.e. two slab workgroups per CU (LM's stacked 18432-row operand has 288 slabs: 9.3 -> 8.5 ms).
+// (Look-ahead -- panel k+1's passes on a high-priority stream beside the update of panel k -- was built on top of this and
+//  measured: the passes do start beside the update, but both stretch; 8.0 ms against 7.55 at C3.  Dropped.)
+constexpr int CQ_LDS_DOUBLES = 2 * S64_MAT + S64_TMP;
+static_assert(S64_MAT + S64_TMP >= 64 * CQ_QST, "slab image over R + scratch");
 constexpr size_t CQ_LDS = (size_t)CQ_LDS_DOUBLES * sizeof(double);
 constexpr size_t CQ_LDS_LU = (size_t)(4 * S64_MAT + S64_TMP) * sizeof(double);
 constexpr size_t CQ_LDS_TW = (size_t)(2 * S64_MAT) * sizeof(double);
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(256)
 k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__restrict__ G, double *__restrict__ Gp,
            double *__restrict__ R1g, double *__restrict__ Vb, int ldv, int *__restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *M1 = sm, *M2 = sm + S64_MAT, *T = sm + 2 * S64_MAT, *Qs = sm + 2 * S64_MAT + S64_TMP;
+    double *M2 = sm, *M1 = sm + S64_MAT, *T = sm + 2 * S64_MAT, *Qs = M1;   // (Qs aliases R and the scratch: used after them)
     __shared__ int s_fail;
     __shared__ double s_red[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -212,6 +217,7 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
     CQ_T(PASS * 16 + 2);
     if (PASS == 1 && slab == 0)
         for (int e = tid; e < 4096; e += 256) R1g[e] = M1[(e >> 6) * S64_LS + (e & 63)];
+    __syncthreads();                                              // R is dead from here on: its LDS becomes the slab image
     // ---- slab product  Qslab = Pslab * inv(R) ------------------------------------------------------------------
     CQ_T(PASS * 16 + 3);
     {
@@ -239,12 +245,12 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
     CQ_T(PASS * 16 + 6);
 }
 
-// G = sum of the slab partials (fixed order): 64 outputs per workgroup, 16 partial sums per output (one batch of loads
+// G = sum of the slab partials (fixed order): 16 outputs per workgroup, 16 partial sums per output (one batch of loads
 // per thread for up to 256 slabs), combined in index order
-__global__ void __launch_bounds__(1024) k_cqr_reduce(const double *__restrict__ Gp, int nslab, double *__restrict__ G) {
-    __shared__ double part[16][64];
-    const int tid = threadIdx.x, o = tid & 63, p = tid >> 6;
-    const int e = blockIdx.x * 64 + o;
+__global__ void __launch_bounds__(256) k_cqr_reduce(const double *__restrict__ Gp, int nslab, double *__restrict__ G) {
+    __shared__ double part[16][17];
+    const int tid = threadIdx.x, o = tid & 15, p = tid >> 4;
+    const int e = blockIdx.x * 16 + o;
     const int per = (nslab + 15) / 16, s0 = p * per, s1 = min(nslab, s0 + per);
     double acc = 0.0;
     int s = s0;
@@ -414,21 +420,22 @@ void lsq_cqr_free(CqrWork *w) {
 
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err) {
     const int rows = M - c0, nslab = (rows + CQ_RS - 1) / CQ_RS;
-    hipLaunchKernelGGL(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, c->stream, A, M, c0, rows, (const double *)nullptr, w->Gp,
+    hipStream_t ps = c->stream;
+    hipLaunchKernelGGL(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
                        w->R1, Vb, ldv, d_err);
-    hipLaunchKernelGGL(k_cqr_reduce, dim3(64), dim3(1024), 0, c->stream, (const double *)w->Gp, nslab, w->G);
-    hipLaunchKernelGGL(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, c->stream, A, M, c0, rows, (const double *)w->G, w->Gp,
+    hipLaunchKernelGGL(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G);
+    hipLaunchKernelGGL(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G, w->Gp,
                        w->R1, Vb, ldv, d_err);
-    hipLaunchKernelGGL(k_cqr_reduce, dim3(64), dim3(1024), 0, c->stream, (const double *)w->Gp, nslab, w->G2);
+    hipLaunchKernelGGL(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G2);
     LSQ_HIP(hipGetLastError());
     // everything that hangs on the top 64 rows (the 64-step LU among it) runs on the side stream from here on, beside
     // pass 2 and the caller's V'[A2 | b] product
-    LSQ_HIP(hipEventRecord(w->ev_q, c->stream));
+    LSQ_HIP(hipEventRecord(w->ev_q, ps));
     LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
     hipLaunchKernelGGL(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1, A, M, c0,
                        w->Binv, w->S, d_err);
     LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
-    hipLaunchKernelGGL(k_cqr_pass<2>, dim3(nslab), dim3(256), CQ_LDS, c->stream, A, M, c0, rows, (const double *)w->G2, w->Gp,
+    hipLaunchKernelGGL(k_cqr_pass<2>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G2, w->Gp,
                        w->R1, Vb, ldv, d_err);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
