@@ -196,7 +196,7 @@ struct lsq_mat {
     int *d_bmap = nullptr;  // bcsc position -> csc position
     double *d_bpart = nullptr;
     double *d_dpart = nullptr;   // dense matrices with few columns: per-window partials of J'y (nwin x n)
-    int dpart_cap = 0;
+    size_t dpart_cap = 0;
     LsqSell srows, scols;   // when active they carry the values instead of csr / bcsc (whose d_val is freed)
     // matrix-free operator (LSQ_MAT_OP): host callbacks on device pointers + one scratch vector of max(m, n)
     int (*op_mul)(int, const double *, double *, void *) = nullptr;
@@ -372,6 +372,7 @@ int lsq_sparse_mul(lsq_mat *J, int trans, double alpha, const double *d_x, doubl
 int lsq_dense_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);
 int lsq_dense_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_dense_part(lsq_mat *J, int nwin);   // makes sure J->d_dpart holds nwin x n doubles
+int lsq_dense_part_elems(lsq_mat *J, size_t need);   // ... or `need` doubles
 int lsq_sparse_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_ensure_csr(lsq_mat *J);
 int lsq_ensure_csc(lsq_mat *J);

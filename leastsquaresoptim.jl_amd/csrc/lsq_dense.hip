@@ -54,9 +54,9 @@ struct EpiStoreD {
     __device__ void finalize(double) const {}
 };
 
-int lsq_dense_part(lsq_mat *J, int nwin) {
-    const int need = nwin * J->n;
-    if (J->dpart_cap < need) {
+int lsq_dense_part(lsq_mat *J, int nwin) { return lsq_dense_part_elems(J, (size_t)nwin * J->n); }
+int lsq_dense_part_elems(lsq_mat *J, size_t need) {
+    if ((size_t)J->dpart_cap < need) {
         hipFree(J->d_dpart);
         J->d_dpart = nullptr;
         LSQ_HIP(hipMalloc(&J->d_dpart, ((size_t)need + 8) * sizeof(double)));

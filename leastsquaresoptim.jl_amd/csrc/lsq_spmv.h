@@ -671,6 +671,40 @@ __global__ void __launch_bounds__(LSQ_NT) k_dense_n(const double *__restrict__ A
     finish_block(epi, racc, sh);
 }
 
+// The same for a matrix whose row blocks alone do not fill the device (m / 256 workgroups: 64 at C3, 16 at C2 -- the
+// one-thread-per-row kernel above then streams at 0.4-1 TB/s): a block takes (row block rb, column chunk cw) and writes
+// its partial dot products to part[cw * m + i]; k_combine adds the chunks in index order and runs the caller's epilogue.
+template <int = 0>
+__global__ void __launch_bounds__(LSQ_NT) k_dense_n_win(const double *__restrict__ A, int m, int n, const double *__restrict__ x,
+                                                         int ccols, int nrb, double *__restrict__ part, const int *done) {
+    if (done && *done) return;
+    const int rb = blockIdx.x % nrb, cw = blockIdx.x / nrb;
+    const int i = rb * LSQ_NT + threadIdx.x;
+    const int j0 = cw * ccols, j1 = min(n, j0 + ccols);
+    if (i >= m) return;
+    const double *p = A + i;
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.0;
+    int j = j0;
+    for (; j + 7 < j1; j += 8) {      // eight loads in flight per thread
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(j + u) * m];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += t[u] * x[j + u];
+    }
+    for (; j < j1; ++j) a[0] += p[(size_t)j * m] * x[j];
+    part[(size_t)cw * m + i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+// column chunks for J*x of a dense m x n matrix (0: one thread per row fills the device by itself)
+static inline int lsq_dense_n_chunks(const lsq_ctx *c, int m, int n) {
+    const int nrb = (m + LSQ_NT - 1) / LSQ_NT;
+    if (n < 64 || nrb >= 4 * c->num_cus) return 0;
+    int nch = std::min((n + 31) / 32, (8 * c->num_cus + nrb - 1) / nrb);
+    return nch > 1 ? nch : 0;
+}
+
 // x = J' y (SQ: column sums of squares): one block per column, contiguous reads.
 template <class Epi, bool SQ>
 __global__ void __launch_bounds__(LSQ_NT) k_dense_t(const double *__restrict__ A, int m, int n,
@@ -952,7 +986,16 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
         LSQ_TRY(lsq_ensure_csc(J));
         return launch_segs<false>(c, J->csc, x, epi);
     }
-    if (!trans) {
+    if (!trans && lsq_dense_n_chunks(c, J->m, J->n)) {
+        const int nch = lsq_dense_n_chunks(c, J->m, J->n), nrb = lsq_div_up(J->m, LSQ_NT);
+        const int ccols = ((J->n + nch - 1) / nch + 7) / 8 * 8, nchunks = (J->n + ccols - 1) / ccols;
+        LSQ_TRY(lsq_dense_part_elems(J, (size_t)nchunks * J->m));
+        hipLaunchKernelGGL(k_dense_n_win<0>, dim3(nrb * nchunks), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x, ccols, nrb,
+                           J->d_dpart, epi.done);
+        int nb = lsq_div_up(J->m, LSQ_CMB_COLS);
+        int grid = cap((long long)nb + epi.extra_blocks);
+        hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dpart, J->m, nchunks, epi, nb);
+    } else if (!trans) {
         int nb = lsq_div_up(J->m, LSQ_NT);
         int grid = cap((long long)nb + epi.extra_blocks);
         if (grid > 0)
