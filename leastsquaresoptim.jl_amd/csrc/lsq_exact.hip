@@ -171,19 +171,31 @@ int lsq_exact_colsumabs2(lsq_mat *J, double *out) {
 // sequential reductions (one thread; n <= LSQ_EXACT_MAX_DIM)
 //   0 sum(x)   1 sum(x^2)   2 sum(w*x*y) (wdot, utils.jl:165-175)   3 sum((x - y)^2)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_seq_reduce(int mode, int n, const double *x, const double *y, const double *w, double *out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// The TERMS are formed by all threads (element-wise: same roundings as in a loop) and parked in LDS; one thread then adds
+// them left to right.  (A one-thread loop over global memory paid a memory latency per element: 347 us for n = 2048.)
+__global__ void __launch_bounds__(256) k_seq_reduce(int mode, int n, const double *x, const double *y, const double *w, double *out) {
+    __shared__ double term[2048];
     double acc = 0.0;
-    for (int i = 0; i < n; ++i) {
-        if (mode == 0) acc += x[i];
-        else if (mode == 1) acc += x[i] * x[i];
-        else if (mode == 2) acc += w ? w[i] * x[i] * y[i] : x[i] * y[i];   // wdot (utils.jl:165-172) / dot
-        else { double r = x[i] + -1.0 * y[i]; acc += r * r; }   // axpy!(-1, fcur, fpredict) then abs2
+    for (int base = 0; base < n; base += 2048) {
+        const int cnt = min(2048, n - base);
+        for (int k = threadIdx.x; k < cnt; k += 256) {
+            const int i = base + k;
+            double t;
+            if (mode == 0) t = x[i];
+            else if (mode == 1) t = x[i] * x[i];
+            else if (mode == 2) t = w ? w[i] * x[i] * y[i] : x[i] * y[i];   // wdot (utils.jl:165-172) / dot
+            else { const double r = x[i] + -1.0 * y[i]; t = r * r; }        // axpy!(-1, fcur, fpredict) then abs2
+            term[k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 0; k < cnt; ++k) acc += term[k];
+        __syncthreads();
     }
-    *out = acc;
+    if (threadIdx.x == 0) *out = acc;
 }
 int lsq_seq_reduce(lsq_ctx *c, int mode, int n, const double *x, const double *y, const double *w, double *d_out) {
-    hipLaunchKernelGGL(k_seq_reduce, dim3(1), dim3(64), 0, c->stream, mode, n, x, y, w, d_out);
+    hipLaunchKernelGGL(k_seq_reduce, dim3(1), dim3(256), 0, c->stream, mode, n, x, y, w, d_out);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -192,9 +204,12 @@ int lsq_seq_reduce(lsq_ctx *c, int mode, int n, const double *x, const double *y
 __global__ void __launch_bounds__(LSQ_NT)
 k_lm_damp_seq(int n, const double *__restrict__ colsum, double inv_delta, double *__restrict__ dtd) {
     __shared__ double s_mean;
+    __shared__ double cs_l[LSQ_EXACT_MAX_DIM];   // (n <= LSQ_EXACT_MAX_DIM here: staged, then added left to right)
+    for (int i = threadIdx.x; i < n; i += LSQ_NT) cs_l[i] = colsum[i];
+    __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
-        for (int i = 0; i < n; ++i) t += colsum[i];
+        for (int i = 0; i < n; ++i) t += cs_l[i];
         s_mean = t / n;
     }
     __syncthreads();
