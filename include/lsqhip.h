@@ -164,7 +164,9 @@ int lsq_solver_qr_path(const lsq_solver *s, int *path);
 int lsq_solver_qr_panel(const lsq_solver *s, int *kind);
 /* the same for Cholesky() (dense_cholesky.jl:29-59):  0 none yet, 1 one-workgroup kernel (dpotf2 / pivoted dpstf2),
  * 2 blocked unpivoted factorisation (LM: J'J + damp),  3 blocked unpivoted factorisation + full-rank certificate
- * (Dogleg: 1 / ||inv(U)||_F^2 > 16 n eps max diag proves that cholesky!(.., Val(true)) would not stop early) */
+ * (Dogleg: 1 / ||inv(U)||_F^2 > 16 n eps max diag proves that cholesky!(.., Val(true)) would not stop early),
+ * 4 like 2 with the whole factorisation in ONE launch (k_chol_tiles: one resident workgroup per 64 x 64 upper tile,
+ * n <= 1408; repeated as 2 if one of its bounded waits gives up) */
 int lsq_solver_chol_path(const lsq_solver *s, int *path);
 
 /* ---- whole trust-region loop on device buffers (host control, device arrays) ---- */

@@ -473,7 +473,7 @@ class AllocatedSolver:
         return dict(lsmr_iter=it.value, lsmr_istop=st.value, qr_rank=rk.value,
                     qr_panel={0: None, 1: "householder-steps", 2: "cholqr2"}[panel.value],
                     qr_path={0: None, 1: "one-stage", 2: "two-stage-pivoted", 3: "two-stage-certified"}[path.value],
-                    chol_path={0: None, 1: "one-workgroup", 2: "blocked", 3: "blocked-certified"}[cpath.value])
+                    chol_path={0: None, 1: "one-workgroup", 2: "blocked", 3: "blocked-certified", 4: "blocked-one-launch"}[cpath.value])
 
     def free(self):
         if self.h:

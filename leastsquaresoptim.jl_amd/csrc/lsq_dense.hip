@@ -12,7 +12,8 @@
 #include "lsq_solver.h"
 #include "lsq_spmv.h"
 
-int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax);
+// allow_tiles: the one-launch factorisation (k_chol_tiles) may be used; the caller then handles info == -1 (a bounded wait gave up)
+int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax, bool allow_tiles = false);
 int lsq_cholesky_blocked_solve(lsq_solver *s, int n, double *d_x);
 int lsq_tri_inv_fro2(lsq_solver *s, const double *U, int n, double *fro2_inv);   // lsq_qr.hip
 void lsq_tri_pipe_err_copy(lsq_solver *s, int *h_dst);                           // lsq_qr.hip
@@ -286,7 +287,7 @@ int lsq_dense_solver_alloc(lsq_solver *s) {
 
 void lsq_dense_solver_free(lsq_solver *s) {
     hipFree(s->d_info); hipFree(s->d_chol); hipFree(s->d_Ds); hipFree(s->d_rhs); hipFree(s->d_work); hipFree(s->d_tau);
-    hipFree(s->d_qr); hipFree(s->d_qu); hipFree(s->d_T);
+    hipFree(s->d_qr); hipFree(s->d_qu); hipFree(s->d_T); hipFree(s->d_chol_flags);
     if (s->qr2 && s->qr2_free) s->qr2_free(s->qr2);
     if (s->tripipe && s->tripipe_free) s->tripipe_free(s->tripipe);
     hipFree(s->tri_X); hipFree(s->tri_T); hipFree(s->tri_fro);
@@ -350,12 +351,21 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
         // MFMA SYRK + blocked Cholesky + pipelined solves (lsq_dense_mfma.hip); measured crossover against the
         // single-workgroup kernel: 200 x 16 0.15 vs 0.11 ms, 300 x 32 0.15 vs 0.18, 500 x 64 0.16 vs 0.32, 2000 x 127 0.24 vs 0.93
         LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
-        LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr));
-        s->last_chol_path = 2;
+        LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, true));
+        s->last_chol_path = s->last_chol_tiles ? 4 : 2;
         int info = 0, perr = 0;
         LSQ_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         lsq_tri_pipe_err_copy(s, &perr);
         LSQ_HIP(hipStreamSynchronize(c->stream));
+        if (info == -1) {                         // k_chol_tiles gave up on a wait: never again for this solver, and redo
+            s->chol_tiles_off = true;
+            s->last_chol_path = 2;
+            LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));
+            LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, false));
+            LSQ_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            lsq_tri_pipe_err_copy(s, &perr);
+            LSQ_HIP(hipStreamSynchronize(c->stream));
+        }
         if (info != 0) {
             lsq_set_error("PosDefException: matrix is not positive definite; Cholesky failed at %d", info);
             return LSQ_ENOTPD;

@@ -204,6 +204,144 @@ k_chol_panel_mfma(double *__restrict__ C, int n, int j0, int *__restrict__ info,
     }
 }
 
+// ---- the whole blocked factorisation as ONE launch for n <= 64 * 22 (at most one 64 x 64 upper tile per CU) ------------
+// Workgroup (i, j), i <= j, owns tile (i, j) of J'J + D and keeps it in LDS from the first to the last instruction:
+//     for k < i:   wait for U(k, i) and U(k, j);   tile -= U(k, i)' U(k, j)                 (right-looking, MFMA)
+//     i == j:      U(i, i) = chol(tile), inv(U(i, i)) -> Xd[i]; publish
+//     i <  j:      wait for (i, i);   U(i, j) = inv(U(i, i))' tile; publish
+// "publish" = the tile goes to global memory with agent-scope stores, every wave drains them, then one epoch-tagged flag
+// is released (flags are never reset: the epoch changes with every factorisation).  Workgroup (i, j) only ever waits for
+// tiles of rows < i or for (i, i), so the waits cannot form a cycle as long as every workgroup is resident -- one per CU
+// here (the caller checks tiles <= CUs).  Waits are bounded (CHT_SPIN_LIMIT polls): a workgroup that gives up writes
+// info = -1, releases its own flag so that nobody waits for IT, and the host repeats the factorisation with the
+// launch-per-panel path.  Against that path (8 x (24 us panel + 10 us update + launch gaps) at n = 512) the chain per
+// 64 columns is: factor + inverse 14 us, one flag, 5 us row-panel tile, one flag, 4 us update of the next diagonal tile.
+constexpr size_t CHT_LDS = (size_t)(3 * S64_MAT + S64_TMP) * sizeof(double);
+constexpr int CHT_SPIN_LIMIT = 1 << 22;
+__device__ __forceinline__ bool cht_wait(const unsigned *flag, unsigned epoch, int *info, int spin_limit) {
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        int ok = 1, spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > spin_limit) {
+                ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!ok) atomicExch(info, -1);
+        s_ok = ok;
+    }
+    __syncthreads();
+    const bool r = s_ok != 0;
+    __syncthreads();
+    return r;
+}
+// tile (rows 64 ti.., columns 64 tj..) of the column-major n x n matrix C -> LDS image [r][c]; entries outside the matrix:
+// identity on a diagonal tile, zero elsewhere
+__device__ __forceinline__ void cht_load(double *__restrict__ M, const double *__restrict__ C, int n, int ti, int tj, int tid) {
+    double g[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, r = e & 63, c = e >> 6;
+        const int gr = 64 * ti + r, gc = 64 * tj + c;
+        g[q] = (gr < n && gc < n) ? C[(size_t)gc * n + gr] : ((ti == tj && r == c) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, r = e & 63, c = e >> 6;
+        M[r * S64_LS + c] = g[q];
+    }
+}
+__device__ __forceinline__ void cht_publish(double *__restrict__ C, int n, int ti, int tj, const double *__restrict__ M, bool upper_only,
+                                            unsigned *flag, unsigned epoch, int tid) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, r = e & 63, c = e >> 6;
+        const int gr = 64 * ti + r, gc = 64 * tj + c;
+        if (gr < n && gc < n && (!upper_only || r <= c))
+            __hip_atomic_store(C + (size_t)gc * n + gr, M[r * S64_LS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256)
+k_chol_tiles(double *__restrict__ C, int n, int nt, int *__restrict__ info, double *__restrict__ Xd, unsigned *__restrict__ flags,
+             unsigned epoch, unsigned wait_epoch, int spin_limit) {   // (wait_epoch != epoch: the tests' fault injector)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *M0 = sm, *M1 = sm + S64_MAT, *M2 = sm + 2 * S64_MAT, *T = sm + 3 * S64_MAT;
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int t = blockIdx.x, ti = 0;
+    while (t >= nt - ti) { t -= nt - ti; ++ti; }
+    const int tj = ti + t;
+    unsigned *myflag = flags + ti * nt + tj;
+    cht_load(M0, C, n, ti, tj, tid);
+    __syncthreads();
+    bool ok = true;
+    for (int k = 0; k < ti && ok; ++k) {
+        ok = cht_wait(flags + k * nt + ti, wait_epoch, info, spin_limit);
+        if (ok && tj != ti) ok = cht_wait(flags + k * nt + tj, wait_epoch, info, spin_limit);
+        if (!ok) break;
+        cht_load(M1, C, n, k, ti, tid);                     // U(k, i): rows = the k index
+        if (tj != ti) cht_load(M2, C, n, k, tj, tid);
+        __syncthreads();
+        const double *B = tj != ti ? M2 : M1;
+        for (int q = wv; q < 16; q += 4) {                  // tile -= U(k, i)' U(k, j)
+            const int a = q >> 2, b = q & 3;
+            if (ti == tj && a > b) continue;                // (only the upper triangle of a diagonal tile is read later)
+            s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            s64_tile_mma<true, false>(acc, M1, 0, 16 * a, B, 0, 16 * b, 4, lane);
+            s64_tile_store<true>(M0, 16 * a, 16 * b, acc, -1.0, lane);
+        }
+        __syncthreads();
+    }
+    if (!ok) {   // a tile this one needs never arrived: let the tiles waiting for THIS one go (the host sees info = -1)
+        if (tid == 0) __hip_atomic_store(myflag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (ti == tj) {
+        const int bad = s64_chol(M0, M1, &s_fail, tid);
+        if (bad) {
+            if (tid == 0) {
+                atomicCAS(info, 0, 64 * ti + bad);          // PosDefException position (1-based); the first failure wins
+                __hip_atomic_store(myflag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        s64_chol_inverse(M0, M1, T, tid);                   // M1 = inv(U(i, i))
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {                      // the pipelined triangular solves and the row panel read Xd[i]
+            const int e = tid + 256 * q, r = e & 63, c = e >> 6;
+            const bool in = 64 * ti + r < n && 64 * ti + c < n;
+            __hip_atomic_store(Xd + (size_t)ti * 4096 + (size_t)c * 64 + r, in ? M1[r * S64_LS + c] : 0.0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cht_publish(C, n, ti, tj, M0, true, myflag, epoch, tid);
+    } else {
+        if (!cht_wait(flags + ti * nt + ti, wait_epoch, info, spin_limit)) {
+            if (tid == 0) __hip_atomic_store(myflag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        {   // inv(U(i, i)) (column-major 64 x 64 in Xd) -> M1 [r][c]
+            double g[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g[q] = Xd[(size_t)ti * 4096 + tid + 256 * q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = tid + 256 * q, r = e & 63, c = e >> 6;
+                M1[r * S64_LS + c] = g[q];
+            }
+        }
+        __syncthreads();
+        s64_gemm<true, false, S64_LF>(M2, M1, M0, 1.0, tid);   // U(i, j) = inv(U(i, i))' tile
+        cht_publish(C, n, ti, tj, M2, false, myflag, epoch, tid);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_chol_diag_restore(double *__restrict__ C, int n, const double *__restrict__ Ds, const int *__restrict__ info) {
     const int j0 = blockIdx.x * NB, nb = min(NB, n - j0);
@@ -369,7 +507,7 @@ k_diag_max(const double *__restrict__ C, int n, double *__restrict__ out) {
 
 // dense_cholesky.jl:43-59: returns LSQ_ENOTPD through *info like the small kernel.  d_x == nullptr: factor only
 // (the caller decides about the solves); d_dmax != nullptr: also max_j (J'J + damp)_jj before the factorisation.
-int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax) {
+int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax, bool allow_tiles) {
     lsq_ctx *c = s->ctx;
     const int m = J->m, n = J->n;
     const int nt = (n + MT - 1) / MT, ntiles = nt * (nt + 1) / 2;
@@ -405,6 +543,30 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
     }
     if (d_dmax) hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);
+    // one launch for the whole factorisation when every 64 x 64 upper tile gets a CU of its own (k_chol_tiles)
+    if (allow_tiles && !s->chol_tiles_off && ntiles <= c->num_cus && n >= 2 * NB && !getenv("LSQ_CHOL_PANELS")) {
+        double *Xt = lsq_tri_chol_diagbuf(s, n);
+        if (Xt) {
+            if (!s->d_chol_flags) {
+                LSQ_HIP(hipMalloc(&s->d_chol_flags, 32 * 32 * sizeof(unsigned)));
+                LSQ_HIP(hipMemset(s->d_chol_flags, 0, 32 * 32 * sizeof(unsigned)));
+            }
+            if (++s->chol_epoch == 0) ++s->chol_epoch;
+            LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_tiles, CHT_LDS));
+            const bool inject = getenv("LSQ_TEST_EXCHANGE_TIMEOUT") != nullptr;   // the waits never see their flag
+            hipLaunchKernelGGL(k_chol_tiles, dim3(ntiles), dim3(256), CHT_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
+                               s->d_chol_flags, s->chol_epoch, inject ? s->chol_epoch ^ 0x40000000u : s->chol_epoch,
+                               inject ? 64 : CHT_SPIN_LIMIT);
+            s->chol_have_diaginv = true;
+            s->last_chol_tiles = true;
+            if (!d_x) { LSQ_HIP(hipGetLastError()); return LSQ_OK; }
+            if (lsq_tri_chol_solve(s, s->d_chol, n, d_x) != LSQ_OK)
+                hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
+            LSQ_HIP(hipGetLastError());
+            return LSQ_OK;
+        }
+    }
+    s->last_chol_tiles = false;
     // parking space for the factored diagonal blocks (k_chol_panel_mfma)
     bool merged = false;
     double *Ds = s->d_Ds;

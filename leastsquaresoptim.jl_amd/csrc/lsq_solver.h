@@ -61,6 +61,10 @@ struct lsq_solver {
     int last_chol_path = 0;         // lsq_solver_chol_path
     int pipe_off = 0;               // a wait of the pipelined triangular solves gave up once: single-workgroup solves from then on
     bool chol_have_diaginv = false; // the last blocked factorisation left inv(U_kk) in the solve pipeline's buffer
+    unsigned *d_chol_flags = nullptr; // k_chol_tiles: epoch-tagged 'tile published' flags
+    unsigned chol_epoch = 0;
+    bool chol_tiles_off = false;    // a wait of k_chol_tiles gave up once: launch-per-panel factorisation from then on
+    bool last_chol_tiles = false;   // the last blocked factorisation was the one-launch one
 };
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx);
 // buffer of the inverted 64 x 64 diagonal blocks of the pipelined solves (allocates the pipeline; nullptr when it is off)

@@ -293,7 +293,7 @@ def test_ldiv_lsmr(ctx, sparse, damped):
     assert nmul0 == 0 and np.all(dxo.get() == 0)
 
 
-@pytest.mark.parametrize("n", [1, 9, 70, 200])
+@pytest.mark.parametrize("n", [1, 9, 70, 129, 200, 512, 700])
 def test_ldiv_cholesky(ctx, n):
     rng = np.random.default_rng(30 + n)
     m = 3 * n + 5
@@ -306,6 +306,8 @@ def test_ldiv_cholesky(ctx, n):
     _, nmul = sv.ldiv_(dxo, dy, lsq.DeviceVector(ctx, n, damp))
     st, xr, _, _ = O.ldiv(O.CHOLESKY, O.Mat(dense=D), y, damp)
     assert nmul == 1 and np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
+    # n >= 128 (and at most one 64 x 64 upper tile per CU): the whole factorisation is one launch (k_chol_tiles)
+    assert sv.info()["chol_path"] == ("blocked-one-launch" if n >= 128 else "blocked" if n >= 32 else "one-workgroup")
     sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=False)  # pivoted (Dogleg)
     _, nmul = sv.ldiv_(dxo, dy)
     st, xr, _ = O.ldiv(O.CHOLESKY, O.Mat(dense=D), y)
@@ -365,6 +367,14 @@ def test_cholesky_failures(ctx):
     J = lsq.DeviceMatrix(ctx, D)
     with pytest.raises(lsq.PosDefException):
         lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True).ldiv_(dxo, dy, lsq.DeviceVector(ctx, 6))
+    # the same through the one-launch blocked factorisation: a zero column in the third 64-block, no damping there
+    D = rng.standard_normal((900, 256))
+    D[:, 150] = 0.0
+    J = lsq.DeviceMatrix(ctx, D)
+    sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+    with pytest.raises(lsq.PosDefException, match="151"):
+        sv.ldiv_(lsq.DeviceVector(ctx, 256), lsq.DeviceVector(ctx, 900, rng.standard_normal(900)), lsq.DeviceVector(ctx, 256))
+    assert sv.info()["chol_path"] == "blocked-one-launch"
 
 
 @pytest.mark.parametrize("m,n,rank", [(40, 10, 10), (12, 12, 12), (30, 12, 7), (9, 6, 5), (20, 8, 1),
@@ -667,6 +677,7 @@ def test_dense_exchange_timeout_falls_back(ctx, monkeypatch):
             if for_lm:
                 svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
                 xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y, damp)[1]
+                assert svc.info()["chol_path"] == "blocked"      # the one-launch factorisation gave up and stays off
             else:
                 svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
                 xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y)[1]
