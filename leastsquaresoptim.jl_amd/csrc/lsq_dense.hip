@@ -308,7 +308,7 @@ static bool chol_certified(lsq_solver *s, lsq_mat *J, const double *d_y, double 
     const int n = J->n;
     *rc = LSQ_OK;
     auto fail = [&](int code) { *rc = code; return true; };
-    if (lsq_cholesky_blocked(s, J, nullptr, nullptr, s->d_work) != LSQ_OK) return fail(LSQ_EHIP);
+    if (lsq_cholesky_blocked(s, J, nullptr, nullptr, s->d_work, true) != LSQ_OK) return fail(LSQ_EHIP);
     // the solves run before the decision is known (discarded if the certificate refuses): the one synchronisation
     // below then also shows whether a wait of the pipelined solves gave up
     if (lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x) != LSQ_OK) return fail(LSQ_EHIP);   // mul!(x, J', y)
@@ -322,6 +322,10 @@ static bool chol_certified(lsq_solver *s, lsq_mat *J, const double *d_y, double 
     if (hipMemcpy(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(&dmax, s->d_work, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(LSQ_EHIP);
+    if (info == -1 && !s->chol_tiles_off) {       // the one-launch factorisation gave up on a wait: panel launches from now on
+        s->chol_tiles_off = true;
+        return chol_certified(s, J, d_y, d_x, rc);
+    }
     const bool ok = info == 0 && std::isfinite(fro2) && fro2 > 0.0 && std::isfinite(dmax) &&
                     1.0 / fro2 > 16.0 * n * DBL_EPSILON * dmax;
     if (!ok) return false;
