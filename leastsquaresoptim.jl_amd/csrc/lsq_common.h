@@ -154,11 +154,11 @@ struct LsqSegs {
 struct LsqSell {
     bool active = false;
     int nblocks = 0, nslices = 0;
+    int spw = 0;                   // slices per block (every block is padded to the same count: block b starts at slice b * spw)
     long long nstore = 0;          // stored entries incl. padding
     int wrows = 0;                 // J*x: output rows per block
     int ncb = 0, ccols = 0;        // J'*y: column blocks per gather window, columns per block
     int ngw = 0, grows = 0;        // J'*y: gather windows, rows per gather window
-    int *d_wslice = nullptr;       // nblocks+1
     int2 *d_smeta = nullptr;       // nslices x {entry offset, padded count}
     unsigned *d_info = nullptr;    // nslices*64: output position in the block | entry count << 13
     unsigned short *d_idx16 = nullptr;  // gather index per stored entry

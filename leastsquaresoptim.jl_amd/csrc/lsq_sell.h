@@ -17,6 +17,8 @@
 //     in pairs:  slot(j, lane) = off + ((j/2)*64 + lane)*2 + (j%2)   -> a lane reads one 16-byte
 //     value pair and one 4-byte index pair per step, a wave reads 1 KiB + 256 B contiguous.
 //     Sorting makes the padding small (~7 % on the Poisson(10) rows of the C4 workload).
+//   * every block is padded to the same number of slices (empty ones at the end), so block b owns slices
+//     [b * spw, (b + 1) * spw) and no per-block table has to be read at the head of a launch;
 //   * info[slice*64 + lane] = position of the output inside the block | true entry count << 13;
 //     slices are stored in "snake" order so that the 16 waves (slice s0+wave, +16, ...) get equal work.
 //   * results are dropped into an LDS window at their ORIGINAL position, then one coalesced pass
@@ -31,12 +33,12 @@ constexpr int LSQ_SELL_GROWS_MAX = 8192;   // J'*y: rows of the gather window (6
 constexpr int LSQ_SELL_CCOLS_MAX = 5120;   // J'*y: output columns per block (40 KiB, twice with squares)
 
 struct SellDev {
-    const int *wslice;            // nblocks+1 slice ranges
     const int2 *smeta;            // per slice {entry offset, padded entry count}
     const unsigned *info;         // per (slice, lane)
     const unsigned short *idx16;  // gather index per stored entry
     const double *val;
     int nblocks;
+    int spw;                      // slices per block: block b owns slices [b * spw, (b + 1) * spw)
 };
 
 // CM (a "column map", rows kernel only): besides the dot, every stored value times cm.f(x[col]) is written to `mp` at the same
@@ -199,8 +201,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
 #pragma unroll
     for (int q = 0; q < XR; ++q) xr[q] = x[min(tid + q * LSQ_BIG_NT, nx - 1)];
     const int dflag = epi.done ? *epi.done : 0;
-    const int wfirst = min((int)blockIdx.x, S.nblocks - 1);
-    const int ws0 = S.wslice[wfirst], ws1 = S.wslice[wfirst + 1];   // (slice range of the first window: same round trip)
+
     if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     if constexpr (EpiHasPrepare<Epi>::value) epi.prepare();
 #pragma unroll
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
     double racc = 0.0;
     for (int w = blockIdx.x; w < S.nblocks; w += gridDim.x) {
         const int base = w * wrows, rows = min(wrows, m - base);
-        const int s0 = w == (int)blockIdx.x ? ws0 : S.wslice[w], s1 = w == (int)blockIdx.x ? ws1 : S.wslice[w + 1];
+        const int s0 = w * S.spw, s1 = s0 + S.spw;
         double pre[Q];
         if constexpr (EpiHasPre<Epi>::value) {   // epilogue inputs of this window: in flight during the stream
 #pragma unroll
@@ -256,12 +257,11 @@ __device__ __forceinline__ void sell_cols_stage_y(int b, int ncb, int grows, int
         if (tid + j * LSQ_BIG_NT < grows) yl[tid + j * LSQ_BIG_NT] = (tid + j * LSQ_BIG_NT < rows) ? yr[j] : 0.0;
 }
 // the workgroup's blocks (blockIdx.x, + gridDim.x, ...); the y window of the first one is already on its way to LDS
-// (sell_cols_stage_y) and its slice range is (ws0, ws1)
+// (sell_cols_stage_y)
 template <bool SQ, bool SCALE>
 __device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int ccols, int grows, int m, int n,
                                                const double *__restrict__ y, double *__restrict__ part,
-                                               const double *__restrict__ scale, double *__restrict__ dval, double *smem, int ws0,
-                                               int ws1) {
+                                               const double *__restrict__ scale, double *__restrict__ dval, double *smem) {
     double *yl = smem;                          // LSQ_SELL_GROWS_MAX doubles
     double *ow = smem + LSQ_SELL_GROWS_MAX;     // LSQ_SELL_CCOLS_MAX doubles (+ the same again for SQ)
     double *ow2 = ow + LSQ_SELL_CCOLS_MAX;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int cc
             __syncthreads();   // the previous block's output pass is done with ow / yl
             sell_cols_stage_y(b, ncb, grows, m, y, yl, tid);
         }
-        const int s0 = b == (int)blockIdx.x ? ws0 : S.wslice[b], s1 = b == (int)blockIdx.x ? ws1 : S.wslice[b + 1];
+        const int s0 = b * S.spw, s1 = s0 + S.spw;
         sell_wave_slices<SQ, SCALE, SellNoColMap>(S, s0, s1, wv, lane, yl, SellNoColMap(), dval,
                                                   [&](unsigned pos) { return scale[cbase + (int)pos]; },   // (lane = one column)
                                                   [&](unsigned pos, double sum, double sq) {
@@ -297,9 +297,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, in
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the first window is fetched together with the `done` flag of a finished solve (one latency, not two in a row)
     const int dflag = done ? *done : 0;
-    const int bfirst = min((int)blockIdx.x, S.nblocks - 1);
-    const int ws0 = S.wslice[bfirst], ws1 = S.wslice[bfirst + 1];
     if ((int)blockIdx.x < S.nblocks) sell_cols_stage_y(blockIdx.x, ncb, grows, m, y, smem, threadIdx.x);
     if (dflag) return;
-    sell_cols_pass<SQ, SCALE>(S, ncb, ccols, grows, m, n, y, part, scale, dval, smem, ws0, ws1);
+    sell_cols_pass<SQ, SCALE>(S, ncb, ccols, grows, m, n, y, part, scale, dval, smem);
 }

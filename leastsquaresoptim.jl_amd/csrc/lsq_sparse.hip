@@ -142,16 +142,23 @@ static void free_segs(LsqSegs &S) {
 template <class SegRange, class Idx16, class ColOf>
 static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, const std::vector<int> &srcmap,
                       SegRange seg_range, Idx16 idx16_of, ColOf col_of, bool want_col16) {
-    std::vector<int> wslice(nblocks + 1, 0), map;
+    std::vector<int> map;
     std::vector<int2> smeta;
     std::vector<unsigned> info;
     std::vector<unsigned short> idx16, col16;
     long long nstore = 0;
     std::vector<int> ord;
+    // every block gets the same number of slices (empty ones at the end of the shorter blocks): a kernel then knows
+    // its first slice from its block index alone, one dependent load less at the head of every launch
+    int spw = 0;
     for (int b = 0; b < nblocks; ++b) {
         int first, count;
         seg_range(b, first, count);
-        wslice[b] = (int)smeta.size();
+        spw = std::max(spw, (count + 63) / 64);
+    }
+    for (int b = 0; b < nblocks; ++b) {
+        int first, count;
+        seg_range(b, first, count);
         ord.resize(count);
         for (int i = 0; i < count; ++i) ord[i] = i;
         std::stable_sort(ord.begin(), ord.end(), [&](int a, int c2) {
@@ -195,16 +202,18 @@ static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, cons
                 }
             }
         }
+        for (int slot = ngroups; slot < spw; ++slot) {      // empty slices: no entries, no outputs
+            smeta.push_back(make_int2((int)nstore, 0));
+            for (int l = 0; l < 64; ++l) info.push_back(LSQ_SELL_POS_MASK);
+        }
     }
-    wslice[nblocks] = (int)smeta.size();
+    S.spw = spw;
     S.nblocks = nblocks;
     S.nslices = (int)smeta.size();
     S.nstore = nstore;
     const size_t pad = 1024;   // the unrolled loads of the last slice may run a few groups past the end
     map.resize(nstore + pad, -1);
     idx16.resize(nstore + pad, 0);
-    LSQ_HIP(hipMalloc(&S.d_wslice, wslice.size() * sizeof(int)));
-    LSQ_HIP(hipMemcpy(S.d_wslice, wslice.data(), wslice.size() * sizeof(int), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&S.d_smeta, (smeta.size() + 1) * sizeof(int2)));
     LSQ_HIP(hipMemcpy(S.d_smeta, smeta.data(), smeta.size() * sizeof(int2), hipMemcpyHostToDevice));
     LSQ_HIP(hipMalloc(&S.d_info, (info.size() + 64) * sizeof(unsigned)));
@@ -225,7 +234,7 @@ static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, cons
 }
 
 static void free_sell(LsqSell &S) {
-    hipFree(S.d_wslice); hipFree(S.d_smeta); hipFree(S.d_info); hipFree(S.d_idx16); hipFree(S.d_col16);
+    hipFree(S.d_smeta); hipFree(S.d_info); hipFree(S.d_idx16); hipFree(S.d_col16);
     hipFree(S.d_val); hipFree(S.d_map); hipFree(S.d_part);
     S = LsqSell();
 }
@@ -816,7 +825,7 @@ k_sell_rowsq(SellDev S, int wrows, int m, double *__restrict__ out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int w = blockIdx.x; w < S.nblocks; w += gridDim.x) {
         const int base = w * wrows;
-        for (int s = S.wslice[w] + wv; s < S.wslice[w + 1]; s += 4) {
+        for (int s = w * S.spw + wv; s < (w + 1) * S.spw; s += 4) {
             const int2 sm = S.smeta[s];
             const unsigned inf = S.info[(size_t)s * 64 + lane];
             const unsigned pos = inf & LSQ_SELL_POS_MASK;

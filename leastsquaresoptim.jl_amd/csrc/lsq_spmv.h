@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ p
 #include "lsq_sell.h"
 
 static inline SellDev sell_dev(const LsqSell &s, const double *val = nullptr) {
-    return SellDev{s.d_wslice, s.d_smeta, s.d_info, s.d_idx16, val ? val : s.d_val, s.nblocks};
+    return SellDev{s.d_smeta, s.d_info, s.d_idx16, val ? val : s.d_val, s.nblocks, s.spw};
 }
 
 // J*x over the sliced rows, with `val` optionally replacing J's values (same pattern, e.g. a model's A)
