@@ -549,7 +549,7 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         if (Xt) {
             if (!s->d_chol_flags) {
                 LSQ_HIP(hipMalloc(&s->d_chol_flags, 32 * 32 * sizeof(unsigned)));
-                LSQ_HIP(hipMemset(s->d_chol_flags, 0, 32 * 32 * sizeof(unsigned)));
+                LSQ_ZERO(s->d_chol_flags, 0, 32 * 32 * sizeof(unsigned));   // (waits for the memset: see LSQ_ZERO)
             }
             if (++s->chol_epoch == 0) ++s->chol_epoch;
             LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_tiles, CHT_LDS));

@@ -388,7 +388,8 @@ k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Bi
 int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
     w->max_slabs = (M + CQ_RS - 1) / CQ_RS;
     LSQ_HIP(hipMalloc(&w->Gp, (size_t)w->max_slabs * 4096 * sizeof(double)));
-    LSQ_HIP(hipMemset(w->Gp, 0, (size_t)w->max_slabs * 4096 * sizeof(double)));   // (the strictly lower tiles are never written)
+    LSQ_ZERO(w->Gp, 0, (size_t)w->max_slabs * 4096 * sizeof(double));   // (the strictly lower tiles are never written; LSQ_ZERO waits:
+    // a bare hipMemset runs on the null stream, which the context's non-blocking stream does not order itself after)
     LSQ_HIP(hipMalloc(&w->G, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->R1, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->G2, 4096 * sizeof(double)));

@@ -314,6 +314,25 @@ def test_ldiv_cholesky(ctx, n):
     assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
 
 
+def test_cholesky_one_launch_is_repeatable(ctx):
+    """k_chol_tiles: workgroups hand tiles to each other inside ONE launch (epoch-tagged flags, bounded waits).  300 solves on
+    one solver: every result equals the first bit for bit and no wait ever gave up (the path would fall back to
+    'blocked' and stay there).  tools/chol_stress.py runs the same check for thousands of solves."""
+    rng = np.random.default_rng(5)
+    m, n = 3000, 700                       # 11 x 11 tiles, ragged last tile
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    J = lsq.DeviceMatrix(ctx, A)
+    y, damp, x = lsq.DeviceVector(ctx, m, rng.standard_normal(m)), lsq.DeviceVector(ctx, n, rng.random(n) + 0.01), lsq.DeviceVector(ctx, n)
+    sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+    sv.ldiv_(x, y, damp)
+    ref = x.get().copy()
+    assert np.allclose(ref, O.ldiv(O.CHOLESKY, O.Mat(dense=A), y.get(), damp.get())[1], rtol=1e-9, atol=1e-12)
+    for _ in range(300):
+        sv.ldiv_(x, y, damp)
+        assert sv.info()["chol_path"] == "blocked-one-launch"
+        assert np.array_equal(x.get(), ref)
+
+
 @pytest.mark.parametrize("cond,certified", [(1e1, True), (1e4, True), (1e7, False)])
 def test_ldiv_cholesky_dogleg_certificate(ctx, cond, certified):
     """Dogleg's Cholesky() is the pivoted cholesky!(Symmetric(J'J), Val(true)) (dense_cholesky.jl:33).  The blocked
