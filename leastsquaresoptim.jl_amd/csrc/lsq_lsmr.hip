@@ -347,6 +347,100 @@ k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp
     }
 }
 
+// ---- LM + LSMR, n <= LSMR_LM_PREP_MAX_N: the LM loop's damping + projected gradient norm (k_lm_damp_grad,
+// levenberg_marquardt.jl:82-86, 102-104) and k_lsmr_setup as ONE launch of 1024-thread workgroups.  The damping needs
+// mean(colsum) -- a reduction over all n -- before the first element can be written: every workgroup takes it itself, over
+// all n, in exactly the order of the one-workgroup kernel it replaces (thread-sequential with stride 1024, wave tree, 16
+// waves in order: same bits), then handles its own 1024 elements.  One n-length launch (~6 us of latency) less per outer
+// iteration; sum(v~^2) is taken per 1024 elements instead of per 256.
+__global__ void __launch_bounds__(1024)
+k_lm_lsmr_setup(int n, LsmrLmPrep lm, double *__restrict__ damp, double *__restrict__ P, double *__restrict__ dg,
+                double *__restrict__ ux, const double *__restrict__ g, double *__restrict__ v, LsmrState *st, double *pu, int *npu,
+                double ysumsq, double *pv, int *npv, double atol, double btol, double ctol, int maxiter, unsigned epoch) {
+    constexpr int R = LSMR_LM_PREP_MAX_N / 1024;
+    __shared__ double sh[16], shm[16];
+    __shared__ double s_mean;
+    const int tid = threadIdx.x;
+    double cs[R], gv[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {   // every load is issued before the first use
+        const int i = tid + k * 1024;
+        cs[k] = i < n ? lm.colsum[i] : 0.0;
+        gv[k] = i < n ? g[i] : 0.0;
+    }
+    double acc = 0.0, mg = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int i = tid + k * 1024;
+        if (i < n) {
+            acc += cs[k];
+            double gi = gv[k];
+            if (lm.lo && lm.x[i] <= lm.lo[i] && gi > 0.0) gi = 0.0;
+            else if (lm.hi && lm.x[i] >= lm.hi[i] && gi < 0.0) gi = 0.0;
+            double a = fabs(gi);
+            if (isnan(a)) a = INFINITY;
+            mg = fmax(mg, a);
+        }
+    }
+    acc = wave_sum(acc);
+    mg = wave_max(mg);
+    if ((tid & 63) == 0) {
+        sh[tid >> 6] = acc;
+        shm[tid >> 6] = mg;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tt = 0.0, tm = shm[0];
+        for (int w = 0; w < 16; ++w) tt += sh[w];
+        for (int w = 1; w < 16; ++w) tm = fmax(tm, shm[w]);
+        s_mean = tt / n;
+        if (blockIdx.x == 0) {
+            *lm.out_grad = tm;
+            st->iter = 0; st->istop = 0; st->done = 0; st->first = 1;
+            st->atol = atol; st->btol = btol; st->ctol = ctol;
+            st->maxiter = maxiter; st->epoch = epoch; st->cu = 0.0;
+            pu[0] = ysumsq;
+            *npu = 1;
+        }
+    }
+    __syncthreads();
+    const double lo_d = lm.min_diag * s_mean, hi_d = lm.max_diag * s_mean;
+    const double beta = dampened_norm(ysumsq, 0.0);   // u_x = 0 (zerosvector, il:246)
+    const bool beta_zero = !(beta > 0.0);
+    const double inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
+    double a2 = 0.0;
+    const int j = blockIdx.x * 1024 + tid;             // (this workgroup's own elements: blockIdx.x-th group of 1024)
+    if (j < n) {
+        // the values of element j sit in this thread's registers when blockIdx.x < R: cs / gv are indexed by a constant after
+        // unrolling, so pick by selection
+        double c0 = 0.0, g0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (k == (int)blockIdx.x) { c0 = cs[k]; g0 = gv[k]; }
+        double c = c0;
+        c = c > hi_d ? hi_d : (c < lo_d ? lo_d : c);
+        const double d = c * lm.inv_delta;     // rmul!(dtd, 1/Delta)
+        const double s = c0 + d;               // iterative_lsmr.jl:251
+        const double r = sqrt(d);              // :252
+        dg[j] = r;
+        damp[j] = r;
+        ux[j] = 0.0;                           // zerosvector (:246)
+        const double Pj = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+        P[j] = Pj;
+        if (!beta_zero) {                      // lsmr.jl:76 (beta == 0: v is left untouched, :120)
+            const double w = g0 * inv_beta * Pj;
+            v[j] = w;
+            a2 = w * w;
+        }
+    }
+    __syncthreads();
+    const double bv = block_sum<1024>(a2, sh);
+    if (tid == 0) {
+        pv[blockIdx.x] = bv;
+        if (blockIdx.x == 0) *npv = (int)gridDim.x;
+    }
+}
+
 int lsq_lsmr_alloc(lsq_solver *s) {
     size_t nb = (size_t)(s->n > 0 ? s->n : 1) * sizeof(double);
     LSQ_HIP(hipMalloc(&s->d_state, sizeof(LsmrState)));
@@ -377,8 +471,12 @@ static inline int nvec_grid(const lsq_ctx *c, int n) {
 }
 
 // d_damp == nullptr: undamped (Dogleg, atol = btol = 1e-6); else LM (btol = 0.5).
+bool lsq_lsmr_takes_lm_prep(const lsq_solver *s, const lsq_mat *J) {
+    return s->kind == LSQ_LSMR && J->n <= LSMR_LM_PREP_MAX_N && !lsq_small_mat(J) && !s->precond_cb && !getenv("LSQ_LSMR_SEPARATE_SETUP");
+}
+
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
-                   const double *d_Jty, double y_sumsq) {
+                   const double *d_Jty, double y_sumsq, const LsmrLmPrep *lm) {
     lsq_ctx *c = s->ctx;
     const int m = J->m, n = J->n;
     if (m != s->m || n != s->n) {
@@ -427,7 +525,18 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         hipLaunchKernelGGL(k_lsmr_begin, dim3((int)gb), dim3(LSQ_NT), 0, c->stream, m, d_y, st, pu, npu, atol,
                            btol, 1.0 / conlim, maxiter, epoch);
     };
-    if (d_Jty) {
+    if (lm) {
+        if (!(d_Jty && y_sumsq >= 0.0 && damped && lsq_lsmr_takes_lm_prep(s, J))) {
+            lsq_set_error("lsmr: LM preparation requested where it does not apply");
+            return LSQ_EARG;
+        }
+        hipLaunchKernelGGL(k_lm_lsmr_setup, dim3(lsq_div_up(n, 1024)), dim3(1024), 0, c->stream, n, *lm, d_damp, s->d_P, s->d_dg,
+                           s->d_ux, d_Jty, s->d_v, st, pu, npu, y_sumsq, pv, npv, atol, btol, 1.0 / conlim, maxiter, epoch);
+        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
+                           (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
+                           s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
+        LSQ_HIP(hipGetLastError());
+    } else if (d_Jty) {
         if (!(y_sumsq >= 0.0)) launch_begin();
         hipLaunchKernelGGL(k_lsmr_setup, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P, s->d_dg,
                            s->d_ux, d_Jty, s->d_v, st, pu, npu, y_sumsq >= 0.0 ? y_sumsq : -1.0, pv, npv, atol, btol,

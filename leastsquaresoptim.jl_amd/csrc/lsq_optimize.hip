@@ -276,13 +276,19 @@ struct EpiSumsq {
 // x_trial = x - dx, max|dx| and first non-finite index of x_trial in one pass
 __global__ void __launch_bounds__(LSQ_NT)
 k_step(int n, const double *__restrict__ x, const double *__restrict__ dx, double *__restrict__ xt,
-       double *partials, unsigned *counters, double *out_dx, double *out_nonfin) {
+       double *partials, unsigned *counters, double *out_dx, double *out_nonfin, double *__restrict__ t_out,
+       double *__restrict__ s_out) {
     __shared__ double sh[LSQ_NT / 64];
     double mx = 0.0, code = 0.0;
     for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
         double d = dx[i];
         double v = x[i] + -1.0 * d;  // axpy!(-1, dx, x)
         xt[i] = v;
+        if (t_out) {                 // the built-in model's tanh(x_trial) and 1 - tanh^2 (k_tanh_sfac), while x_trial is in a register
+            const double th = tanh(v);
+            t_out[i] = th;
+            s_out[i] = 1.0 - th * th;
+        }
         double a = fabs(d);
         if (isnan(a)) a = INFINITY;
         mx = fmax(mx, a);
@@ -400,6 +406,8 @@ static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, i
 // sum rides in the residual kernel's epilogue (no second pass over the m-vector: 8 MB and a launch less per iteration at C4)
 static int model_f(double *out, const double *x, void *user);
 static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done);
+// buffers for tanh(xt) and 1 - tanh(xt)^2 when the model's next f!(., xt) can take them from the step kernel (else nulls)
+static void model_trial_buffers(void *user, const double *xt, double **t_out, double **s_out);
 static int f_then_sumsq(lsq_ctx *c, bool exact, lsq_f_callback f, void *user, long long m, double *out, const double *x, int ctr,
                         double *d_out, LsqSlotPublish pub = LsqSlotPublish()) {
     if (!exact && f == model_f) {
@@ -679,13 +687,15 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
         if (!cs) return LSQ_EHIP;
         const bool one_wg = !exact && n <= LSQ_ONE_WG_N;
+        const bool lm_prep = one_wg && sv->kind == LSQ_LSMR && lsq_lsmr_takes_lm_prep(sv, J);
         if (exact) LSQ_TRY(lsq_exact_lm_damp(c, n, cs, 1.0 / delta, b.dtd));
         else if (!one_wg) hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
         {   // :102-104 gradient g = J'f at the pre-step x.  The reference forms it AFTER the solve
             // (into dtd); J and fcur do not change in between, so it is formed once, before the
             // solve, and LSMR's setup product A'b = P.*(J'f)/beta reuses it (saves one pass over J).
             if (!have_grad) LSQ_TRY(gradient_into(c, exact, J, fcur, b.grad));
-            if (one_wg)
+            if (lm_prep) {}   // (damping and gradient norm ride in the LSMR setup launch below)
+            else if (one_wg)
                 hipLaunchKernelGGL(k_lm_damp_grad, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd, b.grad,
                                    x, b.lo, b.hi, c->d_slots + SL_GRAD);
             else
@@ -710,15 +720,20 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             if (sv->kind != LSQ_LSMR || exact) lsq_run_idle_hook(c);
         }
         int lmiter = 0;
-        if (sv->kind == LSQ_LSMR) LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr));  // :87
+        if (sv->kind == LSQ_LSMR) {
+            const LsmrLmPrep prep{cs, 1.0 / delta, MIN_DIAGONAL, MAX_DIAGONAL, x, b.lo, b.hi, c->d_slots + SL_GRAD};
+            LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr, lm_prep ? &prep : nullptr));  // :87
+        }
         else LSQ_TRY(lsq_ldiv_damped(sv, J, fcur, b.dtd, b.dx, &lmiter));
         lsq_run_idle_hook(c);   // (a solve that never filled its window)
         if (o->allreduce && c->idle_status != LSQ_OK) return c->idle_status;
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
         mul_calls += lmiter;
         inner_total += lmiter / 2;
+        double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
+        if (!exact && f == model_f) model_trial_buffers(user, xt, &t_out, &s_out);
         hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
-                           lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN);   // :106
+                           lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out);   // :106
         LSQ_HIP(hipGetLastError());
         double sl[5];
         if (exact) {
@@ -901,8 +916,10 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
             wnorm_dx = std::sqrt(w2);
         }
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                 // :148-160
+        double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
+        if (!exact && f == model_f) model_trial_buffers(user, b.xt, &t_out, &s_out);
         hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
-                           lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN);    // :160
+                           lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out);    // :160
         LSQ_HIP(hipGetLastError());
         LSQ_TRY(f_then_sumsq(c, exact, f, user, m, b.ftrial, b.xt, 7, c->d_slots + SL_TRIAL));   // :164, :168
         f_calls++;
@@ -1023,6 +1040,7 @@ struct lsq_model {
     // adopts the buffer instead of scaling A again
     double *d_Jspec = nullptr;
     const double *spec_x = nullptr;   // device vector the speculative values belong to (null: none)
+    const double *tanh_x = nullptr;   // device vector whose tanh / 1 - tanh^2 the step kernel has already put into d_t / d_sspec
 };
 
 __global__ void __launch_bounds__(LSQ_NT) k_tanh(int n, const double *__restrict__ x, double *__restrict__ t) {
@@ -1194,6 +1212,7 @@ static int model_f(double *out, const double *x, void *user) {
     lsq_ctx *c = md->ctx;
     lsq_mat *J = md->J;
     md->spec_x = nullptr;
+    md->tanh_x = nullptr;
     hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     EpiResidual e{nullptr, 0, md->d_b, out, nullptr, nullptr};
     if (J->kind == LSQ_MAT_CSC && J->srows.active) {
@@ -1210,6 +1229,16 @@ static int model_f(double *out, const double *x, void *user) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+static void model_trial_buffers(void *user, const double *xt, double **t_out, double **s_out) {
+    lsq_model *md = (lsq_model *)user;
+    md->tanh_x = nullptr;
+    if (model_rows_by_lds(md->J) && !getenv("LSQ_NO_SPEC_JAC") && md->d_Jspec) {   // (from the second trial point on)
+        *t_out = md->d_t;
+        *s_out = md->d_sspec;
+        md->tanh_x = xt;
+    }
+}
+
 // f! + sum(abs2, out) in one pass (sliced rows only; *done tells whether it applied)
 static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done) {
     lsq_model *md = (lsq_model *)user;
@@ -1219,6 +1248,8 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
     if (!(J->kind == LSQ_MAT_CSC && J->srows.active)) return model_f(out, x, user);
     EpiResidualSq e{nullptr, 0, md->d_b, out, c->d_partials, lsq_ctr(c, ctr), d_out, pub};
     md->spec_x = nullptr;
+    const bool have_tanh = md->tanh_x == x;   // k_step formed tanh(x) and 1 - tanh(x)^2 while it wrote x
+    md->tanh_x = nullptr;
     if (model_rows_by_lds(J) && !getenv("LSQ_NO_SPEC_JAC")) {
         // x is a trial point that becomes the next linearisation point if the step is accepted: the Jacobian's row layout there
         // costs one extra store stream in this pass (A's entries and t are already in registers / LDS)
@@ -1227,7 +1258,8 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
             if (hipMalloc(&md->d_Jspec, rb) != hipSuccess) return 1;
             if (hipMemsetAsync(md->d_Jspec, 0, rb, c->stream) != hipSuccess) return 1;
         }
-        hipLaunchKernelGGL(k_tanh_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t, md->d_sspec);
+        if (!have_tanh)
+            hipLaunchKernelGGL(k_tanh_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t, md->d_sspec);
         EpiResidualSqJac ej{e, TanhJacMap{md->d_Jspec}};
         if (launch_sell_rows(J, md->d_Acsr, md->d_t, ej) != LSQ_OK) return 1;
         md->spec_x = x;
@@ -1320,6 +1352,7 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
             hipLaunchKernelGGL(k_scale_dense, dim3(J->n, chunks), dim3(LSQ_NT), 0, c->stream, J->m, md->d_Acsc, x, J->d_dense);
     }
     md->spec_x = nullptr;
+    md->tanh_x = nullptr;
     J->version++;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -130,8 +130,20 @@ int lsq_lsmr_alloc(lsq_solver *s);
 void lsq_lsmr_free(lsq_solver *s);
 // d_Jty (optional): J'*y already formed by the caller (the LM gradient) -- skips the setup product;
 // y_sumsq (optional, < 0 = unknown): sum(y.^2) when the caller already holds it (the LM loop's ssr)
+// lm (optional, with d_Jty and y_sumsq): the LM loop's damping and projected gradient norm (levenberg_marquardt.jl:82-86,
+// 102-104) are formed by the solve's own setup launch -- d_damp is then an OUTPUT (dtd/Delta, left as its square root like
+// after every damped solve) and *lm->out_grad receives max|g| -- instead of a launch of their own in front of it
+struct LsmrLmPrep {
+    const double *colsum;     // colsumabs2(J)
+    double inv_delta, min_diag, max_diag;
+    const double *x, *lo, *hi;
+    double *out_grad;
+};
+constexpr int LSMR_LM_PREP_MAX_N = 16384;   // every workgroup of that launch reduces colsum and g over all n itself
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
-                   const double *d_Jty = nullptr, double y_sumsq = -1.0);
+                   const double *d_Jty = nullptr, double y_sumsq = -1.0, const LsmrLmPrep *lm = nullptr);
+// whether lsq_lsmr_solve takes the LsmrLmPrep route for this solver / Jacobian (else the caller launches its own damping)
+bool lsq_lsmr_takes_lm_prep(const lsq_solver *s, const lsq_mat *J);
 // implemented in lsq_exact.hip (reference-order kernels for small problems)
 int lsq_lsmr_exact_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul);
 // implemented in lsq_dense.hip
