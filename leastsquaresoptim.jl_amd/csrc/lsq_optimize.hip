@@ -803,9 +803,11 @@ static int optimize_dogleg(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *
     ShardedExit ex{c, o};
     return ex.finish(optimize_dogleg_loop(c, sv, b, J, x, fcur, f, g, user, o, r));
 }
-static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x, double *fcur,
+static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x_user, double *fcur_user,
                                 lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r) {
     const int m = J->m, n = J->n;
+    double *x = x_user, *fcur = fcur_user, *xt = b.xt, *ftrial = b.ftrial;   // (accepted trial points become the iterate by swapping)
+    IterateGuard guard{c, x, fcur, x_user, fcur_user, m, n};
     double delta = o->delta > 0 ? o->delta : 1.0;
     bool reuse = false, converged = false;
     double wnorm_dgn = 0.0, wnorm_dgr = 0.0, alpha = 0.0, wdot_gr_gn = 0.0;
@@ -917,11 +919,11 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
         }
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                 // :148-160
         double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
-        if (!exact && f == model_f) model_trial_buffers(user, b.xt, &t_out, &s_out);
-        hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, b.xt, c->d_partials,
+        if (!exact && f == model_f) model_trial_buffers(user, xt, &t_out, &s_out);
+        hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
                            lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out);    // :160
         LSQ_HIP(hipGetLastError());
-        LSQ_TRY(f_then_sumsq(c, exact, f, user, m, b.ftrial, b.xt, 7, c->d_slots + SL_TRIAL));   // :164, :168
+        LSQ_TRY(f_then_sumsq(c, exact, f, user, m, ftrial, xt, 7, c->d_slots + SL_TRIAL));   // :164, :168
         f_calls++;
         LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));  // :171-174
         mul_calls++;
@@ -936,13 +938,13 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
         converged = assess(maxabs_dx, maxabs_gr, ssr, trial_ssr, o->x_tol, o->f_tol, o->g_tol, accepted, &xc, &fc, &gc);
         if (accepted) {
             reuse = false;
-            LSQ_TRY(lsq_d2d(c, fcur, b.ftrial, (size_t)m * sizeof(double)));
-            LSQ_TRY(lsq_d2d(c, x, b.xt, (size_t)n * sizeof(double)));
+            std::swap(fcur, ftrial);                                          // copyto!(fcur, ftrial), copyto!(x, x_trial)
+            std::swap(x, xt);
             ssr = trial_ssr;
             nonfinite_at = trial_nonfinite;
         } else {
             reuse = true;
-            hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.xt, b.dx, x);
+            hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, xt, b.dx, x);
             nonfinite_at = trial_nonfinite;   // (x - dx) + dx keeps a non-finite component non-finite (see optimize_lm)
         }
         if (rho < DECREASE_THRESHOLD) delta = std::max(MIN_DELTA, delta * 0.5);           // :193-197
