@@ -881,11 +881,11 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
             LSQ_TRY(wdot_to_slot(c, exact, n, b.dgn, b.dgn, b.dtd, 5, c->d_slots + SL_W1));     // :117
             LSQ_TRY(wdot_to_slot(c, exact, n, b.dgr, b.dgn, b.dtd, 5, c->d_slots + SL_W2));     // :134 (case 3)
             LSQ_HIP(hipGetLastError());
-            double s0[1];
-            LSQ_TRY(lsq_read_slots(c, SL_GRAD, 1, s0));
-            maxabs_gr = s0[0];
-            double w[4];
-            LSQ_TRY(lsq_read_slots(c, SL_W0, 4, w));
+            double sl10[10];                                              // SL_GRAD .. SL_SUM in ONE hand-over to the host
+            static_assert(SL_SUM - SL_GRAD == 9 && SL_W0 - SL_GRAD == 6, "slot layout");
+            LSQ_TRY(lsq_read_slots(c, SL_GRAD, 10, sl10));
+            maxabs_gr = sl10[0];
+            const double *w = sl10 + (SL_W0 - SL_GRAD);
             wnorm_dgr = std::sqrt(w[0]);
             wnorm_dgn = std::sqrt(w[1]);
             alpha = wnorm_dgr * wnorm_dgr / w[3];
