@@ -672,11 +672,16 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
     # host, PCIe rate instead of the pageable-copy rate.  SURVEY 8f-1; levenberg_marquardt.jl:77-81 is where the upload sits.
     stage = None
     J_user = nls.J
-    if not is_op:
+    data_user = None
+    J_for_g = None
+
+    def bind_stage():
+        # (called inside the try below: whatever happens after the rebinding, the finally hands J.data back)
+        nonlocal stage, data_user, J_for_g
         stage = allocated._stage if allocated is not None and allocated._stage is not None else PinnedBuffer(ctx, Jd.nnz)
         if Jd.sparse:
-            np.copyto(stage.array, nls.J.data)
             data_user = nls.J.data
+            np.copyto(stage.array, data_user)
             nls.J.data = stage.array
             J_for_g = nls.J
         else:
@@ -712,22 +717,31 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
 
     F, G = _lib.F_CALLBACK(fcb), _lib.G_CALLBACK(gcb)
     tracing = store_trace or show_trace or full_trace
-    pc = None
-    if getattr(solver, "preconditioner", None) is not None:
-        pc = _precond_trampoline(solver.preconditioner, ctx, Jd)
+    st = res = tr = None
     try:
+        if not is_op:
+            bind_stage()
+        pc = None
+        if getattr(solver, "preconditioner", None) is not None:
+            pc = _precond_trampoline(solver.preconditioner, ctx, Jd)
         st, res, tr = _run_native(ctx, optimizer.kind, solver.kind, Jd, dx, dy, F, G, None, x_tol, f_tol,
                                   g_tol, iterations, delta, lower, upper, tracing, n, preconditioner=pc)
     finally:
         if stage is not None:       # hand the values back in ordinary memory before the pinned buffer can go away
             Jd.upload_wait()
             if Jd.sparse:
-                data_user[:] = stage.array
-                nls.J.data = data_user
-            else:
+                if data_user is not None:
+                    data_user[:] = stage.array
+                    nls.J.data = data_user
+            elif J_for_g is not None:
                 np.copyto(J_user, J_for_g)
             if allocated is None or allocated._stage is None:
                 stage.free()
+        if st is not None:
+            # optimize! mutates nls.x / nls.y in place (levenberg_marquardt.jl:46): when an iteration throws
+            # (RankDeficientException, IsFiniteException, ...) they hold that iteration's iterate, as in the reference
+            nls.x[:] = dx.get()
+            nls.y[:] = dy.get()
     if err:
         raise err[0]
     if st == _lib.ENONFINITE:
@@ -735,8 +749,6 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
         e.indices = [res.bad_index]
         raise e
     check(st)
-    nls.x[:] = dx.get()
-    nls.y[:] = dy.get()
     r = LeastSquaresResult()
     r.optimizer = optimizer.name
     r.minimizer = nls.x

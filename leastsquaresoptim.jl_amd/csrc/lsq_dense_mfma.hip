@@ -235,18 +235,26 @@ __device__ __forceinline__ bool cht_wait(const unsigned *flag, unsigned epoch, i
     }
     __syncthreads();
     const bool r = s_ok != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave, not only the polling one
     __syncthreads();
     return r;
 }
 // tile (rows 64 ti.., columns 64 tj..) of the column-major n x n matrix C -> LDS image [r][c]; entries outside the matrix:
 // identity on a diagonal tile, zero elsewhere
-__device__ __forceinline__ void cht_load(double *__restrict__ M, const double *__restrict__ C, int n, int ti, int tj, int tid) {
+// PUBLISHED = the tile was written by ANOTHER workgroup of this launch (cht_publish): agent-scope atomic loads, so that
+// neither the compiler (no invariance / no-alias assumption) nor a non-coherent cache level can serve a stale value
+template <bool PUBLISHED>
+__device__ __forceinline__ void cht_load(double *M, const double *C, int n, int ti, int tj, int tid) {
     double g[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int e = tid + 256 * q, r = e & 63, c = e >> 6;
         const int gr = 64 * ti + r, gc = 64 * tj + c;
-        g[q] = (gr < n && gc < n) ? C[(size_t)gc * n + gr] : ((ti == tj && r == c) ? 1.0 : 0.0);
+        if (gr < n && gc < n)
+            g[q] = PUBLISHED ? __hip_atomic_load(C + (size_t)gc * n + gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : C[(size_t)gc * n + gr];
+        else
+            g[q] = (ti == tj && r == c) ? 1.0 : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -254,7 +262,7 @@ __device__ __forceinline__ void cht_load(double *__restrict__ M, const double *_
         M[r * S64_LS + c] = g[q];
     }
 }
-__device__ __forceinline__ void cht_publish(double *__restrict__ C, int n, int ti, int tj, const double *__restrict__ M, bool upper_only,
+__device__ __forceinline__ void cht_publish(double *C, int n, int ti, int tj, const double *M, bool upper_only,
                                             unsigned *flag, unsigned epoch, int tid) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -269,7 +277,7 @@ __device__ __forceinline__ void cht_publish(double *__restrict__ C, int n, int t
 }
 
 __global__ void __launch_bounds__(256)
-k_chol_tiles(double *__restrict__ C, int n, int nt, int *__restrict__ info, double *__restrict__ Xd, unsigned *__restrict__ flags,
+k_chol_tiles(double *C, int n, int nt, int *info, double *Xd, unsigned *flags,   // (no __restrict__: workgroups exchange tiles through C and Xd)
              unsigned epoch, unsigned wait_epoch, int spin_limit) {   // (wait_epoch != epoch: the tests' fault injector)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *M0 = sm, *M1 = sm + S64_MAT, *M2 = sm + 2 * S64_MAT, *T = sm + 3 * S64_MAT;
@@ -279,15 +287,15 @@ k_chol_tiles(double *__restrict__ C, int n, int nt, int *__restrict__ info, doub
     while (t >= nt - ti) { t -= nt - ti; ++ti; }
     const int tj = ti + t;
     unsigned *myflag = flags + ti * nt + tj;
-    cht_load(M0, C, n, ti, tj, tid);
+    cht_load<false>(M0, C, n, ti, tj, tid);
     __syncthreads();
     bool ok = true;
     for (int k = 0; k < ti && ok; ++k) {
         ok = cht_wait(flags + k * nt + ti, wait_epoch, info, spin_limit);
         if (ok && tj != ti) ok = cht_wait(flags + k * nt + tj, wait_epoch, info, spin_limit);
         if (!ok) break;
-        cht_load(M1, C, n, k, ti, tid);                     // U(k, i): rows = the k index
-        if (tj != ti) cht_load(M2, C, n, k, tj, tid);
+        cht_load<true>(M1, C, n, k, ti, tid);               // U(k, i): rows = the k index
+        if (tj != ti) cht_load<true>(M2, C, n, k, tj, tid);
         __syncthreads();
         const double *B = tj != ti ? M2 : M1;
         for (int q = wv; q < 16; q += 4) {                  // tile -= U(k, i)' U(k, j)
@@ -329,7 +337,8 @@ k_chol_tiles(double *__restrict__ C, int n, int nt, int *__restrict__ info, doub
         {   // inv(U(i, i)) (column-major 64 x 64 in Xd) -> M1 [r][c]
             double g[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) g[q] = Xd[(size_t)ti * 4096 + tid + 256 * q];
+            for (int q = 0; q < 16; ++q)
+                g[q] = __hip_atomic_load(Xd + (size_t)ti * 4096 + tid + 256 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int e = tid + 256 * q, r = e & 63, c = e >> 6;

@@ -560,15 +560,22 @@ static int check_start(const double *hx, int n, const lsq_options *o) {
 // Callback protocol (include/lsqhip.h, lsq_options.allreduce): vals = {ssr, maxabs_gr, converged}; converged < 0 on
 // the way in announces "this rank is leaving with an error"; converged < 0 on the way out (or return code 2) says
 // that some rank did -- every rank then leaves its loop with LSQ_ERCCL instead of waiting in a collective forever.
+// Every rank issues exactly one exchange per outer iteration (frozen ranks at the top, active ones behind queued work), so
+// the exchange count of a loop equals its iteration count on every rank: once `iterations` exchanges have been issued no
+// peer will enter another collective.  (Per host thread: a context is driven by one thread at a time.)
+static thread_local int t_xchg_issued = 0;          // exchanges issued by the loop running on this thread
+static thread_local bool t_xchg_hook_failed = false;  // the hook itself failed: it must not be called again
 static int global_exchange(const lsq_options *o, double *ssr, double *gnorm, int *all_converged) {
     if (!o->allreduce) return LSQ_OK;
     double v[3] = {*ssr, *gnorm, (double)*all_converged};
+    t_xchg_issued++;
     const int rc = o->allreduce(v, 3, o->allreduce_user);
     if (rc == 2 || (rc == 0 && v[2] < -0.5)) {
         lsq_set_error("sharded run: a peer rank left its loop with an error");
         return LSQ_ERCCL;
     }
     if (rc != 0) {
+        t_xchg_hook_failed = true;
         lsq_set_error("allreduce callback failed");
         return LSQ_ECALLBACK;
     }
@@ -579,14 +586,20 @@ static int global_exchange(const lsq_options *o, double *ssr, double *gnorm, int
 }
 
 // Every exit of a sharded loop: the idle hook (which points at a stack object of the loop) is disarmed, and a rank
-// that leaves with an error tells its peers so with one last exchange.
+// that leaves with an error tells its peers so with one last exchange -- unless nobody can be there to match it: the
+// failing call was the hook itself, or this rank has already issued the exchange of its LAST allowed iteration (its
+// peers are in theirs, or past it, and will not enter another collective: a farewell would wait forever).
 struct ShardedExit {
     lsq_ctx *c;
     const lsq_options *o;
+    ShardedExit(lsq_ctx *c_, const lsq_options *o_) : c(c_), o(o_) {
+        t_xchg_issued = 0;
+        t_xchg_hook_failed = false;
+    }
     int finish(int st) {
         c->idle_hook = nullptr;
         c->idle_user = nullptr;
-        if (st != LSQ_OK && st != LSQ_ERCCL && o->allreduce) {
+        if (st != LSQ_OK && st != LSQ_ERCCL && o->allreduce && !t_xchg_hook_failed && t_xchg_issued < o->iterations) {
             double v[3] = {0.0, 0.0, -1.0};
             (void)o->allreduce(v, 3, o->allreduce_user);
         }
@@ -687,7 +700,9 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
         if (!cs) return LSQ_EHIP;
         const bool one_wg = !exact && n <= LSQ_ONE_WG_N;
-        const bool lm_prep = one_wg && sv->kind == LSQ_LSMR && lsq_lsmr_takes_lm_prep(sv, J);
+        // (ssr = NaN, i.e. f(x) not finite: the fused preparation takes ssr as the norm of the right-hand side; the
+        //  separate kernels re-form it and let the NaN travel to the reference's check_isfinite at the next iteration)
+        const bool lm_prep = one_wg && sv->kind == LSQ_LSMR && ssr >= 0.0 && lsq_lsmr_takes_lm_prep(sv, J);
         if (exact) LSQ_TRY(lsq_exact_lm_damp(c, n, cs, 1.0 / delta, b.dtd));
         else if (!one_wg) hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
         {   // :102-104 gradient g = J'f at the pre-step x.  The reference forms it AFTER the solve

@@ -11,7 +11,10 @@ Error protocol (include/lsqhip.h): the loop calls the hook a last time with conv
 with an error; every rank that sees a non-zero abort count gets return code 2 (-> LSQ_ERCCL) and issues
 no further collective, so all ranks issue the same number of all-reduces and nobody waits forever.
 """
+import datetime
+import os
 import sys
+import time
 
 from . import _lib
 
@@ -73,16 +76,29 @@ def make_allreduce_callback(dist, rank, world, device, group=None):
     # exchange cost 9-11 % of the C4 rate at one rank that way, ~2 % from a side stream)
     xstream = torch.cuda.Stream(device=device) if on_gpu else None
 
+    # a peer that died without its farewell must not hang this rank forever: the wait for an exchange is bounded
+    # (LSQ_EXCHANGE_TIMEOUT_S, default 120 s) and a timeout surfaces as a failed hook (-> LSQ_ECALLBACK, no further call)
+    timeout_s = float(os.environ.get("LSQ_EXCHANGE_TIMEOUT_S", "120"))
+
     def _finish(work, k):
-        work.wait()
         if on_gpu:
+            work.wait()      # (RCCL: orders this stream behind the collective; returns at once)
             hosts[k].copy_(bufs[k], non_blocking=True)
             # (polled, not stream.synchronize(): the blocking wait's wake-up costs ~50 us of host time, and this thread
             #  is the one that feeds the LM loop's launches)
             done_ev.record()
+            deadline = None
+            spins = 0
             while not done_ev.query():
-                pass
+                spins += 1
+                if spins & 0xFFFF == 0:
+                    now = time.monotonic()
+                    deadline = deadline or now + timeout_s
+                    if now > deadline:
+                        raise TimeoutError("exchange not completed after %.0f s (a peer rank is gone?)" % timeout_s)
         else:
+            if not work.wait(datetime.timedelta(seconds=timeout_s)):
+                raise TimeoutError("exchange not completed after %.0f s (a peer rank is gone?)" % timeout_s)
             hosts[k].copy_(bufs[k])
         hv = views[k]
         if hv[2] > 0.5:

@@ -81,3 +81,58 @@ def test_synthetic_generator_is_deterministic_and_well_formed():
     assert abs(d.std() * np.sqrt(200) - 1.0) < 0.1
     u = lsq.synthetic.uniform(1000, 3)
     assert u.min() >= -1 and u.max() <= 1 and abs(u.mean()) < 0.1
+
+
+# ------------------------------------------------------------------ the Julia shim of INTEGRATION.md
+def test_julia_shim_matches_the_header():
+    """Every ccall in INTEGRATION.md against include/lsqhip.h: symbol declared and exported, return type, arity, number of
+    values passed, and the C type class of every argument; the option / result structs field by field."""
+    import julia_shim_lint as JL
+    protos = JL.header_prototypes()
+    assert set(protos) == set(lsq.declared_symbols())              # the lint's header parser sees what the loader sees
+    calls = JL.ccalls()
+    assert len(calls) >= 40
+    L = lsq.lib()
+    for name, ret, types, nvalues, line in calls:
+        where = "INTEGRATION.md julia line %d: ccall(:%s)" % (line, name)
+        assert name in protos and hasattr(L, name), where
+        cret, cparams = protos[name]
+        assert ret in JL.JULIA_CLASS and cret in JL.JULIA_CLASS[ret], (where, "return", ret, cret)
+        assert len(types) == len(cparams), (where, "arity", len(types), len(cparams))
+        assert nvalues == len(types), (where, "values passed", nvalues, len(types))
+        for k, (jt, ct) in enumerate(zip(types, cparams)):
+            assert jt in JL.JULIA_CLASS, (where, "unknown Julia type", jt)
+            assert ct in JL.JULIA_CLASS[jt], (where, "argument %d" % (k + 1), jt, ct)
+    # the hot-path entry points are all bound
+    bound = {c[0] for c in calls}
+    for need in ("lsq_mul", "lsq_colsumabs2", "lsq_rowsumabs2", "lsq_ldiv", "lsq_ldiv_damped", "lsq_solver_create",
+                 "lsq_solver_destroy", "lsq_csc_create", "lsq_dense_create", "lsq_mat_set_values", "lsq_mat_set_values_async",
+                 "lsq_optimize", "lsq_options_default", "lsq_wdot", "lsq_amax_projected", "lsq_box_clip", "lsq_first_nonfinite"):
+        assert need in bound, need
+    for jname, cname in (("LsqOptions", "lsq_options"), ("LsqResult", "lsq_result")):
+        jf, cf = JL.julia_struct(jname), JL.header_struct(cname)
+        assert [f for f, _ in jf] == [f for f, _ in cf], (jname, jf, cf)
+        for (f, jt), (_, ct) in zip(jf, cf):
+            assert ct in JL.JULIA_CLASS[jt], (jname, f, jt, ct)
+    # the ctypes mirror (what the tests actually drive) has the same layout
+    assert [f for f, _ in lsq._lib.Options._fields_] == [f for f, _ in JL.header_struct("lsq_options")]
+    assert [f for f, _ in lsq._lib.Result._fields_] == [f for f, _ in JL.header_struct("lsq_result")]
+
+
+def test_julia_shim_defines_what_the_reference_loops_call():
+    """The two load-time defects a reader found in round 2 cannot come back: (a) `J'` needs Base.adjoint on the handle types
+    (levenberg_marquardt.jl:102, dogleg.jl:99); (b) AbstractAllocatedSolver methods must not be ambiguous with the reference's
+    (iterative_lsmr.jl:173,233; dense_qr.jl:25,50; dense_cholesky.jl:19): argument 1 narrower, argument 2 identical."""
+    import re
+    import julia_shim_lint as JL
+    src = JL.julia_blocks()
+    for pattern, why in JL.REQUIRED_METHODS:
+        assert re.search(pattern, src), "shim lacks a method matching %r (needed by %s)" % (pattern, why)
+    assert not re.search(r"Adjoint\{[^}]*Hip", src), "LinearAlgebra.Adjoint of a non-AbstractMatrix handle"
+    methods = JL.allocated_solver_methods()
+    assert {a2 for _, a2 in methods} == set(JL.REFERENCE_SOLVER_METHODS), methods
+    for a1, a2 in methods:
+        assert a1 == "HipProblem", (a1, a2)         # narrower than the reference's `nls::LeastSquaresProblem{...}`
+    m = re.search(r"const HipProblem = LeastSquaresProblem\{(.*)\}", src)
+    assert m and m.group(1).count(",") == 4          # LeastSquaresProblem{Tx, Ty, Tf, TJ, Tg}: types.jl:7
+    assert "<:HipVector,<:HipVector,<:Any,<:HipJacobian" in m.group(1)

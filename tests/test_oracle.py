@@ -324,29 +324,73 @@ def test_golden_trajectories():
 # values of the 16 NIST StRD problems in test/nonlinearfitting.jl (restated as data in tests/golden/nist.json).
 # The reference runs Dogleg(QR()) and LevenbergMarquardt(QR()) from every column of `parameters` with
 # x_tol = 1e-50, f_tol = 1e-36, g_tol = 1e-50 and PRINTS how many land within 1e-3 of the certified values (it only
-# asserts !isnan).  The starts below are NIST's "start 1" of the higher-difficulty problems, from which these
-# optimizers are known not to reach the certified minimum; everywhere else the certified values must be hit.
-NIST_KNOWN_MISSES = {("MGH09", "dogleg", 0), ("BoxBOD", "lm", 0), ("MGH10", "dogleg", 0), ("MGH10", "lm", 0)}
-NIST_KW = dict(x_tol=1e-50, f_tol=1e-36, g_tol=1e-50, iterations=1000)      # nonlinearfitting.jl:1465
+# asserts !isnan).  Here the same vectors go through ALL solvers of the hot path (tests/nist_cases.py), and every run
+# that does not end at the certified values is classified WITH EVIDENCE recomputed here -- there is no exclusion list.
+import nist_cases as NC  # noqa: E402
+
+NIST_KEYS = [NC.config_key(o, s, st, jac) for (o, s, st) in NC.CONFIGS for jac in ("central", "analytic")]
 
 
-@pytest.mark.parametrize("opt", ["dogleg", "lm"])
-@pytest.mark.parametrize("jac", ["central", "analytic"])
-def test_nist_certified_values(opt, jac):
+@pytest.mark.parametrize("key", NIST_KEYS)
+def test_nist_certified_values(key):
+    """All six optimizer x solver pairs (LSMR on the dense J and on the same J as a fixed-pattern CSC) from all 33 starts:
+    the class of every run -- hit / slow_in_basin / plateau / stationary / stalled_far / rank_deficient, each asserted with
+    its evidence inside NC.classify -- equals the committed table tests/golden/nist_outcomes.json."""
     import nist
-    hits = total = 0
+    opt, solver, storage, jac = key.split("/")
+    fx = NC.load_outcomes()
+    run = NC.oracle_runner()
+    want = fx["classes"][key]
+    got = {}
     for p in nist.problems():
-        for si, start in enumerate(p.starts):
-            J = O.Mat(dense=np.zeros((p.m, p.n)))
-            g = p.g_flat if jac == "analytic" else nist.central_difference_g(p.f, p.m, p.n)
-            r = O.optimize(O.DOGLEG if opt == "dogleg" else O.LM, O.QR, J, start, p.f, g, trace=False, **NIST_KW)
-            assert r.status == O.OK and not np.isnan(np.mean(r.minimizer)), (p.name, si)      # the reference's assert
-            ok = np.linalg.norm(r.minimizer - p.certified) <= 1e-3                            # the reference's count
-            total += 1
-            hits += ok
-            if (p.name, opt, si) not in NIST_KNOWN_MISSES:
-                assert ok, (p.name, opt, jac, si, r.minimizer, p.certified)
-    assert total == 33 and hits >= total - 2, (hits, total)
+        for si in range(len(p.starts)):
+            cls, ev = NC.classify(p, si, opt, solver, storage, jac, run, fx["plateaus"])
+            got["%s/%d" % (p.name, si)] = cls
+    assert len(got) == 33
+    assert got == {k: v["class"] for k, v in want.items()}
+    if solver == "qr":          # the reference's own configuration: its printed count would read 31 / 33
+        assert sum(c == "hit" for c in got.values()) == 31
+
+
+def test_nist_misses_are_explained():
+    """What the table must say for the claim "every solver reaches the certified values wherever QR does, or the difference
+    is explained": (1) no run is unclassified; (2) a run of Cholesky or LSMR that ends away from the certified minimum's
+    basin (plateau, stalled_far) does so only from a start from which QR() with the same optimizer does too; (3) the
+    other differences are the inexact inner solve (slow_in_basin: QR from the endpoint arrives), another stationary point
+    (stationary, cosine <= 1e-6), or the exception the reference's pivoted Cholesky throws on a numerically singular
+    J'J (rank_deficient, cond(J) >= 1e6); (4) the hard starts are hard for independent solvers as well."""
+    fx = NC.load_outcomes()
+    classes = fx["classes"]
+    known = {"hit", "slow_in_basin", "plateau", "stationary", "stalled_far", "rank_deficient"}
+    for key, table in classes.items():
+        opt, solver, storage, jac = key.split("/")
+        assert len(table) == 33 and {v["class"] for v in table.values()} <= known
+        for start, v in table.items():
+            qr_classes = {classes[NC.config_key(opt, "qr", "dense", j)][start]["class"] for j in ("central", "analytic")}
+            if v["class"] in ("plateau", "stalled_far"):
+                assert qr_classes & {"plateau", "stalled_far"}, (key, start, v, qr_classes)
+            if v["class"] == "slow_in_basin":
+                assert solver == "lsmr" and v["qr_from_endpoint_hits"]
+            if v["class"] == "stationary":
+                assert v["optimality_cosine"] <= 1e-6
+            if v["class"] == "rank_deficient":
+                assert (opt, solver) == ("dogleg", "cholesky") and v["cond_J"] >= 1e6
+    # starts no configuration reaches the certified values from: MINPACK (scipy 'lm') either fails there too or needs more
+    # evaluations than anywhere else in the suite
+    ind = fx["independent"]
+    worst = sorted(ind, key=lambda k: -ind[k]["lm"]["nfev"])[:4]
+    for start in {s for t in classes.values() for s, v in t.items() if v["class"] in ("plateau", "stalled_far")}:
+        assert (not ind[start]["lm"]["hit"]) or (not ind[start]["dogbox"]["hit"]) or start in worst, start
+    # runs whose class is decided by round-off (it changes under the oracle's summation-order models / rounding-noise modes):
+    # few, all on three knife-edge starts, and never between "reaches the certified minimum's basin" and "leaves it" except on
+    # BoxBOD start 1, where LM either escapes the plateau or does not (MINPACK does not)
+    od = fx["order_dependent"]
+    assert sum(len(v) for v in od.values()) <= 12
+    for key, runs in od.items():
+        for start, seen in runs.items():
+            assert start in ("BoxBOD/0", "MGH10/1", "Bennett5/0", "Bennett5/1"), (key, start)
+            assert classes[key][start]["class"] in seen
+            assert set(seen) <= {"hit", "stationary", "slow_in_basin"} or start == "BoxBOD/0", (key, start, seen)
 
 
 def test_nist_fixture_is_consistent():

@@ -126,6 +126,68 @@ def test_two_ranks_lm_with_exchange():
     assert ssr0 == pytest.approx(s0 + s1, rel=1e-12) and ssr1 == pytest.approx(ssr0, rel=1e-15)
 
 
+def _worker_lm_failing(rank, world, port, q, fail_at_f_call, iterations):
+    """Rank 1's f! fails at its `fail_at_f_call`-th call (call 1 = f(x0), call k+1 = the trial point of iteration k)."""
+    import ctypes as C
+    _init(rank, world, port)
+    os.environ["LSQ_EXCHANGE_TIMEOUT_S"] = "20"
+    ctx = lsq.Context(0)
+    pr = lsq.synthetic.TanhProblem(4000, 40, sparse=True, per_col=100, seed=21 + rank, ctx=ctx)
+    pr.reset()
+    L = lsq.lib()
+    model_f = L.lsq_model_f()
+    calls = [0]
+
+    def f(d_out, d_x, user):
+        calls[0] += 1
+        if rank == 1 and calls[0] == fail_at_f_call:
+            return 1
+        return model_f(d_out, d_x, user)
+
+    class _H:
+        pass
+
+    Jd = _H()
+    Jd.h = pr.J
+    cb = lsq.sharding.make_allreduce_callback(dist, rank, world, "cpu")
+    st, res, _ = lsq.api._run_native(ctx, lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, Jd, pr.x, pr.fcur,
+                                     lsq._lib.F_CALLBACK(f), L.lsq_model_g(), pr.model, 0.0, 0.0, 0.0, iterations, None,
+                                     None, None, False, pr.n, allreduce=cb)
+    lsq.sharding.drain_all()
+    q.put((rank, st, res.iterations, calls[0]))
+    pr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("when", ["last_iteration", "mid_run"])
+def test_rank_failing_after_its_exchange_does_not_hang(when):
+    """a rank whose callback fails in its LAST allowed iteration, after that iteration's exchange, must not issue
+    a farewell exchange -- its peers are leaving their loops and would never match it (it used to wait forever).  Mid-run
+    the farewell IS matched and the peer leaves with LSQ_ERCCL."""
+    from lsq_amd import api as _api  # noqa: F401  (lsq.api)
+    iterations = 6
+    fail_at = 1 + iterations if when == "last_iteration" else 3
+    world, port = 2, _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    ps = [mpc.Process(target=_worker_lm_failing, args=(r, world, port, q, fail_at, iterations)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rec = q.get(timeout=180)
+        res[rec[0]] = rec[1:]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[1][0] == lsq._lib.ECALLBACK and res[1][2] == fail_at
+    if when == "last_iteration":
+        assert res[0][0] == lsq._lib.OK and res[0][1] == iterations      # the peer finished all its iterations
+    else:
+        assert res[0][0] == lsq._lib.ERCCL                                # the peer was told and left
+
+
 def _worker_lm_rccl(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
