@@ -81,6 +81,22 @@ double *lsq_mat_values(lsq_mat *J);
 /* ... after which the CSR mirror must be refreshed (no-op for dense). */
 int lsq_mat_refresh(lsq_mat *J);
 
+/* ---- column-scaled Jacobians J = V diag(s) ----
+ * Models of the form r(x) = V phi(x) - b (phi elementwise) have J(x) = V diag(phi'(x)): the pattern AND the stored values V
+ * are fixed, only n factors change from one g!(J, x) to the next (test/nonlinearleastsquares.jl:47-86 is the general case,
+ * where g! rewrites nonzeros(J); this is the structured special case).  lsq_mat_set_colscale(J, d_s) declares the values J
+ * holds at that moment (lsq_mat_set_values / lsq_mat_values) to be V and d_s (n device doubles, owned by the caller, read
+ * whenever J is used) to be s; every operation on the handle -- lsq_mul, lsq_colsumabs2, lsq_rowsumabs2, lsq_ldiv*,
+ * lsq_optimize -- then acts on V diag(s).  On the sliced layouts of big sparse patterns nothing is multiplied out: J*x
+ * gathers s.*x, J'y = s.*(V'y), colsumabs2(J) = s.^2 .* colsumabs2(V) (cached): a g! costs an n-vector instead of two passes
+ * over nnz values.  Other matrices (small, dense, segment-kernel patterns) keep V aside and multiply the values out each
+ * time.  A g! that changed s calls lsq_mat_colscale_changed(J) (instead of lsq_mat_refresh); lsq_mat_set_values /
+ * lsq_mat_values / lsq_mat_get_values keep addressing V.  d_s = NULL turns J back into the plain matrix V.
+ * Entry (i,j) of J is used as V_ij * s_j formed on the fly where the reference would have stored fl(V_ij s_j): results agree
+ * with a multiplied-out J to a few ulp per product, not bit for bit (tests/test_gpu_parity.py::test_column_scaled_jacobian). */
+int lsq_mat_set_colscale(lsq_mat *J, const double *d_s);
+int lsq_mat_colscale_changed(lsq_mat *J);
+
 /* ---- custom Jacobian operators (README.md:37-47: any type with mul!, mul! of the adjoint, colsumabs2!,
  *      size, eltype works with LSMR) ----
  * A matrix-free handle: `mul(trans, d_x, d_out, user)` must write J*x (trans = 0, m entries) or J'*x

@@ -104,6 +104,8 @@ def lib():
         "lsq_emul": (i, [vp, i, vp, vp, vp]),
         "lsq_mat_values": (vp, [vp]),
         "lsq_mat_refresh": (i, [vp]),
+        "lsq_mat_set_colscale": (i, [vp, vp]),
+        "lsq_mat_colscale_changed": (i, [vp]),
         "lsq_mul": (i, [vp, i, d, vp, d, vp]),
         "lsq_solver_set_preconditioner": (i, [vp, PRECOND_CALLBACK, vp]),
         "lsq_op_create": (i, [vp, i, i, OP_MUL_CALLBACK, OP_COLSUM_CALLBACK, vp, C.POINTER(vp)]),

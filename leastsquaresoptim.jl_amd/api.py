@@ -267,6 +267,17 @@ class DeviceMatrix:
         check(lib().lsq_mat_get_values(self.h, out.ctypes.data_as(_lib.c_dp)))
         return out
 
+    def set_colscale(self, s):
+        """J = V diag(s) (lsq_mat_set_colscale): the values held now are V, `s` a DeviceVector of n factors that stays alive
+        (and may be rewritten, followed by colscale_changed()) as long as the scale is set; None removes it."""
+        if s is not None and s.n != self.n:
+            raise DimensionMismatch(_lib.EDIM, "column scale has length %d, expected %d" % (s.n, self.n))
+        check(lib().lsq_mat_set_colscale(self.h, s.ptr if s is not None else None))
+        self._colscale = s
+
+    def colscale_changed(self):
+        check(lib().lsq_mat_colscale_changed(self.h))
+
     def free(self):
         if self.h:
             lib().lsq_mat_destroy(self.h)

@@ -182,10 +182,16 @@ struct lsq_mat {
     bool csr_fresh = false;
     bool csc_fresh = true;  // false: a device g! wrote the mirrors only (see lsq_ensure_csc)
     bool upload_pending = false;   // lsq_mat_set_values_async: the host buffer is still being read
-    // a device-side g! of the form J = A diag(s) may leave the sliced COLUMN copy unmaterialised: the next pass over it
-    // (gradient + colsumabs2, right after g! in both loops) scales A's entries as it streams them and writes the copy
-    const double *cols_pending_src = nullptr;     // A's values in the sliced-column layout
-    const double *cols_pending_scale = nullptr;   // s (n entries)
+    // COLUMN-SCALED Jacobian J = V diag(s) (lsq_mat_set_colscale): V = the stored values, s = n factors in a device buffer
+    // of the caller.  On the sliced layouts nothing is ever multiplied out: J*x gathers s .* x, J'y scales the combined dots,
+    // colsumabs2(J) = s.^2 .* colsumabs2(V) with colsumabs2(V) cached.  Elsewhere (small / dense / segment-kernel matrices)
+    // the handle keeps V aside (d_cs_base) and multiplies the values out whenever s changes.
+    const double *d_colscale = nullptr;        // fused mode only: what the product kernels read
+    const double *d_cs_user = nullptr;         // the caller's s (both modes)
+    double *d_cs_base = nullptr;               // materialising mode: V in CSC order / dense column-major
+    double *d_colsum_base = nullptr;           // fused mode: colsumabs2(V)
+    unsigned long long base_version = 0;       // bumps whenever V changes
+    unsigned long long colsum_base_version = ~0ull;
     // Row-window-blocked CSC for J'*y when the gathered m-vector outgrows an XCD's L2 (4 MiB):
     // rows are cut into `nwin` windows; segment (w, j) holds column j's entries with rows in
     // window w, so all gathers of a window hit a <= 1 MiB slice of y that stays L2-resident on
@@ -383,6 +389,7 @@ int lsq_mirror_cols(lsq_mat *J, const double *d_csc_vals, double *d_out);
 long long lsq_mirror_rows_len(const lsq_mat *J);
 long long lsq_mirror_cols_len(const lsq_mat *J);
 bool lsq_can_fuse_grad_colsum(const lsq_mat *J);
+bool lsq_colscale_fusable(const lsq_mat *J);   // lsq_mat_set_colscale would take the fused (never multiplied out) mode
 int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g);  // g = J'f, fills the colsum cache
 const double *lsq_cached_colsum(lsq_mat *J);  // nullptr on failure (error set)
 // reads slot values to host (synchronises the stream)

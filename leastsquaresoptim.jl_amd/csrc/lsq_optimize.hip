@@ -617,7 +617,8 @@ struct ShardedExit {
 
 static int call_g(lsq_g_callback g, lsq_mat *J, const double *x, void *user) {
     J->version++;
-    if (J->kind == LSQ_MAT_CSC) J->csr_fresh = false;
+    // (a column-scaled handle's g! says itself what it changed: lsq_mat_colscale_changed / lsq_mat_refresh)
+    if (J->kind == LSQ_MAT_CSC && !J->d_cs_user) J->csr_fresh = false;
     CB(g(J, x, user));
     return lsq_ensure_csr(J);
 }
@@ -1046,18 +1047,18 @@ extern "C" int lsq_optimize(lsq_ctx *c, int optimizer, int solver_kind, lsq_mat 
 struct lsq_model {
     lsq_ctx *ctx;
     lsq_mat *J;
-    double *d_Acsc = nullptr;  // A values, CSC order (or dense column-major)
-    double *d_Acsr = nullptr;  // A values in J's row-mirror layout (CSR order or sliced rows)
+    // fused: J is a COLUMN-SCALED handle on the sliced layouts (lsq_mat_set_colscale): J's own storage holds A once, g! writes
+    // the n factors s = 1 - tanh(x)^2 and nothing else; every product applies them on the fly
+    bool fused = false;
+    double *d_Acsc = nullptr;  // A values, CSC order (or dense column-major)                       } not fused: J's values are
+    double *d_Acsr = nullptr;  // A values in J's row-mirror layout (CSR order or sliced rows)      } multiplied out by g!
     double *d_Ab = nullptr;    // A values in J's column-mirror layout (window-blocked CSC or sliced columns)
     double *d_b = nullptr;
     double *d_t = nullptr;     // tanh(x) of the latest f!
-    double *d_s = nullptr;     // 1 - tanh(x)^2 of the latest g! (its own buffer: a pending column copy still reads it)
-    double *d_sspec = nullptr; // the same at the speculative point
-    // J's sliced-row values at the latest trial point, written by the residual pass there (model_f_sumsq); g! at that point
-    // adopts the buffer instead of scaling A again
-    double *d_Jspec = nullptr;
-    const double *spec_x = nullptr;   // device vector the speculative values belong to (null: none)
-    const double *tanh_x = nullptr;   // device vector whose tanh / 1 - tanh^2 the step kernel has already put into d_t / d_sspec
+    double *d_s = nullptr;     // 1 - tanh(x)^2 of the latest g! (fused: this IS J's column scale)
+    double *d_sspec = nullptr; // the same at the latest trial point (written by the step kernel)
+    const double *tanh_x = nullptr;   // device vector whose tanh the step kernel has already put into d_t
+    const double *sfac_x = nullptr;   // device vector whose 1 - tanh^2 the step kernel has already put into d_sspec
 };
 
 __global__ void __launch_bounds__(LSQ_NT) k_tanh(int n, const double *__restrict__ x, double *__restrict__ t) {
@@ -1107,16 +1108,6 @@ struct EpiResidualSq {  // out = A t - b, and sum(out.^2) -> slot (+ the iterati
             __hip_atomic_store(pub.seq_word, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-};
-
-struct TanhJacMap {   // J = A diag(1 - t.^2) from the staged t = tanh(x) (same arithmetic as k_sfac + k_scale_lds)
-    static constexpr bool on = true;
-    double *dval;
-    __device__ double f(double t) const { return 1.0 - t * t; }
-};
-struct EpiResidualSqJac : EpiResidualSq {
-    using colmap = TanhJacMap;
-    TanhJacMap cm;
 };
 
 // column scaling of a column-segmented value array (CSC nzval or dense columns)
@@ -1219,21 +1210,17 @@ k_scale_bcsc_thread(int nseg, int n, const int *__restrict__ ptr, const double *
     }
 }
 
-// g!'s LDS-staged scaling of the row layout applies (and with it the speculative variant of the residual pass)
-static bool model_rows_by_lds(const lsq_mat *J) {
-    return J->kind == LSQ_MAT_CSC && J->srows.active && J->srows.d_idx16 && J->n <= 12000 && J->nnz >= (1 << 20);
-}
-
 static int model_f(double *out, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
     lsq_mat *J = md->J;
-    md->spec_x = nullptr;
     md->tanh_x = nullptr;
+    md->sfac_x = nullptr;
     hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     EpiResidual e{nullptr, 0, md->d_b, out, nullptr, nullptr};
     if (J->kind == LSQ_MAT_CSC && J->srows.active) {
-        if (launch_sell_rows(J, md->d_Acsr, md->d_t, e) != LSQ_OK) return 1;   // same pattern, A's values
+        // the stored values themselves (fused: J's storage IS A; else A in the same layout), no column scale: r = A t - b
+        if (launch_sell_rows(J, nullptr, md->d_t, e, md->fused ? nullptr : md->d_Acsr) != LSQ_OK) return 1;
     } else if (J->kind == LSQ_MAT_CSC) {
         LsqSegs A = J->csr;  // same pattern, A's values
         A.d_val = md->d_Acsr;
@@ -1246,13 +1233,15 @@ static int model_f(double *out, const double *x, void *user) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// the step kernel of both loops writes tanh(x_trial) and 1 - tanh(x_trial)^2 next to x_trial itself: the model's f!(., x_trial)
+// and -- if the step is accepted -- its g!(., x_trial) then need no n-length launch of their own
 static void model_trial_buffers(void *user, const double *xt, double **t_out, double **s_out) {
     lsq_model *md = (lsq_model *)user;
-    md->tanh_x = nullptr;
-    if (model_rows_by_lds(md->J) && !getenv("LSQ_NO_SPEC_JAC") && md->d_Jspec) {   // (from the second trial point on)
+    md->tanh_x = md->sfac_x = nullptr;
+    if (md->J->kind == LSQ_MAT_CSC && md->J->srows.active) {
         *t_out = md->d_t;
         *s_out = md->d_sspec;
-        md->tanh_x = xt;
+        md->tanh_x = md->sfac_x = xt;
     }
 }
 
@@ -1264,26 +1253,13 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
     *done = false;
     if (!(J->kind == LSQ_MAT_CSC && J->srows.active)) return model_f(out, x, user);
     EpiResidualSq e{nullptr, 0, md->d_b, out, c->d_partials, lsq_ctr(c, ctr), d_out, pub};
-    md->spec_x = nullptr;
-    const bool have_tanh = md->tanh_x == x;   // k_step formed tanh(x) and 1 - tanh(x)^2 while it wrote x
+    const bool have_tanh = md->tanh_x == x;   // k_step formed tanh(x) while it wrote x
     md->tanh_x = nullptr;
-    if (model_rows_by_lds(J) && !getenv("LSQ_NO_SPEC_JAC")) {
-        // x is a trial point that becomes the next linearisation point if the step is accepted: the Jacobian's row layout there
-        // costs one extra store stream in this pass (A's entries and t are already in registers / LDS)
-        if (!md->d_Jspec) {
-            const size_t rb = (size_t)(lsq_mirror_rows_len(J) + 1024) * sizeof(double);
-            if (hipMalloc(&md->d_Jspec, rb) != hipSuccess) return 1;
-            if (hipMemsetAsync(md->d_Jspec, 0, rb, c->stream) != hipSuccess) return 1;
-        }
-        if (!have_tanh)
-            hipLaunchKernelGGL(k_tanh_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t, md->d_sspec);
-        EpiResidualSqJac ej{e, TanhJacMap{md->d_Jspec}};
-        if (launch_sell_rows(J, md->d_Acsr, md->d_t, ej) != LSQ_OK) return 1;
-        md->spec_x = x;
-    } else {
+    if (!have_tanh) {
+        md->sfac_x = nullptr;
         hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
-        if (launch_sell_rows(J, md->d_Acsr, md->d_t, e) != LSQ_OK) return 1;
     }
+    if (launch_sell_rows(J, nullptr, md->d_t, e, md->fused ? nullptr : md->d_Acsr) != LSQ_OK) return 1;
     *done = true;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -1291,6 +1267,16 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
 static int model_g(lsq_mat *J, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
+    // s = 1 - tanh(x)^2: already there if x is the trial point the step kernel has just written
+    if (md->sfac_x == x) std::swap(md->d_s, md->d_sspec);
+    else hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_s);
+    md->sfac_x = nullptr;
+    md->tanh_x = nullptr;
+    if (md->fused) {
+        // J = A diag(s) is never multiplied out: handing the handle its (new) factor vector is all of g!
+        if (lsq_mat_set_colscale(J, md->d_s) != LSQ_OK) return 1;
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
     if (J->kind == LSQ_MAT_CSC) {
         // mirrors the products read: rows (CSR or sliced rows) and columns (window-blocked CSC or sliced
         // columns), each with a 16-bit column per stored entry when the LDS-staged scaling applies
@@ -1315,14 +1301,8 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
             LSQ_TRY(lsq_set_lds(c, (const void *)k_scale_lds<true>, 12000 * 8));
             LSQ_TRY(lsq_set_lds(c, (const void *)k_scale_lds<false>, 12000 * 8));
         }
-        const bool adopt = md->spec_x == x && md->d_Jspec && J->srows.active && J->nnz > 0;
-        if (adopt) std::swap(md->d_s, md->d_sspec);   // (the factors 1 - tanh(x)^2 came with it)
-        else hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_s);
         if (J->nnz > 0) {
-            if (adopt) {
-                // the residual pass at this very point already wrote the row layout: adopt its buffer
-                std::swap(J->srows.d_val, md->d_Jspec);
-            } else if (lds_ok && rcol) {
+            if (lds_ok && rcol) {
                 hipLaunchKernelGGL(k_scale_lds<true>, dim3(c->num_cus), dim3(1024), lds, c->stream, (rlen + 3) / 4, rcol,
                                    md->d_Acsr, md->d_s, J->n, rval);
             } else if (!J->srows.active) {
@@ -1330,21 +1310,17 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
                 hipLaunchKernelGGL(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
                                    md->d_Acsr, md->d_s, J->csr.d_val);
             } else {
-                return 1;   // (sliced rows always carry 16-bit columns)
+                // sliced rows without the LDS-staged scaling (forced onto a small pattern): rebuild from the CSC copy
+                if (lazy_csc) return 1;
+                if (lsq_mirror_rows(J, J->csc.d_val, rval) != LSQ_OK) return 1;
             }
         }
         if (have_cols) {
-            if (lds_ok && ccol && lazy_csc && J->scols.active && !getenv("LSQ_EAGER_COLS")) {
-                // the sliced-column copy is NOT written here: the gradient + colsumabs2 pass that follows g! in both loops
-                // scales A's entries as it streams them and writes the copy (launch_sell_cols): 106 MB less traffic per
-                // accepted step at C4 than scaling first and streaming the result again
-                J->cols_pending_src = md->d_Ab;
-                J->cols_pending_scale = md->d_s;
-            } else if (lds_ok && ccol) {
+            if (lds_ok && ccol) {
                 hipLaunchKernelGGL(k_scale_lds<false>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
                                    ccol, md->d_Ab, md->d_s, J->n, cval);
             } else if (J->scols.active) {
-                // n > 65535: no 16-bit columns; rebuild the sliced columns from the CSC copy instead
+                // no LDS-staged scaling: rebuild the sliced columns from the CSC copy instead
                 if (lazy_csc) return 1;
                 if (lsq_mirror_cols(J, J->csc.d_val, cval) != LSQ_OK) return 1;
             } else if (J->nnz < 16LL * J->bcsc.nseg) {
@@ -1368,8 +1344,6 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         if (tot > 0)
             hipLaunchKernelGGL(k_scale_dense, dim3(J->n, chunks), dim3(LSQ_NT), 0, c->stream, J->m, md->d_Acsc, x, J->d_dense);
     }
-    md->spec_x = nullptr;
-    md->tanh_x = nullptr;
     J->version++;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -1383,15 +1357,26 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
     lsq_model *md = new lsq_model();
     md->ctx = c;
     md->J = J;
+    const size_t nb = (size_t)(J->n > 0 ? J->n : 1) * sizeof(double);
+    LSQ_HIP(hipMalloc(&md->d_b, (size_t)(J->m > 0 ? J->m : 1) * sizeof(double)));
+    LSQ_HIP(hipMemcpy(md->d_b, hb, (size_t)J->m * sizeof(double), hipMemcpyHostToDevice));
+    LSQ_HIP(hipMalloc(&md->d_t, nb));
+    LSQ_HIP(hipMalloc(&md->d_s, nb));
+    LSQ_HIP(hipMalloc(&md->d_sspec, nb));
+    if (lsq_colscale_fusable(J)) {
+        // J's own storage takes A (once, in every layout); from here on J = A diag(s) through the handle's column scale
+        LSQ_TRY(lsq_mat_set_values(J, hA));
+        LSQ_TRY(lsq_fill(c, J->n, 1.0, md->d_s));
+        LSQ_TRY(lsq_mat_set_colscale(J, md->d_s));
+        md->fused = true;
+        LSQ_HIP(hipStreamSynchronize(c->stream));
+        *out = md;
+        return LSQ_OK;
+    }
     size_t vb = (size_t)(J->nnz + 8) * sizeof(double);
     LSQ_HIP(hipMalloc(&md->d_Acsc, vb));
     LSQ_ZERO(md->d_Acsc, 0, vb);
     LSQ_HIP(hipMemcpy(md->d_Acsc, hA, (size_t)J->nnz * sizeof(double), hipMemcpyHostToDevice));
-    LSQ_HIP(hipMalloc(&md->d_b, (size_t)(J->m > 0 ? J->m : 1) * sizeof(double)));
-    LSQ_HIP(hipMemcpy(md->d_b, hb, (size_t)J->m * sizeof(double), hipMemcpyHostToDevice));
-    LSQ_HIP(hipMalloc(&md->d_t, (size_t)(J->n > 0 ? J->n : 1) * sizeof(double)));
-    LSQ_HIP(hipMalloc(&md->d_s, (size_t)(J->n > 0 ? J->n : 1) * sizeof(double)));
-    LSQ_HIP(hipMalloc(&md->d_sspec, (size_t)(J->n > 0 ? J->n : 1) * sizeof(double)));
     if (J->kind == LSQ_MAT_CSC) {
         // A in the layouts the products of J read (same maps as J's own mirrors), permuted once
         const size_t rb = (size_t)(lsq_mirror_rows_len(J) + 1024) * sizeof(double);
@@ -1413,7 +1398,8 @@ extern "C" int lsq_model_tanh_create(lsq_ctx *c, lsq_mat *J, const double *hA, c
 extern "C" int lsq_model_destroy(lsq_model *md) {
     if (!md) return LSQ_OK;
     hipStreamSynchronize(md->ctx->stream);
-    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_Ab); hipFree(md->d_b); hipFree(md->d_t); hipFree(md->d_s); hipFree(md->d_sspec); hipFree(md->d_Jspec);
+    if (md->fused && md->J) lsq_mat_set_colscale(md->J, nullptr);   // (the factor vector goes away with the model)
+    hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_Ab); hipFree(md->d_b); hipFree(md->d_t); hipFree(md->d_s); hipFree(md->d_sspec);
     delete md;
     return LSQ_OK;
 }

@@ -41,14 +41,6 @@ struct SellDev {
     int spw;                      // slices per block: block b owns slices [b * spw, (b + 1) * spw)
 };
 
-// CM (a "column map", rows kernel only): besides the dot, every stored value times cm.f(x[col]) is written to `mp` at the same
-// offset -- a second matrix with the same pattern whose column factors are a function of the gathered vector (the model
-// Jacobian A diag(1 - t.^2) while the residual A t - b is being formed).
-struct SellNoColMap {
-    static constexpr bool on = false;
-    __device__ double f(double) const { return 0.0; }
-};
-typedef double sell_d2 __attribute__((ext_vector_type(2)));
 // One batch of U value/index pairs of a lane: ALL loads first (each lane has U 20-byte requests in flight), then the sums.
 // CLAMP: the slice has fewer than U pairs left; the surplus loads re-read the last pair and their products are dropped by the
 // `len` selection, like every padding entry.  (Measured alternatives on C4, J*v launch: skipping the surplus loads behind
@@ -69,17 +61,8 @@ __device__ __forceinline__ void sell_batch_load(SellBatch<U> &B, const double *_
         B.c[u] = *reinterpret_cast<const unsigned *>(ip + (size_t)q * 128);
     }
 }
-template <int U, bool CLAMP, bool SQ, bool SCALE, class CM>
-__device__ __forceinline__ void sell_batch_sum(SellBatch<U> &B, int p0, int np, int len, const double *xl, double &sum, double &sq,
-                                               double sc, double *__restrict__ dp, const CM &cm, double *__restrict__ mp) {
-    if constexpr (SCALE) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            B.a[u].x *= sc;
-            B.a[u].y *= sc;
-            if (!CLAMP || p0 + u < np) *reinterpret_cast<double2 *>(dp + (size_t)(p0 + u) * 128) = B.a[u];
-        }
-    }
+template <int U, bool CLAMP, bool SQ>
+__device__ __forceinline__ void sell_batch_sum(SellBatch<U> &B, int p0, int np, int len, const double *xl, double &sum, double &sq) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         // every operand is fetched and every sum formed unconditionally; padding is dropped by SELECTION (a
@@ -88,14 +71,6 @@ __device__ __forceinline__ void sell_batch_sum(SellBatch<U> &B, int p0, int np, 
         const double x0 = xl[B.c[u] & 0xffffu], x1 = xl[B.c[u] >> 16];
         double p0v = B.a[u].x * x0, p1v = B.a[u].y * x1;
         asm volatile("" : "+v"(p0v), "+v"(p1v));   // (the products exist here, whatever the selections below)
-        if constexpr (CM::on) {
-            if (!CLAMP || p0 + u < np) {
-                sell_d2 o;
-                o.x = B.a[u].x * cm.f(x0);
-                o.y = B.a[u].y * cm.f(x1);
-                __builtin_nontemporal_store(o, reinterpret_cast<sell_d2 *>(mp + (size_t)(p0 + u) * 128));
-            }
-        }
         const int j = 2 * (p0 + u);
         const bool in0 = j < len, in1 = j + 1 < len;   // (len <= 2 np: clamped surplus pairs are never selected)
         const double t0 = sum + p0v;
@@ -114,39 +89,34 @@ __device__ __forceinline__ void sell_batch_sum(SellBatch<U> &B, int p0, int np, 
 // all products of one lane's output inside one slice (L entries per lane, even and wave-uniform; `len` of them real), added in
 // index order.  A slice of the C4 workload holds 4-10 pairs per lane: one batch, one memory round trip (the round-1 loop paid one
 // per 4 pairs plus one per leftover pair, in sequence).
-// SCALE: the stored values are `vp[..] * sc` (a column-scaled model Jacobian J = A diag(s) whose column copy has not been
-// materialised yet): every value pair is scaled as it is loaded and written to `dp` at the same offset, so that this pass IS
-// the materialisation (the padding entries are zeros in the source and stay zeros).
-template <bool SQ, bool SCALE = false, class CM = SellNoColMap>
+template <bool SQ>
 __device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L, int len,
-                                              const double *xl, double &sum, double &sq, double sc = 1.0,
-                                              double *__restrict__ dp = nullptr, CM cm = CM(), double *__restrict__ mp = nullptr) {
+                                              const double *xl, double &sum, double &sq) {
     const int np = L >> 1;
     int p0 = 0;
     for (; p0 + 8 <= np; p0 += 8) {
         SellBatch<8> B;
         sell_batch_load<8, false>(B, vp, ip, p0, np);
-        sell_batch_sum<8, false, SQ, SCALE, CM>(B, p0, np, len, xl, sum, sq, sc, dp, cm, mp);
+        sell_batch_sum<8, false, SQ>(B, p0, np, len, xl, sum, sq);
     }
     const int rem = np - p0;
     if (rem > 4) {
         SellBatch<8> B;
         sell_batch_load<8, true>(B, vp, ip, p0, np);
-        sell_batch_sum<8, true, SQ, SCALE, CM>(B, p0, np, len, xl, sum, sq, sc, dp, cm, mp);
+        sell_batch_sum<8, true, SQ>(B, p0, np, len, xl, sum, sq);
     } else if (rem > 2) {
         SellBatch<4> B;
         sell_batch_load<4, true>(B, vp, ip, p0, np);
-        sell_batch_sum<4, true, SQ, SCALE, CM>(B, p0, np, len, xl, sum, sq, sc, dp, cm, mp);
+        sell_batch_sum<4, true, SQ>(B, p0, np, len, xl, sum, sq);
     } else if (rem > 0) {
         SellBatch<2> B;
         sell_batch_load<2, true>(B, vp, ip, p0, np);
-        sell_batch_sum<2, true, SQ, SCALE, CM>(B, p0, np, len, xl, sum, sq, sc, dp, cm, mp);
+        sell_batch_sum<2, true, SQ>(B, p0, np, len, xl, sum, sq);
     }
 }
 
 // The slices of one wave (s0 + wave, + 16, ...), with the next slice's descriptor requested before the current slice's stream.
-//   `scf(pos)` -> the lane's scale factor (SCALE only), `out(pos, sum, sq)` stores a lane's result, `wdst` the value array the
-//   SCALE / column-map variants fill.
+//   `out(pos, sum, sq)` stores a lane's result.
 // Contains the workgroup barrier that separates staging the gather vector from the first gather: the first descriptor is
 // requested before it.  (Requesting TWO slices per wave up front made the J*v launch slower, 29.5 us against 23.7 us: the
 // stream is not short of requests in flight, a CU's miss queue is already full with 16 waves x 5-8 KB.)
@@ -164,9 +134,8 @@ __device__ __forceinline__ SellSliceRef sell_slice_ref(const SellDev &S, int s, 
     }
     return r;
 }
-template <bool SQ, bool SCALE, class CM, class ScaleF, class Out>
-__device__ __forceinline__ void sell_wave_slices(const SellDev &S, int s0, int s1, int wv, int lane, const double *xl, const CM &cm,
-                                                 double *__restrict__ wdst, ScaleF scf, Out out) {
+template <bool SQ, class Out>
+__device__ __forceinline__ void sell_wave_slices(const SellDev &S, int s0, int s1, int wv, int lane, const double *xl, Out out) {
     constexpr int NW = LSQ_BIG_NT / 64;
     int s = s0 + wv;
     SellSliceRef A = sell_slice_ref(S, s, s1, lane);
@@ -176,19 +145,18 @@ __device__ __forceinline__ void sell_wave_slices(const SellDev &S, int s0, int s
         A = sell_slice_ref(S, s + NW, s1, lane);
         const size_t oa = (size_t)a.sm.x + lane * 2;
         const unsigned pos = a.inf & LSQ_SELL_POS_MASK;
-        double sc = 1.0;
-        if constexpr (SCALE) sc = pos != LSQ_SELL_POS_MASK ? scf(pos) : 0.0;
-        double *da = (SCALE || CM::on) ? wdst + oa : nullptr;
         double sum = 0.0, sq = 0.0;
-        sell_lane_sum<SQ, SCALE, CM>(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), xl, sum, sq, sc, da, cm, da);
+        sell_lane_sum<SQ>(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
         if (pos != LSQ_SELL_POS_MASK) out(pos, sum, sq);
     }
 }
 
 // ---- J*x: dot of every row with x, then the epilogue on (row, dot) in row order ----------------
+// xscale (or null): the matrix is the stored values times diag(xscale) -- a COLUMN-SCALED Jacobian J = V diag(s) whose scaled
+// entries are never materialised (lsq_mat::d_colscale): the gather vector is staged as s .* x, the stream is V's.
 template <class Epi>
 __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, int m, const double *__restrict__ x,
-                                                          int nx, int nxpad, Epi epi) {
+                                                          const double *__restrict__ xscale, int nx, int nxpad, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sh[LSQ_BIG_NT / 64];
     double *xl = smem;            // nxpad doubles
@@ -200,6 +168,13 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
     double xr[XR];
 #pragma unroll
     for (int q = 0; q < XR; ++q) xr[q] = x[min(tid + q * LSQ_BIG_NT, nx - 1)];
+    if (xscale) {   // (wave-uniform; the factors travel with the gather vector: still one latency at the head)
+        double sr[XR];
+#pragma unroll
+        for (int q = 0; q < XR; ++q) sr[q] = xscale[min(tid + q * LSQ_BIG_NT, nx - 1)];
+#pragma unroll
+        for (int q = 0; q < XR; ++q) xr[q] *= sr[q];
+    }
     const int dflag = epi.done ? *epi.done : 0;
 
     if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
@@ -219,12 +194,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
             for (int q = 0; q < Q; ++q) pre[q] = epi.pre(base + min(tid + q * LSQ_BIG_NT, rows - 1));
         }
         // (the barrier inside: x staged / the previous window's epilogue is done with yw)
-        if constexpr (EpiHasColMap<Epi>::value)
-            sell_wave_slices<false, false, typename Epi::colmap>(S, s0, s1, wv, lane, xl, epi.cm, epi.cm.dval, [](unsigned) { return 1.0; },
-                                                                 [&](unsigned pos, double sum, double) { yw[pos] = sum; });
-        else
-            sell_wave_slices<false, false, SellNoColMap>(S, s0, s1, wv, lane, xl, SellNoColMap(), nullptr, [](unsigned) { return 1.0; },
-                                                         [&](unsigned pos, double sum, double) { yw[pos] = sum; });
+        sell_wave_slices<false>(S, s0, s1, wv, lane, xl, [&](unsigned pos, double sum, double) { yw[pos] = sum; });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -243,8 +213,6 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
 
 // ---- J'*y: per (gather window, column) partial sums; k_combine adds the windows ----------------
 // block b = gw * ncb + cb; part layout [gw][n] (SQ: [gw][2n] = dots | squares)
-// SCALE (see sell_lane_sum): S.val is the UNSCALED source, `scale[col]` the column factors, `dval` the layout's own value
-// array, which this pass fills.
 // window of y -> LDS, all loads of a thread issued before the first use
 __device__ __forceinline__ void sell_cols_stage_y(int b, int ncb, int grows, int m, const double *__restrict__ y, double *yl, int tid) {
     constexpr int YR = LSQ_SELL_GROWS_MAX / LSQ_BIG_NT;
@@ -258,10 +226,9 @@ __device__ __forceinline__ void sell_cols_stage_y(int b, int ncb, int grows, int
 }
 // the workgroup's blocks (blockIdx.x, + gridDim.x, ...); the y window of the first one is already on its way to LDS
 // (sell_cols_stage_y)
-template <bool SQ, bool SCALE>
+template <bool SQ>
 __device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int ccols, int grows, int m, int n,
-                                               const double *__restrict__ y, double *__restrict__ part,
-                                               const double *__restrict__ scale, double *__restrict__ dval, double *smem) {
+                                               const double *__restrict__ y, double *__restrict__ part, double *smem) {
     double *yl = smem;                          // LSQ_SELL_GROWS_MAX doubles
     double *ow = smem + LSQ_SELL_GROWS_MAX;     // LSQ_SELL_CCOLS_MAX doubles (+ the same again for SQ)
     double *ow2 = ow + LSQ_SELL_CCOLS_MAX;
@@ -274,12 +241,10 @@ __device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int cc
             sell_cols_stage_y(b, ncb, grows, m, y, yl, tid);
         }
         const int s0 = b * S.spw, s1 = s0 + S.spw;
-        sell_wave_slices<SQ, SCALE, SellNoColMap>(S, s0, s1, wv, lane, yl, SellNoColMap(), dval,
-                                                  [&](unsigned pos) { return scale[cbase + (int)pos]; },   // (lane = one column)
-                                                  [&](unsigned pos, double sum, double sq) {
-                                                      ow[pos] = sum;
-                                                      if constexpr (SQ) ow2[pos] = sq;
-                                                  });
+        sell_wave_slices<SQ>(S, s0, s1, wv, lane, yl, [&](unsigned pos, double sum, double sq) {   // (lane = one column)
+            ow[pos] = sum;
+            if constexpr (SQ) ow2[pos] = sq;
+        });
         __syncthreads();
         double *dst = part + (size_t)gw * (SQ ? 2 : 1) * n + cbase;
         for (int i = tid; i < cols; i += LSQ_BIG_NT) {
@@ -289,15 +254,14 @@ __device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int cc
     }
 }
 
-template <bool SQ, bool SCALE = false>
+template <bool SQ>
 __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, int ccols, int grows, int m, int n,
                                                           const double *__restrict__ y, double *__restrict__ part,
-                                                          const int *done, const double *__restrict__ scale = nullptr,
-                                                          double *__restrict__ dval = nullptr) {
+                                                          const int *done) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the first window is fetched together with the `done` flag of a finished solve (one latency, not two in a row)
     const int dflag = done ? *done : 0;
     if ((int)blockIdx.x < S.nblocks) sell_cols_stage_y(blockIdx.x, ncb, grows, m, y, smem, threadIdx.x);
     if (dflag) return;
-    sell_cols_pass<SQ, SCALE>(S, ncb, ccols, grows, m, n, y, part, scale, dval, smem);
+    sell_cols_pass<SQ>(S, ncb, ccols, grows, m, n, y, part, smem);
 }

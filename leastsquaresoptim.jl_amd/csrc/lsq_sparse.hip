@@ -503,6 +503,8 @@ extern "C" int lsq_mat_destroy(lsq_mat *J) {
     hipFree(J->d_dpart);
     hipFree(J->d_optmp);
     hipFree(J->d_colsum);
+    hipFree(J->d_cs_base);
+    hipFree(J->d_colsum_base);
     delete J;
     return LSQ_OK;
 }
@@ -516,7 +518,9 @@ extern "C" int lsq_mat_size(const lsq_mat *J, int *m, int *n, long long *nnz) {
 
 extern "C" double *lsq_mat_values(lsq_mat *J) {
     J->version++;
+    J->base_version++;
     if (J->kind == LSQ_MAT_OP) return nullptr;   // no entries to expose
+    if (J->d_cs_base) return J->d_cs_base;       // column-scaled, multiplied out on refresh: the stored values V live here
     if (J->kind == LSQ_MAT_DENSE) return J->d_dense;
     if (lsq_ensure_csc(J) != LSQ_OK) return nullptr;
     J->csr_fresh = false;
@@ -601,15 +605,95 @@ int lsq_ensure_csc(lsq_mat *J) {
 // refreshes every mirror of the user-visible CSC values
 int lsq_ensure_csr(lsq_mat *J) {
     if (J->kind != LSQ_MAT_CSC || J->csr_fresh) return LSQ_OK;
-    J->cols_pending_src = J->cols_pending_scale = nullptr;   // (every mirror is rebuilt from the CSC copy below)
     LSQ_TRY(lsq_mirror_rows(J, J->csc.d_val, J->srows.active ? J->srows.d_val : J->csr.d_val));
     LSQ_TRY(lsq_mirror_cols(J, J->csc.d_val, J->scols.active ? J->scols.d_val : J->bcsc.d_val));
     J->csr_fresh = true;
     return LSQ_OK;
 }
 
+// ---- column-scaled Jacobians J = V diag(s) (include/lsqhip.h: lsq_mat_set_colscale) --------------------------------
+// out[k] = base[k] * s[column of k]: CSC order (colptr) or dense column-major (m_dense rows per column)
+__global__ void __launch_bounds__(LSQ_NT)
+k_colscale_apply(int n, const int *__restrict__ colptr, int m_dense, const double *__restrict__ base,
+                 const double *__restrict__ s, double *__restrict__ out) {
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        const double f = s[j];
+        const long long k0 = colptr ? colptr[j] : (long long)j * m_dense;
+        const long long k1 = colptr ? colptr[j + 1] : (long long)(j + 1) * m_dense;
+        for (long long k = k0 + threadIdx.x; k < k1; k += LSQ_NT) out[k] = base[k] * f;
+    }
+}
+static bool colscale_can_fuse(const lsq_mat *J);
+bool lsq_colscale_fusable(const lsq_mat *J) { return colscale_can_fuse(J); }
+static bool colscale_can_fuse(const lsq_mat *J) {
+    return J->kind == LSQ_MAT_CSC && J->srows.active && J->scols.active && !lsq_small_mat(J) && !getenv("LSQ_NO_COLSCALE");
+}
+// materialising mode: values = V .* s (the mirrors follow through lsq_ensure_csr)
+static int colscale_multiply_out(lsq_mat *J) {
+    if (!J->d_cs_base || J->nnz == 0) return LSQ_OK;
+    lsq_ctx *c = J->ctx;
+    const int grid = std::max(1, std::min(J->n, c->num_cus * 16));
+    if (J->kind == LSQ_MAT_DENSE)
+        hipLaunchKernelGGL(k_colscale_apply, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, (const int *)nullptr, J->m,
+                           J->d_cs_base, J->d_cs_user, J->d_dense);
+    else
+        hipLaunchKernelGGL(k_colscale_apply, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, J->d_cs_base,
+                           J->d_cs_user, J->csc.d_val);
+    LSQ_HIP(hipGetLastError());
+    if (J->kind == LSQ_MAT_CSC) {
+        J->csr_fresh = false;
+        J->csc_fresh = true;
+    }
+    return LSQ_OK;
+}
+
+extern "C" int lsq_mat_colscale_changed(lsq_mat *J) {
+    if (!J || !J->d_cs_user) {
+        lsq_set_error("lsq_mat_colscale_changed: the matrix has no column scale (lsq_mat_set_colscale)");
+        return LSQ_EARG;
+    }
+    J->version++;
+    if (J->d_colscale) return LSQ_OK;          // fused: the products read s themselves
+    LSQ_TRY(colscale_multiply_out(J));
+    return lsq_ensure_csr(J);
+}
+
+extern "C" int lsq_mat_set_colscale(lsq_mat *J, const double *d_s) {
+    if (!J || J->kind == LSQ_MAT_OP) {
+        lsq_set_error("lsq_mat_set_colscale: needs a matrix with stored values");
+        return LSQ_EARG;
+    }
+    lsq_ctx *c = J->ctx;
+    double *vals = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
+    if (!d_s) {   // back to an ordinary matrix holding V
+        if (J->d_cs_base) {
+            if (J->nnz) LSQ_TRY(lsq_d2d(c, vals, J->d_cs_base, (size_t)J->nnz * sizeof(double)));
+            LSQ_HIP(hipStreamSynchronize(c->stream));
+            hipFree(J->d_cs_base);
+            J->d_cs_base = nullptr;
+        }
+        J->d_colscale = J->d_cs_user = nullptr;
+        return lsq_mat_refresh(J);
+    }
+    if (!J->d_cs_user) {   // from now on the values held so far are V
+        LSQ_TRY(lsq_ensure_csc(J));
+        if (colscale_can_fuse(J)) {
+            if (!J->d_colsum_base) LSQ_HIP(hipMalloc(&J->d_colsum_base, (size_t)std::max(J->n, 1) * sizeof(double)));
+            J->colsum_base_version = ~0ull;
+        } else {
+            LSQ_HIP(hipMalloc(&J->d_cs_base, (size_t)(J->nnz + 8) * sizeof(double)));
+            if (J->nnz) LSQ_TRY(lsq_d2d(c, J->d_cs_base, vals, (size_t)J->nnz * sizeof(double)));
+        }
+    }
+    J->d_cs_user = d_s;
+    J->d_colscale = J->d_cs_base ? nullptr : d_s;
+    return lsq_mat_colscale_changed(J);
+}
+
 extern "C" int lsq_mat_refresh(lsq_mat *J) {
     J->version++;
+    J->base_version++;
+    if (J->d_cs_base) LSQ_TRY(colscale_multiply_out(J));   // (the caller wrote V: multiply out again)
     if (J->kind == LSQ_MAT_CSC) {
         J->csr_fresh = false;
         J->csc_fresh = true;  // the CSC copy is the authority here
@@ -622,7 +706,7 @@ extern "C" int lsq_mat_set_values(lsq_mat *J, const double *h) {
         lsq_set_error("a matrix-free operator has no stored values");
         return LSQ_EARG;
     }
-    double *dst = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
+    double *dst = J->d_cs_base ? J->d_cs_base : J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
     if (J->nnz)
         LSQ_HIP(hipMemcpyAsync(dst, h, J->nnz * sizeof(double), hipMemcpyHostToDevice, J->ctx->stream));
     LSQ_HIP(hipStreamSynchronize(J->ctx->stream));  // h is borrowed for the call only
@@ -643,7 +727,7 @@ extern "C" int lsq_mat_set_values_async(lsq_mat *J, const double *h) {
         LSQ_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         LSQ_HIP(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     }
-    double *dst = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
+    double *dst = J->d_cs_base ? J->d_cs_base : J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
     // the copy may overwrite the staging copy only after the compute stream is done reading it (a mirror refresh of the
     // previous upload), and the compute stream may touch J again only after the copy: two device-side waits, no host wait
     LSQ_HIP(hipEventRecord(c->copy_done, c->stream));
@@ -668,7 +752,8 @@ extern "C" int lsq_mat_get_values(const lsq_mat *J, double *h) {
         return LSQ_EARG;
     }
     LSQ_TRY(lsq_ensure_csc(const_cast<lsq_mat *>(J)));
-    const double *src = J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
+    // (a column-scaled matrix hands back its stored values V, not V diag(s))
+    const double *src = J->d_cs_base ? J->d_cs_base : J->kind == LSQ_MAT_DENSE ? J->d_dense : J->csc.d_val;
     if (J->nnz)
         LSQ_HIP(hipMemcpyAsync(h, src, J->nnz * sizeof(double), hipMemcpyDeviceToHost, J->ctx->stream));
     LSQ_HIP(hipStreamSynchronize(J->ctx->stream));
@@ -748,9 +833,49 @@ bool lsq_can_fuse_grad_colsum(const lsq_mat *J) {
            lsq_set_lds(J->ctx, (const void *)k_bcsc_lds<false, true>, lds) == LSQ_OK;
 }
 
+// column-scaled, fused: colsumabs2(J) = s.^2 .* colsumabs2(V), the latter formed once per V (reference order: CSC segments)
+struct EpiGradCs {   // g[j] = (scaled dot), cs[j] = s[j]^2 * base[j]
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    double *g, *cs;
+    const double *s, *base;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int j, double dot, double &) const {
+        g[j] = dot;
+        const double f = s[j];
+        cs[j] = (f * f) * base[j];
+    }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+__global__ void __launch_bounds__(LSQ_NT)
+k_colsum_scaled(int n, const double *__restrict__ s, const double *__restrict__ base, double *__restrict__ cs) {
+    for (int j = blockIdx.x * LSQ_NT + threadIdx.x; j < n; j += gridDim.x * LSQ_NT) cs[j] = (s[j] * s[j]) * base[j];
+}
+static int colsum_base_ready(lsq_mat *J) {
+    if (J->colsum_base_version == J->base_version) return LSQ_OK;
+    LSQ_TRY(lsq_sparse_colsumabs2(J, J->d_colsum_base));     // over csc.d_val = V
+    J->colsum_base_version = J->base_version;
+    return LSQ_OK;
+}
+
 int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {
     lsq_ctx *c = J->ctx;
     LSQ_TRY(lsq_ensure_csr(J));
+    if (J->d_colscale) {
+        LSQ_TRY(colsum_base_ready(J));
+        LSQ_TRY(launch_sell_cols<false>(J, f, nullptr));
+        EpiGradCs e{nullptr, 0, g, J->d_colsum, J->d_colscale, J->d_colsum_base, nullptr, nullptr};
+        int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
+        int grid = std::min(nb, c->num_cus * 8);
+        hipLaunchKernelGGL((k_combine<EpiGradCs>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, J->n, J->scols.ngw,
+                           e, nb, J->d_colscale);
+        LSQ_HIP(hipGetLastError());
+        J->colsum_version = J->version;
+        return LSQ_OK;
+    }
     if (J->scols.active) {
         LSQ_TRY(launch_sell_cols<true>(J, f, nullptr));
         EpiGradSq e{nullptr, 0, J->n, g, J->d_colsum, nullptr, nullptr};
@@ -789,6 +914,13 @@ const double *lsq_cached_colsum(lsq_mat *J) {
         }
         return J->d_colsum;
     }
+    if (J->d_colscale && J->colsum_version != J->version) {
+        if (colsum_base_ready(J) != LSQ_OK) return nullptr;
+        hipLaunchKernelGGL(k_colsum_scaled, dim3(std::max(1, std::min(lsq_div_up(J->n, LSQ_NT), J->ctx->num_cus * 4))), dim3(LSQ_NT),
+                           0, J->ctx->stream, J->n, J->d_colscale, J->d_colsum_base, J->d_colsum);
+        if (hipGetLastError() != hipSuccess) return nullptr;
+        J->colsum_version = J->version;
+    }
     if (J->colsum_version != J->version) {
         int st = lsq_small_mat(J) ? lsq_exact_colsumabs2(J, J->d_colsum)
                  : J->kind == LSQ_MAT_DENSE ? lsq_dense_colsumabs2(J, J->d_colsum)
@@ -821,7 +953,7 @@ extern "C" int lsq_colsumabs2(lsq_mat *J, double *out) {
 // sliced rows: the lane that owns a row adds its squares left to right (the reference's order: the
 // CSC sweep reaches a row's entries in column order)
 __global__ void __launch_bounds__(256)
-k_sell_rowsq(SellDev S, int wrows, int m, double *__restrict__ out) {
+k_sell_rowsq(SellDev S, int wrows, int m, double *__restrict__ out, const double *__restrict__ cscale) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int w = blockIdx.x; w < S.nblocks; w += gridDim.x) {
         const int base = w * wrows;
@@ -831,9 +963,11 @@ k_sell_rowsq(SellDev S, int wrows, int m, double *__restrict__ out) {
             const unsigned pos = inf & LSQ_SELL_POS_MASK;
             const int len = (int)(inf >> LSQ_SELL_POS_BITS);
             const double *vp = S.val + (size_t)sm.x + lane * 2;
+            const unsigned short *ip = S.idx16 + (size_t)sm.x + lane * 2;
             double acc = 0.0;
             for (int j = 0; j < len; ++j) {
-                const double a = vp[(size_t)(j / 2) * 128 + (j & 1)];
+                double a = vp[(size_t)(j / 2) * 128 + (j & 1)];
+                if (cscale) a *= cscale[ip[(size_t)(j / 2) * 128 + (j & 1)]];   // (column-scaled: the entry of J)
                 acc += a * a;
             }
             if (pos != LSQ_SELL_POS_MASK && base + (int)pos < m) out[base + pos] = acc;
@@ -868,7 +1002,7 @@ extern "C" int lsq_rowsumabs2(lsq_mat *J, double *out) {
         LSQ_TRY(lsq_ensure_csr(J));
         if (J->srows.active) {
             int grid = std::max(1, std::min(J->srows.nblocks, c->num_cus * 4));
-            hipLaunchKernelGGL(k_sell_rowsq, dim3(grid), dim3(256), 0, c->stream, sell_dev(J->srows), J->srows.wrows, J->m, out);
+            hipLaunchKernelGGL(k_sell_rowsq, dim3(grid), dim3(256), 0, c->stream, sell_dev(J->srows), J->srows.wrows, J->m, out, J->d_colscale);
         } else {
             EpiStore e{nullptr, 0, out, nullptr, nullptr};
             LSQ_TRY(launch_segs<true>(c, J->csr, nullptr, e));

@@ -245,10 +245,6 @@ struct EpiHasPrepare : std::false_type {};
 template <class E>
 struct EpiHasPrepare<E, std::void_t<typename E::has_prepare>> : std::true_type {};
 template <class E, class = void>
-struct EpiHasColMap : std::false_type {};   // E::colmap cm: see sell_lane_sum
-template <class E>
-struct EpiHasColMap<E, std::void_t<typename E::colmap>> : std::true_type {};
-template <class E, class = void>
 struct EpiHasPre : std::false_type {};
 template <class E>
 struct EpiHasPre<E, std::void_t<typename E::has_pre>> : std::true_type {};
@@ -789,9 +785,11 @@ struct EpiPart {
 // the 8 group sums are added in index order -- a fixed association, hence deterministic.
 constexpr int LSQ_CMB_COLS = 32;
 constexpr int LSQ_CMB_GROUPS = LSQ_NT / LSQ_CMB_COLS;
+// cscale (or null): every combined dot is multiplied by cscale[j] before the epilogue sees it -- J'y = s .* (V'y) for a
+// column-scaled Jacobian J = V diag(s) (lsq_mat::d_colscale).
 template <class Epi>
 __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ part, int n, int nwin, Epi epi,
-                                                     int ncolblocks) {
+                                                     int ncolblocks, const double *__restrict__ cscale = nullptr) {
     __shared__ double sh[LSQ_NT / 64];
     __shared__ double grp[LSQ_CMB_GROUPS][LSQ_CMB_COLS + 1];
     const int nwork = ncolblocks + epi.extra_blocks;
@@ -815,6 +813,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ p
         }
         const int j = b * LSQ_CMB_COLS + cidx;
         double acc = 0.0;
+        const double cs0 = (cscale && g == 0 && j < n) ? cscale[j] : 1.0;   // (in flight with the partials)
         if (j < n) {
             int w = g;
             if (pre0 && b == (int)blockIdx.x) {       // (same additions in the same order)
@@ -837,6 +836,7 @@ __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ p
             double dot = 0.0;
 #pragma unroll
             for (int q = 0; q < LSQ_CMB_GROUPS; ++q) dot += grp[q][cidx];
+            if (cscale) dot *= cs0;
             epi.seg(j, dot, racc);
         }
         __syncthreads();
@@ -850,9 +850,11 @@ static inline SellDev sell_dev(const LsqSell &s, const double *val = nullptr) {
     return SellDev{s.d_smeta, s.d_info, s.d_idx16, val ? val : s.d_val, s.nblocks, s.spw};
 }
 
-// J*x over the sliced rows, with `val` optionally replacing J's values (same pattern, e.g. a model's A)
+// (stored values) * diag(xscale) * x over the sliced rows; xscale = J->d_colscale gives J*x of a column-scaled Jacobian,
+// nullptr the product with the stored values V themselves (what a model r = V phi(x) - b needs)
+// `val`: another value array in the same layout (a model's A beside a multiplied-out J) instead of J's own
 template <class Epi>
-static inline int launch_sell_rows(lsq_mat *J, const double *val, const double *x, const Epi &epi) {
+static inline int launch_sell_rows(lsq_mat *J, const double *xscale, const double *x, const Epi &epi, const double *val = nullptr) {
     lsq_ctx *c = J->ctx;
     const LsqSell &S = J->srows;
     const int nxpad = (J->n + 1) & ~1;
@@ -863,22 +865,12 @@ static inline int launch_sell_rows(lsq_mat *J, const double *val, const double *
     hipEvent_t e0, e1;
     if (lsq_prof_take(c, &e0, &e1))
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S, val), S.wrows,
-                              J->m, x, J->n, nxpad, epi);
+                              J->m, x, xscale, J->n, nxpad, epi);
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S, val), S.wrows, J->m, x,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S, val), S.wrows, J->m, x, xscale,
                            J->n, nxpad, epi);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
-}
-
-// sliced-column copy of a column-scaled Jacobian that was left unmaterialised (lsq_mat::cols_pending_*): plain element-wise
-// materialisation, for consumers other than the fused gradient pass
-template <int = 0>
-__global__ void __launch_bounds__(LSQ_NT) k_sell_scale_cols(long long count, const unsigned short *__restrict__ col16,
-                                                            const double *__restrict__ src, const double *__restrict__ s,
-                                                            double *__restrict__ dst) {
-    for (long long k = blockIdx.x * (long long)LSQ_NT + threadIdx.x; k < count; k += (long long)gridDim.x * LSQ_NT)
-        dst[k] = src[k] * s[col16[k]];
 }
 
 // first pass of J'*y over the sliced columns: per gather-window partials into J->scols.d_part
@@ -887,32 +879,16 @@ static inline int launch_sell_cols(lsq_mat *J, const double *y, const int *done)
     lsq_ctx *c = J->ctx;
     const LsqSell &S = J->scols;
     const size_t lds = (size_t)(LSQ_SELL_GROWS_MAX + (SQ ? 2 : 1) * LSQ_SELL_CCOLS_MAX) * sizeof(double);
-    if (J->cols_pending_src) {
-        const double *src = J->cols_pending_src, *scale = J->cols_pending_scale;
-        J->cols_pending_src = J->cols_pending_scale = nullptr;
-        if (SQ && !done) {   // the gradient + colsumabs2 pass right after g!: it materialises the copy as it goes
-            auto kern = k_sell_cols<SQ, true>;
-            LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
-            const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S, src), S.ncb, S.ccols, S.grows,
-                               J->m, J->n, y, S.d_part, done, scale, S.d_val);
-            LSQ_HIP(hipGetLastError());
-            return LSQ_OK;
-        }
-        const int g = (int)std::min<long long>((S.nstore + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
-        hipLaunchKernelGGL(k_sell_scale_cols<0>, dim3(std::max(1, g)), dim3(LSQ_NT), 0, c->stream, (long long)S.nstore, S.d_col16, src,
-                           scale, S.d_val);
-    }
     auto kern = k_sell_cols<SQ>;
     LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
     hipEvent_t e0, e1;
     if (lsq_prof_take(c, &e0, &e1))
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.ncb, S.ccols,
-                              S.grows, J->m, J->n, y, S.d_part, done, (const double *)nullptr, (double *)nullptr);
+                              S.grows, J->m, J->n, y, S.d_part, done);
     else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.ncb, S.ccols, S.grows,
-                           J->m, J->n, y, S.d_part, done, (const double *)nullptr, (double *)nullptr);
+                           J->m, J->n, y, S.d_part, done);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -942,7 +918,7 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
     if (J->kind == LSQ_MAT_CSC) {
         if (!trans) {
             LSQ_TRY(lsq_ensure_csr(J));
-            if (J->srows.active) return launch_sell_rows(J, nullptr, x, epi);
+            if (J->srows.active) return launch_sell_rows(J, J->d_colscale, x, epi);
             return launch_segs<false>(c, J->csr, x, epi);
         }
         if (J->scols.active) {
@@ -951,7 +927,7 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
             int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
             int grid = cap((long long)nb + epi.extra_blocks);
             hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, J->n,
-                               J->scols.ngw, epi, nb);
+                               J->scols.ngw, epi, nb, J->d_colscale);
             LSQ_HIP(hipGetLastError());
             return LSQ_OK;
         }

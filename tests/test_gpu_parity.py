@@ -1309,37 +1309,44 @@ def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("opt", ["lm", "dogleg"])
-def test_tanh_model_fused_passes_change_nothing(ctx, opt, monkeypatch):
-    """The built-in model fuses around g!: the residual pass at a trial point also writes the Jacobian's row layout
-    there (adopted by g! when the step is accepted) and the sliced-column copy is written by the gradient + colsumabs2
-    pass.  Both are pure re-schedulings: with them switched off (LSQ_NO_SPEC_JAC / LSQ_EAGER_COLS) every iterate has
-    the same bits."""
+def test_tanh_model_column_scaled_vs_multiplied_out(ctx, opt, monkeypatch):
+    """The built-in model keeps J = A diag(1 - tanh(x)^2) as a COLUMN-SCALED handle on big sparse patterns (nothing is
+    multiplied out, g! writes n factors).  With LSQ_NO_COLSCALE=1 the same model multiplies J out into both sliced copies
+    after every accepted step, as rounds 1-2 did.  Same algorithm, entries used as A_ij*s_j on the fly instead of the
+    stored fl(A_ij*s_j): identical iteration counts, accept pattern and inner counts; iterates to 1e-10."""
     m, n, per_col = 300000, 2000, 600
     okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
-    xs = []
-    for env in ({}, {"LSQ_NO_SPEC_JAC": "1"}, {"LSQ_NO_SPEC_JAC": "1", "LSQ_EAGER_COLS": "1"}):
+    runs = []
+    for env in ({}, {"LSQ_NO_COLSCALE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=7, ctx=ctx)
-        pr.reset()
-        r = pr.optimize(okind, lsq._lib.LSMR, trace=True, iterations=12)
-        xs.append((r.iterations, r.ssr, np.array(r.trace["x"]), np.array(r.trace["accepted"]) if "accepted" in r.trace else None))
-        pr.close()
         for k in env:
             monkeypatch.delenv(k)
-    assert xs[0][0] > 3
-    for other in xs[1:]:
-        assert other[0] == xs[0][0] and other[1] == xs[0][1]
-        assert np.array_equal(other[2], xs[0][2])
+        pr.reset()
+        r = pr.optimize(okind, lsq._lib.LSMR, trace=True, iterations=12)
+        runs.append((r.iterations, r.ssr, np.array(r.trace["x"]), np.array(r.trace["inner"]), np.array(r.trace["accept"]),
+                     r.mul_calls))
+        pr.close()
+    a, b = runs
+    assert a[0] > 3 and a[0] == b[0] and a[5] == b[5]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert a[1] == pytest.approx(b[1], rel=1e-11)
+    assert np.max(np.abs(a[2] - b[2])) <= 1e-10 * max(1.0, np.max(np.abs(b[2])))
 
 
 @pytest.mark.gpu
-def test_device_g_leaves_csc_copy_lazy_but_consistent(ctx):
-    """On big sparse problems the built-in device g! writes only the mirrors the products read;
-    the CSC-ordered nzval must still read back correctly (rebuilt on demand), and colsumabs2 /
-    J'u taken afterwards must agree with the values."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_device_g_values_stay_consistent(ctx, fused, monkeypatch):
+    """After the built-in device g!: column-scaled handle (default on big patterns) -- the stored values read back as A and
+    every operation acts on A diag(s); multiplied-out mode (LSQ_NO_COLSCALE=1) -- only the mirrors the products read were
+    written and the CSC-ordered nzval is rebuilt on demand.  Either way colsumabs2 / J'u / J v / rowsumabs2 taken afterwards
+    must agree with J(x) = A diag(1 - tanh(x)^2)."""
     m, n, per_col = 300000, 2000, 600
+    if not fused:
+        monkeypatch.setenv("LSQ_NO_COLSCALE", "1")
     pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=5, ctx=ctx)
+    monkeypatch.delenv("LSQ_NO_COLSCALE", raising=False)
     x0 = lsq.synthetic.uniform(n, 3)
     pr.reset(x0)
     L = lsq.lib()
@@ -1349,7 +1356,10 @@ def test_device_g_leaves_csc_copy_lazy_but_consistent(ctx):
     want = pr.A * sfac[cols]
     got = np.empty_like(pr.A)
     lsq._lib.check(L.lsq_mat_get_values(pr.J, got.ctypes.data_as(lsq._lib.c_dp)))
-    np.testing.assert_allclose(got, want, rtol=4e-16 * 8, atol=0)
+    if fused:
+        assert np.array_equal(got, pr.A)
+    else:
+        np.testing.assert_allclose(got, want, rtol=4e-16 * 8, atol=0)
     cs = lsq.DeviceVector(ctx, n)
     lsq._lib.check(L.lsq_colsumabs2(pr.J, cs.ptr))
     np.testing.assert_allclose(cs.get(), np.add.reduceat(want * want, pr.colptr[:-1]), rtol=1e-12)
@@ -1358,7 +1368,82 @@ def test_device_g_leaves_csc_copy_lazy_but_consistent(ctx):
     lsq._lib.check(L.lsq_mul(pr.J, 1, 1.0, u.ptr, 0.0, g.ptr))
     ref = np.add.reduceat(want * u.get()[pr.rowval], pr.colptr[:-1])
     np.testing.assert_allclose(g.get(), ref, rtol=1e-10, atol=1e-10 * np.max(np.abs(ref)))
+    S = sp.csc_matrix((want, pr.rowval, pr.colptr), shape=(m, n))
+    v = lsq.synthetic.normal(n, 4)
+    out = lsq.DeviceVector(ctx, m)
+    lsq._lib.check(L.lsq_mul(pr.J, 0, 1.0, lsq.DeviceVector(ctx, n, v).ptr, 0.0, out.ptr))
+    np.testing.assert_allclose(out.get(), S @ v, rtol=0, atol=1e-12 * (1 + np.max(np.abs(S @ v))))
+    rs = lsq.DeviceVector(ctx, m)
+    lsq._lib.check(L.lsq_rowsumabs2(pr.J, rs.ptr))
+    np.testing.assert_allclose(rs.get(), np.asarray(S.multiply(S).sum(axis=1)).ravel(), rtol=1e-12)
     pr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sliced", "segments", "small", "dense"])
+def test_column_scaled_jacobian(ctx, kind, monkeypatch):
+    """lsq_mat_set_colscale (include/lsqhip.h): a handle holding V with n factors s acts as J = V diag(s) in every operation of
+    the hot path -- products, colsumabs2, rowsumabs2, the damped LSMR solve -- on the sliced layouts (fused, nothing multiplied
+    out), on segment-kernel patterns, on small matrices (reference-order kernels) and on dense ones (values multiplied out
+    behind the handle).  Checked against the oracle on the multiplied-out matrix; then s changes (colscale_changed), then V
+    changes (set_values), then the scale is removed."""
+    rng = np.random.default_rng(11)
+    if kind in ("sliced", "segments"):
+        m, n = 200000, 1500
+        S = rand_csc(m, n, 0.004, 5)
+        if kind == "segments":
+            monkeypatch.setenv("LSQ_NO_SELL", "1")
+    elif kind == "small":
+        m, n = 300, 20
+        S = rand_csc(m, n, 0.3, 6)
+    else:
+        m, n = 900, 40
+        S = rng.standard_normal((m, n))
+    J = lsq.DeviceMatrix(ctx, S)
+    monkeypatch.delenv("LSQ_NO_SELL", raising=False)
+    V = S.tocsc() if kind != "dense" else S
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    damp = rng.uniform(0.5, 2.0, n)
+
+    def check_all(Vm, s):
+        Jm = (Vm @ sp.diags(s)).tocsc() if kind != "dense" else Vm * s[None, :]
+        A = O.Mat.from_scipy(Jm) if kind != "dense" else O.Mat(dense=Jm)
+        scale = 1 + (np.abs(Jm).sum(axis=1).max() if kind != "dense" else np.abs(Jm).sum(axis=1).max())
+        out = lsq.mul_(lsq.DeviceVector(ctx, m, y), J, lsq.DeviceVector(ctx, n, x), 1.5, -0.5).get()
+        assert np.max(np.abs(out - O.mul(A, x, 1.5, -0.5, y))) <= 1e-12 * scale
+        scale_t = 1 + np.abs(Jm).sum(axis=0).max()
+        out = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, lsq.DeviceVector(ctx, m, y), -2.0, 0.25, trans=True).get()
+        assert np.max(np.abs(out - O.mulT(A, y, -2.0, 0.25, x))) <= 1e-12 * scale_t
+        assert np.allclose(lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get(), O.colsumabs2(A), rtol=1e-13, atol=0)
+        assert np.allclose(lsq.rowsumabs2_(lsq.DeviceVector(ctx, m), J).get(), O.rowsumabs2(A), rtol=1e-13, atol=1e-300)
+        sv = lsq.AllocatedSolver(J, lsq.LSMR(), for_lm=True)
+        xg, nmul = sv.ldiv_(lsq.DeviceVector(ctx, n), lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+        st, xo, nmo, _ = O.ldiv(O.LSMR, A, y, damp)
+        assert st == O.OK and nmul == nmo
+        assert np.max(np.abs(xg.get() - xo)) <= 1e-8 * max(1.0, np.max(np.abs(xo)))
+        sv.free()
+
+    s1 = rng.uniform(0.2, 1.5, n)
+    ds = lsq.DeviceVector(ctx, n, s1)
+    J.set_colscale(ds)
+    vals0 = J.values()
+    assert np.array_equal(vals0, V.data if kind != "dense" else np.asfortranarray(V).reshape(-1, order="F"))   # still V
+    check_all(V, s1)
+    s2 = rng.uniform(0.1, 3.0, n)
+    ds.set(s2)
+    J.colscale_changed()
+    check_all(V, s2)
+    if kind != "dense":
+        V2 = V.copy()
+        V2.data = rng.standard_normal(V2.nnz)
+        J.set_values(V2.data)
+    else:
+        V2 = rng.standard_normal((m, n))
+        J.set_values(np.asfortranarray(V2).reshape(-1, order="F"))
+    check_all(V2, s2)
+    J.set_colscale(None)
+    check_all(V2, np.ones(n))
+    J.free()
 
 
 @pytest.mark.gpu
