@@ -82,6 +82,11 @@ def spawn_ranks(a):
 
 
 def main():
+    # What RCCL / device-memory sharing between the ranks need on this driver must be in the environment BEFORE torch (and
+    # with it the HIP runtime) is loaded -- also when a launcher (torch.distributed.run from the driver) started this rank
+    # and spawn_ranks() below never ran: the host driver only supports dmabuf IPC.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a)                      # re-executes under torch.distributed.run; never returns
@@ -199,6 +204,7 @@ def main():
     L.lsq_prof_select(ctx.h, 3)
     ev_ovh = C.c_double(0.0)   # what an EMPTY event pair measures on this stream (marker overhead)
     L.lsq_prof_overhead(ctx.h, 50, C.byref(ev_ovh))
+    region_s_local = list(region_s)
     if dist is not None:
         tt = torch.tensor(region_s, dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)       # every region: the slowest rank's time
@@ -208,6 +214,10 @@ def main():
         inner_total = float(it.item())
     else:
         inner_total = float(inner_local)
+    # every rank's own rate on stderr: a straggler among N ranks is visible next to the max-over-ranks headline
+    own = sorted(region_s_local)
+    print("bench: rank %d/%d own median region %.3f ms = %.1f LM it/s (inner %d)"
+          % (rank, world, own[len(own) // 2] * 1e3, a.steps / own[len(own) // 2], inner_local), file=sys.stderr)
     srt = sorted(region_s)
     dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     inner_total /= reps                                  # per region
@@ -247,7 +257,7 @@ def main():
 
     # HBM traffic of that kernel comes from rocprofv3 PMC passes (it cannot be read inside this
     # process): the committed measurement for exactly this workload, newest round first
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))
             if tr["config"] == {"m": m, "n": n, "nnz": nnz}:
@@ -285,8 +295,14 @@ def main():
                       "lsmr_inner_iterations_total": inner_total,
                       "lsmr_inner_per_outer": inner_total / (a.steps * world),
                       "lsmr_inner_iterations_per_sec": inner_total / dt, "iters_per_solve": a.iters_per_solve,
+                      "jacobian": "column-scaled handle J = A diag(1 - tanh(x)^2) on the sliced layouts: g! writes n factors, "
+                                  "no Jacobian copy is multiplied out (lsq_mat_set_colscale; LSQ_NO_COLSCALE=1 restores the "
+                                  "multiplied-out copies of rounds 1-2)" if not os.environ.get("LSQ_NO_COLSCALE") else
+                                  "multiplied out into both sliced copies by g!",
                       "final_ssr": r.ssr, "setup_seconds": t_setup},
-           "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense}
+           "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense,
+           # bounded-wait give-ups of the fast paths that assume co-resident workgroups (include/lsqhip.h: lsq_solver_stats)
+           "fallback_giveups": ctx.fallback_stats()}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -491,5 +507,21 @@ def cpu_baseline(a, pr, inputs):
     return out
 
 
+def guarded_main():
+    """Every rank's failure ends with ONE line of reason on stderr and a non-zero exit code (under torch.distributed.run the
+    launcher then stops the other ranks and reports which one failed first)."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:   # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        print("bench: rank %s FAILED: %s: %s" % (os.environ.get("RANK", "0"), type(e).__name__, str(e).splitlines()[0] if str(e) else ""),
+              file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(1)      # (not sys.exit: a rank stuck in a collective's teardown must not keep the job alive)
+
+
 if __name__ == "__main__":
-    main()
+    guarded_main()

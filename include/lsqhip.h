@@ -185,6 +185,18 @@ int lsq_solver_qr_panel(const lsq_solver *s, int *kind);
  * n <= 1408; repeated as 2 if one of its bounded waits gives up) */
 int lsq_solver_chol_path(const lsq_solver *s, int *path);
 
+/* The fast paths above that rely on co-resident workgroups (one-launch Cholesky, pipelined triangular solves, the QR panel's slab
+ * exchange + pipelined certified solve) wait with a bound; a wait that gives up makes the solve repeat itself on the
+ * launch-per-step path, is COUNTED, and pauses that fast path for a number of solves (16, then 64, ... up to 4096 while it
+ * keeps failing right after being armed again; back to 16 after a clean run) instead of switching it off for good: a
+ * neighbour on the device (an RCCL kernel of a sharded run) may be gone by then.  Index: 0 one-launch Cholesky (k_chol_tiles),
+ * 1 pipelined triangular solves, 2 QR slab exchange / pipelined certified solve, 3 CholeskyQR2 panel breakdowns (numerical:
+ * ill-conditioned panels -- counted and paused the same way).  h_giveups: totals of this solver; h_paused: solves left before
+ * the path is tried again (0 = armed).  Either pointer may be NULL. */
+int lsq_solver_stats(const lsq_solver *s, int h_giveups[4], int h_paused[4]);
+/* the same totals over every solver the context has run (the solver lsq_optimize keeps inside the context included) */
+int lsq_ctx_fallback_stats(const lsq_ctx *ctx, int h_giveups[4]);
+
 /* ---- whole trust-region loop on device buffers (host control, device arrays) ---- */
 /* f!(out, x) and g!(J, x) on DEVICE pointers; g writes lsq_mat_values(J) (the library refreshes
  * the CSR mirror afterwards).  Return non-zero to abort with LSQ_ECALLBACK. */
@@ -266,6 +278,11 @@ int lsq_synth_normal(int n, unsigned long long seed, double *h_out);
  * events on the context stream; returns the average milliseconds per launch. */
 int lsq_bench_mul(lsq_mat *J, int trans, int reps, const double *d_x, double *d_y, double beta,
                   float *h_ms_per_launch);
+
+/* A neighbour on the device, for tests and measurements of the paths above: `workgroups` workgroups of 256 threads, each
+ * holding lds_bytes of LDS, spin for `milliseconds` on a stream of their own (returns at once; lsq_bench_occupy_wait joins). */
+int lsq_bench_occupy(lsq_ctx *ctx, int workgroups, int lds_bytes, double milliseconds);
+int lsq_bench_occupy_wait(lsq_ctx *ctx);
 
 /* Reference-order arithmetic for small problems (m, n <= 2048, nnz <= 2^18): every sum is taken in
  * the order of the reference's serial loops, so iteration / mul counts reproduce the CPU

@@ -133,6 +133,10 @@ def lib():
         "lsq_solver_qr_path": (i, [vp, c_ip]),
         "lsq_solver_qr_panel": (i, [vp, c_ip]),
         "lsq_solver_chol_path": (i, [vp, c_ip]),
+        "lsq_solver_stats": (i, [vp, c_ip, c_ip]),
+        "lsq_ctx_fallback_stats": (i, [vp, c_ip]),
+        "lsq_bench_occupy": (i, [vp, i, i, d]),
+        "lsq_bench_occupy_wait": (i, [vp]),
         "lsq_options_default": (None, [C.POINTER(Options)]),
         "lsq_optimize": (i, [vp, i, i, vp, vp, vp, F_CALLBACK, G_CALLBACK, vp, C.POINTER(Options),
                              C.POINTER(Result)]),

@@ -129,6 +129,19 @@ class Context:
     def sync(self):
         check(lib().lsq_ctx_sync(self.h))
 
+    def fallback_stats(self):
+        """lsq_ctx_fallback_stats: how often the co-residency fast paths of this context's solvers gave up on a bounded wait."""
+        g = (C.c_int * 4)()
+        check(lib().lsq_ctx_fallback_stats(self.h, g))
+        return dict(zip(("chol_one_launch", "tri_pipeline", "qr_exchange", "cholqr_panel"), (int(v) for v in g)))
+
+    def occupy(self, workgroups, lds_bytes=65536, milliseconds=10.0):
+        """A neighbour on the device (lsq_bench_occupy): workgroups that hold LDS and spin, on a stream of their own."""
+        check(lib().lsq_bench_occupy(self.h, int(workgroups), int(lds_bytes), float(milliseconds)))
+
+    def occupy_wait(self):
+        check(lib().lsq_bench_occupy_wait(self.h))
+
     def close(self):
         if self.h:
             lib().lsq_ctx_destroy(self.h)
@@ -485,6 +498,13 @@ class AllocatedSolver:
                     qr_panel={0: None, 1: "householder-steps", 2: "cholqr2"}[panel.value],
                     qr_path={0: None, 1: "one-stage", 2: "two-stage-pivoted", 3: "two-stage-certified"}[path.value],
                     chol_path={0: None, 1: "one-workgroup", 2: "blocked", 3: "blocked-certified", 4: "blocked-one-launch"}[cpath.value])
+
+    def stats(self):
+        """lsq_solver_stats: give-ups of the co-residency fast paths and how many solves each stays paused."""
+        g, p = (C.c_int * 4)(), (C.c_int * 4)()
+        check(lib().lsq_solver_stats(self.h, g, p))
+        names = ("chol_one_launch", "tri_pipeline", "qr_exchange", "cholqr_panel")
+        return {k: {"giveups": g[i], "paused": p[i]} for i, k in enumerate(names)}
 
     def free(self):
         if self.h:

@@ -70,6 +70,11 @@ struct lsq_ctx {
     std::vector<hipEvent_t> prof_pool;   // events created by lsq_prof_begin, so that a timed launch creates nothing
     // kernels whose dynamic-LDS limit has been raised on THIS context's device (function attributes may be per device)
     std::unordered_map<const void *, size_t> lds_cfg;
+    // give-ups of the fast paths that rely on co-resident workgroups, summed over every solver of this context
+    // (LsqFallback in lsq_solver.h; index: 0 one-launch Cholesky, 1 pipelined triangular solves, 2 QR slab exchange /
+    // pipelined certified solve, 3 CholeskyQR2 panel breakdowns)
+    int fallback_giveups[4] = {0, 0, 0, 0};
+    hipStream_t occupy_stream = nullptr;   // lsq_bench_occupy
     // uploads that overlap compute (lsq_mat_set_values_async): created on first use
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
@@ -349,6 +354,7 @@ struct LsqSlotPublish {
 };
 LsqSlotPublish lsq_slots_ticket(lsq_ctx *c, int first, int count);
 int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, double *h_out);
+int lsq_read_ints(lsq_ctx *c, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]);   // null pointers read as 0
 
 static inline void lsq_run_idle_hook(lsq_ctx *c) {
     if (!c->idle_hook) return;

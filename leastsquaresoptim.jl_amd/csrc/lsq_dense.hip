@@ -18,6 +18,7 @@ int lsq_cholesky_blocked_solve(lsq_solver *s, int n, double *d_x);
 int lsq_tri_inv_fro2(lsq_solver *s, const double *U, int n, double *fro2_inv);   // lsq_qr.hip
 void lsq_tri_pipe_err_copy(lsq_solver *s, int *h_dst);                           // lsq_qr.hip
 void lsq_tri_pipe_disable(lsq_solver *s);                                        // lsq_qr.hip
+const int *lsq_tri_pipe_err_ptr(lsq_solver *s);                                  // lsq_qr.hip (null: the pipeline is off)
 
 
 // ---------------------------------------------------------------------------------------------
@@ -322,8 +323,8 @@ static bool chol_certified(lsq_solver *s, lsq_mat *J, const double *d_y, double 
     if (hipMemcpy(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(&dmax, s->d_work, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(LSQ_EHIP);
-    if (info == -1 && !s->chol_tiles_off) {       // the one-launch factorisation gave up on a wait: panel launches from now on
-        s->chol_tiles_off = true;
+    if (info == -1 && !s->fb_tiles.off()) {       // the one-launch factorisation gave up on a wait: panel launches for a while
+        s->fb_tiles.gave_up(s->ctx, LSQ_FB_CHOL_TILES);
         return chol_certified(s, J, d_y, d_x, rc);
     }
     const bool ok = info == 0 && std::isfinite(fro2) && fro2 > 0.0 && std::isfinite(dmax) &&
@@ -357,18 +358,20 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
         LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
         LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, true));
         s->last_chol_path = s->last_chol_tiles ? 4 : 2;
-        int info = 0, perr = 0;
-        LSQ_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        lsq_tri_pipe_err_copy(s, &perr);
-        LSQ_HIP(hipStreamSynchronize(c->stream));
-        if (info == -1) {                         // k_chol_tiles gave up on a wait: never again for this solver, and redo
-            s->chol_tiles_off = true;
+        // the two status words (PosDefException position / "a wait gave up", and the solve pipeline's flag) reach the host
+        // through the pinned slot mirror and a spin, as the loops' scalars do: a hipStreamSynchronize wake-up here cost
+        // ~50 us of every 0.35 ms solve
+        int st4[4] = {0, 0, 0, 0};
+        LSQ_TRY(lsq_read_ints(c, s->d_info, lsq_tri_pipe_err_ptr(s), nullptr, nullptr, st4));
+        int info = st4[0], perr = st4[1];
+        if (info == -1) {                         // k_chol_tiles gave up on a wait: panel launches for a while, and redo
+            s->fb_tiles.gave_up(c, LSQ_FB_CHOL_TILES);
             s->last_chol_path = 2;
             LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));
             LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, false));
-            LSQ_HIP(hipMemcpyAsync(&info, s->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            lsq_tri_pipe_err_copy(s, &perr);
-            LSQ_HIP(hipStreamSynchronize(c->stream));
+            LSQ_TRY(lsq_read_ints(c, s->d_info, lsq_tri_pipe_err_ptr(s), nullptr, nullptr, st4));
+            info = st4[0];
+            perr = st4[1];
         }
         if (info != 0) {
             lsq_set_error("PosDefException: matrix is not positive definite; Cholesky failed at %d", info);
@@ -411,6 +414,9 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
             return LSQ_ERANK;
         }
     }
+    // (fast paths that gave up on a bounded wait are armed again after a pause: LsqFallback)
+    s->fb_tiles.solve_done(s->last_chol_path == 4);
+    s->fb_pipe.solve_done(s->last_chol_path >= 2 && s->tripipe != nullptr);
     if (nmul) *nmul = 1;
     return LSQ_OK;
 }

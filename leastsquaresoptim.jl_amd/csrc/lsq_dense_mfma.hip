@@ -553,7 +553,7 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     }
     if (d_dmax) hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);
     // one launch for the whole factorisation when every 64 x 64 upper tile gets a CU of its own (k_chol_tiles)
-    if (allow_tiles && !s->chol_tiles_off && ntiles <= c->num_cus && n >= 2 * NB && !getenv("LSQ_CHOL_PANELS")) {
+    if (allow_tiles && !s->fb_tiles.off() && ntiles <= c->num_cus && n >= 2 * NB && !getenv("LSQ_CHOL_PANELS")) {
         double *Xt = lsq_tri_chol_diagbuf(s, n);
         if (Xt) {
             if (!s->d_chol_flags) {

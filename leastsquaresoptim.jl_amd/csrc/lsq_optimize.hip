@@ -100,6 +100,16 @@ extern "C" int lsq_solver_qr_path(const lsq_solver *s, int *path) {
     return LSQ_OK;
 }
 
+extern "C" int lsq_solver_stats(const lsq_solver *s, int h_giveups[4], int h_paused[4]) {
+    if (!s) { lsq_set_error("lsq_solver_stats: null argument"); return LSQ_EARG; }
+    const LsqFallback *fb[4] = {&s->fb_tiles, &s->fb_pipe, &s->fb_qrx, &s->fb_cholqr};
+    for (int i = 0; i < 4; ++i) {
+        if (h_giveups) h_giveups[i] = fb[i]->giveups;
+        if (h_paused) h_paused[i] = fb[i]->cooldown;
+    }
+    return LSQ_OK;
+}
+
 extern "C" int lsq_solver_chol_path(const lsq_solver *s, int *path) {
     if (!s || !path) { lsq_set_error("lsq_solver_chol_path: null argument"); return LSQ_EARG; }
     *path = s->last_chol_path;

@@ -1184,8 +1184,8 @@ static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double 
         // shared with other work) -- this solver stops using them;  bit 1: a CholeskyQR2 panel broke down (ill-conditioned
         // or rank-deficient panel) -- this solver goes back to the column-by-column panel.  Either way: once more.
         LSQ_ZERO(q->d_err, 0, sizeof(int));
-        if (ev & 1) q->no_exchange = true;
-        if (ev & 2) q->no_cholqr = true;
+        if (ev & 1) { q->no_exchange = true; s->fb_qrx.gave_up(c, LSQ_FB_QR_EXCHANGE); }
+        if (ev & 2) { q->no_cholqr = true; s->fb_cholqr.gave_up(c, LSQ_FB_CHOLQR); }
         *timed_out = true;
         return LSQ_OK;
     }
@@ -1215,7 +1215,7 @@ static void tripipe_free(void *p) {
 static int tri_chol_pipe(lsq_solver *s, int n, TriPipe **out) {
     const int nblk = lsq_div_up(n, 64);
     *out = nullptr;
-    if (nblk > 256 || s->pipe_off) return LSQ_EARG;
+    if (nblk > 256 || s->fb_pipe.off()) return LSQ_EARG;
     TriPipe *t = (TriPipe *)s->tripipe;
     if (!t || t->n != n) {
         if (t) tripipe_free(t);
@@ -1268,12 +1268,16 @@ int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
 void lsq_tri_pipe_err_copy(lsq_solver *s, int *h_dst) {
     TriPipe *t = (TriPipe *)s->tripipe;
     *h_dst = 0;
-    if (t && !s->pipe_off) (void)hipMemcpyAsync(h_dst, t->d_err, sizeof(int), hipMemcpyDeviceToHost, s->ctx->stream);
+    if (t && !s->fb_pipe.off()) (void)hipMemcpyAsync(h_dst, t->d_err, sizeof(int), hipMemcpyDeviceToHost, s->ctx->stream);
+}
+const int *lsq_tri_pipe_err_ptr(lsq_solver *s) {
+    TriPipe *t = (TriPipe *)s->tripipe;
+    return t && !s->fb_pipe.off() ? t->d_err : nullptr;
 }
 void lsq_tri_pipe_disable(lsq_solver *s) {
     TriPipe *t = (TriPipe *)s->tripipe;
     if (t) (void)hipMemsetAsync(t->d_err, 0, sizeof(int), s->ctx->stream);
-    s->pipe_off = 1;
+    s->fb_pipe.gave_up(s->ctx, LSQ_FB_TRI_PIPE);
 }
 
 // sum of squares of inv(U) for the n x n upper triangle U (explicit inverse: k_tri_diaginv + k_tri_level levels);
@@ -1319,6 +1323,10 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
     const int lu = d_damp ? M : std::max(m, n);
     if (n > 0 && M > 0)
     for (int attempt = 0; attempt < 3; ++attempt) {     // (again only after an in-kernel exchange timed out / a CholeskyQR2 panel broke down)
+        if (s->qr2) {   // the paths that gave up are armed again after a pause (LsqFallback)
+            ((Qr2Work *)s->qr2)->no_exchange = s->fb_qrx.off();
+            ((Qr2Work *)s->qr2)->no_cholqr = s->fb_cholqr.off();
+        }
         long long tot = (long long)M * n;
         int grid = (int)std::min<long long>((tot + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
         hipLaunchKernelGGL(k_stack, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, m, n, d_damp, s->d_qr);
@@ -1354,6 +1362,8 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
                 LSQ_HIP(hipGetLastError());
                 s->last_rank = -1;
                 s->last_qr_path = 3;
+                s->fb_qrx.solve_done(!q->no_exchange);
+                s->fb_cholqr.solve_done(q->cholqr_used);
                 if (nmul) *nmul = 1;
                 return LSQ_OK;
             }
@@ -1426,6 +1436,8 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
         break;
     }
     s->last_rank = -1;  // fetched lazily by lsq_solver_info
+    s->fb_qrx.solve_done(false);
+    s->fb_cholqr.solve_done(false);
     if (nmul) *nmul = 1;
     return LSQ_OK;
 }

@@ -20,6 +20,29 @@ struct LsmrState {
     unsigned epoch;
 };
 
+// A fast path that relies on what the hardware does but HIP does not promise (all workgroups of a launch co-resident and
+// dispatched in index order: in-kernel tile / slab exchanges) has bounded waits; a wait that gives up is COUNTED and the path
+// is switched off for a while -- not for ever: after `cooldown` further solves it is armed again (a neighbour on the device,
+// e.g. an RCCL kernel of a sharded run, may be gone by then); if it gives up again right away the next pause is four times
+// as long (16, 64, ... 4096 solves), a clean armed solve resets the pause to 16.
+struct LsqFallback {
+    int giveups = 0;        // how often a bounded wait of this path gave up (lsq_solver_stats)
+    int cooldown = 0;       // solves left before the path is armed again (0: armed)
+    int next_pause = 16;
+    bool off() const { return cooldown > 0; }
+    void gave_up(lsq_ctx *c, int which) {
+        giveups++;
+        c->fallback_giveups[which]++;
+        cooldown = next_pause;
+        next_pause = next_pause < 4096 ? next_pause * 4 : 4096;
+    }
+    void solve_done(bool used_and_clean) {      // once per solve of the owning solver
+        if (cooldown > 0) --cooldown;
+        else if (used_and_clean) next_pause = 16;
+    }
+};
+enum { LSQ_FB_CHOL_TILES = 0, LSQ_FB_TRI_PIPE = 1, LSQ_FB_QR_EXCHANGE = 2, LSQ_FB_CHOLQR = 3 };
+
 struct lsq_solver {
     lsq_ctx *ctx;
     int kind;
@@ -59,11 +82,13 @@ struct lsq_solver {
     void (*tripipe_free)(void *) = nullptr;
     double *tri_X = nullptr, *tri_T = nullptr, *tri_fro = nullptr, *tri_hfro = nullptr;   // explicit inverse of the Cholesky factor (Dogleg certificate)
     int last_chol_path = 0;         // lsq_solver_chol_path
-    int pipe_off = 0;               // a wait of the pipelined triangular solves gave up once: single-workgroup solves from then on
+    LsqFallback fb_pipe;            // pipelined triangular solves (else single-workgroup solves)
     bool chol_have_diaginv = false; // the last blocked factorisation left inv(U_kk) in the solve pipeline's buffer
     unsigned *d_chol_flags = nullptr; // k_chol_tiles: epoch-tagged 'tile published' flags
     unsigned chol_epoch = 0;
-    bool chol_tiles_off = false;    // a wait of k_chol_tiles gave up once: launch-per-panel factorisation from then on
+    LsqFallback fb_tiles;           // one-launch factorisation k_chol_tiles (else launch-per-panel)
+    LsqFallback fb_qrx;             // QR: slab exchange of the panel steps + pipelined certified solve (mirrors Qr2Work::no_exchange)
+    LsqFallback fb_cholqr;          // QR: CholeskyQR2 panels (numerical breakdowns; mirrors Qr2Work::no_cholqr)
     bool last_chol_tiles = false;   // the last blocked factorisation was the one-launch one
 };
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx);

@@ -265,6 +265,49 @@ int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, dou
     return LSQ_OK;
 }
 
+// up to four device ints (status words of the dense solvers) -> host, through the same pinned mirror and the same spin: a
+// hipMemcpyAsync + hipStreamSynchronize wake-up costs ~50 us of host latency, this one launch + poll a few
+__global__ void k_publish_ints(const int *a, const int *b, const int *c2, const int *d, double *dst, unsigned long long *seq_word,
+                               unsigned long long seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int *src[4] = {a, b, c2, d};
+        for (int i = 0; i < 4; ++i)
+            __hip_atomic_store(dst + i, src[i] ? (double)*src[i] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+int lsq_read_ints(lsq_ctx *c, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]) {
+    constexpr int FIRST = LSQ_NSLOTS - 8;     // (slots 56..59: not used by any reduction)
+    LsqSlotPublish p = lsq_slots_ticket(c, FIRST, 4);
+    hipLaunchKernelGGL(k_publish_ints, dim3(1), dim3(64), 0, c->stream, d_a, d_b, d_c, d_d, p.dst, p.seq_word, p.seq);
+    LSQ_HIP(hipGetLastError());
+    // (the fallback copy of lsq_wait_slots reads d_slots, which this kernel does not fill: only reached if the pinned word
+    //  never becomes visible although the stream drained)
+    double v[4];
+    volatile unsigned long long *hw = (volatile unsigned long long *)(c->h_slots + LSQ_NSLOTS);
+    unsigned long long spins = 0;
+    while (*hw != p.seq) {
+        if ((++spins & 0xfffffu) != 0) continue;
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipErrorNotReady) continue;
+        if (q != hipSuccess) {
+            lsq_set_error("HIP error while waiting for a solver status word: %s", hipGetErrorString(q));
+            return LSQ_EHIP;
+        }
+        if (*hw != p.seq) {   // drained, word not visible: read the ints the slow way
+            const int *src[4] = {d_a, d_b, d_c, d_d};
+            for (int i = 0; i < 4; ++i) {
+                h_out[i] = 0;
+                if (src[i]) LSQ_HIP(hipMemcpy(&h_out[i], src[i], sizeof(int), hipMemcpyDeviceToHost));
+            }
+            return LSQ_OK;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < 4; ++i) { v[i] = ((volatile double *)c->h_slots)[FIRST + i]; h_out[i] = (int)v[i]; }
+    return LSQ_OK;
+}
+
 int lsq_read_slots(lsq_ctx *c, int first, int count, double *h_out) {
     LsqSlotPublish p = lsq_slots_ticket(c, first, count);
     hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(64), 0, c->stream, p.src, p.count, p.dst, p.seq_word, p.seq);
@@ -476,5 +519,43 @@ extern "C" int lsq_first_nonfinite(lsq_ctx *c, int n, const double *x, int *h_in
     double v;
     LSQ_TRY(lsq_read_slots(c, 0, 1, &v));
     *h_index = (int)v;
+    return LSQ_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// measurement / test helpers: a neighbour on the device
+// ---------------------------------------------------------------------------------------------
+// `workgroups` workgroups of 256 threads that each hold `lds_bytes` of LDS and spin for `milliseconds`: what an RCCL kernel
+// or any other tenant of the device does to the fast paths that assume co-resident workgroups (include/lsqhip.h)
+__global__ void __launch_bounds__(256) k_occupy(long long ticks, double *sink) {
+    extern __shared__ double hog[];
+    hog[threadIdx.x] = (double)threadIdx.x;
+    const long long t0 = wall_clock64();
+    double acc = 0.0;
+    while (wall_clock64() - t0 < ticks) {
+        acc += hog[(threadIdx.x * 7 + (int)acc) & 255];
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (acc == -1.0) sink[0] = acc;
+}
+extern "C" int lsq_bench_occupy(lsq_ctx *c, int workgroups, int lds_bytes, double milliseconds) {
+    if (!c || workgroups <= 0 || lds_bytes < 2048 || lds_bytes > 160 * 1024 || !(milliseconds > 0)) return LSQ_EARG;
+    if (!c->occupy_stream) LSQ_HIP(hipStreamCreateWithFlags(&c->occupy_stream, hipStreamNonBlocking));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_occupy, 160 * 1024));
+    int rate_khz = 100000;   // wall_clock64 ticks at 100 MHz on gfx9
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c->device);
+    const long long ticks = (long long)(milliseconds * (double)rate_khz);
+    hipLaunchKernelGGL(k_occupy, dim3(workgroups), dim3(256), (size_t)lds_bytes, c->occupy_stream, ticks, c->d_slots + LSQ_NSLOTS - 2);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+extern "C" int lsq_bench_occupy_wait(lsq_ctx *c) {
+    if (c && c->occupy_stream) LSQ_HIP(hipStreamSynchronize(c->occupy_stream));
+    return LSQ_OK;
+}
+extern "C" int lsq_ctx_fallback_stats(const lsq_ctx *c, int h_giveups[4]) {
+    if (!c || !h_giveups) return LSQ_EARG;
+    for (int i = 0; i < 4; ++i) h_giveups[i] = c->fallback_giveups[i];
     return LSQ_OK;
 }

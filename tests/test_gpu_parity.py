@@ -686,21 +686,81 @@ def test_dense_exchange_timeout_falls_back(ctx, monkeypatch):
     dxo = lsq.DeviceVector(ctx, n)
     xr, rk, *_ = O.qr_solve(A, y)
     sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
-    for _ in range(2):                     # first solve: timeout + retry; second: exchanges already off
+    for k in range(2):                     # first solve: timeout + retry; second: exchanges paused
         sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
         assert sv.info()["qr_rank"] == rk == n
         assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
+        st = sv.stats()["qr_exchange"]     # counted once, and paused (16 solves) rather than switched off for good
+        assert st["giveups"] == 1 and st["paused"] == 16 - (k + 1), st
     for for_lm in (True, False):
         svc = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=for_lm)
         for _ in range(2):
             if for_lm:
                 svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
                 xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y, damp)[1]
-                assert svc.info()["chol_path"] == "blocked"      # the one-launch factorisation gave up and stays off
+                assert svc.info()["chol_path"] == "blocked"      # the one-launch factorisation gave up and is paused
+                assert svc.stats()["chol_one_launch"]["giveups"] == 1 and svc.stats()["chol_one_launch"]["paused"] > 0
+                assert svc.stats()["tri_pipeline"]["giveups"] == 1
             else:
                 svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
                 xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y)[1]
             assert np.allclose(dxo.get(), xc, rtol=1e-9, atol=1e-12), for_lm
+
+
+def test_fast_paths_are_rearmed_after_a_pause(ctx, monkeypatch):
+    """A give-up pauses a co-residency fast path for 16 solves, then it is armed again (no one-way latches): with
+    the fault injector on for the first solve only, solve 1 falls back, solves 2..17 run the launch-per-panel path, solve 18
+    is the one-launch factorisation again -- and every answer is the oracle's."""
+    rng = np.random.default_rng(5)
+    m, n = 4096, 512
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y, damp = rng.standard_normal(m), rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+    xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y, damp)[1]
+    dxo = lsq.DeviceVector(ctx, n)
+    paths = []
+    for k in range(19):
+        if k == 0:
+            monkeypatch.setenv("LSQ_TEST_EXCHANGE_TIMEOUT", "1")
+        sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+        monkeypatch.delenv("LSQ_TEST_EXCHANGE_TIMEOUT", raising=False)
+        assert np.allclose(dxo.get(), xc, rtol=1e-9, atol=1e-12), k
+        paths.append(sv.info()["chol_path"])
+    assert paths[0] == "blocked" and set(paths[1:16]) == {"blocked"}
+    assert paths[-1] == "blocked-one-launch", paths
+    st = sv.stats()
+    assert st["chol_one_launch"] == {"giveups": 1, "paused": 0}
+    assert ctx.fallback_stats()["chol_one_launch"] >= 1
+
+
+def test_dense_solves_next_to_a_busy_neighbour(ctx):
+    """The situation a sharded run creates (an RCCL kernel, or any other tenant, holding CUs while the solvers' one-launch /
+    pipelined paths assume their workgroups are co-resident): C2-sized Cholesky and a QR solve while a second stream keeps
+    224 workgroups x 96 KB of LDS busy for 30 ms at a time.  Results must be the oracle's whatever the fast paths decide;
+    how often they gave up is reported (and bounded: a give-up pauses the path)."""
+    rng = np.random.default_rng(6)
+    m, n = 4096, 512
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y, damp = rng.standard_normal(m), rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    svc = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+    svq = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+    xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y, damp)[1]
+    xq = O.qr_solve(A, y)[0]
+    dxo = lsq.DeviceVector(ctx, n)
+    before = ctx.fallback_stats()
+    for k in range(6):
+        ctx.occupy(224, 96 * 1024, 30.0)
+        svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+        assert np.allclose(dxo.get(), xc, rtol=1e-9, atol=1e-12), k
+        svq.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+        assert np.allclose(dxo.get(), xq, rtol=1e-9, atol=1e-12), k
+        ctx.occupy_wait()
+    after = ctx.fallback_stats()
+    fired = {k: after[k] - before[k] for k in after}
+    print("fallbacks fired next to a busy neighbour:", fired, svc.stats(), svq.stats())
+    assert all(v <= 2 for v in fired.values()), fired          # a path that gave up is paused, not retried every solve
 
 
 @pytest.mark.parametrize("cond,certified", [(1e2, True), (1e6, True), (1e11, True), (1e12, False)])

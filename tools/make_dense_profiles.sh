@@ -50,12 +50,13 @@ for name, title in cases:
     out.append("")
 # ---- MFMA counters (north_star: "MFMA-util counters against CDNA4 peak") --------------------------------------------
 import collections
-CLK = 2.4e9          # shader clock used to turn a kernel's duration into cycles
 NSIMD = 256 * 4
+NXCD = 8             # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the launch = GRBM_GUI_ACTIVE / 8 (the MEASURED clock)
 out += ["## fp64 MFMA counters of the MFMA kernels (`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES "
         "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE`, own pass)", "",
-        "`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES summed over the device / (kernel duration x 2.4 GHz x 1024 SIMDs): the fraction of "
-        "all SIMD-cycles of the launch in which an MFMA was executing.  `MOPS_F64` x 512 = fp64 MFMA flops issued (a 16x16x4 "
+        "`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES summed over the device / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of "
+        "all SIMD-cycles of the launch in which an MFMA was executing, with the launch's cycles MEASURED in the same pass "
+        "(`clock` = GRBM_GUI_ACTIVE / 8 / duration: what the shader clock really was, no assumed frequency).  `MOPS_F64` x 512 = fp64 MFMA flops issued (a 16x16x4 "
         "f64 MFMA = 2048 flops = 4 MOPS); `TFLOP/s` = that / duration, against the 78.6 TFLOP/s fp64 matrix peak.", ""]
 for name, title in (("c2_pmc", "C2 (`chol:4096:512:1`)"), ("c3_pmc", "C3 (`qr:16384:2048:0`)")):
     f = glob.glob("gpurun_out/denseprof/%s/**/*counter_collection.csv" % name, recursive=True)
@@ -72,14 +73,17 @@ for name, title in (("c2_pmc", "C2 (`chol:4096:512:1`)"), ("c3_pmc", "C3 (`qr:16
         if key not in cnt[k]:
             cnt[k].add(key)
             dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-    out += ["### " + title, "", "| kernel | launches | avg us | MFMA busy | MOPS_F64 per launch | TFLOP/s (MFMA) | % of 78.6 |", "|---|---|---|---|---|---|---|"]
+    out += ["### " + title, "", "| kernel | launches | avg us | clock GHz | MFMA busy | MOPS_F64 per launch | TFLOP/s (MFMA) | % of 78.6 |", "|---|---|---|---|---|---|---|---|"]
     for k in sorted(agg, key=lambda k: -agg[k].get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)):
         mops, busy, n = agg[k].get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0), agg[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), len(cnt[k])
         if mops <= 0 or dur[k] <= 0:
             continue
         tf = mops * 512 / dur[k] / 1e12
-        out.append("| `%s` | %d | %.1f | %.1f %% | %.3g | %.1f | %.1f %% |" % (k[:60], n, dur[k] / n * 1e6, 100 * busy / (dur[k] * CLK * NSIMD),
-                                                                    mops / n, tf, 100 * tf / 78.6))
+        cyc = agg[k].get("GRBM_GUI_ACTIVE", 0.0) / NXCD
+        if cyc <= 0:
+            continue
+        out.append("| `%s` | %d | %.1f | %.2f | %.1f %% | %.3g | %.1f | %.1f %% |" % (k[:60], n, dur[k] / n * 1e6, cyc / dur[k] / 1e9,
+                                                                           100 * busy / (cyc * NSIMD), mops / n, tf, 100 * tf / 78.6))
     out.append("")
 open("gpurun_out/denseprof/dense_kernel_summary.md", "w").write("\n".join(out))
 print("\n".join(out[-40:]))

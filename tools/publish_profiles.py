@@ -35,6 +35,14 @@ def find(sub):
     return None
 k1f = find("k_sell_rows<EpiU>")
 cal = find("k_scale_lds<true>")
+if cal is None and os.path.exists(os.path.join(src, "pmc_fetch_cal", "f_counter_collection.csv")):
+    # since round 3 the default run multiplies nothing out: the calibration kernel comes from the LSQ_NO_COLSCALE=1 passes
+    pmc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"),
+                          os.path.join(src, "pmc_fetch_cal", "f_counter_collection.csv"),
+                          os.path.join(src, "pmc_write_cal", "w_counter_collection.csv")], capture_output=True, text=True).stdout
+    for l in pmc.splitlines():
+        if l.startswith("| `") and "k_scale_lds<true>" in l:
+            cal = (float(l.split("|")[3]), float(l.split("|")[4]))
 cfg = bench["config"]
 with open(os.path.join(dst, "pmc_traffic.md"), "w") as fh:
     fh.write(pm)
