@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "liblsqhip.so")
+# LSQ_LIB_PATH: another build of the same library (same-box A/B measurements of kernel variants, tools/ab_bench.sh)
+LIB_PATH = os.environ.get("LSQ_LIB_PATH") or os.path.join(_HERE, "liblsqhip.so")
 HEADER = os.path.join(ROOT, "include", "lsqhip.h")
 
 c_dp = C.POINTER(C.c_double)

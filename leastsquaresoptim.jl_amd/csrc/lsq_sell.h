@@ -29,8 +29,12 @@
 constexpr int LSQ_SELL_POS_BITS = 13;
 constexpr unsigned LSQ_SELL_POS_MASK = (1u << LSQ_SELL_POS_BITS) - 1u;   // 0x1fff = "no output" (padding lane)
 constexpr int LSQ_SELL_ROWS_MAX = 4096;    // J*x: output rows per block
-constexpr int LSQ_SELL_GROWS_MAX = 8192;   // J'*y: rows of the gather window (64 KiB of y in LDS)
-constexpr int LSQ_SELL_CCOLS_MAX = 5120;   // J'*y: output columns per block (40 KiB, twice with squares)
+// J'*y: a block = (gather window of <= 16384 rows of y in LDS: 128 KiB) x (<= 2560 output columns: 20 KiB).  Round 3: twice the
+// rows and half the columns of rounds 1-2 (8192 x 5120) -- same number of blocks, but a column's entries inside a window
+// double (C4: 7.8 -> 15.6), so the padding of the pair-interleaved slices halves (6.4 % -> 3 %), there are half as many
+// per-window partials to write and to combine (C4: 128 -> 64 per column) and half as many lane descriptors to read.
+constexpr int LSQ_SELL_GROWS_MAX = 16384;
+constexpr int LSQ_SELL_CCOLS_MAX = 2560;
 
 struct SellDev {
     const int2 *smeta;            // per slice {entry offset, padded entry count}
@@ -230,8 +234,7 @@ template <bool SQ>
 __device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int ccols, int grows, int m, int n,
                                                const double *__restrict__ y, double *__restrict__ part, double *smem) {
     double *yl = smem;                          // LSQ_SELL_GROWS_MAX doubles
-    double *ow = smem + LSQ_SELL_GROWS_MAX;     // LSQ_SELL_CCOLS_MAX doubles (+ the same again for SQ)
-    double *ow2 = ow + LSQ_SELL_CCOLS_MAX;
+    double *ow = smem + LSQ_SELL_GROWS_MAX;     // LSQ_SELL_CCOLS_MAX doubles
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int b = blockIdx.x; b < S.nblocks; b += gridDim.x) {
         const int gw = b / ncb, cb = b - gw * ncb;
@@ -241,16 +244,15 @@ __device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int cc
             sell_cols_stage_y(b, ncb, grows, m, y, yl, tid);
         }
         const int s0 = b * S.spw, s1 = s0 + S.spw;
+        double *dst = part + (size_t)gw * (SQ ? 2 : 1) * n + cbase;
         sell_wave_slices<SQ>(S, s0, s1, wv, lane, yl, [&](unsigned pos, double sum, double sq) {   // (lane = one column)
             ow[pos] = sum;
-            if constexpr (SQ) ow2[pos] = sq;
+            // (the squares -- the gradient + colsumabs2 pass of multiplied-out matrices, once per g! -- go straight to
+            //  memory: a second LDS staging buffer would not fit next to the 128 KiB window)
+            if constexpr (SQ) dst[n + pos] = sq;
         });
         __syncthreads();
-        double *dst = part + (size_t)gw * (SQ ? 2 : 1) * n + cbase;
-        for (int i = tid; i < cols; i += LSQ_BIG_NT) {
-            dst[i] = ow[i];
-            if constexpr (SQ) dst[n + i] = ow2[i];
-        }
+        for (int i = tid; i < cols; i += LSQ_BIG_NT) dst[i] = ow[i];
     }
 }
 

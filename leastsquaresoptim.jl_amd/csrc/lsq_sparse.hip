@@ -312,7 +312,7 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
             free_sell(J->srows);
         }
     }
-    // sliced columns for J'*y: gather windows of <= 8192 rows of y in LDS, <= 5120 output columns per block
+    // sliced columns for J'*y: gather windows of <= 16384 rows of y in LDS, <= 2560 output columns per block (lsq_sell.h)
     if (sell_ok && (sell_force || m > 131072) && n >= 1 && !getenv("LSQ_PLAN_BCSC") && !getenv("LSQ_WINDOW_ROWS")) {
         const int ncb = (n + LSQ_SELL_CCOLS_MAX - 1) / LSQ_SELL_CCOLS_MAX;
         const int ccols = (n + ncb - 1) / ncb;

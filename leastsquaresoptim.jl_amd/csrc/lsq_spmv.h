@@ -878,7 +878,7 @@ template <bool SQ>
 static inline int launch_sell_cols(lsq_mat *J, const double *y, const int *done) {
     lsq_ctx *c = J->ctx;
     const LsqSell &S = J->scols;
-    const size_t lds = (size_t)(LSQ_SELL_GROWS_MAX + (SQ ? 2 : 1) * LSQ_SELL_CCOLS_MAX) * sizeof(double);
+    const size_t lds = (size_t)(LSQ_SELL_GROWS_MAX + LSQ_SELL_CCOLS_MAX) * sizeof(double);
     auto kern = k_sell_cols<SQ>;
     LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
