@@ -167,6 +167,19 @@ int lsq_ldiv_damped(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp
  * reference-order small-problem path is not used with a custom preconditioner.  NULL restores the default. */
 typedef int (*lsq_precond_callback)(double *d_P, lsq_mat *J, const double *d_damp, void *user);
 int lsq_solver_set_preconditioner(lsq_solver *s, lsq_precond_callback cb, void *user);
+/* Row-sharded SINGLE problem: J is split by residual rows, rank p holds the m_p x n block J_p and the
+ * matching slices of the m-vectors; every n-vector is replicated and every rank runs the same scalar control flow.  What
+ * crosses ranks is a SUM all-reduce of a device buffer, IN PLACE, ordered on the library's stream (the hook enqueues it
+ * there -- e.g. ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, comm, hip_stream): RCCL over xGMI -- or makes that
+ * stream wait for it; it must not need the host to wait).  Called per LSMR inner iteration with n + 1 doubles (J_p'u_p with
+ * sum(u_p.^2) riding along: u is kept unnormalised, so the norm the reference needs BEFORE the adjoint product,
+ * lsmr.jl:119-122, travels WITH it), and per outer iteration for colsumabs2 (n, only after g!), the gradient J'f (n) and
+ * {trial ssr, predicted ssr} (2).  LevenbergMarquardt(LSMR()) only. */
+typedef int (*lsq_device_allreduce_callback)(double *d_buf, int count, void *hip_stream, void *user);
+
+/* row-sharded operator-level use (lsq_ldiv / lsq_ldiv_damped with LSMR on a row block J_p; y is the local slice, x the
+ * replicated solution): installs the all-reduce hook of lsq_options.row_allreduce on this solver.  NULL removes it. */
+int lsq_solver_set_row_allreduce(lsq_solver *s, lsq_device_allreduce_callback cb, void *user, long long global_rows);
 /* diagnostics of the last solve: LSMR istop / iterations, QR numerical rank */
 int lsq_solver_info(const lsq_solver *s, int *lsmr_iter, int *lsmr_istop, int *qr_rank);
 /* which factorisation the last QR solve used (dense_qr.jl:37,83 always runs geqp3; this build only needs the
@@ -233,6 +246,9 @@ typedef struct {
     double *trace_x;            /* trace_cap * n, or NULL */
     lsq_precond_callback preconditioner;   /* LSMR only; NULL = default Jacobi */
     void *preconditioner_user;
+    lsq_device_allreduce_callback row_allreduce;   /* row-sharded single problem (see above); NULL = J holds all rows */
+    void *row_allreduce_user;
+    long long global_rows;      /* row-sharded: sum of the ranks' row counts (lsmr.jl:55 maxiter = max(size(A)...)) */
 } lsq_options;
 
 typedef struct {

@@ -23,6 +23,7 @@ ALLREDUCE_CALLBACK = C.CFUNCTYPE(C.c_int, c_dp, C.c_int, C.c_void_p)
 OP_MUL_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)   # (trans, d_x, d_out, user)
 OP_COLSUM_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)                  # (d_out, user)
 PRECOND_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)   # (d_P, J, d_damp, user)
+ROW_ALLREDUCE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)   # (d_buf, count, hip_stream, user)
 
 OK, EDIM, ENOTPD, ERANK, ENONFINITE, EBOUNDS, EHIP, EARG, ECALLBACK, ERCCL = range(10)
 QR, CHOLESKY, LSMR = 0, 1, 2
@@ -36,7 +37,9 @@ class Options(C.Structure):
                 ("trace_cap", C.c_int), ("trace_ssr", c_dp), ("trace_gnorm", c_dp),
                 ("trace_delta", c_dp), ("trace_rho", c_dp), ("trace_inner", c_ip),
                 ("trace_accept", c_ip), ("trace_x", c_dp),
-                ("preconditioner", PRECOND_CALLBACK), ("preconditioner_user", C.c_void_p)]
+                ("preconditioner", PRECOND_CALLBACK), ("preconditioner_user", C.c_void_p),
+                ("row_allreduce", ROW_ALLREDUCE_CALLBACK), ("row_allreduce_user", C.c_void_p),
+                ("global_rows", C.c_longlong)]
 
 
 class Result(C.Structure):
@@ -61,7 +64,7 @@ def declared_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = re.findall(r"\b(lsq_[a-z0-9_]+)\s*\(", txt)
-    skip = {"lsq_f_callback", "lsq_g_callback", "lsq_allreduce_callback"}
+    skip = {"lsq_f_callback", "lsq_g_callback", "lsq_allreduce_callback", "lsq_device_allreduce_callback"}
     return sorted(set(n for n in names if n not in skip))
 
 
@@ -130,6 +133,7 @@ def lib():
         "lsq_solver_destroy": (i, [vp]),
         "lsq_ldiv": (i, [vp, vp, vp, vp, c_ip]),
         "lsq_ldiv_damped": (i, [vp, vp, vp, vp, vp, c_ip]),
+        "lsq_solver_set_row_allreduce": (i, [vp, ROW_ALLREDUCE_CALLBACK, vp, C.c_longlong]),
         "lsq_solver_info": (i, [vp, c_ip, c_ip, c_ip]),
         "lsq_solver_qr_path": (i, [vp, c_ip]),
         "lsq_solver_qr_panel": (i, [vp, c_ip]),

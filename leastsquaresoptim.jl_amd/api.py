@@ -618,7 +618,8 @@ def converged(r):
 
 
 def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_tol, f_tol, g_tol,
-                iterations, delta, lower, upper, trace, n, allreduce=None, preconditioner=None):
+                iterations, delta, lower, upper, trace, n, allreduce=None, preconditioner=None, row_allreduce=None,
+                row_allreduce_user=None, global_rows=0):
     L = lib()
     opt = _lib.Options()
     L.lsq_options_default(C.byref(opt))
@@ -646,6 +647,11 @@ def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_
     if preconditioner is not None:
         opt.preconditioner = preconditioner
         keep.append(preconditioner)
+    if row_allreduce is not None:       # row-sharded single problem (lsq_options.row_allreduce; rowshard.py)
+        opt.row_allreduce = row_allreduce
+        opt.row_allreduce_user = row_allreduce_user
+        opt.global_rows = int(global_rows)
+        keep.append(row_allreduce)
     tr = None
     if trace:
         cap = int(iterations)
@@ -671,7 +677,7 @@ def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_
 
 def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iterations=1000, delta=None,
               store_trace=False, show_trace=False, show_every=1, lower=(), upper=(), ctx=None,
-              full_trace=False):
+              full_trace=False, row_allreduce=None, global_rows=0):
     """optimize!(nls, optimizer; kwargs...)  -- types.jl:207-209 then
     levenberg_marquardt.jl:39-144 / dogleg.jl:41-203.  Mutates nls.x, nls.y, nls.J in place."""
     allocated = nls if isinstance(nls, LeastSquaresProblemAllocated) else None
@@ -755,8 +761,13 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
         pc = None
         if getattr(solver, "preconditioner", None) is not None:
             pc = _precond_trampoline(solver.preconditioner, ctx, Jd)
+        # row_allreduce: a rowshard.RcclRowAllreduce / HostStagedRowAllreduce -- nls then holds this rank's ROWS of one
+        # larger problem (J, y local; x replicated), SURVEY 8f-4
         st, res, tr = _run_native(ctx, optimizer.kind, solver.kind, Jd, dx, dy, F, G, None, x_tol, f_tol,
-                                  g_tol, iterations, delta, lower, upper, tracing, n, preconditioner=pc)
+                                  g_tol, iterations, delta, lower, upper, tracing, n, preconditioner=pc,
+                                  row_allreduce=row_allreduce.callback if row_allreduce is not None else None,
+                                  row_allreduce_user=row_allreduce.user if row_allreduce is not None else None,
+                                  global_rows=global_rows)
     finally:
         if stage is not None:       # hand the values back in ordinary memory before the pinned buffer can go away
             Jd.upload_wait()

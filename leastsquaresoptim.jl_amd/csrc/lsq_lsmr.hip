@@ -441,6 +441,63 @@ k_lm_lsmr_setup(int n, LsmrLmPrep lm, double *__restrict__ damp, double *__restr
     }
 }
 
+// ---- row-sharded adjoint product: buf[0..n) = J_p'u_p, buf[n] = sum(u_p.^2) -> all-reduce -> epilogue ----
+struct EpiBuf {   // out[j] = dot
+    static constexpr bool REDUCE = false;
+    const int *done;
+    int extra_blocks;
+    double *out;
+    double *partials;
+    unsigned *counter;
+    __device__ void seg(int j, double dot, double &) const { out[j] = dot; }
+    __device__ void extra(int, double &) const {}
+    __device__ void finalize(double) const {}
+};
+__global__ void __launch_bounds__(LSQ_NT) k_rowshard_sumsq(const double *pu, const int *npu, double *out, const int *done) {
+    if (done && *done) return;
+    double a, b, c2;
+    ordered_sum256x3(pu, npu, nullptr, nullptr, nullptr, nullptr, a, b, c2);
+    if (threadIdx.x == 0) *out = a;
+}
+extern "C" int lsq_solver_set_row_allreduce(lsq_solver *s, lsq_device_allreduce_callback cb, void *user, long long global_rows) {
+    if (!s || s->kind != LSQ_LSMR) {
+        lsq_set_error("row-sharded solves: LSMR() only");
+        return LSQ_EARG;
+    }
+    s->row_cb = cb;
+    s->row_user = user;
+    s->global_rows = cb ? global_rows : 0;
+    if (cb && !s->d_xbuf) {
+        // (n + 1 doubles travel; the slot behind them is read as a partial-sum array of count 1, and ordered_sum256x3
+        //  fetches the first 256 entries of such an array before it looks at the count)
+        LSQ_HIP(hipMalloc(&s->d_xbuf, (size_t)(s->n + 2 + 256) * sizeof(double)));
+        LSQ_ZERO(s->d_xbuf, 0, (size_t)(s->n + 2 + 256) * sizeof(double));
+        LSQ_HIP(hipMalloc(&s->d_one, sizeof(int)));
+        const int one = 1;
+        LSQ_HIP(hipMemcpy(s->d_one, &one, sizeof(int), hipMemcpyHostToDevice));
+    }
+    return LSQ_OK;
+}
+// v~ <- epilogue(sum over ranks of J_p'src_p) with beta from the summed sum(src.^2); `ev` is the unsharded epilogue
+static int rowshard_adjoint(lsq_solver *s, lsq_mat *J, const double *src, EpiV ev, const double *pu, const int *npu) {
+    lsq_ctx *c = s->ctx;
+    const int n = J->n;
+    EpiBuf eb{ev.done, 0, s->d_xbuf, nullptr, nullptr};
+    LSQ_TRY(launch_product(J, 1, src, eb));
+    hipLaunchKernelGGL(k_rowshard_sumsq, dim3(1), dim3(LSQ_NT), 0, c->stream, pu, npu, s->d_xbuf + n, ev.done);
+    LSQ_HIP(hipGetLastError());
+    if (s->row_cb(s->d_xbuf, n + 1, (void *)c->stream, s->row_user) != 0) {
+        lsq_set_error("row all-reduce callback reported failure");
+        return LSQ_ECALLBACK;
+    }
+    ev.pu = s->d_xbuf + n;
+    ev.npu = s->d_one;
+    const int nb = lsq_div_up(n, LSQ_CMB_COLS);
+    hipLaunchKernelGGL((k_combine<EpiV>), dim3(std::min(nb, 2048)), dim3(LSQ_NT), 0, c->stream, s->d_xbuf, n, 1, ev, nb);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
 int lsq_lsmr_alloc(lsq_solver *s) {
     size_t nb = (size_t)(s->n > 0 ? s->n : 1) * sizeof(double);
     LSQ_HIP(hipMalloc(&s->d_state, sizeof(LsmrState)));
@@ -462,6 +519,7 @@ int lsq_lsmr_alloc(lsq_solver *s) {
 void lsq_lsmr_free(lsq_solver *s) {
     hipFree(s->d_state); hipFree(s->d_u); hipFree(s->d_ux); hipFree(s->d_v); hipFree(s->d_h);
     hipFree(s->d_hbar); hipFree(s->d_t); hipFree(s->d_P); hipFree(s->d_dg); hipFree(s->d_rhs); hipFree(s->d_red);
+    hipFree(s->d_xbuf); hipFree(s->d_one);
 }
 
 static inline int nvec_grid(const lsq_ctx *c, int n) {
@@ -483,7 +541,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         lsq_set_error("lsmr: solver allocated for %dx%d, Jacobian is %dx%d", s->m, s->n, m, n);
         return LSQ_EDIM;
     }
-    if (lsq_small_mat(J) && !s->precond_cb) return lsq_lsmr_exact_solve(s, J, d_y, d_damp, d_x, nmul);  // reference-order kernel
+    const bool sharded = s->row_cb != nullptr;     // J is a row block: the adjoint product is summed over the ranks
+    if (lsq_small_mat(J) && !s->precond_cb && !sharded) return lsq_lsmr_exact_solve(s, J, d_y, d_damp, d_x, nmul);  // reference-order kernel
     static const int lookahead = [] {
         const char *e = getenv("LSQ_LOOKAHEAD");
         int v = e ? atoi(e) : LSQ_LOOKAHEAD_DEFAULT;
@@ -491,7 +550,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     }();
     const bool damped = d_damp != nullptr;
     const double atol = 1e-6, btol = damped ? 0.5 : 1e-6, conlim = 1e8;  // lsmr.jl:54, il:255
-    const long long rows = damped ? (long long)m + n : m;
+    const long long rows = (sharded ? s->global_rows : (long long)m) + (damped ? n : 0);
     const int maxiter = (int)std::max<long long>(rows, n);               // lsmr.jl:55
     const unsigned epoch = (++c->mail_epoch) & 0x7fffffu;
     LsmrState *st = s->d_state;
@@ -551,9 +610,11 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         launch_begin();
         LSQ_HIP(hipGetLastError());
         // v~ = A'u (setup), then K3 in "first" mode
-        LSQ_TRY(launch_product(J, 1, d_y, ev));
+        if (sharded) LSQ_TRY(rowshard_adjoint(s, J, d_y, ev, pu, npu));
+        else LSQ_TRY(launch_product(J, 1, d_y, ev));
         // setup K3: u~x is still zero, so only sum(u~_y^2) enters beta_1; it already forms iteration 1's u~x
-        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
+        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
+                           sharded ? (const double *)(s->d_xbuf + n) : (const double *)pu, sharded ? (const int *)s->d_one : (const int *)npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
                            s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
         LSQ_HIP(hipGetLastError());
@@ -577,7 +638,16 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                 break;
             }
         }
-        if (enq - it < lookahead && enq < maxiter) {
+        // Row-sharded: every rank must enqueue the SAME number of inner iterations (each carries a collective), so the count
+        // cannot depend on when this host happens to see the mailbox: iterations go out in chunks of `lookahead`, and the
+        // next chunk only once the last one has reported "not done" -- ceil(stop / lookahead) * lookahead on every rank.
+        // (and the first chunk only once the SETUP has reported: a solve that is over before it starts -- A'b = 0 -- must not
+        //  get a chunk on the ranks whose host looked too early)
+        const bool reported = (unsigned)(w >> 41) == epoch;
+        const bool want = sharded ? (reported && enq == it && enq < maxiter) : (enq - it < lookahead && enq < maxiter);
+        if (want) {
+          const int chunk = sharded ? (int)std::min<long long>(lookahead, (long long)maxiter - enq) : 1;
+          for (int q = 0; q < chunk; ++q) {
             if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 0);
             {
                 const size_t before = c->prof_ev[0].size();
@@ -592,16 +662,20 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 0);
             {
                 const size_t before = c->prof_ev[1].size();
-                LSQ_TRY(launch_product(J, 1, s->d_u, ev));   // K2
+                if (sharded) LSQ_TRY(rowshard_adjoint(s, J, s->d_u, ev, pu, npu));   // K2 with the ranks' sum in the middle
+                else LSQ_TRY(launch_product(J, 1, s->d_u, ev));   // K2
                 if (c->prof_ev[1].size() > before) prof_iter[1].push_back(enq + 1);
             }
             if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 1);
-            hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu,
+            hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
+                               sharded ? (const double *)(s->d_xbuf + n) : (const double *)pu,
+                               sharded ? (const int *)s->d_one : (const int *)npu,
                                pv, npv, (const double *)(damped ? pxb[cur] : nullptr), (const int *)npxb[cur],
                                pxb[cur ^ 1], npxb[cur ^ 1], dgk, s->d_ux, s->d_P, s->d_v, s->d_h, s->d_hbar, xs,
                                d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
             LSQ_HIP(hipGetLastError());
             ++enq;
+          }
             spins = 0;
             continue;
         }

@@ -668,14 +668,31 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
     CB(f(fcur, x, user));
     f_calls++;
     double ssr;
-    LSQ_TRY(lsq_sumsq(c, m, fcur, &ssr));
+    // row-sharded single problem: J, fcur, ftrial are this rank's rows; sums over residuals are completed across the ranks
+    // by the hook (a device buffer, in place, ordered on the stream) before the host reads them
+    const bool sharded = o->row_allreduce != nullptr;
+    auto rows_sum = [&](double *d_buf, int count) -> int {
+        if (o->row_allreduce(d_buf, count, (void *)c->stream, o->row_allreduce_user) != 0) {
+            lsq_set_error("row all-reduce callback reported failure");
+            return LSQ_ECALLBACK;
+        }
+        return LSQ_OK;
+    };
+    if (sharded) {
+        LSQ_TRY(sumsq_to_slot(c, false, m, fcur, 7, c->d_slots + SL_TRIAL));
+        LSQ_TRY(rows_sum(c->d_slots + SL_TRIAL, 1));
+        LSQ_TRY(lsq_read_slots(c, SL_TRIAL, 1, &ssr));
+    } else {
+        LSQ_TRY(lsq_sumsq(c, m, fcur, &ssr));
+    }
     r->ssr0 = ssr;
     double maxabs_gr = INFINITY;
     bool need_jac = true;
     int iter = 0, nonfinite_at = -1;
     LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
     const int gn = ngrid(c, n);
-    const bool exact = lsq_small_mat(J);  // reference summation order for small problems (lsq_exact.hip)
+    const bool exact = lsq_small_mat(J) && !sharded;  // reference summation order for small problems (lsq_exact.hip)
+    unsigned long long colsum_global_version = ~0ull;   // (sharded) version of J whose cached colsumabs2 holds the ranks' sum
     int local_done = 0;
     double gssr = ssr, ggr = maxabs_gr;
     long long inner_total = 0;
@@ -710,6 +727,10 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         }
         const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
         if (!cs) return LSQ_EHIP;
+        if (sharded && colsum_global_version != J->version) {   // colsumabs2(J) = sum_p colsumabs2(J_p): once per g!
+            LSQ_TRY(rows_sum(J->d_colsum, n));
+            colsum_global_version = J->version;
+        }
         const bool one_wg = !exact && n <= LSQ_ONE_WG_N;
         // (ssr = NaN, i.e. f(x) not finite: the fused preparation takes ssr as the norm of the right-hand side; the
         //  separate kernels re-form it and let the NaN travel to the reference's check_isfinite at the next iteration)
@@ -720,6 +741,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             // (into dtd); J and fcur do not change in between, so it is formed once, before the
             // solve, and LSMR's setup product A'b = P.*(J'f)/beta reuses it (saves one pass over J).
             if (!have_grad) LSQ_TRY(gradient_into(c, exact, J, fcur, b.grad));
+            if (sharded) LSQ_TRY(rows_sum(b.grad, n));                  // J'f = sum_p J_p'f_p
             if (lm_prep) {}   // (damping and gradient norm ride in the LSMR setup launch below)
             else if (one_wg)
                 hipLaunchKernelGGL(k_lm_damp_grad, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd, b.grad,
@@ -769,6 +791,15 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));   // :114-117
             LSQ_HIP(hipGetLastError());
             LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));   // the one host sync of the outer iteration
+        } else if (sharded) {
+            // the two sums over residual rows are completed across the ranks (one all-reduce of 2 doubles) before the
+            // iteration's scalars go to the host
+            static_assert(SL_PRED == SL_TRIAL + 1, "trial and predicted ssr travel together");
+            LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));
+            LSQ_TRY(f_then_sumsq(c, exact, f, user, m, ftrial, xt, 7, c->d_slots + SL_TRIAL));
+            f_calls++;
+            LSQ_TRY(rows_sum(c->d_slots + SL_TRIAL, 2));
+            LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));
         } else {
             // the predicted residual (:114-117) does not depend on f!(x_trial): formed first, while the
             // row copy of J that the last LSMR iterations streamed is still (partly) in the Infinity Cache
@@ -1041,6 +1072,18 @@ extern "C" int lsq_optimize(lsq_ctx *c, int optimizer, int solver_kind, lsq_mat 
     if (w->solver->kind == LSQ_LSMR) {   // LSMR(preconditioner!, P): per call, the cached solver may have had another one
         w->solver->precond_cb = opt->preconditioner;
         w->solver->precond_user = opt->preconditioner_user;
+    }
+    if (opt->row_allreduce) {   // row-sharded single problem
+        if (!lm || w->solver->kind != LSQ_LSMR || opt->allreduce || J->kind == LSQ_MAT_OP) {
+            lsq_set_error("row-sharded runs (lsq_options.row_allreduce): LevenbergMarquardt(LSMR()) on stored Jacobians only, and "
+                          "not together with the independent-problems exchange (lsq_options.allreduce)");
+            res->status = LSQ_EARG;
+            return LSQ_EARG;
+        }
+        LSQ_TRY(lsq_solver_set_row_allreduce(w->solver, opt->row_allreduce, opt->row_allreduce_user,
+                                             opt->global_rows > 0 ? opt->global_rows : (long long)J->m));
+    } else if (w->solver->kind == LSQ_LSMR) {
+        LSQ_TRY(lsq_solver_set_row_allreduce(w->solver, nullptr, nullptr, 0));
     }
     auto t0 = std::chrono::steady_clock::now();
     int st = lm ? optimize_lm(c, w->solver, *w->buf, J, x, fcur, f, g, user, opt, res)

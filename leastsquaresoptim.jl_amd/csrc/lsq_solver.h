@@ -58,6 +58,13 @@ struct lsq_solver {
     double *d_red = nullptr;   // deferred-reduction partials: pu[4096] | pv[4096] | int counts[2]
     unsigned epoch = 0;
     int last_iter = 0, last_istop = 0;
+    // row-sharded single problem (lsq_options.row_allreduce): J is this rank's row block; J'u and sum(u^2) are summed over
+    // the ranks in d_xbuf (n + 1 doubles) between the adjoint product and its epilogue
+    int (*row_cb)(double *, int, void *, void *) = nullptr;
+    void *row_user = nullptr;
+    long long global_rows = 0;
+    double *d_xbuf = nullptr;  // n + 2
+    int *d_one = nullptr;      // the constant 1 (partial count of a sum that is already complete)
     // --- dense Cholesky (dense_cholesky.jl:7-21) ---
     double *d_chol = nullptr;  // n*n
     double *d_Ds = nullptr;    // ceil(n/64) factored 64 x 64 diagonal blocks in flight (blocked Cholesky)

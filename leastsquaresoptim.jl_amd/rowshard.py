@@ -16,7 +16,15 @@ WITH it -- one collective of 80 KB + 8 B per inner iteration at C4's width inste
 runs the v-update on the result; the row-sharded variant adds the ranks' vectors at the same place.  J*v needs nothing
 (rows are local), |v| and |x| are norms of replicated vectors.
 
-Two backends run the SAME driver: NumpyBackend (scipy CSR/CSC slices; the executable specification, used by the world-2
+ON THE DEVICE the whole loop is `lsq_optimize` itself with `lsq_options.row_allreduce` set (include/lsqhip.h): the rank's
+row block goes through the same fused kernels as an unsharded problem, and the collectives above are sum all-reduces of
+DEVICE buffers enqueued on the library's stream -- between the adjoint product and its epilogue for the inner iteration
+(k_sell_cols -> k_combine into a buffer of n + 1 doubles, sum(u^2) in the last slot -> all-reduce -> EpiV + update): no host
+round trip, no staging copy.  `RcclRowAllreduce` is that hook as a direct RCCL call (liblsqrccl.so: ncclAllReduce on the
+stream); `HostStagedRowAllreduce` carries it over any torch.distributed group through the host (the world-2 tests: two ranks
+cannot share one GPU under RCCL).  `optimize_device` below is the entry point.
+
+Two backends run the SAME host-level driver (the executable specification of where the collectives sit): NumpyBackend (scipy CSR/CSC slices; the executable specification, used by the world-2
 gloo test on CPU and compared with the oracle) and HipBackend (a DeviceMatrix per rank, every array operation a C-ABI
 call on device memory; the n-vector exchange is staged through page-locked host memory).  Summation order differs from the
 unsharded run only in the cross-rank sums.
@@ -354,3 +362,109 @@ def lm_lsmr(B, comm, x0, m_total, iterations=1000, x_tol=1e-8, f_tol=1e-8, g_tol
     r.f_calls, r.g_calls, r.mul_calls, r.lsmr_iterations = f_calls, g_calls, mul_calls, inner_total
     r.allreduce_calls, r.allreduce_doubles = comm.calls, comm.doubles
     return r
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# device-resident row-sharded runs: lsq_optimize with lsq_options.row_allreduce
+# ------------------------------------------------------------------------------------------------------------------------
+class RcclRowAllreduce:
+    """The row all-reduce as a direct RCCL call on the library's stream (include/lsqrccl.h, liblsqrccl.so).
+
+    One communicator per instance; `dist` (any initialised torch.distributed group, or None for a one-rank world) only
+    carries the 128-byte unique id from rank 0 to the others.  The HIP device must be current (lsq.Context(device) /
+    torch.cuda.set_device) before construction."""
+
+    def __init__(self, rank=0, world=1, dist=None, librccl=None):
+        import ctypes as C
+        import os
+        from . import _lib
+        here = os.path.dirname(os.path.abspath(__file__))
+        path = os.path.join(here, "liblsqrccl.so")
+        if not os.path.exists(path):
+            raise RuntimeError("liblsqrccl.so is not built (make -C leastsquaresoptim.jl_amd/csrc)")
+        L = C.CDLL(path)
+        L.lsq_rccl_last_error.restype = C.c_char_p
+        L.lsq_rccl_load.argtypes = [C.c_char_p]
+        L.lsq_rccl_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.lsq_rccl_comm_destroy.argtypes = [C.c_void_p]
+        L.lsq_rccl_allreduce_callback.restype = C.c_void_p
+        L.lsq_rccl_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        if librccl is None:      # the copy PyTorch ships (and has loaded if torch is in the process): one RCCL per process
+            try:
+                import torch
+                cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+                librccl = cand if os.path.exists(cand) else None
+            except Exception:   # pragma: no cover
+                librccl = None
+        if L.lsq_rccl_load(librccl.encode() if librccl else None) != 0:
+            raise RuntimeError("RCCL: " + L.lsq_rccl_last_error().decode())
+        idbuf = C.create_string_buffer(128)
+        if rank == 0 and L.lsq_rccl_unique_id(idbuf) != 0:
+            raise RuntimeError("RCCL: " + L.lsq_rccl_last_error().decode())
+        if world > 1:
+            box = [idbuf.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            idbuf = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        if L.lsq_rccl_comm_create(idbuf, rank, world, C.byref(h)) != 0:
+            raise RuntimeError("RCCL: " + L.lsq_rccl_last_error().decode())
+        self._L, self.comm, self.rank, self.world = L, h, rank, world
+        self.callback = C.cast(L.lsq_rccl_allreduce_callback(), _lib.ROW_ALLREDUCE_CALLBACK)
+        self.user = h
+
+    def stats(self):
+        import ctypes as C
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self._L.lsq_rccl_comm_stats(self.comm, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if self.comm:
+            self._L.lsq_rccl_comm_destroy(self.comm)
+            self.comm = None
+
+
+class HostStagedRowAllreduce:
+    """The same hook over ANY torch.distributed group (gloo in the tests), staged through the host: drain the stream, copy
+    the buffer out, all-reduce, copy it back.  For worlds RCCL cannot form (two ranks on one GPU) -- not for speed."""
+
+    def __init__(self, ctx, dist=None, group=None):
+        import ctypes as C
+        from . import _lib
+        self.calls = self.doubles = 0
+        L = _lib.lib()
+
+        def cb(d_buf, count, _stream, _user):
+            try:
+                h = np.empty(count)
+                _lib.check(L.lsq_d2h(ctx.h, h.ctypes.data_as(C.c_void_p), d_buf, count * 8))     # (synchronises the stream)
+                if dist is not None and dist.get_world_size(group) > 1:
+                    import torch
+                    dist.all_reduce(torch.from_numpy(h), group=group)
+                _lib.check(L.lsq_h2d(ctx.h, d_buf, h.ctypes.data_as(C.c_void_p), count * 8))
+                self.calls += 1
+                self.doubles += count
+                return 0
+            except Exception as e:   # pragma: no cover
+                import sys
+                print("row all-reduce failed:", e, file=sys.stderr)
+                return 1
+
+        self.callback = _lib.ROW_ALLREDUCE_CALLBACK(cb)
+        self.user = None
+
+    def stats(self):
+        return self.calls, self.doubles
+
+    def close(self):
+        pass
+
+
+def optimize_device(problem, hook, global_rows, iterations=1000, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, delta=None, trace=False):
+    """optimize!(nls, LevenbergMarquardt(LSMR())) for the row block held by `problem` (a synthetic.TanhProblem built on this
+    rank's rows of A and b, or anything with the same .optimize) with the cross-rank sums done by `hook`
+    (RcclRowAllreduce / HostStagedRowAllreduce).  Every rank gets the same replicated minimizer and scalars."""
+    from . import _lib
+    return problem.optimize(_lib.LEVENBERG_MARQUARDT, _lib.LSMR, x_tol=x_tol, f_tol=f_tol, g_tol=g_tol, iterations=iterations,
+                            delta=delta, trace=trace, row_allreduce=hook.callback, row_allreduce_user=hook.user,
+                            global_rows=global_rows)

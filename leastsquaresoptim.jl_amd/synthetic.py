@@ -61,7 +61,7 @@ def csc_matvec(m, colptr, rowval, nzval, t):
 class TanhProblem:
     """Device-resident problem: Jacobian handle + model (A, b) + x / fcur vectors."""
 
-    def __init__(self, m, n, sparse=True, per_col=None, seed=BASE_SEED, ctx=None, inputs=None):
+    def __init__(self, m, n, sparse=True, per_col=None, seed=BASE_SEED, ctx=None, inputs=None, b=None):
         self.ctx = ctx or default_context()
         self.m, self.n, self.sparse = m, n, sparse
         L = lib()
@@ -84,7 +84,10 @@ class TanhProblem:
             Amat = self.A.reshape((m, n), order="F")
             mv = lambda t: Amat @ t
         self.J = h
-        self.x_true, self.b = rhs_for(mv, m, n, seed)
+        if b is None:
+            self.x_true, self.b = rhs_for(mv, m, n, seed)
+        else:                       # (a row block of a larger problem: the caller owns the right-hand side)
+            self.x_true, self.b = None, np.ascontiguousarray(b, dtype=np.float64)
         md = C.c_void_p()
         check(L.lsq_model_tanh_create(self.ctx.h, self.J, self.A.ctypes.data_as(_lib.c_dp),
                                       self.b.ctypes.data_as(_lib.c_dp), C.byref(md)))
@@ -96,7 +99,8 @@ class TanhProblem:
         self.x.set(np.zeros(self.n) if x0 is None else x0)
 
     def optimize(self, optimizer_kind, solver_kind, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iterations=1000,
-                 delta=None, trace=False, allreduce=None, fetch_x=True):
+                 delta=None, trace=False, allreduce=None, fetch_x=True, row_allreduce=None, row_allreduce_user=None,
+                 global_rows=0):
         L = lib()
 
         class _H:  # minimal handle wrappers for _run_native
@@ -106,7 +110,8 @@ class TanhProblem:
         Jd.h = self.J
         st, res, tr = _run_native(self.ctx, optimizer_kind, solver_kind, Jd, self.x, self.fcur,
                                   L.lsq_model_f(), L.lsq_model_g(), self.model, x_tol, f_tol, g_tol,
-                                  iterations, delta, None, None, trace, self.n, allreduce=allreduce)
+                                  iterations, delta, None, None, trace, self.n, allreduce=allreduce,
+                                  row_allreduce=row_allreduce, row_allreduce_user=row_allreduce_user, global_rows=global_rows)
         check(st)
         r = LeastSquaresResult()
         r.optimizer = "LevenbergMarquardt" if res.optimizer == _lib.LEVENBERG_MARQUARDT else "Dogleg"

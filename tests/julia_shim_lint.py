@@ -29,7 +29,7 @@ def c_class(ctype):
     t = t.replace(" *", "*").replace("* ", "*")
     stars = t.count("*")
     base = t.replace("*", "").strip()
-    callbacks = {"lsq_f_callback", "lsq_g_callback", "lsq_allreduce_callback", "lsq_precond_callback",
+    callbacks = {"lsq_f_callback", "lsq_g_callback", "lsq_allreduce_callback", "lsq_precond_callback", "lsq_device_allreduce_callback",
                  "lsq_op_mul_callback", "lsq_op_colsum_callback"}
     handles = {"lsq_ctx", "lsq_mat", "lsq_solver", "lsq_model", "void"}
     if base in callbacks and stars == 0:

@@ -86,7 +86,7 @@ def _run_world2(backend):
         p.start()
     res = {}
     for _ in range(2):
-        rec = q.get(timeout=600)
+        rec = q.get(timeout=240)
         res[rec[0]] = rec[1:]
     for p in ps:
         p.join(120)
@@ -120,19 +120,120 @@ def test_row_sharded_gloo_world2_equals_oracle():
     assert np.array_equal(res[0][7], res[1][7])          # replicated n-vectors: bit-identical on every rank
 
 
+def _local_rows_csc(S, b, rank, world):
+    """This rank's row block of A as the (colptr, rowval, nzval) triple TanhProblem takes, and its slice of b."""
+    lo, hi = RS.row_slice(S.shape[0], rank, world)
+    Ap = S.tocsr()[lo:hi].tocsc()
+    Ap.sort_indices()
+    return (hi - lo, Ap.indptr.astype(np.int32), Ap.indices.astype(np.int32), np.ascontiguousarray(Ap.data)), b[lo:hi]
+
+
+def _check_against_oracle(ro, rec, n, lookahead=2):
+    """Same trajectory as the UNSHARDED ORACLE (counts, accept pattern, inner counts; ssr to 1e-10, iterates to 1e-8), and the
+    collective count the design promises: 1 (initial ssr) + per outer iteration 1 (gradient) + 1 (trial, predicted ssr) +
+    1 per g! (colsumabs2) + per ENQUEUED inner iteration 1 (n + 1 doubles) -- inner iterations are enqueued in chunks of the
+    look-ahead so that every rank issues the same number whatever its host's timing."""
+    it, inner, ssr, conv, fcalls, gcalls, mulc, x, calls, dbl, tr_inner = rec
+    assert (it, fcalls, gcalls, mulc, conv) == (ro.iterations, ro.f_calls, ro.g_calls, ro.mul_calls, ro.converged)
+    assert np.array_equal(tr_inner, ro.trace["inner"]) and inner == int(ro.trace["inner"].sum()) // 2
+    assert ssr == pytest.approx(ro.ssr, rel=1e-10) and np.max(np.abs(x - ro.minimizer)) <= 1e-8
+    enq = sum(-(-(k // 2) // lookahead) * lookahead for k in ro.trace["inner"])
+    assert calls == 1 + 2 * it + gcalls + enq, (calls, it, gcalls, enq)
+    assert dbl == 1 + it * (n + 2) + gcalls * n + enq * (n + 1)
+
+
+BIG = (300000, 2000, 600, 4)     # nnz 1.2e6, m > 131072: the sliced layouts and the column-scaled (never multiplied out) J
+MID = (120000, 400, 300, 3)      # segment kernels, g! multiplies J out
+
+
+def _worker_device(rank, world, port, q, mode, shape):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, n, colptr, rowval, A, S, b = _problem(*shape)
+    (mp_, cp, rv, nz), bp = _local_rows_csc(S, b, rank, world)
+    ctx = lsq.Context(0)
+    pr = lsq.synthetic.TanhProblem(mp_, n, sparse=True, ctx=ctx, inputs=(cp, rv, nz), b=bp)
+    pr.reset()
+    hook = RS.RcclRowAllreduce(rank, world, dist if world > 1 else None) if mode == "rccl" else \
+        RS.HostStagedRowAllreduce(ctx, dist if world > 1 else None)
+    r = RS.optimize_device(pr, hook, m, iterations=40, trace=True)
+    calls, dbl = hook.stats()
+    q.put((rank, r.iterations, r.lsmr_iterations, r.ssr, r.converged, r.f_calls, r.g_calls, r.mul_calls, r.minimizer, calls, dbl,
+           np.array(r.trace["inner"])))
+    pr.close()
+    hook.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_device(world, mode, shape):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_device, args=(r, world, port, q, mode, shape)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rec = q.get(timeout=240)
+        res[rec[0]] = rec[1:]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
 @pytest.mark.gpu
-def test_row_sharded_on_device_world2():
-    """The same driver with every array operation on the device (two ranks share the box's one GPU; exchange over gloo):
-    same trajectory as the unsharded device-resident run of the same problem."""
+@pytest.mark.parametrize("shape", [BIG, MID], ids=["sliced_colscaled", "segments"])
+def test_row_sharded_device_loop_through_rccl_equals_oracle(shape):
+    """SURVEY 8f-4 on the device: lsq_optimize with lsq_options.row_allreduce = a DIRECT ncclAllReduce on the library's stream
+    (liblsqrccl.so; a one-rank communicator: a GPU box has one device).  The inner iteration's J'u + |u|^2 go through the
+    collective between k_combine and the EpiV epilogue -- no host round trip, no staging -- and the run equals the unsharded
+    ORACLE (not the product's own unsharded run)."""
+    res = _run_device(1, "rccl", shape)
+    m, n, colptr, rowval, A, S, b = _problem(*shape)
+    ro = _oracle(m, n, colptr, rowval, A, b, 40)
+    _check_against_oracle(ro, res[0], n)
+
+
+@pytest.mark.gpu
+def test_row_sharded_device_loop_world2_equals_oracle():
+    """Two ranks, each with half of the rows on the device (they share the box's one GPU, which RCCL cannot do: the hook is
+    the host-staged gloo one), against the unsharded oracle; the replicated minimizer is bit-identical on both ranks."""
+    res = _run_device(2, "gloo", MID)
+    m, n, colptr, rowval, A, S, b = _problem(*MID)
+    ro = _oracle(m, n, colptr, rowval, A, b, 40)
+    for rank in (0, 1):
+        _check_against_oracle(ro, res[rank], n)
+    assert np.array_equal(res[0][7], res[1][7])
+
+
+@pytest.mark.gpu
+def test_row_sharded_host_driver_on_device_world2():
+    """The host-level driver (lm_lsmr over the operator-level C ABI, every array operation a call on device memory; exchange
+    over gloo) against the unsharded ORACLE."""
     res = _run_world2("hip")
     m, n, colptr, rowval, A, S, b = _problem(120000, 400, 300, 3)
-    ctx = lsq.Context(0)
-    J = sp.csc_matrix((np.zeros_like(A), rowval, colptr), shape=(m, n))
-    cols = np.repeat(np.arange(n), np.diff(colptr))
-    nls = lsq.LeastSquaresProblem(x=np.zeros(n), y=np.zeros(m), f_=lambda out, x: out.__setitem__(slice(None), S @ np.tanh(x) - b),
-                                  g_=lambda Jm, x: np.multiply(A, (1.0 - np.tanh(x) ** 2)[cols], out=Jm.data), J=J)
-    r1 = lsq.optimize_(nls, lsq.LevenbergMarquardt(lsq.LSMR()), iterations=40, ctx=ctx)
+    ro = _oracle(m, n, colptr, rowval, A, b, 40)
+    inner = int(ro.trace["inner"].sum()) // 2
     for rank in (0, 1):
         it, li, ssr, conv, fcalls, gcalls, mulc, x, calls, dbl = res[rank]
-        assert (it, fcalls, gcalls, mulc, conv) == (r1.iterations, r1.f_calls, r1.g_calls, r1.mul_calls, r1.converged)
-        assert ssr == pytest.approx(r1.ssr, rel=1e-9) and np.max(np.abs(x - r1.minimizer)) <= 1e-7
+        assert (it, fcalls, gcalls, mulc, li, conv) == (ro.iterations, ro.f_calls, ro.g_calls, ro.mul_calls, inner, ro.converged)
+        assert ssr == pytest.approx(ro.ssr, rel=1e-10) and np.max(np.abs(x - ro.minimizer)) <= 1e-8
+
+
+def test_rccl_shim_exports_its_header():
+    """include/lsqrccl.h vs liblsqrccl.so: every declared symbol is exported (no RCCL call without a GPU)."""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "lsqrccl.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(lsq_rccl_\w+)\s*\(", txt)))
+    assert len(names) == 7, names
+    L = C.CDLL(os.path.join(root, "leastsquaresoptim.jl_amd", "liblsqrccl.so"))
+    for nme in names:
+        assert hasattr(L, nme), nme
