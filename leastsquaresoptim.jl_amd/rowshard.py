@@ -389,13 +389,17 @@ class RcclRowAllreduce:
         L.lsq_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.lsq_rccl_allreduce_callback.restype = C.c_void_p
         L.lsq_rccl_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
-        if librccl is None:      # the copy PyTorch ships (and has loaded if torch is in the process): one RCCL per process
-            try:
-                import torch
-                cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-                librccl = cand if os.path.exists(cand) else None
-            except Exception:   # pragma: no cover
-                librccl = None
+        if librccl is None:
+            # ONE RCCL and ONE HIP runtime per process: if PyTorch is already in the process its bundled librccl (and the HIP
+            # runtime both libraries then share) is the one to bind; otherwise ROCm's own, next to the libamdhip64 that
+            # liblsqhip.so was linked against.  (Binding PyTorch's copy into a process that runs on ROCm's HIP runtime makes
+            # ncclCommInitRank fail with "unhandled cuda error": two runtimes, two notions of the current device.)
+            import sys
+            cands = []
+            if "torch" in sys.modules:
+                cands.append(os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "librccl.so"))
+            cands += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "librccl.so")]
+            librccl = next((c_ for c_ in cands if os.path.exists(c_)), None)
         if L.lsq_rccl_load(librccl.encode() if librccl else None) != 0:
             raise RuntimeError("RCCL: " + L.lsq_rccl_last_error().decode())
         idbuf = C.create_string_buffer(128)
