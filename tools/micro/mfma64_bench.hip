@@ -15,17 +15,24 @@ __global__ void __launch_bounds__(256) k(double *out, int iters) {
     for (int a = 0; a < NACC; ++a) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+template <int NACC>
+static void run(double *d, int blocks, int iters) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<NACC><<<blocks, 256>>>(d, iters); hipDeviceSynchronize();
+    hipEventRecord(e0); k<NACC><<<blocks, 256>>>(d, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)blocks * 4 * iters * NACC * 2048.0;
+    printf("NACC %d blocks %d (%d waves/SIMD): %.3f ms  %.1f TFLOP/s\n", NACC, blocks, blocks / 256, ms, flops / ms / 1e9);
+}
+// Run under `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE` to get the
+// MFMA-busy fraction and the MEASURED shader clock of each launch (tools/c3_pmc.sh): whether a shortfall against 78.6 TFLOP/s
+// is the clock (power) or the issue rate.
 int main() {
     double *d; hipMalloc(&d, 8 * 256 * 4096);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int blocks : {256, 512, 1024}) {
-        const int iters = 4096;
-        k<4><<<blocks, 256>>>(d, iters); hipDeviceSynchronize();
-        hipEventRecord(e0); k<4><<<blocks, 256>>>(d, iters); hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        double flops = (double)blocks * 4 * iters * 4 * 2048.0;
-        printf("blocks %d: %.3f ms  %.1f TFLOP/s  (%.1f cycles@2.4GHz per MFMA per SIMD)\n", blocks, ms, flops / ms / 1e9,
-               ms * 1e-3 * 2.4e9 / ((double)blocks / 256 * iters * 4));
-    }
+    const int iters = 8192;
+    for (int blocks : {256, 512, 1024, 2048}) run<4>(d, blocks, iters);
+    for (int blocks : {256, 512, 1024}) run<8>(d, blocks, iters);
+    for (int blocks : {256, 1024}) run<2>(d, blocks, iters);
+    for (int blocks : {256, 1024}) run<1>(d, blocks, iters);
     return 0;
 }
