@@ -302,7 +302,9 @@ def main():
                       "final_ssr": r.ssr, "setup_seconds": t_setup},
            "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense,
            # bounded-wait give-ups of the fast paths that assume co-resident workgroups (include/lsqhip.h: lsq_solver_stats)
-           "fallback_giveups": ctx.fallback_stats()}
+           "fallback_giveups": ctx.fallback_stats(),
+           # LM+LSMR: solves whose follow-up kernels were queued behind a guessed last inner iteration, and wrong guesses
+           "tail_speculation": dict(zip(("guesses", "wrong"), ctx.tail_stats()))}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

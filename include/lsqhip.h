@@ -210,6 +210,11 @@ int lsq_solver_stats(const lsq_solver *s, int h_giveups[4], int h_paused[4]);
 /* the same totals over every solver the context has run (the solver lsq_optimize keeps inside the context included) */
 int lsq_ctx_fallback_stats(const lsq_ctx *ctx, int h_giveups[4]);
 
+/* LM + LSMR with a device-side f!: the kernels that follow the inner solve (step, predicted residual, trial residual) are
+ * enqueued behind the inner iteration at which the PREVIOUS solve stopped and skip themselves if this one is not over by then
+ * (DESIGN 4.2).  h_out = {solves that were given such a guess, guesses that were wrong}; LSQ_NO_TAIL_SPECULATION=1 turns it off. */
+int lsq_ctx_tail_stats(const lsq_ctx *ctx, long long h_out[2]);
+
 /* ---- whole trust-region loop on device buffers (host control, device arrays) ---- */
 /* f!(out, x) and g!(J, x) on DEVICE pointers; g writes lsq_mat_values(J) (the library refreshes
  * the CSR mirror afterwards).  Return non-zero to abort with LSQ_ECALLBACK. */

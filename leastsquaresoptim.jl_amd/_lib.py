@@ -140,6 +140,7 @@ def lib():
         "lsq_solver_chol_path": (i, [vp, c_ip]),
         "lsq_solver_stats": (i, [vp, c_ip, c_ip]),
         "lsq_ctx_fallback_stats": (i, [vp, c_ip]),
+        "lsq_ctx_tail_stats": (i, [vp, C.POINTER(C.c_longlong)]),
         "lsq_bench_occupy": (i, [vp, i, i, d]),
         "lsq_bench_occupy_wait": (i, [vp]),
         "lsq_options_default": (None, [C.POINTER(Options)]),

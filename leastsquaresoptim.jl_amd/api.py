@@ -135,6 +135,12 @@ class Context:
         check(lib().lsq_ctx_fallback_stats(self.h, g))
         return dict(zip(("chol_one_launch", "tri_pipeline", "qr_exchange", "cholqr_panel"), (int(v) for v in g)))
 
+    def tail_stats(self):
+        """lsq_ctx_tail_stats: (LSMR solves whose follow-up kernels were queued behind a guessed last iteration, wrong guesses)."""
+        v = (C.c_longlong * 2)()
+        check(lib().lsq_ctx_tail_stats(self.h, v))
+        return int(v[0]), int(v[1])
+
     def occupy(self, workgroups, lds_bytes=65536, milliseconds=10.0):
         """A neighbour on the device (lsq_bench_occupy): workgroups that hold LDS and spin, on a stream of their own."""
         check(lib().lsq_bench_occupy(self.h, int(workgroups), int(lds_bytes), float(milliseconds)))

@@ -74,6 +74,8 @@ struct lsq_ctx {
     // (LsqFallback in lsq_solver.h; index: 0 one-launch Cholesky, 1 pipelined triangular solves, 2 QR slab exchange /
     // pipelined certified solve, 3 CholeskyQR2 panel breakdowns)
     int fallback_giveups[4] = {0, 0, 0, 0};
+    // LSMR solves whose caller's next kernels were enqueued behind a guessed last iteration (LsmrTail): {guesses, wrong ones}
+    long long tail_spec[2] = {0, 0};
     hipStream_t occupy_stream = nullptr;   // lsq_bench_occupy
     // uploads that overlap compute (lsq_mat_set_values_async): created on first use
     hipStream_t copy_stream = nullptr;

@@ -58,6 +58,7 @@ k_lsmr_begin(int m, const double *__restrict__ y, LsmrState *st, double *pu, int
         st->iter = 0;
         st->istop = 0;
         st->done = 0;
+        st->notdone = 1;
         st->first = 1;
         st->atol = atol;
         st->btol = btol;
@@ -196,7 +197,7 @@ __device__ __forceinline__ void lsmr_scalars(LsmrState &ns, double beta2, double
 __device__ __forceinline__ void lsmr_commit(LsmrState &s, double total, LsmrState *st, LsqMailbox *mail) {
     if (s.first) {
         s.first = 0;
-        if (!(s.normAr != 0.0)) s.done = 1;      // lsmr.jl:115: exit if b = 0 or A'b = 0
+        if (!(s.normAr != 0.0)) { s.done = 1; s.notdone = 0; }      // lsmr.jl:115: exit if b = 0 or A'b = 0
         *st = s;
         publish(mail, st);
         return;
@@ -217,7 +218,7 @@ __device__ __forceinline__ void lsmr_commit(LsmrState &s, double total, LsmrStat
     else if (test2 <= s.atol) istop = 2;
     else if (test1 <= rtol) istop = 1;
     s.istop = istop;
-    if (istop) s.done = 1;
+    if (istop) { s.done = 1; s.notdone = 0; }
     *st = s;
     publish(mail, st);
 }
@@ -310,7 +311,7 @@ k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp
     __shared__ double sh[LSQ_NT / 64];
     const double beta2 = ysumsq >= 0.0 ? ysumsq : ordered_sum256(pu, *npu);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->iter = 0; st->istop = 0; st->done = 0; st->first = 1;
+        st->iter = 0; st->istop = 0; st->done = 0; st->notdone = 1; st->first = 1;
         st->atol = atol; st->btol = btol; st->ctol = ctol;
         st->maxiter = maxiter; st->epoch = epoch; st->cu = 0.0;
         if (ysumsq >= 0.0) {
@@ -396,7 +397,7 @@ k_lm_lsmr_setup(int n, LsmrLmPrep lm, double *__restrict__ damp, double *__restr
         s_mean = tt / n;
         if (blockIdx.x == 0) {
             *lm.out_grad = tm;
-            st->iter = 0; st->istop = 0; st->done = 0; st->first = 1;
+            st->iter = 0; st->istop = 0; st->done = 0; st->notdone = 1; st->first = 1;
             st->atol = atol; st->btol = btol; st->ctol = ctol;
             st->maxiter = maxiter; st->epoch = epoch; st->cu = 0.0;
             pu[0] = ysumsq;
@@ -534,7 +535,7 @@ bool lsq_lsmr_takes_lm_prep(const lsq_solver *s, const lsq_mat *J) {
 }
 
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
-                   const double *d_Jty, double y_sumsq, const LsmrLmPrep *lm) {
+                   const double *d_Jty, double y_sumsq, const LsmrLmPrep *lm, const LsmrTail *tail) {
     lsq_ctx *c = s->ctx;
     const int m = J->m, n = J->n;
     if (m != s->m || n != s->n) {
@@ -542,7 +543,10 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         return LSQ_EDIM;
     }
     const bool sharded = s->row_cb != nullptr;     // J is a row block: the adjoint product is summed over the ranks
-    if (lsq_small_mat(J) && !s->precond_cb && !sharded) return lsq_lsmr_exact_solve(s, J, d_y, d_damp, d_x, nmul);  // reference-order kernel
+    if (lsq_small_mat(J) && !s->precond_cb && !sharded) {   // reference-order kernel
+        LSQ_TRY(lsq_lsmr_exact_solve(s, J, d_y, d_damp, d_x, nmul));
+        return tail && tail->fn ? tail->fn(nullptr, tail->user) : LSQ_OK;
+    }
     static const int lookahead = [] {
         const char *e = getenv("LSQ_LOOKAHEAD");
         int v = e ? atoi(e) : LSQ_LOOKAHEAD_DEFAULT;
@@ -625,6 +629,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
 
     int enq = 0, it = 0, istop = 0;
     bool finished = false;
+    const bool spec = tail && tail->fn && tail->predict > 0 && !sharded && !c->idle_hook;
+    int tail_at = 0;             // iteration behind which the speculative tail was enqueued (0: not yet)
     const size_t prof_base[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
     std::vector<int> prof_iter[2];   // iteration number of every timed launch of this solve
     unsigned long long spins = 0;
@@ -644,7 +650,9 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         // (and the first chunk only once the SETUP has reported: a solve that is over before it starts -- A'b = 0 -- must not
         //  get a chunk on the ranks whose host looked too early)
         const bool reported = (unsigned)(w >> 41) == epoch;
-        const bool want = sharded ? (reported && enq == it && enq < maxiter) : (enq - it < lookahead && enq < maxiter);
+        // (a speculative tail sits behind iteration tail_at: nothing more is queued until that iteration has reported)
+        const bool hold = tail_at > 0 && enq == tail_at && it < tail_at;
+        const bool want = sharded ? (reported && enq == it && enq < maxiter) : (!hold && enq - it < lookahead && enq < maxiter);
         if (want) {
           const int chunk = sharded ? (int)std::min<long long>(lookahead, (long long)maxiter - enq) : 1;
           for (int q = 0; q < chunk; ++q) {
@@ -675,6 +683,10 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                                d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
             LSQ_HIP(hipGetLastError());
             ++enq;
+            if (spec && tail_at == 0 && enq == tail->predict) {   // the caller's next kernels, right behind the predicted last iteration
+                LSQ_TRY(tail->fn(&st->notdone, tail->user));
+                tail_at = enq;
+            }
           }
             spins = 0;
             continue;
@@ -720,5 +732,11 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     s->last_iter = it;
     s->last_istop = istop;
     if (nmul) *nmul = 2 * it;  // lsmr.jl:236 ch.mvps
+    // the speculative tail ran iff the solve was over when its kernels reached the device: stop iteration <= tail_at
+    if (tail_at > 0) {
+        c->tail_spec[0]++;
+        if (it > tail_at) c->tail_spec[1]++;
+    }
+    if (tail && tail->fn && !(tail_at > 0 && it <= tail_at)) LSQ_TRY(tail->fn(nullptr, tail->user));
     return LSQ_OK;
 }

@@ -287,8 +287,9 @@ struct EpiSumsq {
 __global__ void __launch_bounds__(LSQ_NT)
 k_step(int n, const double *__restrict__ x, const double *__restrict__ dx, double *__restrict__ xt,
        double *partials, unsigned *counters, double *out_dx, double *out_nonfin, double *__restrict__ t_out,
-       double *__restrict__ s_out) {
+       double *__restrict__ s_out, const int *skip = nullptr) {
     __shared__ double sh[LSQ_NT / 64];
+    if (skip && *skip) return;       // (queued behind an LSMR solve that turned out not to be over: LsmrTail)
     double mx = 0.0, code = 0.0;
     for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) {
         double d = dx[i];
@@ -415,14 +416,15 @@ static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, i
 // f!(out, x) followed by sum(out.^2) -> slot.  When f! is the library's own device-side model on the sliced-row layout the
 // sum rides in the residual kernel's epilogue (no second pass over the m-vector: 8 MB and a launch less per iteration at C4)
 static int model_f(double *out, const double *x, void *user);
-static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done);
+static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done,
+                         const int *skip = nullptr);
 // buffers for tanh(xt) and 1 - tanh(xt)^2 when the model's next f!(., xt) can take them from the step kernel (else nulls)
 static void model_trial_buffers(void *user, const double *xt, double **t_out, double **s_out);
 static int f_then_sumsq(lsq_ctx *c, bool exact, lsq_f_callback f, void *user, long long m, double *out, const double *x, int ctr,
-                        double *d_out, LsqSlotPublish pub = LsqSlotPublish()) {
+                        double *d_out, LsqSlotPublish pub = LsqSlotPublish(), const int *skip = nullptr) {
     if (!exact && f == model_f) {
         bool fused = false;
-        if (model_f_sumsq(user, out, x, ctr, d_out, pub, &fused) != 0) {
+        if (model_f_sumsq(user, out, x, ctr, d_out, pub, &fused, skip) != 0) {
             lsq_set_error("user callback reported failure");
             return LSQ_ECALLBACK;
         }
@@ -435,7 +437,7 @@ static int f_then_sumsq(lsq_ctx *c, bool exact, lsq_f_callback f, void *user, lo
 }
 // sum((J d - f)^2) -> slot (f may be null: sum((J d)^2))
 static int predicted_to_slot(lsq_ctx *c, bool exact, lsq_mat *J, const double *d, const double *f, double *scratch,
-                             int ctr, double *d_out, LsqSlotPublish pub = LsqSlotPublish());
+                             int ctr, double *d_out, LsqSlotPublish pub = LsqSlotPublish(), const int *skip = nullptr);
 static int wdot_to_slot(lsq_ctx *c, bool exact, int n, const double *x, const double *y, const double *w, int ctr,
                         double *d_out);
 // g = J'f
@@ -497,13 +499,13 @@ static int alloc_loop(LoopBuffers &b, lsq_ctx *c, int m, int n, const lsq_option
 }
 
 static int predicted_to_slot(lsq_ctx *c, bool exact, lsq_mat *J, const double *d, const double *f, double *scratch,
-                             int ctr, double *d_out, LsqSlotPublish pub) {
+                             int ctr, double *d_out, LsqSlotPublish pub, const int *skip) {
     if (exact) {
         LSQ_TRY(lsq_exact_product(J, 0, d, scratch));
         return lsq_seq_reduce(c, f ? 3 : 1, J->m, scratch, f, nullptr, d_out);
     }
     if (f) {
-        EpiPredict ep{nullptr, 0, f, d_out, c->d_partials, lsq_ctr(c, ctr), pub};
+        EpiPredict ep{skip, 0, f, d_out, c->d_partials, lsq_ctr(c, ctr), pub};
         return launch_product(J, 0, d, ep);
     }
     EpiSumsq es{nullptr, 0, d_out, c->d_partials, lsq_ctr(c, ctr)};
@@ -693,6 +695,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
     const int gn = ngrid(c, n);
     const bool exact = lsq_small_mat(J) && !sharded;  // reference summation order for small problems (lsq_exact.hip)
     unsigned long long colsum_global_version = ~0ull;   // (sharded) version of J whose cached colsumabs2 holds the ranks' sum
+    int last_inner = 0;          // inner iterations of the previous LSMR solve of this run: the guess for the next one (LsmrTail)
     int local_done = 0;
     double gssr = ssr, ggr = maxabs_gr;
     long long inner_total = 0;
@@ -768,22 +771,64 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             if (sv->kind != LSQ_LSMR || exact) lsq_run_idle_hook(c);
         }
         int lmiter = 0;
+        // What follows the solve -- x_trial = x - dx, the predicted residual |J dx - f|^2 (:114-117) and f!(x_trial) with its
+        // sum of squares (:107, :111) -- depends on the solve only through dx.  With LSMR on the sliced layouts and a
+        // device-side f! it is handed to the solve as its TAIL: enqueued right behind the inner iteration at which the
+        // previous solve stopped, every kernel skipping itself if LSMR turns out not to be over by then (lsq_solver.h:
+        // LsmrTail).  When the guess holds the device runs from the last inner iteration straight into the step kernel: no
+        // early-exit launches of the look-ahead, no wait for the host to notice the stop.  (The predicted residual is formed
+        // BEFORE f!(x_trial): it does not depend on it, and the row copy of J that the last LSMR iterations streamed is then
+        // still partly in the Infinity Cache.)
+        struct TailCtx {
+            lsq_ctx *c; lsq_mat *J; LoopBuffers *b; lsq_f_callback f; void *user;
+            const double *x, *fcur; double *xt, *ftrial;
+            int m, n, gn; bool is_model; LsqSlotPublish pub; int launched;
+        } tc{c, J, &b, f, user, x, fcur, xt, ftrial, m, n, gn, !exact && f == model_f, LsqSlotPublish(), 0};
+        auto tail_fn = [](const int *skip, void *u) -> int {
+            TailCtx &t = *(TailCtx *)u;
+            lsq_ctx *c = t.c;
+            double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
+            if (t.is_model) model_trial_buffers(t.user, t.xt, &t_out, &s_out);
+            hipLaunchKernelGGL(k_step, dim3(t.gn), dim3(LSQ_NT), 0, c->stream, t.n, t.x, t.b->dx, t.xt, c->d_partials,
+                               lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out, skip);   // :106
+            LSQ_HIP(hipGetLastError());
+            LSQ_TRY(predicted_to_slot(c, false, t.J, t.b->dx, t.fcur, t.b->fpred, 8, c->d_slots + SL_PRED, LsqSlotPublish(), skip));
+            // the last kernel of the iteration hands the scalars to the host
+            t.pub = lsq_slots_ticket(c, SL_GRAD, 5);
+            LSQ_TRY(f_then_sumsq(c, false, t.f, t.user, t.m, t.ftrial, t.xt, 7, c->d_slots + SL_TRIAL, t.pub, skip));
+            LSQ_HIP(hipGetLastError());
+            t.launched++;
+            return LSQ_OK;
+        };
+        const bool tail_ok = !exact && !sharded && !o->allreduce && sv->kind == LSQ_LSMR && !b.lo && !b.hi;
+        bool tail_done = false;
         if (sv->kind == LSQ_LSMR) {
             const LsmrLmPrep prep{cs, 1.0 / delta, MIN_DIAGONAL, MAX_DIAGONAL, x, b.lo, b.hi, c->d_slots + SL_GRAD};
-            LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr, lm_prep ? &prep : nullptr));  // :87
+            // (speculation needs kernels that honour the skip flag: the device model on the sliced rows)
+            static const bool no_spec = getenv("LSQ_NO_TAIL_SPECULATION") != nullptr;
+            const bool guardable = tc.is_model && J->kind == LSQ_MAT_CSC && J->srows.active && !no_spec;
+            LsmrTail tail{guardable ? last_inner : 0, tail_fn, &tc};
+            LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr, lm_prep ? &prep : nullptr,
+                                   tail_ok ? &tail : nullptr));  // :87
+            tail_done = tail_ok;
+            last_inner = lmiter / 2;
         }
         else LSQ_TRY(lsq_ldiv_damped(sv, J, fcur, b.dtd, b.dx, &lmiter));
         lsq_run_idle_hook(c);   // (a solve that never filled its window)
         if (o->allreduce && c->idle_status != LSQ_OK) return c->idle_status;
-        LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
         mul_calls += lmiter;
         inner_total += lmiter / 2;
+        double sl[5];
+        if (tail_done) {
+            f_calls++;
+            LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, tc.pub.seq, sl));
+        } else {
+        LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
         double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
         if (!exact && f == model_f) model_trial_buffers(user, xt, &t_out, &s_out);
         hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
                            lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out);   // :106
         LSQ_HIP(hipGetLastError());
-        double sl[5];
         if (exact) {
             CB(f(ftrial, xt, user));                                      // :107
             f_calls++;
@@ -801,8 +846,6 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             LSQ_TRY(rows_sum(c->d_slots + SL_TRIAL, 2));
             LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));
         } else {
-            // the predicted residual (:114-117) does not depend on f!(x_trial): formed first, while the
-            // row copy of J that the last LSMR iterations streamed is still (partly) in the Infinity Cache
             LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));
             // f!(x_trial) and sum(abs2, ftrial) (:107, :111); the last kernel of the iteration hands the scalars to the host
             LsqSlotPublish pub = lsq_slots_ticket(c, SL_GRAD, 5);
@@ -810,6 +853,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             f_calls++;
             LSQ_HIP(hipGetLastError());
             LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, pub.seq, sl));
+        }
         }
         mul_calls++;
         maxabs_gr = sl[0];
@@ -1299,13 +1343,14 @@ static void model_trial_buffers(void *user, const double *xt, double **t_out, do
 }
 
 // f! + sum(abs2, out) in one pass (sliced rows only; *done tells whether it applied)
-static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done) {
+static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done,
+                         const int *skip) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
     lsq_mat *J = md->J;
     *done = false;
     if (!(J->kind == LSQ_MAT_CSC && J->srows.active)) return model_f(out, x, user);
-    EpiResidualSq e{nullptr, 0, md->d_b, out, c->d_partials, lsq_ctr(c, ctr), d_out, pub};
+    EpiResidualSq e{skip, 0, md->d_b, out, c->d_partials, lsq_ctr(c, ctr), d_out, pub};
     const bool have_tanh = md->tanh_x == x;   // k_step formed tanh(x) while it wrote x
     md->tanh_x = nullptr;
     if (!have_tanh) {

@@ -18,6 +18,8 @@ struct LsmrState {
     int beta_zero;    // lsmr.jl:120: beta == 0 skips the v update
     int first;        // setup pass (lsmr.jl:73-78)
     unsigned epoch;
+    int notdone;      // !done: the skip flag of launches that were queued to run AFTER the solve (the LM loop's step /
+                      // predicted residual / trial residual chain, enqueued behind the predicted last iteration)
 };
 
 // A fast path that relies on what the hardware does but HIP does not promise (all workgroups of a launch co-resident and
@@ -172,8 +174,20 @@ struct LsmrLmPrep {
     double *out_grad;
 };
 constexpr int LSMR_LM_PREP_MAX_N = 16384;   // every workgroup of that launch reduces colsum and g over all n itself
+// tail (optional): what the caller will launch once the solve is over and which depends on nothing but d_x.  `predict` > 0:
+// the tail is enqueued right behind inner iteration `predict` with skip = &state->notdone (its kernels return at once if the
+// solve is NOT over by then) and no further iteration is queued until that iteration has reported -- if the prediction holds
+// (the usual case: the inner count of an LM run changes slowly) the device goes from the last inner iteration straight into
+// the caller's next kernels, without the early-exit launches of the look-ahead and without waiting for the host to notice.
+// Otherwise, and always when predict == 0, the tail is called (again) with skip = nullptr after the solve.
+struct LsmrTail {
+    int predict = 0;
+    int (*fn)(const int *skip, void *user) = nullptr;
+    void *user = nullptr;
+};
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
-                   const double *d_Jty = nullptr, double y_sumsq = -1.0, const LsmrLmPrep *lm = nullptr);
+                   const double *d_Jty = nullptr, double y_sumsq = -1.0, const LsmrLmPrep *lm = nullptr,
+                   const LsmrTail *tail = nullptr);
 // whether lsq_lsmr_solve takes the LsmrLmPrep route for this solver / Jacobian (else the caller launches its own damping)
 bool lsq_lsmr_takes_lm_prep(const lsq_solver *s, const lsq_mat *J);
 // implemented in lsq_exact.hip (reference-order kernels for small problems)

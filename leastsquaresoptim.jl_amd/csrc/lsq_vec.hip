@@ -559,3 +559,9 @@ extern "C" int lsq_ctx_fallback_stats(const lsq_ctx *c, int h_giveups[4]) {
     for (int i = 0; i < 4; ++i) h_giveups[i] = c->fallback_giveups[i];
     return LSQ_OK;
 }
+extern "C" int lsq_ctx_tail_stats(const lsq_ctx *c, long long h_out[2]) {
+    if (!c || !h_out) return LSQ_EARG;
+    h_out[0] = c->tail_spec[0];
+    h_out[1] = c->tail_spec[1];
+    return LSQ_OK;
+}
