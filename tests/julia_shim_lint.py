@@ -12,6 +12,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "lsqhip.h")
+RCCL_HEADER = os.path.join(ROOT, "include", "lsqrccl.h")
 DOC = os.path.join(ROOT, "INTEGRATION.md")
 
 
@@ -42,14 +43,15 @@ def c_class(ctype):
             return "ptr:void"
         if base in ("lsq_options", "lsq_result"):
             return "ptr:" + base
-        return "ptr:" + {"int": "int", "double": "double", "float": "float", "char": "char", "long long": "longlong"}[base]
+        return "ptr:" + {"int": "int", "double": "double", "float": "float", "char": "char", "long long": "longlong",
+                         "unsigned char": "uchar"}[base]
     if stars == 2 and base in handles:
         return "ptrptr"
     raise ValueError("unclassified C type %r" % ctype)
 
 
-def header_prototypes():
-    txt = _strip_comments(open(HEADER).read())
+def header_prototypes(path=None):
+    txt = _strip_comments(open(path or HEADER).read())
     txt = re.sub(r"typedef\s+(struct|enum)\s*\{.*?\}\s*\w+\s*;", " ", txt, flags=re.S)
     txt = re.sub(r"typedef[^;]*;", " ", txt)
     protos = {}
@@ -92,7 +94,8 @@ JULIA_CLASS = {"Cint": {"int"}, "Cdouble": {"double"}, "Csize_t": {"size_t"}, "C
                "Ptr{Cvoid}": {"ptr:void", "ptr:lsq_options", "ptr:lsq_result", "ptrptr"},
                "Ptr{Cdouble}": {"ptr:double"}, "Ref{Cdouble}": {"ptr:double"},
                "Ptr{Cint}": {"ptr:int"}, "Ref{Cint}": {"ptr:int"}, "Ptr{Cfloat}": {"ptr:float"}, "Ref{Cfloat}": {"ptr:float"},
-               "Ref{Ptr{Cvoid}}": {"ptrptr"}, "Ref{LsqOptions}": {"ptr:lsq_options"}, "Ref{LsqResult}": {"ptr:lsq_result"}}
+               "Ref{Ptr{Cvoid}}": {"ptrptr"}, "Ref{LsqOptions}": {"ptr:lsq_options"}, "Ref{LsqResult}": {"ptr:lsq_result"},
+               "Ptr{UInt8}": {"ptr:uchar"}, "Ptr{Clonglong}": {"ptr:longlong"}, "Ref{Clonglong}": {"ptr:longlong"}}
 
 
 def julia_blocks():
@@ -136,15 +139,18 @@ def _balanced(s, start):
     raise ValueError("unbalanced")
 
 
-def ccalls():
-    """[(name, ret, [argtypes], nvalues, line)] for every ccall in the julia blocks of INTEGRATION.md."""
+def ccalls(libname="lib"):
+    """[(name, ret, [argtypes], nvalues, line)] for every ccall((:name, <libname>), ...) in the julia blocks of INTEGRATION.md
+    (lib = liblsqhip.so / include/lsqhip.h, rlib = liblsqrccl.so / include/lsqrccl.h)."""
     src = "\n".join(line.split(" # ")[0] if not line.lstrip().startswith("#") else "" for line in julia_blocks().split("\n"))
     found = []
     for m in re.finditer(r"ccall\(", src):
         end = _balanced(src, m.end() - 1)
         parts = _split_top(src[m.end():end - 1])
-        sym = re.match(r"\(\s*:(\w+)\s*,\s*lib\s*\)", parts[0])
-        assert sym, "ccall without (:name, lib): %s" % parts[0]
+        sym = re.match(r"\(\s*:(\w+)\s*,\s*(r?lib)\s*\)", parts[0])
+        assert sym, "ccall without (:name, lib) / (:name, rlib): %s" % parts[0]
+        if sym.group(2) != libname:
+            continue
         ret = parts[1]
         assert parts[2].startswith("(") and parts[2].endswith(")"), parts[2]
         types = _split_top(parts[2][1:-1])

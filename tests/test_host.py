@@ -114,6 +114,15 @@ def test_julia_shim_matches_the_header():
         assert [f for f, _ in jf] == [f for f, _ in cf], (jname, jf, cf)
         for (f, jt), (_, ct) in zip(jf, cf):
             assert ct in JL.JULIA_CLASS[jt], (jname, f, jt, ct)
+    # the RCCL shim's calls (rlib) against include/lsqrccl.h
+    rprotos = JL.header_prototypes(JL.RCCL_HEADER)
+    rcalls = JL.ccalls("rlib")
+    assert {c[0] for c in rcalls} >= {"lsq_rccl_unique_id", "lsq_rccl_comm_create", "lsq_rccl_allreduce_callback"}
+    for name, ret, types, nvalues, line in rcalls:
+        cret, cparams = rprotos[name]
+        assert cret in JL.JULIA_CLASS[ret] and len(types) == len(cparams) == nvalues, (name, ret, types, cparams)
+        for jt, ct in zip(types, cparams):
+            assert ct in JL.JULIA_CLASS[jt], (name, jt, ct)
     # the ctypes mirror (what the tests actually drive) has the same layout
     assert [f for f, _ in lsq._lib.Options._fields_] == [f for f, _ in JL.header_struct("lsq_options")]
     assert [f for f, _ in lsq._lib.Result._fields_] == [f for f, _ in JL.header_struct("lsq_result")]
