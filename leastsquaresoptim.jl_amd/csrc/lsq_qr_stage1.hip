@@ -118,13 +118,12 @@ __device__ __forceinline__ void qr_static_for(F &&f) {
     }
 }
 //
-// TSQR = 1 (tall and thin operands, n <= K; kept for reference, not instantiated): every workgroup is on its own -- its slab of RPT*NT rows of ALL n
-// columns and of b sits in registers, the K rounds factor the slab locally (pivot rows = the slab's first rows, no
-// exchange), and the only thing written is the slab's n x n triangle and the first n entries of its Q'b, stacked
-// for the next level (tsq_S: (slabs*n) x n, tsq_r): ONE pass over the matrix.
-// TSQR = 2 (the one in use): the same with one WAVEFRONT per slab (64*RPT rows): the reductions are wave reductions, the
-// row-c elements come from their owner lane by v_readlane -- no LDS, no barrier anywhere in the rounds.
-template <int NT, int RPT, int K, int S, int TSQR = 0>
+// TSQR (tall and thin operands, n <= K): every WAVEFRONT is on its own -- its slab of 64*RPT rows of ALL n columns and of b
+// sits in registers, the K rounds factor the slab locally (pivot rows = the slab's first rows, no exchange: the reductions are
+// wave reductions, the row-c elements come from their owner lane by v_readlane -- no LDS, no barrier anywhere in the rounds),
+// and the only thing written is the slab's n x n triangle and the first n entries of its Q'b, stacked for the next level
+// (tsq_S: (slabs*n) x n, tsq_r): ONE pass over the matrix.
+template <int NT, int RPT, int K, int S, bool TSQR = false>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live pivots, <= K */, double *__restrict__ tau,
                  double *__restrict__ beta_out, double *__restrict__ scale_out, int G /* groups = target columns (>= 1) */,
@@ -138,11 +137,11 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     __shared__ double sx[S][NS];
     __shared__ double sat[NS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int QS = TSQR == 2 ? 64 : NT;      // rows between two elements of a thread
+    constexpr int QS = TSQR ? 64 : NT;           // rows between two elements of a thread
     int g = (int)blockIdx.x, sidx = 0;
-    if (TSQR) {                      // one workgroup (or wavefront) per slab, a single "group" whose target is b
+    if (TSQR) {                      // one wavefront per slab, a single "group" whose target is b
         g = 0;
-        sidx = TSQR == 2 ? (int)blockIdx.x * NW + wv : (int)blockIdx.x;
+        sidx = (int)blockIdx.x * NW + wv;
     } else if (S > 1 && S < 64) {           // members 8 apart: one XCD; 8 * S workgroups must be resident together
         const int kq = (int)blockIdx.x >> 3;
         sidx = kq % S;
@@ -159,7 +158,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     // ONE shared 32-bit VGPR offset + a scalar offset; rows beyond M read as zero and their stores are dropped by
     // the bounds check, and a dead column (ragged last launch, no target) gets an empty descriptor
     typedef unsigned v2u_qr __attribute__((ext_vector_type(2)));
-    const int t = i + sidx * (RPT * QS) + (TSQR == 2 ? lane : tid);    // row of element 0
+    const int t = i + sidx * (RPT * QS) + (TSQR ? lane : tid);    // row of element 0
     const unsigned tb = (unsigned)t * 8u;
     const unsigned colbytes = (unsigned)M * 8u;
     double pv[K][RPT], a[RPT];
@@ -213,7 +212,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
 #pragma unroll
         for (int e = 0; e < NS; e += 2)
             if (e < NSr) sm[e] = wave_allsum(sm[e]);
-        if constexpr (TSQR == 2) {
+        if constexpr (TSQR) {
             // wave slab: the sums are complete; the row-c elements sit in lane r
             sm[1] = readlane_f64(pv[r][0], r);
 #pragma unroll
@@ -240,8 +239,8 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         for (int e = 0; e < NS; e += 2)
             if (e < NSr) sm[e] = row_allsum((lane & 15) < NW ? sh[lane & 15][e] : 0.0);
         }
-        if constexpr (TSQR == 2) {
-        } else if (S == 1 || TSQR) {
+        if constexpr (TSQR) {
+        } else if (S == 1) {
 #pragma unroll
             for (int e = 1; e < NS; e += 2)
                 if (e < NSr) sm[e] = sat[e];
@@ -300,7 +299,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
         }
         if (!live) ti = 0.0;
         if (TSQR) {
-            if ((TSQR == 2 ? lane : tid) == r) mybeta = beta;   // R(r, r) of this slab, kept by the owner of the slab's row r
+            if (lane == r) mybeta = beta;   // R(r, r) of this slab, kept by the owner of the slab's row r
         } else if (live && g == 0 && sidx == 0 && tid == 0) { tau[c] = ti; beta_out[c] = beta; scale_out[c] = sc; }
         if (ti != 0.0) {
             double tw[K + 1];
@@ -328,7 +327,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
     if (TSQR) {
         // rows 0 .. kk-1 of the slab: R(r, x) = element 0 of thread r in column x (x > r), beta on the diagonal, zeros
         // before it; and entry r of the slab's Q'b
-        const int own = TSQR == 2 ? lane : tid;
+        const int own = lane;
         if (own < kk && sidx < G) {                  // (G: number of slabs; a workgroup's last wavefronts may have none)
             const size_t row = (size_t)sidx * kk + own;
 #pragma unroll
@@ -789,13 +788,13 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
                 hipLaunchKernelGGL(kern, dim3(lsq_div_up(S, slabs_per_block)), dim3(256), 0, c->stream, Acur, Mcur, n, 0, n, q->tau1,
                                    q->lazy, q->lazy + n, S, q->xslot, ++q->epoch, q->d_err, q->Pn, 0, bcur, So, Ms, ro);
             };
-            if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, 2>, 4);
-            else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, 2>, 4);
-            else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, 2>, 4);
-            else if (n <= 20) go(k_qr1_step_multi<256, 3, 20, 1, 2>, 4);
-            else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, 2>, 4);
-            else if (n <= 28) go(k_qr1_step_multi<256, 2, 28, 1, 2>, 4);
-            else go(k_qr1_step_multi<256, 2, 32, 1, 2>, 4);
+            if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, true>, 4);
+            else if (n <= 12) go(k_qr1_step_multi<256, 6, 12, 1, true>, 4);
+            else if (n <= 16) go(k_qr1_step_multi<256, 4, 16, 1, true>, 4);
+            else if (n <= 20) go(k_qr1_step_multi<256, 3, 20, 1, true>, 4);
+            else if (n <= 24) go(k_qr1_step_multi<256, 3, 24, 1, true>, 4);
+            else if (n <= 28) go(k_qr1_step_multi<256, 2, 28, 1, true>, 4);
+            else go(k_qr1_step_multi<256, 2, 32, 1, true>, 4);
             Acur = So; bcur = ro; Mcur = Ms;
         }
         LSQ_HIP(hipGetLastError());

@@ -1074,7 +1074,8 @@ def test_minpack_fast_kernels(opt, sol, sparse):
     and 1e-5 iterates on the ROBUST set of tests/golden/count_stable.json -- the runs whose counts the oracle keeps
     under every modelled summation order (the stdlib's plausible ones, wave trees, random orders) and under last-bit
     perturbations of every reduction.  On the other runs (LSMR far past the loss of orthogonality on ill-conditioned
-    Jacobians) any such change, the fast kernels' included, moves the stop iteration by a few counts."""
+    Jacobians) any such change, the fast kernels' included, moves the stop iteration by a few counts: there the drift from
+    the oracle is BOUNDED instead (iterations, mul_calls, minimiser)."""
     stable = _count_stable()
     lsq.set_exact(False)
     try:
@@ -1084,11 +1085,22 @@ def test_minpack_fast_kernels(opt, sol, sparse):
             assert rg.ssr <= 1e-3, (P.label(p), rg.ssr)          # test/nonlinearsolvers.jl:532
             if sol == "cholesky":
                 assert rg.converged                              # :592
+            ro = oracle_run(p, OPT[opt][1], SOL[sol][1], sparse)
             if stable[(P.label(p), opt, sol, sparse)]:
-                ro = oracle_run(p, OPT[opt][1], SOL[sol][1], sparse)
                 # iterates: 1e-5 for the direct solvers; 1e-4 for LSMR, whose inner solves are themselves only
                 # accurate to atol = btol = 1e-6 on operators with cond ~ 1e6+ (wood(4): 1.3e-5 mid-trajectory)
                 compare(rg, ro, (P.label(p), opt, sol, sparse), xtol=1e-4 if sol == "lsmr" else 1e-5)
+            else:
+                # NOT robust: the oracle's own counts move under reordered sums here, so equality is not the claim -- but the
+                # drift is bounded (measured with tools/fast_vs_oracle_nonrobust.py: iteration counts within
+                # 0-2 except watson(6) +7 % and watson(9) -20 % under Dogleg+LSMR, minimisers within 2.5e-3 in watson(9)'s
+                # flat valley, 5e-5 elsewhere): a regression in the fused LSMR kernels could not hide in these runs
+                key = (P.label(p), opt, sol, sparse)
+                assert rg.converged == ro.converged, key
+                assert abs(rg.iterations - ro.iterations) <= max(3, ro.iterations // 4), (key, rg.iterations, ro.iterations)
+                assert abs(rg.mul_calls - ro.mul_calls) <= max(12, ro.mul_calls // 3), (key, rg.mul_calls, ro.mul_calls)
+                scale = max(1.0, float(np.max(np.abs(ro.minimizer))))
+                assert np.max(np.abs(rg.minimizer - ro.minimizer)) <= (5e-3 if "watson(9)" in key[0] else 2e-4) * scale, key
     finally:
         lsq.set_exact(None)
 
@@ -1365,6 +1377,34 @@ def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big, monkeypatch):
         xr = ro.trace["x"][k]
         assert np.max(np.abs(rg.trace["x"][k] - xr)) <= 1e-8 * max(1.0, np.max(np.abs(xr)))
     pr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("big", [False, True])
+def test_lm_fused_setup_matches_separate_kernels(ctx, big, monkeypatch):
+    """LM's damping + projected gradient norm + LSMR's setup as ONE launch (k_lm_lsmr_setup) against the separate
+    kernels it replaces (k_lm_damp_grad + k_lsmr_setup; LSQ_LSMR_SEPARATE_SETUP=1).  Same arithmetic per element; the only
+    difference is that sum(v~^2) is grouped per 1024 instead of per 256 elements: identical counts, accept pattern, inner
+    counts and Delta; ssr and iterates to 1e-12."""
+    m, n, per_col = (300000, 2000, 600) if big else (20000, 200, 100)
+    runs = []
+    for env in ({}, {"LSQ_LSMR_SEPARATE_SETUP": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=9, ctx=ctx)
+        pr.reset()
+        r = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, trace=True, iterations=12)
+        for k in env:
+            monkeypatch.delenv(k)
+        runs.append(r)
+        pr.close()
+    a, b = runs
+    assert a.iterations == b.iterations > 3 and a.mul_calls == b.mul_calls and a.f_calls == b.f_calls
+    assert np.array_equal(a.trace["inner"], b.trace["inner"]) and np.array_equal(a.trace["accept"], b.trace["accept"])
+    assert np.array_equal(a.trace["delta"], b.trace["delta"])
+    assert np.allclose(a.trace["ssr"], b.trace["ssr"], rtol=1e-12, atol=0)
+    assert np.allclose(a.trace["gnorm"], b.trace["gnorm"], rtol=1e-12, atol=0)
+    assert np.max(np.abs(np.array(a.trace["x"]) - np.array(b.trace["x"]))) <= 1e-12
 
 
 @pytest.mark.gpu
