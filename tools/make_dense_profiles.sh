@@ -56,7 +56,9 @@ out += ["## fp64 MFMA counters of the MFMA kernels (`rocprofv3 --kernel-trace --
         "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE`, own pass)", "",
         "`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES summed over the device / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of "
         "all SIMD-cycles of the launch in which an MFMA was executing, with the launch's cycles MEASURED in the same pass "
-        "(`clock` = GRBM_GUI_ACTIVE / 8 / duration: what the shader clock really was, no assumed frequency).  `MOPS_F64` x 512 = fp64 MFMA flops issued (a 16x16x4 "
+        "(`clock` = GRBM_GUI_ACTIVE / 8 / duration: what the shader clock really was, no assumed frequency; for launches shorter "
+        "than ~30 us the counter also covers the dispatch's ramp outside the kernel's timestamps, so the derived clock overstates "
+        "-- 3-5 GHz -- and MFMA-busy understates there: read it for the 40+ us kernels).  `MOPS_F64` x 512 = fp64 MFMA flops issued (a 16x16x4 "
         "f64 MFMA = 2048 flops = 4 MOPS); `TFLOP/s` = that / duration, against the 78.6 TFLOP/s fp64 matrix peak.", ""]
 for name, title in (("c2_pmc", "C2 (`chol:4096:512:1`)"), ("c3_pmc", "C3 (`qr:16384:2048:0`)")):
     f = glob.glob("gpurun_out/denseprof/%s/**/*counter_collection.csv" % name, recursive=True)

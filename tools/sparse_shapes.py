@@ -21,5 +21,6 @@ for m, n, pc in shapes:
             ms = (time.perf_counter() - t0) / max(r.iterations, 1) * 1e3
             best = ms if best is None else min(best, ms)
         nnz = pr.nnz
-        print("%8dx%-6d nnz %9d  %-6s LSMR  %8.3f ms / outer  (%.1f us per stored entry per 1e6)  ssr %.4e" % (m, n, nnz, oname, best, best * 1e3 / (nnz / 1e6), r.ssr), flush=True)
+        print("%8dx%-6d nnz %9d  %-6s LSMR  %8.3f ms / outer  (%.1f us per stored entry per 1e6; %.1f LSMR inner iterations per outer)  ssr %.4e"
+              % (m, n, nnz, oname, best, best * 1e3 / (nnz / 1e6), r.lsmr_iterations / max(r.iterations, 1), r.ssr), flush=True)
     pr.close()
