@@ -167,6 +167,21 @@ int lsq_ldiv_damped(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp
  * reference-order small-problem path is not used with a custom preconditioner.  NULL restores the default. */
 typedef int (*lsq_precond_callback)(double *d_P, lsq_mat *J, const double *d_damp, void *user);
 int lsq_solver_set_preconditioner(lsq_solver *s, lsq_precond_callback cb, void *user);
+/* LSMR(preconditioner!, P) with ANY P that supports ldiv! (types.jl:82-86; README.md:47: "The preconditioner can be any type
+ * that supports A_ldiv_B!(x, P, y)") -- block-diagonal, incomplete factors, whatever the caller keeps behind `user`:
+ *   update(J, d_damp, user) = preconditioner!(P, x, J, damp): refresh P for J'J + diag(damp) (d_damp un-rooted; NULL for the
+ *                             undamped Dogleg solve); may be NULL if P never changes;
+ *   ldiv(d_out, d_in, user) = ldiv!(out, P, in) on n-vectors in device memory.
+ * Both are HOST callbacks on device pointers; the library drains its stream before each call and the callback must have
+ * finished its device work when it returns.  A general P cannot be folded into the fused kernels, so the solve runs as the
+ * reference's own structure at the operator level (lsmr.jl:53-238 on PreconditionedMatrix(DampenedMatrix(J, sqrt(damp)), P),
+ * every vector operation a launch, scalars on the host: lsq_lsmr_general.hip) -- the slow path, as a user-supplied P is in the
+ * reference.  Like the reference (iterative_lsmr.jl:36-51) the adjoint applies ldiv!(., P, .) again, i.e. P is taken to be
+ * symmetric.  ldiv = NULL restores the built-in path. */
+typedef int (*lsq_precond_update_callback)(lsq_mat *J, const double *d_damp, void *user);
+typedef int (*lsq_precond_ldiv_callback)(double *d_out, const double *d_in, void *user);
+int lsq_solver_set_general_preconditioner(lsq_solver *s, lsq_precond_update_callback update, lsq_precond_ldiv_callback ldiv,
+                                          void *user);
 /* Row-sharded SINGLE problem: J is split by residual rows, rank p holds the m_p x n block J_p and the
  * matching slices of the m-vectors; every n-vector is replicated and every rank runs the same scalar control flow.  What
  * crosses ranks is a SUM all-reduce of a device buffer, IN PLACE, ordered on the library's stream (the hook enqueues it
@@ -254,6 +269,9 @@ typedef struct {
     lsq_device_allreduce_callback row_allreduce;   /* row-sharded single problem (see above); NULL = J holds all rows */
     void *row_allreduce_user;
     long long global_rows;      /* row-sharded: sum of the ranks' row counts (lsmr.jl:55 maxiter = max(size(A)...)) */
+    lsq_precond_update_callback precond_update;    /* LSMR(preconditioner!, P) with a general P (see */
+    lsq_precond_ldiv_callback precond_ldiv;        /* lsq_solver_set_general_preconditioner); NULL = not used */
+    void *precond_general_user;
 } lsq_options;
 
 typedef struct {

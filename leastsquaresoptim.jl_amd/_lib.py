@@ -24,6 +24,8 @@ OP_MUL_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void
 OP_COLSUM_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)                  # (d_out, user)
 PRECOND_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)   # (d_P, J, d_damp, user)
 ROW_ALLREDUCE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)   # (d_buf, count, hip_stream, user)
+PRECOND_UPDATE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)              # (J, d_damp, user)
+PRECOND_LDIV_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)                # (d_out, d_in, user)
 
 OK, EDIM, ENOTPD, ERANK, ENONFINITE, EBOUNDS, EHIP, EARG, ECALLBACK, ERCCL = range(10)
 QR, CHOLESKY, LSMR = 0, 1, 2
@@ -39,7 +41,9 @@ class Options(C.Structure):
                 ("trace_accept", c_ip), ("trace_x", c_dp),
                 ("preconditioner", PRECOND_CALLBACK), ("preconditioner_user", C.c_void_p),
                 ("row_allreduce", ROW_ALLREDUCE_CALLBACK), ("row_allreduce_user", C.c_void_p),
-                ("global_rows", C.c_longlong)]
+                ("global_rows", C.c_longlong),
+                ("precond_update", PRECOND_UPDATE_CALLBACK), ("precond_ldiv", PRECOND_LDIV_CALLBACK),
+                ("precond_general_user", C.c_void_p)]
 
 
 class Result(C.Structure):
@@ -64,7 +68,8 @@ def declared_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = re.findall(r"\b(lsq_[a-z0-9_]+)\s*\(", txt)
-    skip = {"lsq_f_callback", "lsq_g_callback", "lsq_allreduce_callback", "lsq_device_allreduce_callback"}
+    skip = {"lsq_f_callback", "lsq_g_callback", "lsq_allreduce_callback", "lsq_device_allreduce_callback",
+            "lsq_precond_update_callback", "lsq_precond_ldiv_callback"}
     return sorted(set(n for n in names if n not in skip))
 
 
@@ -112,6 +117,7 @@ def lib():
         "lsq_mat_colscale_changed": (i, [vp]),
         "lsq_mul": (i, [vp, i, d, vp, d, vp]),
         "lsq_solver_set_preconditioner": (i, [vp, PRECOND_CALLBACK, vp]),
+        "lsq_solver_set_general_preconditioner": (i, [vp, PRECOND_UPDATE_CALLBACK, PRECOND_LDIV_CALLBACK, vp]),
         "lsq_op_create": (i, [vp, i, i, OP_MUL_CALLBACK, OP_COLSUM_CALLBACK, vp, C.POINTER(vp)]),
         "lsq_colsumabs2": (i, [vp, vp]),
         "lsq_rowsumabs2": (i, [vp, vp]),

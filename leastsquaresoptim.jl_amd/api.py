@@ -38,20 +38,51 @@ class Cholesky(AbstractSolver):
 
 
 class LSMR(AbstractSolver):
-    """LSMR(preconditioner!, P) (types.jl:82-86).  `preconditioner(P, J, damp)` is the reference's
-    preconditioner!(P, x, J, damp) for DIAGONAL preconditioners: it must fill the DeviceVector P with the
-    factors the preconditioner solve multiplies by (an InverseDiagonal stores the inverse,
-    iterative_lsmr.jl:117-122) for J'J + diag(damp); damp is a DeviceVector with the un-rooted damping or
-    None (Dogleg).  It runs on the host before every solve (the slow path of the reference as well);
-    None = the built-in Jacobi preconditioner (iterative_lsmr.jl:129-141).  The storage argument P of the
-    reference is not needed: the solver owns it."""
+    """LSMR(preconditioner!, P) (types.jl:82-86).
+
+    * `LSMR(preconditioner=fn)` -- DIAGONAL preconditioners, fused into the device-resident recurrence: `fn(P, J, damp)` is
+      the reference's preconditioner!(P, x, J, damp); it must fill the DeviceVector P with the factors the preconditioner
+      solve multiplies by (an InverseDiagonal stores the inverse, iterative_lsmr.jl:117-122) for J'J + diag(damp); damp is a
+      DeviceVector with the un-rooted damping or None (Dogleg).  The solver owns the storage P.
+    * `LSMR(preconditioner=fn, P=obj)` -- ANY preconditioner that supports ldiv! (README.md:47 of the reference): `obj` is the
+      caller's own object with a method `obj.ldiv(out, x)` (= ldiv!(out, P, x) on DeviceVectors); `fn(obj, J, damp)` refreshes
+      it before every solve (None: P never changes).  Runs the operator-level recurrence (lsq_lsmr_general.hip): the slow
+      path, as a user-supplied P is in the reference.
+    Either callback runs on the host before / inside every solve.  None = the built-in Jacobi preconditioner
+    (iterative_lsmr.jl:129-141)."""
     kind = _lib.LSMR
 
     def __init__(self, preconditioner=None, P=None):
-        if P is not None:
-            raise NotImplementedError("LSMR(preconditioner!, P): the solver owns the (diagonal) storage; pass "
-                                      "only the callable")
+        if P is not None and not hasattr(P, "ldiv"):
+            raise TypeError("LSMR(preconditioner!, P): P must provide ldiv(out, x)  (ldiv!(out, P, x))")
         self.preconditioner = preconditioner
+        self.P = P
+
+
+def _general_precond_trampolines(solver, ctx, J):
+    """(update_cb, ldiv_cb) for LSMR(preconditioner!, P) with a general P."""
+    P, fn = solver.P, solver.preconditioner
+
+    def _update(_jh, d_damp, _user):
+        try:
+            if fn is not None:
+                fn(P, J, DeviceVector.borrow(ctx, J.n, d_damp) if d_damp else None)
+            return 0
+        except Exception as e:   # pragma: no cover
+            import sys
+            print("preconditioner! callback failed:", e, file=sys.stderr)
+            return 1
+
+    def _ldiv(d_out, d_in, _user):
+        try:
+            P.ldiv(DeviceVector.borrow(ctx, J.n, d_out), DeviceVector.borrow(ctx, J.n, d_in))
+            return 0
+        except Exception as e:   # pragma: no cover
+            import sys
+            print("preconditioner ldiv callback failed:", e, file=sys.stderr)
+            return 1
+
+    return _lib.PRECOND_UPDATE_CALLBACK(_update), _lib.PRECOND_LDIV_CALLBACK(_ldiv)
 
 
 def _precond_trampoline(fn, ctx, J):
@@ -478,7 +509,10 @@ class AllocatedSolver:
         check(lib().lsq_solver_create(J.ctx.h, J.h, solver.kind, 1 if for_lm else 0, C.byref(h)))
         self.h, self.J = h, J
         self._pc = None
-        if getattr(solver, "preconditioner", None) is not None:
+        if getattr(solver, "P", None) is not None:
+            self._pc = _general_precond_trampolines(solver, J.ctx, J)
+            check(lib().lsq_solver_set_general_preconditioner(self.h, self._pc[0], self._pc[1], None))
+        elif getattr(solver, "preconditioner", None) is not None:
             self._pc = _precond_trampoline(solver.preconditioner, J.ctx, J)
             check(lib().lsq_solver_set_preconditioner(self.h, self._pc, None))
 
@@ -625,7 +659,7 @@ def converged(r):
 
 def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_tol, f_tol, g_tol,
                 iterations, delta, lower, upper, trace, n, allreduce=None, preconditioner=None, row_allreduce=None,
-                row_allreduce_user=None, global_rows=0):
+                row_allreduce_user=None, global_rows=0, general_preconditioner=None):
     L = lib()
     opt = _lib.Options()
     L.lsq_options_default(C.byref(opt))
@@ -653,6 +687,9 @@ def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_
     if preconditioner is not None:
         opt.preconditioner = preconditioner
         keep.append(preconditioner)
+    if general_preconditioner is not None:     # LSMR(preconditioner!, P) with a general P: (update_cb, ldiv_cb)
+        opt.precond_update, opt.precond_ldiv = general_preconditioner
+        keep.append(general_preconditioner)
     if row_allreduce is not None:       # row-sharded single problem (lsq_options.row_allreduce; rowshard.py)
         opt.row_allreduce = row_allreduce
         opt.row_allreduce_user = row_allreduce_user
@@ -764,13 +801,16 @@ def optimize_(nls, optimizer=None, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iteration
     try:
         if not is_op:
             bind_stage()
-        pc = None
-        if getattr(solver, "preconditioner", None) is not None:
+        pc = gpc = None
+        if getattr(solver, "P", None) is not None:
+            gpc = _general_precond_trampolines(solver, ctx, Jd)
+        elif getattr(solver, "preconditioner", None) is not None:
             pc = _precond_trampoline(solver.preconditioner, ctx, Jd)
         # row_allreduce: a rowshard.RcclRowAllreduce / HostStagedRowAllreduce -- nls then holds this rank's ROWS of one
         # larger problem (J, y local; x replicated), SURVEY 8f-4
         st, res, tr = _run_native(ctx, optimizer.kind, solver.kind, Jd, dx, dy, F, G, None, x_tol, f_tol,
                                   g_tol, iterations, delta, lower, upper, tracing, n, preconditioner=pc,
+                                  general_preconditioner=gpc,
                                   row_allreduce=row_allreduce.callback if row_allreduce is not None else None,
                                   row_allreduce_user=row_allreduce.user if row_allreduce is not None else None,
                                   global_rows=global_rows)

@@ -531,7 +531,8 @@ static inline int nvec_grid(const lsq_ctx *c, int n) {
 
 // d_damp == nullptr: undamped (Dogleg, atol = btol = 1e-6); else LM (btol = 0.5).
 bool lsq_lsmr_takes_lm_prep(const lsq_solver *s, const lsq_mat *J) {
-    return s->kind == LSQ_LSMR && J->n <= LSMR_LM_PREP_MAX_N && !lsq_small_mat(J) && !s->precond_cb && !getenv("LSQ_LSMR_SEPARATE_SETUP");
+    return s->kind == LSQ_LSMR && J->n <= LSMR_LM_PREP_MAX_N && !lsq_small_mat(J) && !s->precond_cb && !s->gen_ldiv &&
+           !getenv("LSQ_LSMR_SEPARATE_SETUP");
 }
 
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
@@ -541,6 +542,14 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     if (m != s->m || n != s->n) {
         lsq_set_error("lsmr: solver allocated for %dx%d, Jacobian is %dx%d", s->m, s->n, m, n);
         return LSQ_EDIM;
+    }
+    if (s->gen_ldiv) {     // LSMR(preconditioner!, P) with a general P: the operator-level recurrence (lsq_lsmr_general.hip)
+        if (s->row_cb) {
+            lsq_set_error("row-sharded solves take diagonal preconditioners only");
+            return LSQ_EARG;
+        }
+        LSQ_TRY(lsq_lsmr_general_solve(s, J, d_y, d_damp, d_x, nmul));
+        return tail && tail->fn ? tail->fn(nullptr, tail->user) : LSQ_OK;
     }
     const bool sharded = s->row_cb != nullptr;     // J is a row block: the adjoint product is summed over the ranks
     if (lsq_small_mat(J) && !s->precond_cb && !sharded) {   // reference-order kernel

@@ -693,7 +693,8 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
     int iter = 0, nonfinite_at = -1;
     LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
     const int gn = ngrid(c, n);
-    const bool exact = lsq_small_mat(J) && !sharded;  // reference summation order for small problems (lsq_exact.hip)
+    // reference summation order for small problems (lsq_exact.hip); a general preconditioner runs the operator-level LSMR
+    const bool exact = lsq_small_mat(J) && !sharded && !(sv->kind == LSQ_LSMR && sv->gen_ldiv);
     unsigned long long colsum_global_version = ~0ull;   // (sharded) version of J whose cached colsumabs2 holds the ranks' sum
     int last_inner = 0;          // inner iterations of the previous LSMR solve of this run: the guess for the next one (LsmrTail)
     int local_done = 0;
@@ -1116,6 +1117,9 @@ extern "C" int lsq_optimize(lsq_ctx *c, int optimizer, int solver_kind, lsq_mat 
     if (w->solver->kind == LSQ_LSMR) {   // LSMR(preconditioner!, P): per call, the cached solver may have had another one
         w->solver->precond_cb = opt->preconditioner;
         w->solver->precond_user = opt->preconditioner_user;
+        w->solver->gen_update = opt->precond_update;
+        w->solver->gen_ldiv = opt->precond_ldiv;
+        w->solver->gen_user = opt->precond_general_user;
     }
     if (opt->row_allreduce) {   // row-sharded single problem
         if (!lm || w->solver->kind != LSQ_LSMR || opt->allreduce || J->kind == LSQ_MAT_OP) {

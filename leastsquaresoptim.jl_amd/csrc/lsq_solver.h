@@ -83,8 +83,13 @@ struct lsq_solver {
     size_t work_elems = 0;
     std::vector<double> h_R;   // n*n host copy for pivoting / rank decisions
     int last_rank = -1;
-    int (*precond_cb)(double *, lsq_mat *, const double *, void *) = nullptr;   // LSMR(preconditioner!, P)
+    int (*precond_cb)(double *, lsq_mat *, const double *, void *) = nullptr;   // LSMR(preconditioner!, P), diagonal P
     void *precond_user = nullptr;
+    // LSMR(preconditioner!, P) with ANY P supporting ldiv! (lsq_lsmr_general.hip): update = preconditioner!(P, x, J, damp),
+    // ldiv = ldiv!(out, P, in).  Set => the operator-level LSMR runs instead of the fused one.
+    int (*gen_update)(lsq_mat *, const double *, void *) = nullptr;
+    int (*gen_ldiv)(double *, const double *, void *) = nullptr;
+    void *gen_user = nullptr;
     void *qr2 = nullptr;            // two-stage QR workspace (lsq_dense.hip), allocated on first use
     void (*qr2_free)(void *) = nullptr;
     void *tripipe = nullptr;        // pipelined triangular solves of the blocked Cholesky (lsq_dense.hip)
@@ -190,6 +195,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                    const LsmrTail *tail = nullptr);
 // whether lsq_lsmr_solve takes the LsmrLmPrep route for this solver / Jacobian (else the caller launches its own damping)
 bool lsq_lsmr_takes_lm_prep(const lsq_solver *s, const lsq_mat *J);
+// implemented in lsq_lsmr_general.hip (operator-level LSMR around a caller-supplied ldiv!(., P, .))
+int lsq_lsmr_general_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul);
 // implemented in lsq_exact.hip (reference-order kernels for small problems)
 int lsq_lsmr_exact_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul);
 // implemented in lsq_dense.hip

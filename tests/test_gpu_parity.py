@@ -875,6 +875,101 @@ def test_lsmr_custom_preconditioner(ctx):
         lsq.set_exact(None)
 
 
+def test_lsmr_general_preconditioner(ctx):
+    """LSMR(preconditioner!, P) with ANY P that supports ldiv! (README.md:47 of the reference; types.jl:82-86), through the
+    operator-level recurrence of lsq_lsmr_general.hip:
+    (1) the default Jacobi rule restated as a general P (an object with ldiv) must walk the built-in solver's iterations:
+        identical mvps, solution to 1e-10 -- damped (LM) and undamped (Dogleg);
+    (2) a genuinely NON-diagonal, symmetric P -- the symmetric square root of 4 x 4 diagonal blocks of J'J + diag(damp) --
+        against scipy's LSMR (the same Fong-Saunders algorithm) run on the explicitly preconditioned operator
+        [J; sqrt(damp)] inv(P) with the reference's tolerances: equal iteration counts, x to 1e-8;
+    (3) the whole loop: optimize! with LevenbergMarquardt(LSMR(update, P)) for the Jacobi-as-general P equals the default run."""
+    import scipy.sparse.linalg as spla
+    lsq.set_exact(False)
+    try:
+        m, n = 3000, 120
+        S = rand_csc(m, n, 0.05, 314)
+        rng = np.random.default_rng(15)
+        y = rng.standard_normal(m)
+        damp = rng.random(n) + 0.05
+        J = lsq.DeviceMatrix(ctx, S)
+        Sd = S.toarray()
+
+        class JacobiP:
+            def __init__(self):
+                self.d = np.ones(n)
+
+            def ldiv(self, out, x):            # ldiv!(out, ::InverseDiagonal, x) = x .* stored inverse
+                out.set(x.get() * self.d)
+
+        def jacobi_update(Pobj, Jm, dmp):
+            cs = lsq.colsumabs2_(lsq.DeviceVector(ctx, n), Jm).get() + (dmp.get() if dmp is not None else 0.0)
+            Pobj.d = np.where(cs > 0, 1.0 / np.sqrt(cs), 0.0)
+
+        class BlockP:
+            """P = blockdiag(sqrtm(B_k)), B_k the 4 x 4 diagonal blocks of J'J + diag(damp): symmetric positive definite."""
+
+            def __init__(self):
+                self.Pinv = np.eye(n)
+
+            def ldiv(self, out, x):
+                out.set(self.Pinv @ x.get())
+
+        def block_update(Pobj, Jm, dmp):
+            G = Sd.T @ Sd + (np.diag(dmp.get()) if dmp is not None else 0.0)
+            Pinv = np.zeros((n, n))
+            for k in range(0, n, 4):
+                w, V = np.linalg.eigh(G[k:k + 4, k:k + 4])
+                Pinv[k:k + 4, k:k + 4] = (V / np.sqrt(w)) @ V.T
+            Pobj.Pinv = Pinv
+
+        for damped in (True, False):
+            args = lambda: (lsq.DeviceVector(ctx, m, y),) + ((lsq.DeviceVector(ctx, n, damp),) if damped else ())  # noqa: E731
+            ref = lsq.DeviceVector(ctx, n)
+            _, nm0 = lsq.AllocatedSolver(J, lsq.LSMR(), for_lm=damped).ldiv_(ref, *args())
+            out = lsq.DeviceVector(ctx, n)
+            _, nm1 = lsq.AllocatedSolver(J, lsq.LSMR(jacobi_update, JacobiP()), for_lm=damped).ldiv_(out, *args())
+            assert nm1 == nm0 > 0
+            assert np.max(np.abs(out.get() - ref.get())) <= 1e-10 * max(1.0, np.max(np.abs(ref.get())))
+            # (2) non-diagonal P vs scipy on the explicit operator
+            Pb = BlockP()
+            _, nm2 = lsq.AllocatedSolver(J, lsq.LSMR(block_update, Pb), for_lm=damped).ldiv_(out, *args())
+            A = np.vstack([Sd, np.diag(np.sqrt(damp))]) if damped else Sd
+            b = np.concatenate([y, np.zeros(n)]) if damped else y
+            z, istop, itn = spla.lsmr(A @ Pb.Pinv, b, atol=1e-6, btol=0.5 if damped else 1e-6, conlim=1e8,
+                                      maxiter=max(A.shape))[:3]
+            assert nm2 == 2 * itn, (nm2, itn, istop)
+            xs = Pb.Pinv @ z
+            assert np.max(np.abs(out.get() - xs)) <= 1e-8 * max(1.0, np.max(np.abs(xs)))
+        # only LSMR takes one
+        svc = lsq.AllocatedSolver(lsq.DeviceMatrix(ctx, np.eye(4)), lsq.Cholesky(), for_lm=True)
+        assert lsq.lib().lsq_solver_set_general_preconditioner(svc.h, lsq._lib.PRECOND_UPDATE_CALLBACK(lambda *a: 0),
+                                                               lsq._lib.PRECOND_LDIV_CALLBACK(lambda *a: 0), None) == lsq._lib.EARG
+        # (3) whole loop
+        p = list(P.minpack_all())[0]
+        name, f, g, x0 = p[:4]
+        nn = len(x0)
+
+        class JP:
+            d = np.ones(nn)
+
+            def ldiv(self, o, x):
+                o.set(x.get() * self.d)
+
+        def jp_update(Pobj, Jm, dmp):
+            cs = lsq.colsumabs2_(lsq.DeviceVector(ctx, nn), Jm).get() + (dmp.get() if dmp is not None else 0.0)
+            Pobj.d = np.where(cs > 0, 1.0 / np.sqrt(cs), 0.0)
+
+        res = []
+        for solver in (lsq.LSMR(), lsq.LSMR(jp_update, JP())):
+            nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.zeros(nn), f_=f, g_=g, J=np.zeros((nn, nn), order="F"))
+            res.append(lsq.optimize_(nls, lsq.LevenbergMarquardt(solver)))
+        assert res[0].iterations == res[1].iterations and res[0].mul_calls == res[1].mul_calls
+        assert res[0].ssr == pytest.approx(res[1].ssr, rel=1e-9, abs=1e-20)
+    finally:
+        lsq.set_exact(None)
+
+
 def test_allocated_problem_is_reusable(ctx):
     """LeastSquaresProblemAllocated (types.jl:141-160; exported): allocate once, optimize! repeatedly -- same
     results as fresh problems, from the same and from a different start."""

@@ -59,8 +59,8 @@ def test_problem_constructor_checks():
         lsq.LeastSquaresProblem(x=np.zeros(3), f_=f)
     p = lsq.LeastSquaresProblem(x=np.zeros(3), f_=f, J=np.zeros((5, 3)))
     assert len(p.y) == 5  # output_length defaults to size(J, 1) (test/runtests.jl:54-61)
-    with pytest.raises(NotImplementedError):
-        lsq.LSMR(preconditioner=lambda *a: None, P=1)
+    with pytest.raises(TypeError):
+        lsq.LSMR(preconditioner=lambda *a: None, P=1)        # a general P must provide ldiv(out, x)
 
 
 def test_synthetic_generator_is_deterministic_and_well_formed():
