@@ -218,11 +218,16 @@ k_chol_panel_mfma(double *__restrict__ C, int n, int j0, int *__restrict__ info,
 // 64 columns is: factor + inverse 14 us, one flag, 5 us row-panel tile, one flag, 4 us update of the next diagonal tile.
 constexpr size_t CHT_LDS = (size_t)(3 * S64_MAT + S64_TMP) * sizeof(double);
 constexpr int CHT_SPIN_LIMIT = 1 << 22;
-__device__ __forceinline__ bool cht_wait(const unsigned *flag, unsigned epoch, int *info, int spin_limit) {
+__device__ __forceinline__ bool cht_wait(const unsigned *flag, unsigned epoch, int *info, int spin_limit,
+                                         const unsigned *flag2 = nullptr) {   // flag2: a second flag to wait for (same bound)
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
         int ok = 1, spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        const unsigned *f2 = flag2 ? flag2 : flag;       // (both loads are in flight together)
+        for (;;) {
+            const unsigned a = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned b = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a == epoch && b == epoch) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > spin_limit) {
                 ok = 0;
@@ -244,8 +249,7 @@ __device__ __forceinline__ bool cht_wait(const unsigned *flag, unsigned epoch, i
 // PUBLISHED = the tile was written by ANOTHER workgroup of this launch (cht_publish): agent-scope atomic loads, so that
 // neither the compiler (no invariance / no-alias assumption) nor a non-coherent cache level can serve a stale value
 template <bool PUBLISHED>
-__device__ __forceinline__ void cht_load(double *M, const double *C, int n, int ti, int tj, int tid) {
-    double g[16];
+__device__ __forceinline__ void cht_fetch(double (&g)[16], const double *C, int n, int ti, int tj, int tid) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int e = tid + 256 * q, r = e & 63, c = e >> 6;
@@ -256,11 +260,34 @@ __device__ __forceinline__ void cht_load(double *M, const double *C, int n, int 
         else
             g[q] = (ti == tj && r == c) ? 1.0 : 0.0;
     }
+}
+__device__ __forceinline__ void cht_stash(double *M, const double (&g)[16], int tid) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int e = tid + 256 * q, r = e & 63, c = e >> 6;
         M[r * S64_LS + c] = g[q];
     }
+}
+template <bool PUBLISHED>
+__device__ __forceinline__ void cht_load(double *M, const double *C, int n, int ti, int tj, int tid) {
+    double g[16];
+    cht_fetch<PUBLISHED>(g, C, n, ti, tj, tid);
+    cht_stash(M, g, tid);
+}
+// the stores of cht_publish without the drain and the flag (cht_release later)
+__device__ __forceinline__ void cht_store(double *C, int n, int ti, int tj, const double *M, bool upper_only, int tid) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * q, r = e & 63, c = e >> 6;
+        const int gr = 64 * ti + r, gc = 64 * tj + c;
+        if (gr < n && gc < n && (!upper_only || r <= c))
+            __hip_atomic_store(C + (size_t)gc * n + gr, M[r * S64_LS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void cht_release(unsigned *flag, unsigned epoch, int tid) {   // every wave drains, then one flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void cht_publish(double *C, int n, int ti, int tj, const double *M, bool upper_only,
                                             unsigned *flag, unsigned epoch, int tid) {
@@ -348,6 +375,239 @@ k_chol_tiles(double *C, int n, int nt, int *info, double *Xd, unsigned *flags,  
         __syncthreads();
         s64_gemm<true, false, S64_LF>(M2, M1, M0, 1.0, tid);   // U(i, j) = inv(U(i, i))' tile
         cht_publish(C, n, ti, tj, M2, false, myflag, epoch, tid);
+    }
+}
+
+// ---- the same factorisation with the DIAGONAL CHAIN inside one workgroup ----------------------------------------------
+// In k_chol_tiles every 64 columns of the critical path cross workgroups twice: (i, i) -> flag -> (i, i+1) -> flag ->
+// (i+1, i+1), each hop a drain of the stores, a release, a poll and a reload of a 32 KB tile (~26 us per 64 columns for
+// ~14 us of arithmetic).  Here workgroup 0 (the chain) keeps the whole path local:
+//     chain, step i:   M0 = T2'(i) - U(i-1, i)' U(i-1, i)   (T2' = the diagonal tile with the terms k <= i-2 applied, published
+//                                                             by the helper of (i, i); U(i-1, i) is still in this LDS)
+//                      U(i, i) = chol(M0);  publish it with the four inv(U_kk)' blocks (Wd)              -> flag D(i)
+//                      T1'(i) (tile (i, i+1) with every term k < i applied, published by ITS helper)  -> U(i, i+1) by
+//                      forward block substitution in registers;  publish                                 -> flag F(i, i+1)
+//     helper (i, i):   accumulates k <= i-2, publishes T2' (flag P); later, off the path, turns D(i) into the full inverse
+//                      Xd[i] the pipelined triangular solves read
+//     helper (i, i+1): accumulates k < i, publishes T1' (flag P)
+//     tile (i, j>i+1): as before, but it waits for D(i) only and substitutes with the 16 x 16 inverse blocks (no full inverse
+//                      on anybody's path)
+// The helpers' inputs are ready a whole chain step early (the chain is the slowest producer), so the chain's own waits are
+// normally satisfied at once.  Deadlock: the chain waits for helpers of rows <= i, they wait for tiles of rows < i and for
+// D(<= i); no cycle, all workgroups resident (tiles + 1 <= CUs).  Giving up / a non-positive pivot: as in k_chol_tiles,
+// plus the chain releases every flag it owns.
+// X (64 x 64, LDS) <- inv(U)' X for an upper triangular U whose inv(U_kk)' blocks are the diagonal blocks of W: forward
+// substitution over the four block rows; wavefront = 16 columns, which it carries through all four stages in registers --
+// the accumulator layout of v_mfma_f64_16x16x4 (lane (j, q) holds rows q + 4 r) IS the B-operand layout of the next product
+// when its k index is taken as 4 kk + q, so nothing goes back through LDS between the stages.
+__device__ __forceinline__ void s64_trsm_blocks(double *X, const double *U, const double *W, int tid) {
+    const int lane = tid & 63, c = tid >> 6, ij = lane & 15, kq = lane >> 4;
+    s64_v4d x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s64_v4d t;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) t[rr] = X[(16 * r + kq + 4 * rr) * S64_LS + 16 * c + ij];
+        if (r > 0) {
+            s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < r; ++q)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)      // U(q, r)' X_q : A[i][k] = U[16 q + k][16 r + i]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[(16 * q + 4 * kk + kq) * S64_LS + 16 * r + ij], x[q][kk], acc, 0, 0, 0);
+            t -= acc;
+        }
+        s64_v4d y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            y = __builtin_amdgcn_mfma_f64_16x16x4f64(W[(16 * r + ij) * S64_LS + 16 * r + 4 * kk + kq], t[kk], y, 0, 0, 0);
+        x[r] = y;
+    }
+    __syncthreads();                                  // (every wavefront has read its columns of X)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) X[(16 * r + kq + 4 * rr) * S64_LS + 16 * c + ij] = x[r][rr];
+    __syncthreads();
+}
+// 16 x 16 tile (a, b) of M -= B'B (B: 64 x 64 in LDS), one wavefront; the operands are loaded eight k-steps ahead of the products
+__device__ __forceinline__ void s64_syrk_tile_sub(double *M, const double *B, int a, int b, int lane) {
+    const int ij = lane & 15, kq = lane >> 4;
+    s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double x[8], y[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = 32 * h + 4 * kk + kq;
+            x[kk] = B[k * S64_LS + 16 * a + ij];
+            y[kk] = B[k * S64_LS + 16 * b + ij];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kk], y[kk], acc, 0, 0, 0);
+    }
+    s64_tile_store<true>(M, 16 * a, 16 * b, acc, -1.0, lane);
+}
+// the four inv(U_kk)' blocks of a diagonal tile: LDS image (diagonal block positions of W) <-> Wd[tile][kb][16 x 16]
+__device__ __forceinline__ void chc_store_w(double *Wd, int i, const double *W, int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, o = 16 * (e >> 8), r = (e >> 4) & 15, c = e & 15;
+        __hip_atomic_store(Wd + (size_t)i * 1024 + e, W[(o + r) * S64_LS + o + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// sixteen rows (from R0) of the diagonal tile (i, i) and inverse block kb, stored by `nthreads` threads (t = 0..nthreads-1)
+__device__ __forceinline__ void chc_store_rows(double *C, int n, int i, const double *M, int R0, int t, int nthreads) {
+    for (int e = t; e < 1024; e += nthreads) {
+        const int r = R0 + (e & 15), c = e >> 4;
+        const int gr = 64 * i + r, gc = 64 * i + c;
+        if (gr < n && gc < n && r <= c)
+            __hip_atomic_store(C + (size_t)gc * n + gr, M[r * S64_LS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void chc_store_wblock(double *Wd, int i, const double *W, int kb, int t, int nthreads) {
+    for (int e = t; e < 256; e += nthreads)
+        __hip_atomic_store(Wd + (size_t)i * 1024 + kb * 256 + e, W[(16 * kb + (e >> 4)) * S64_LS + 16 * kb + (e & 15)], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chc_load_w(double *W, const double *Wd, int i, int tid) {
+    double g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = __hip_atomic_load(Wd + (size_t)i * 1024 + tid + 256 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, o = 16 * (e >> 8), r = (e >> 4) & 15, c = e & 15;
+        W[(o + r) * S64_LS + o + c] = g[q];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_chol_chain(double *C, int n, int nt, int *info, double *Xd, double *Wd, unsigned *flags, unsigned *pflags,
+             unsigned epoch, unsigned wait_epoch, int spin_limit, long long *trace) {   // trace: LSQ_CHOL_TRACE (10 ns ticks)
+#define CHC_STAMP(p) do { if (trace && tid == 0) trace[i * 16 + (p)] = wall_clock64(); } while (0)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *M0 = sm, *M1 = sm + S64_MAT, *M2 = sm + 2 * S64_MAT, *T = sm + 3 * S64_MAT;
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x == 0) {                                   // ---- the chain
+        // step i:  chol(i) | stores of D(i) | wait for T1'(i) and T2'(i+1), both fetched at once | T1' -> LDS, D(i) released |
+        //          U(i, i+1) by substitution | its stores | T2'(i+1) -> LDS, -= U(i, i+1)'U(i, i+1) | F(i, i+1) released
+        bool ok = true;
+        cht_load<false>(M0, C, n, 0, 0, tid);
+        __syncthreads();
+        for (int i = 0; i < nt; ++i) {
+            CHC_STAMP(0);
+            // the six tiles of M0 -= U(i-1, i)'U(i-1, i) that the first diagonal block does not touch are formed by wavefronts
+            // 1..3 while wavefront 0 factors that block (the four tiles of block row 0 were formed before: see below)
+            const bool pending = i > 0;
+            // ... and the rows of U(i, i) and the inverse block that the previous diagonal block finished go to memory
+            const int bad = s64_chol<false>(M0, M1, &s_fail, tid, trace ? trace + 512 + i * 16 : nullptr, [&](int kb, int w, int ln) {
+                if (kb == 0) {
+                    if (!pending) return;
+                    if (w == 1) { s64_syrk_tile_sub(M0, M2, 1, 1, ln); s64_syrk_tile_sub(M0, M2, 1, 2, ln); }
+                    if (w == 2) { s64_syrk_tile_sub(M0, M2, 1, 3, ln); s64_syrk_tile_sub(M0, M2, 2, 2, ln); }
+                    if (w == 3) { s64_syrk_tile_sub(M0, M2, 2, 3, ln); s64_syrk_tile_sub(M0, M2, 3, 3, ln); }
+                } else {
+                    chc_store_rows(C, n, i, M0, 16 * (kb - 1), 64 * (w - 1) + ln, 192);
+                    chc_store_wblock(Wd, i, M1, kb - 1, 64 * (w - 1) + ln, 192);
+                }
+            });
+            if (bad) {
+                if (tid == 0) atomicCAS(info, 0, 64 * i + bad);   // PosDefException position (1-based)
+                ok = false;
+                break;
+            }
+            CHC_STAMP(1);
+            chc_store_rows(C, n, i, M0, 48, tid, 256);
+            chc_store_wblock(Wd, i, M1, 3, tid, 256);
+            if (i + 1 == nt) {
+                cht_release(flags + i * nt + i, epoch, tid);
+                break;
+            }
+            ok = cht_wait(pflags + i * nt + i + 1, wait_epoch, info, spin_limit, pflags + (i + 1) * nt + i + 1);
+            if (!ok) break;
+            CHC_STAMP(2);
+            double g1[16], g2[16];
+            cht_fetch<true>(g1, C, n, i, i + 1, tid);         // T1'(i)
+            cht_fetch<true>(g2, C, n, i + 1, i + 1, tid);     // T2'(i+1): in flight during the substitution
+            cht_stash(M2, g1, tid);
+            cht_release(flags + i * nt + i, epoch, tid);      // D(i) (drains the fetches as well; the barrier covers M2)
+            __syncthreads();
+            CHC_STAMP(3);
+            s64_trsm_blocks(M2, M0, M1, tid);
+            CHC_STAMP(4);
+            cht_store(C, n, i, i + 1, M2, false, tid);
+            CHC_STAMP(6);
+            cht_stash(M0, g2, tid);                           // (U(i, i) has been published and used)
+            __syncthreads();
+            CHC_STAMP(7);
+            s64_syrk_tile_sub(M0, M2, 0, wv, lane);           // block row 0 now; the rest inside the next chol
+            CHC_STAMP(5);
+            cht_release(flags + i * nt + i + 1, epoch, tid);  // F(i, i+1)
+            __syncthreads();
+        }
+#undef CHC_STAMP
+        if (!ok && tid < nt) {     // nobody may be left waiting for the chain
+            __hip_atomic_store(flags + tid * nt + tid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid + 1 < nt) __hip_atomic_store(flags + tid * nt + tid + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    int t = blockIdx.x - 1, ti = 0;
+    while (t >= nt - ti) { t -= nt - ti; ++ti; }
+    const int tj = ti + t;
+    const bool diag = tj == ti, sup = tj == ti + 1;
+    unsigned *myflag = (diag || sup) ? pflags + ti * nt + tj : flags + ti * nt + tj;
+    cht_load<false>(M0, C, n, ti, tj, tid);
+    __syncthreads();
+    bool ok = true;
+    const int kend = diag ? ti - 1 : ti;                     // (the chain applies k = i-1 to its diagonal tile itself)
+    for (int k = 0; k < kend && ok; ++k) {
+        ok = cht_wait(flags + k * nt + ti, wait_epoch, info, spin_limit);
+        if (ok && !diag) ok = cht_wait(flags + k * nt + tj, wait_epoch, info, spin_limit);
+        if (!ok) break;
+        cht_load<true>(M1, C, n, k, ti, tid);
+        if (!diag) cht_load<true>(M2, C, n, k, tj, tid);
+        __syncthreads();
+        const double *B = diag ? M1 : M2;
+        for (int q = wv; q < 16; q += 4) {
+            const int a = q >> 2, b = q & 3;
+            if (diag && a > b) continue;
+            s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            s64_tile_mma<true, false>(acc, M1, 0, 16 * a, B, 0, 16 * b, 4, lane);
+            s64_tile_store<true>(M0, 16 * a, 16 * b, acc, -1.0, lane);
+        }
+        __syncthreads();
+    }
+    if (!ok) {
+        if (tid == 0) __hip_atomic_store(myflag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (diag) {
+        if (ti > 0) cht_publish(C, n, ti, ti, M0, true, myflag, epoch, tid);              // T2'(i)
+        if (!cht_wait(flags + ti * nt + ti, wait_epoch, info, spin_limit)) return;
+        cht_load<true>(M0, C, n, ti, ti, tid);               // U(i, i) (the blocks below the diagonal blocks are not read)
+        chc_load_w(M1, Wd, ti, tid);
+        __syncthreads();
+        s64_chol_inverse(M0, M1, T, tid);                    // M1 = inv(U(i, i)): what the pipelined triangular solves read
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e & 63, c = e >> 6;
+            const bool in = 64 * ti + r < n && 64 * ti + c < n;
+            Xd[(size_t)ti * 4096 + (size_t)c * 64 + r] = in ? M1[r * S64_LS + c] : 0.0;
+        }
+    } else if (sup) {
+        cht_publish(C, n, ti, tj, M0, false, myflag, epoch, tid);                           // T1'(i): the chain finishes it
+    } else {
+        if (!cht_wait(flags + ti * nt + ti, wait_epoch, info, spin_limit)) {
+            if (tid == 0) __hip_atomic_store(myflag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        cht_load<true>(M1, C, n, ti, ti, tid);
+        chc_load_w(M2, Wd, ti, tid);
+        __syncthreads();
+        s64_trsm_blocks(M0, M1, M2, tid);
+        cht_publish(C, n, ti, tj, M0, false, myflag, epoch, tid);
     }
 }
 
@@ -556,16 +816,48 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     if (allow_tiles && !s->fb_tiles.off() && ntiles <= c->num_cus && n >= 2 * NB && !getenv("LSQ_CHOL_PANELS")) {
         double *Xt = lsq_tri_chol_diagbuf(s, n);
         if (Xt) {
+            // flags: [0, 1024) 'tile final' (D on the diagonal), [1024, 2048) 'partial tile for the chain'; then the
+            // 16 x 16 inverse blocks of the diagonal tiles (k_chol_chain)
+            constexpr size_t FLAG_BYTES = 2 * 32 * 32 * sizeof(unsigned);
             if (!s->d_chol_flags) {
-                LSQ_HIP(hipMalloc(&s->d_chol_flags, 32 * 32 * sizeof(unsigned)));
-                LSQ_ZERO(s->d_chol_flags, 0, 32 * 32 * sizeof(unsigned));   // (waits for the memset: see LSQ_ZERO)
+                LSQ_HIP(hipMalloc(&s->d_chol_flags, FLAG_BYTES + 32 * 1024 * sizeof(double)));
+                LSQ_ZERO(s->d_chol_flags, 0, FLAG_BYTES);   // (waits for the memset: see LSQ_ZERO)
             }
             if (++s->chol_epoch == 0) ++s->chol_epoch;
-            LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_tiles, CHT_LDS));
             const bool inject = getenv("LSQ_TEST_EXCHANGE_TIMEOUT") != nullptr;   // the waits never see their flag
-            hipLaunchKernelGGL(k_chol_tiles, dim3(ntiles), dim3(256), CHT_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
-                               s->d_chol_flags, s->chol_epoch, inject ? s->chol_epoch ^ 0x40000000u : s->chol_epoch,
-                               inject ? 64 : CHT_SPIN_LIMIT);
+            const unsigned wait_epoch = inject ? s->chol_epoch ^ 0x40000000u : s->chol_epoch;
+            static const bool v1 = getenv("LSQ_CHOL_TILES_V1") != nullptr;      // (A/B: the chain across workgroups)
+            if (!v1 && ntiles + 1 <= c->num_cus) {
+                LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_chain, CHT_LDS));
+                static const bool tracing = getenv("LSQ_CHOL_TRACE") != nullptr;   // (debug: the chain's phase stamps)
+                static long long *d_trace = nullptr;
+                if (tracing && !d_trace) { LSQ_HIP(hipMalloc(&d_trace, 64 * 16 * sizeof(long long))); }
+                hipLaunchKernelGGL(k_chol_chain, dim3(ntiles + 1), dim3(256), CHT_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
+                                   (double *)((char *)s->d_chol_flags + FLAG_BYTES), s->d_chol_flags, s->d_chol_flags + 1024,
+                                   s->chol_epoch, wait_epoch, inject ? 64 : CHT_SPIN_LIMIT, d_trace);
+                if (tracing) {
+                    long long h[64 * 16];
+                    LSQ_HIP(hipStreamSynchronize(c->stream));
+                    LSQ_HIP(hipMemcpy(h, d_trace, sizeof h, hipMemcpyDeviceToHost));
+                    static int shown = 0;
+                    if (shown++ % 50 == 10)
+                        for (int i = 0; i < nt; ++i) {
+                            fprintf(stderr, "chain step %2d:", i);
+                            for (int p = 1; p < 6 && !(i + 1 == nt && p > 1); ++p)
+                                fprintf(stderr, " %.2f", (h[i * 16 + p] - h[i * 16 + p - 1]) * 0.01);
+                            if (i + 1 < nt) fprintf(stderr, "   total %.2f us", (h[(i + 1) * 16] - h[i * 16]) * 0.01);
+                            if (i + 1 < nt) fprintf(stderr, "  [store %.2f stash %.2f syrk %.2f]", (h[i * 16 + 6] - h[i * 16 + 4]) * 0.01,
+                                                    (h[i * 16 + 7] - h[i * 16 + 6]) * 0.01, (h[i * 16 + 5] - h[i * 16 + 7]) * 0.01);
+                            fprintf(stderr, "\n    chol:");
+                            for (int p = 0; p < 12; ++p) fprintf(stderr, " %.2f", (h[512 + i * 16 + p] - (p ? h[512 + i * 16 + p - 1] : h[i * 16])) * 0.01);
+                            fprintf(stderr, "\n");
+                        }
+                }
+            } else {
+                LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_tiles, CHT_LDS));
+                hipLaunchKernelGGL(k_chol_tiles, dim3(ntiles), dim3(256), CHT_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
+                                   s->d_chol_flags, s->chol_epoch, wait_epoch, inject ? 64 : CHT_SPIN_LIMIT);
+            }
             s->chol_have_diaginv = true;
             s->last_chol_tiles = true;
             if (!d_x) { LSQ_HIP(hipGetLastError()); return LSQ_OK; }

@@ -106,11 +106,21 @@ __device__ __forceinline__ int s64_chol16(double *__restrict__ M, double *__rest
     }
     return bad;
 }
+// (An alternative measured and NOT used: tools/micro/chol16_bench.hip keeps a form of this routine in which every update
+// is one v_fmac_f64_dpp row_newbcast instead of two v_readlane_b32 + an fma -- 9.5 clocks instead of 22 per update
+// (tools/micro/dpp_probe.hip) -- with the matrix row copied into the identity lanes' row by v_permlane16_swap_b32.  Same
+// bits, but 4800 clocks per block against 4430 for this one: a single wavefront issues in order, the copy + broadcast
+// lengthen the dependent chain of every pivot by more than the updates save.)
 
 // ---- Cholesky G = U'U of a 64 x 64 matrix (upper triangle of M is read), in place: M <- U (zeros below) --------------
 // W receives the four inv(U_kk)' diagonal blocks (the other entries of W are not touched).  Returns 0, or (uniform)
 // 1 + the index of the first pivot that is not positive -- M then holds garbage.  `fail` is an LDS int.
-__device__ __forceinline__ int s64_chol(double *__restrict__ M, double *__restrict__ W, int *fail, int tid) {
+// idle(kb, wv, lane): what wavefronts 1..3 do while wavefront 0 factors diagonal block kb (no barriers in there; tiles of M
+// other than (kb, kb) and buffers other than W may be touched).
+struct S64NoIdle { __device__ __forceinline__ void operator()(int, int, int) const {} };
+template <bool ZERO_LOWER = true, class F = S64NoIdle>     // ZERO_LOWER = false: the blocks below the diagonal blocks keep G / garbage
+__device__ __forceinline__ int s64_chol(double *M, double *W, int *fail, int tid, long long *tr = nullptr,   // tr: debug stamps (10 ns)
+                                        F idle = F()) {
     const int lane = tid & 63, wv = tid >> 6;
     if (tid == 0) *fail = 0;
     __syncthreads();
@@ -119,7 +129,10 @@ __device__ __forceinline__ int s64_chol(double *__restrict__ M, double *__restri
         if (wv == 0) {
             const int bad = s64_chol16(M, W, o, lane);
             if (bad && lane == 0 && *fail == 0) *fail = o + bad;
+        } else {
+            idle(kb, wv, lane);
         }
+        if (tr && tid == 0) tr[3 * kb] = wall_clock64();
         __syncthreads();
         const int nt = 3 - kb;                   // tiles to the right
         if (wv < nt) {                           // row panel: U[o.., t] = inv(U_kk)' * G[o.., t]
@@ -129,6 +142,7 @@ __device__ __forceinline__ int s64_chol(double *__restrict__ M, double *__restri
             s64_tile_store<false>(M, o, 16 * t, acc, 1.0, lane);
         }
         __syncthreads();
+        if (tr && tid == 0) tr[3 * kb + 1] = wall_clock64();
         // trailing tiles (t <= t') -= U[o.., t]' U[o.., t']
         for (int q = wv; q < nt * (nt + 1) / 2; q += 4) {
             int t = 0, r = q;
@@ -139,13 +153,16 @@ __device__ __forceinline__ int s64_chol(double *__restrict__ M, double *__restri
             s64_tile_store<true>(M, 16 * ta, 16 * tb, acc, -1.0, lane);
         }
         __syncthreads();
+        if (tr && tid == 0) tr[3 * kb + 2] = wall_clock64();
     }
     // zeros below the diagonal blocks (the strictly lower tiles still hold G / garbage)
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        if ((r >> 4) > (c >> 4)) M[r * S64_LS + c] = 0.0;
+    if (ZERO_LOWER) {
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            if ((r >> 4) > (c >> 4)) M[r * S64_LS + c] = 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     return *fail;
 }
 
