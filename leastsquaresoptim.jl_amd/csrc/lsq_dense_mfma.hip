@@ -217,6 +217,7 @@ k_chol_panel_mfma(double *__restrict__ C, int n, int j0, int *__restrict__ info,
 // launch-per-panel path.  Against that path (8 x (24 us panel + 10 us update + launch gaps) at n = 512) the chain per
 // 64 columns is: factor + inverse 14 us, one flag, 5 us row-panel tile, one flag, 4 us update of the next diagonal tile.
 constexpr size_t CHT_LDS = (size_t)(3 * S64_MAT + S64_TMP) * sizeof(double);
+constexpr size_t CHC_LDS = (size_t)(4 * S64_MAT + S64_TMP) * sizeof(double);   // k_chol_chain: + the next diagonal tile
 constexpr int CHT_SPIN_LIMIT = 1 << 22;
 __device__ __forceinline__ bool cht_wait(const unsigned *flag, unsigned epoch, int *info, int spin_limit,
                                          const unsigned *flag2 = nullptr) {   // flag2: a second flag to wait for (same bound)
@@ -456,6 +457,26 @@ __device__ __forceinline__ void chc_store_w(double *Wd, int i, const double *W, 
         __hip_atomic_store(Wd + (size_t)i * 1024 + e, W[(o + r) * S64_LS + o + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// a published tile fetched / put into LDS by 192 threads (wavefronts 1..3 while wavefront 0 factors a diagonal block)
+__device__ __forceinline__ void chc_fetch192(double (&g)[22], const double *C, int n, int ti, int tj, int t) {
+    // element e = t + 192 q: row t & 63 (192 = 3 x 64), column (t >> 6) + 3 q -- one base address, one stride
+    const int r = t & 63, c0 = t >> 6, gr = 64 * ti + r;
+    const double *p = C + (size_t)(64 * tj + c0) * n + gr;
+    const size_t step = (size_t)3 * n;
+    const int cleft = n - (64 * tj + c0);                        // columns c0 + 3 q with 3 q < cleft are inside the matrix
+#pragma unroll
+    for (int q = 0; q < 22; ++q) {
+        const int c = c0 + 3 * q;
+        g[q] = (ti == tj && r == c) ? 1.0 : 0.0;
+        if (c < 64 && gr < n && 3 * q < cleft) g[q] = __hip_atomic_load(p + q * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void chc_stash192(double *M, const double (&g)[22], int t) {
+    const int r = t & 63, c0 = t >> 6;
+#pragma unroll
+    for (int q = 0; q < 22; ++q)
+        if (c0 + 3 * q < 64) M[r * S64_LS + c0 + 3 * q] = g[q];
+}
 // sixteen rows (from R0) of the diagonal tile (i, i) and inverse block kb, stored by `nthreads` threads (t = 0..nthreads-1)
 __device__ __forceinline__ void chc_store_rows(double *C, int n, int i, const double *M, int R0, int t, int nthreads) {
     for (int e = t; e < 1024; e += nthreads) {
@@ -490,61 +511,85 @@ k_chol_chain(double *C, int n, int nt, int *info, double *Xd, double *Wd, unsign
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (blockIdx.x == 0) {                                   // ---- the chain
-        // step i:  chol(i) | stores of D(i) | wait for T1'(i) and T2'(i+1), both fetched at once | T1' -> LDS, D(i) released |
-        //          U(i, i+1) by substitution | its stores | T2'(i+1) -> LDS, -= U(i, i+1)'U(i, i+1) | F(i, i+1) released
+        // step i:  chol(i); in the shadow of its diagonal blocks (wavefronts 1..3 are idle while wavefront 0 factors one):
+        //            block 0: the six tiles of M0 -= U(i-1, i)'U(i-1, i) that block 0 does not touch
+        //            block k: the rows of U(i, i) and the inverse block that block k-1 finished go to memory
+        //            block 2: wait for T2'(i+1) (published a chain step ago, normally) and bring it into the other diagonal buffer
+        //            block 3: the same for T1'(i)
+        //          last rows of D(i), D(i) released | U(i, i+1) by substitution | its stores | block row 0 of
+        //          T2'(i+1) -= U(i, i+1)'U(i, i+1) | F(i, i+1) released
+        // The diagonal tile being factored (Mc) and the next one (Mn, filled in a shadow) swap roles every step.
+        __shared__ int s_pfail;
+        double *Mc = M0, *Mn = sm + 3 * S64_MAT + S64_TMP;
         bool ok = true;
-        cht_load<false>(M0, C, n, 0, 0, tid);
+        cht_load<false>(Mc, C, n, 0, 0, tid);
+        if (tid == 0) s_pfail = 0;
         __syncthreads();
         for (int i = 0; i < nt; ++i) {
             CHC_STAMP(0);
-            // the six tiles of M0 -= U(i-1, i)'U(i-1, i) that the first diagonal block does not touch are formed by wavefronts
-            // 1..3 while wavefront 0 factors that block (the four tiles of block row 0 were formed before: see below)
-            const bool pending = i > 0;
-            // ... and the rows of U(i, i) and the inverse block that the previous diagonal block finished go to memory
-            const int bad = s64_chol<false>(M0, M1, &s_fail, tid, trace ? trace + 512 + i * 16 : nullptr, [&](int kb, int w, int ln) {
+            const bool pending = i > 0, more = i + 1 < nt;
+            const int bad = s64_chol<false>(Mc, M1, &s_fail, tid, trace ? trace + 512 + i * 16 : nullptr, [&](int kb, int w, int ln) {
+                const int t = 64 * (w - 1) + ln;
                 if (kb == 0) {
                     if (!pending) return;
-                    if (w == 1) { s64_syrk_tile_sub(M0, M2, 1, 1, ln); s64_syrk_tile_sub(M0, M2, 1, 2, ln); }
-                    if (w == 2) { s64_syrk_tile_sub(M0, M2, 1, 3, ln); s64_syrk_tile_sub(M0, M2, 2, 2, ln); }
-                    if (w == 3) { s64_syrk_tile_sub(M0, M2, 2, 3, ln); s64_syrk_tile_sub(M0, M2, 3, 3, ln); }
-                } else {
-                    chc_store_rows(C, n, i, M0, 16 * (kb - 1), 64 * (w - 1) + ln, 192);
-                    chc_store_wblock(Wd, i, M1, kb - 1, 64 * (w - 1) + ln, 192);
+                    if (w == 1) { s64_syrk_tile_sub(Mc, M2, 1, 1, ln); s64_syrk_tile_sub(Mc, M2, 1, 2, ln); }
+                    if (w == 2) { s64_syrk_tile_sub(Mc, M2, 1, 3, ln); s64_syrk_tile_sub(Mc, M2, 2, 2, ln); }
+                    if (w == 3) { s64_syrk_tile_sub(Mc, M2, 2, 3, ln); s64_syrk_tile_sub(Mc, M2, 3, 3, ln); }
+                    return;
                 }
+                chc_store_rows(C, n, i, Mc, 16 * (kb - 1), t, 192);
+                chc_store_wblock(Wd, i, M1, kb - 1, t, 192);
+                if (kb == 1 || !more) return;
+                // block 2: T2'(i+1) -> Mn;  block 3: T1'(i) -> M2 (U(i-1, i) in there was last read in the shadow of block 0)
+                const unsigned *f = kb == 2 ? pflags + (i + 1) * nt + i + 1 : pflags + i * nt + i + 1;
+                int got = 1;
+                if (ln == 0) {                                   // (every wavefront polls for itself: no barrier in here)
+                    int spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait_epoch) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > spin_limit) {
+                            got = 0;
+                            break;
+                        }
+                    }
+                    if (!got) {
+                        atomicExch(info, -1);
+                        atomicOr(&s_pfail, 1);
+                    }
+                }
+                got = __builtin_amdgcn_readfirstlane(got);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (!got) return;
+                double g[22];
+                chc_fetch192(g, C, n, kb == 2 ? i + 1 : i, i + 1, t);
+                chc_stash192(kb == 2 ? Mn : M2, g, t);
             });
             if (bad) {
                 if (tid == 0) atomicCAS(info, 0, 64 * i + bad);   // PosDefException position (1-based)
                 ok = false;
                 break;
             }
-            CHC_STAMP(1);
-            chc_store_rows(C, n, i, M0, 48, tid, 256);
-            chc_store_wblock(Wd, i, M1, 3, tid, 256);
-            if (i + 1 == nt) {
-                cht_release(flags + i * nt + i, epoch, tid);
+            if (s_pfail) {                                       // (uniform: read after the barriers that end s64_chol)
+                ok = false;
                 break;
             }
-            ok = cht_wait(pflags + i * nt + i + 1, wait_epoch, info, spin_limit, pflags + (i + 1) * nt + i + 1);
-            if (!ok) break;
-            CHC_STAMP(2);
-            double g1[16], g2[16];
-            cht_fetch<true>(g1, C, n, i, i + 1, tid);         // T1'(i)
-            cht_fetch<true>(g2, C, n, i + 1, i + 1, tid);     // T2'(i+1): in flight during the substitution
-            cht_stash(M2, g1, tid);
-            cht_release(flags + i * nt + i, epoch, tid);      // D(i) (drains the fetches as well; the barrier covers M2)
-            __syncthreads();
+            CHC_STAMP(1);
+            chc_store_rows(C, n, i, Mc, 48, tid, 256);
+            chc_store_wblock(Wd, i, M1, 3, tid, 256);
+            cht_release(flags + i * nt + i, epoch, tid);          // D(i)
+            if (!more) break;
             CHC_STAMP(3);
-            s64_trsm_blocks(M2, M0, M1, tid);
+            s64_trsm_blocks(M2, Mc, M1, tid);
             CHC_STAMP(4);
             cht_store(C, n, i, i + 1, M2, false, tid);
             CHC_STAMP(6);
-            cht_stash(M0, g2, tid);                           // (U(i, i) has been published and used)
-            __syncthreads();
-            CHC_STAMP(7);
-            s64_syrk_tile_sub(M0, M2, 0, wv, lane);           // block row 0 now; the rest inside the next chol
+            s64_syrk_tile_sub(Mn, M2, 0, wv, lane);               // block row 0 now; the rest inside the next chol
             CHC_STAMP(5);
-            cht_release(flags + i * nt + i + 1, epoch, tid);  // F(i, i+1)
+            cht_release(flags + i * nt + i + 1, epoch, tid);      // F(i, i+1)
             __syncthreads();
+            double *sw = Mc;
+            Mc = Mn;
+            Mn = sw;
         }
 #undef CHC_STAMP
         if (!ok && tid < nt) {     // nobody may be left waiting for the chain
@@ -828,11 +873,11 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
             const unsigned wait_epoch = inject ? s->chol_epoch ^ 0x40000000u : s->chol_epoch;
             static const bool v1 = getenv("LSQ_CHOL_TILES_V1") != nullptr;      // (A/B: the chain across workgroups)
             if (!v1 && ntiles + 1 <= c->num_cus) {
-                LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_chain, CHT_LDS));
+                LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_chain, CHC_LDS));
                 static const bool tracing = getenv("LSQ_CHOL_TRACE") != nullptr;   // (debug: the chain's phase stamps)
                 static long long *d_trace = nullptr;
                 if (tracing && !d_trace) { LSQ_HIP(hipMalloc(&d_trace, 64 * 16 * sizeof(long long))); }
-                hipLaunchKernelGGL(k_chol_chain, dim3(ntiles + 1), dim3(256), CHT_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
+                hipLaunchKernelGGL(k_chol_chain, dim3(ntiles + 1), dim3(256), CHC_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
                                    (double *)((char *)s->d_chol_flags + FLAG_BYTES), s->d_chol_flags, s->d_chol_flags + 1024,
                                    s->chol_epoch, wait_epoch, inject ? 64 : CHT_SPIN_LIMIT, d_trace);
                 if (tracing) {
@@ -842,12 +887,11 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
                     static int shown = 0;
                     if (shown++ % 50 == 10)
                         for (int i = 0; i < nt; ++i) {
-                            fprintf(stderr, "chain step %2d:", i);
-                            for (int p = 1; p < 6 && !(i + 1 == nt && p > 1); ++p)
-                                fprintf(stderr, " %.2f", (h[i * 16 + p] - h[i * 16 + p - 1]) * 0.01);
-                            if (i + 1 < nt) fprintf(stderr, "   total %.2f us", (h[(i + 1) * 16] - h[i * 16]) * 0.01);
-                            if (i + 1 < nt) fprintf(stderr, "  [store %.2f stash %.2f syrk %.2f]", (h[i * 16 + 6] - h[i * 16 + 4]) * 0.01,
-                                                    (h[i * 16 + 7] - h[i * 16 + 6]) * 0.01, (h[i * 16 + 5] - h[i * 16 + 7]) * 0.01);
+                            fprintf(stderr, "chain step %2d: chol %.2f", i, (h[i * 16 + 1] - h[i * 16]) * 0.01);
+                            if (i + 1 < nt)
+                                fprintf(stderr, " tail+release %.2f trsm %.2f store %.2f syrk %.2f   total %.2f us", (h[i * 16 + 3] - h[i * 16 + 1]) * 0.01,
+                                        (h[i * 16 + 4] - h[i * 16 + 3]) * 0.01, (h[i * 16 + 6] - h[i * 16 + 4]) * 0.01,
+                                        (h[i * 16 + 5] - h[i * 16 + 6]) * 0.01, (h[(i + 1) * 16] - h[i * 16]) * 0.01);
                             fprintf(stderr, "\n    chol:");
                             for (int p = 0; p < 12; ++p) fprintf(stderr, " %.2f", (h[512 + i * 16 + p] - (p ? h[512 + i * 16 + p - 1] : h[i * 16])) * 0.01);
                             fprintf(stderr, "\n");

@@ -124,6 +124,7 @@ __device__ __forceinline__ int s64_chol(double *M, double *W, int *fail, int tid
     const int lane = tid & 63, wv = tid >> 6;
     if (tid == 0) *fail = 0;
     __syncthreads();
+#pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
         const int o = kb * 16;
         if (wv == 0) {
