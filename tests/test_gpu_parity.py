@@ -394,6 +394,19 @@ def test_cholesky_failures(ctx):
     with pytest.raises(lsq.PosDefException, match="151"):
         sv.ldiv_(lsq.DeviceVector(ctx, 256), lsq.DeviceVector(ctx, 900, rng.standard_normal(900)), lsq.DeviceVector(ctx, 256))
     assert sv.info()["chol_path"] == "blocked-one-launch"
+    # ... in the first block of the chain, and in the ragged last tile (k_chol_chain: the chain workgroup reports the
+    # position and releases every flag it owns, nobody is left waiting); the solver is usable again afterwards
+    for n, col in ((200, 3), (200, 197), (512, 448)):
+        D = rng.standard_normal((3 * n, n))
+        D[:, col] = 0.0
+        sv = lsq.AllocatedSolver(lsq.DeviceMatrix(ctx, D), lsq.Cholesky(), for_lm=True)
+        y = rng.standard_normal(3 * n)
+        with pytest.raises(lsq.PosDefException, match=str(col + 1)):
+            sv.ldiv_(lsq.DeviceVector(ctx, n), lsq.DeviceVector(ctx, 3 * n, y), lsq.DeviceVector(ctx, n))
+        dx = lsq.DeviceVector(ctx, n)
+        sv.ldiv_(dx, lsq.DeviceVector(ctx, 3 * n, y), lsq.DeviceVector(ctx, n, np.ones(n)))
+        assert np.allclose(dx.get(), O.ldiv(O.CHOLESKY, O.Mat(dense=D), y, np.ones(n))[1], rtol=1e-9, atol=1e-12)
+        assert sv.info()["chol_path"] == "blocked-one-launch" and sv.stats()["chol_one_launch"]["giveups"] == 0
 
 
 @pytest.mark.parametrize("m,n,rank", [(40, 10, 10), (12, 12, 12), (30, 12, 7), (9, 6, 5), (20, 8, 1),
