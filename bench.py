@@ -410,7 +410,7 @@ def dense_secondary(ctx, lsq):
         cpu_ms = sorted(ht)[len(ht) // 2]
         err = float(np.linalg.norm(x.get() - ref) / np.linalg.norm(ref))
         if for_lm:    # J'J m n (n+1) + Cholesky n^3/3 + J'y 2mn + two triangular solves 2 n^2
-            flops, dom = m * n * (n + 1) + n ** 3 / 3 + 2 * m * n + 2 * n * n, "k_syrk_mfma (J'J), k_chol_tiles"
+            flops, dom = m * n * (n + 1) + n ** 3 / 3 + 2 * m * n + 2 * n * n, "k_syrk_mfma (J'J), k_chol_chain"
         else:         # Householder QR 2mn^2 - 2n^3/3 (+ Q'b riding along)
             flops, dom = 2 * m * n * n - 2 * n ** 3 / 3 + 4 * m * n, "k_qr1_vtb / k_qr1_update (block reflector), k_cqr_pass (panel)"
         tf = flops / (gpu_ms * 1e-3) / 1e12
