@@ -112,7 +112,9 @@ k_syrk_mfma(const double *__restrict__ A, int lda, int krows, int ncols, int col
 
 // C(upper) = sum over slices of W, + damp on the diagonal (dense_cholesky.jl:51-53)
 __global__ void __launch_bounds__(256)
-k_syrk_reduce(const double *__restrict__ W, int n, int kslices, const double *__restrict__ damp, double *__restrict__ C) {
+k_syrk_reduce(const double *__restrict__ W, int n, int kslices, const double *__restrict__ damp, double *__restrict__ C,
+              int *__restrict__ info) {   // info: the factorisation's status word, cleared here (no memset launch of its own)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
     const int nt = (n + MT - 1) / MT;
     const int ntiles = nt * (nt + 1) / 2;
     const int tile = blockIdx.x / 16, part = blockIdx.x % 16;   // 16 workgroups per tile, 256 entries each
@@ -504,7 +506,8 @@ __device__ __forceinline__ void chc_load_w(double *W, const double *Wd, int i, i
 
 __global__ void __launch_bounds__(256)
 k_chol_chain(double *C, int n, int nt, int *info, double *Xd, double *Wd, unsigned *flags, unsigned *pflags,
-             unsigned epoch, unsigned wait_epoch, int spin_limit, long long *trace) {   // trace: LSQ_CHOL_TRACE (10 ns ticks)
+             unsigned epoch, unsigned wait_epoch, int spin_limit, long long *trace,   // trace: LSQ_CHOL_TRACE (10 ns ticks)
+             const double *bvec, double *zvec, unsigned long long *zslot, unsigned zep, int *zerr) {   // bvec: + U'z = b (see below)
 #define CHC_STAMP(p) do { if (trace && tid == 0) trace[i * 16 + (p)] = wall_clock64(); } while (0)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *M0 = sm, *M1 = sm + S64_MAT, *M2 = sm + 2 * S64_MAT, *T = sm + 3 * S64_MAT;
@@ -598,6 +601,65 @@ k_chol_chain(double *C, int n, int nt, int *info, double *Xd, double *Wd, unsign
         }
         return;
     }
+    if ((int)blockIdx.x > nt * (nt + 1) / 2) {               // ---- U'z = b behind the factorisation (k_tri_fsolve_t's scheme)
+        // workgroup t owns unknowns 64 t ..: for e < t it takes tile U(e, t) as soon as its flag is up, z_e as soon as the
+        // workgroup of block e has published it (flag-in-data slots), subtracts U(e, t)'z_e; X(t) -- the inverse of the
+        // diagonal tile, from the helper of (t, t) -- finishes z_t.  It trails the chain by the helper's inversion + one
+        // product, instead of a launch + 8 x 3.7 us after it.
+        const int t = (int)blockIdx.x - nt * (nt + 1) / 2 - 1;
+        double *sc = sm, *sz = sm + 64, *sp = sm + 128;      // sp[4][64]
+        const int col = tid & 63, part = tid >> 6, c0 = 64 * t;
+        const bool cin = c0 + col < n;
+        if (tid < 64) sc[tid] = cin ? bvec[c0 + tid] : 0.0;
+        double tile[16];
+        auto apply = [&](double sign) {                      // sc += sign * tile' * sz
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += tile[q] * sz[part * 16 + q];
+            sp[part * 64 + col] = acc;
+            __syncthreads();
+            if (tid < 64) sc[tid] += sign * (((sp[tid] + sp[64 + tid]) + sp[128 + tid]) + sp[192 + tid]);
+            __syncthreads();
+        };
+        for (int e = 0; e < t; ++e) {
+            if (!cht_wait(flags + e * nt + t, wait_epoch, info, spin_limit)) return;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                tile[q] = cin ? __hip_atomic_load(C + (size_t)(c0 + col) * n + e * 64 + part * 16 + q, RLX_AGENT) : 0.0;
+            if (tid < 64) {
+                const unsigned long long *f = zslot + ((size_t)e * 64 + tid) * 2;
+                unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+                int spins = 0;
+                while ((unsigned)(w0 >> 32) != zep || (unsigned)(w1 >> 32) != zep) {
+                    if (++spins > spin_limit) { atomicOr(zerr, 1); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    w0 = __hip_atomic_load(f, RLX_AGENT);
+                    w1 = __hip_atomic_load(f + 1, RLX_AGENT);
+                }
+                sz[tid] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+            }
+            __syncthreads();
+            apply(-1.0);
+        }
+        if (!cht_wait(pflags + t * nt, wait_epoch, info, spin_limit)) return;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = part * 16 + q;                     // X_tt(r, col)
+            tile[q] = (cin && c0 + r < n) ? __hip_atomic_load(Xd + (size_t)t * 4096 + (size_t)col * 64 + r, RLX_AGENT) : 0.0;
+        }
+        if (tid < 64) { sz[tid] = sc[tid]; sc[tid] = 0.0; }
+        __syncthreads();
+        apply(1.0);
+        if (tid < 64) {
+            const double v = sc[tid];
+            unsigned long long *mine = zslot + ((size_t)t * 64 + tid) * 2;
+            const unsigned long long hi = (unsigned long long)zep << 32;
+            __hip_atomic_store(mine, hi | (unsigned)__double2loint(v), RLX_AGENT);
+            __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(v), RLX_AGENT);
+            if (cin) zvec[c0 + tid] = v;
+        }
+        return;
+    }
     int t = blockIdx.x - 1, ti = 0;
     while (t >= nt - ti) { t -= nt - ti; ++ti; }
     const int tj = ti + t;
@@ -630,7 +692,11 @@ k_chol_chain(double *C, int n, int nt, int *info, double *Xd, double *Wd, unsign
     }
     if (diag) {
         if (ti > 0) cht_publish(C, n, ti, ti, M0, true, myflag, epoch, tid);              // T2'(i)
-        if (!cht_wait(flags + ti * nt + ti, wait_epoch, info, spin_limit)) return;
+        unsigned *xflag = pflags + ti * nt;                  // X(i): Xd[i] is complete (slot (i, 0) of the P flags is nobody's)
+        if (!cht_wait(flags + ti * nt + ti, wait_epoch, info, spin_limit)) {
+            if (tid == 0) __hip_atomic_store(xflag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         cht_load<true>(M0, C, n, ti, ti, tid);               // U(i, i) (the blocks below the diagonal blocks are not read)
         chc_load_w(M1, Wd, ti, tid);
         __syncthreads();
@@ -639,8 +705,10 @@ k_chol_chain(double *C, int n, int nt, int *info, double *Xd, double *Wd, unsign
         for (int q = 0; q < 16; ++q) {
             const int e = tid + 256 * q, r = e & 63, c = e >> 6;
             const bool in = 64 * ti + r < n && 64 * ti + c < n;
-            Xd[(size_t)ti * 4096 + (size_t)c * 64 + r] = in ? M1[r * S64_LS + c] : 0.0;
+            __hip_atomic_store(Xd + (size_t)ti * 4096 + (size_t)c * 64 + r, in ? M1[r * S64_LS + c] : 0.0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
+        cht_release(xflag, epoch, tid);
     } else if (sup) {
         cht_publish(C, n, ti, tj, M0, false, myflag, epoch, tid);                           // T1'(i): the chain finishes it
     } else {
@@ -788,7 +856,9 @@ k_syrk_small(const double *__restrict__ A, int m, int n, int wrows, double *__re
         if (tid + q * 256 < npairs) W[(size_t)blockIdx.x * npairs + tid + q * 256] = acc[q];
 }
 __global__ void __launch_bounds__(256)
-k_syrk_small_reduce(const double *__restrict__ W, int n, int nwin, const double *__restrict__ damp, double *__restrict__ C) {
+k_syrk_small_reduce(const double *__restrict__ W, int n, int nwin, const double *__restrict__ damp, double *__restrict__ C,
+                    int *__restrict__ info) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
     const int npairs = n * (n + 1) / 2;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= npairs) return;
@@ -836,7 +906,6 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         LSQ_HIP(hipMalloc(&s->d_T, need * sizeof(double)));
         s->work_elems = need;
     }
-    LSQ_HIP(hipMemsetAsync(s->d_info, 0, sizeof(int), c->stream));
     if (n <= SS_MAXN && m >= 16384) {
         // few columns, many rows: the pair kernel (one pass over J, no 64 x 64 tile of mostly padding)
         const int nwin = std::max(1, std::min(2 * c->num_cus, m / 1024));
@@ -850,11 +919,12 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         }
         const int nw = (m + wrows - 1) / wrows;
         hipLaunchKernelGGL(k_syrk_small, dim3(nw), dim3(256), 0, c->stream, J->d_dense, m, n, wrows, s->d_T);
-        hipLaunchKernelGGL(k_syrk_small_reduce, dim3((npairs + 255) / 256), dim3(256), 0, c->stream, s->d_T, n, nw, d_damp, s->d_chol);
+        hipLaunchKernelGGL(k_syrk_small_reduce, dim3((npairs + 255) / 256), dim3(256), 0, c->stream, s->d_T, n, nw, d_damp, s->d_chol,
+                           s->d_info);
     } else {
         hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices), dim3(256), 0, c->stream, J->d_dense, m, m, n, 0, kslices,
                            s->d_T, (double *)nullptr, 0);
-        hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol);
+        hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol, s->d_info);
     }
     if (d_dmax) hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);
     // one launch for the whole factorisation when every 64 x 64 upper tile gets a CU of its own (k_chol_tiles)
@@ -877,9 +947,17 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
                 static const bool tracing = getenv("LSQ_CHOL_TRACE") != nullptr;   // (debug: the chain's phase stamps)
                 static long long *d_trace = nullptr;
                 if (tracing && !d_trace) { LSQ_HIP(hipMalloc(&d_trace, 64 * 16 * sizeof(long long))); }
-                hipLaunchKernelGGL(k_chol_chain, dim3(ntiles + 1), dim3(256), CHC_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
-                                   (double *)((char *)s->d_chol_flags + FLAG_BYTES), s->d_chol_flags, s->d_chol_flags + 1024,
-                                   s->chol_epoch, wait_epoch, inject ? 64 : CHT_SPIN_LIMIT, d_trace);
+                // with a right-hand side at hand the forward half of the solve rides along: nt more workgroups
+                double *zv = nullptr;
+                unsigned long long *zslot = nullptr, zep = 0;
+                int *zerr = nullptr;
+                static const bool nofuse = getenv("LSQ_CHOL_NO_FUSED_FSOLVE") != nullptr;     // (A/B)
+                const bool fuse = d_x && !nofuse && ntiles + 1 + nt <= c->num_cus &&
+                                  lsq_tri_chol_fwd_operands(s, n, &zv, &zslot, &zep, &zerr) == LSQ_OK;
+                hipLaunchKernelGGL(k_chol_chain, dim3(ntiles + 1 + (fuse ? nt : 0)), dim3(256), CHC_LDS, c->stream, s->d_chol, n, nt,
+                                   s->d_info, Xt, (double *)((char *)s->d_chol_flags + FLAG_BYTES), s->d_chol_flags,
+                                   s->d_chol_flags + 1024, s->chol_epoch, wait_epoch, inject ? 64 : CHT_SPIN_LIMIT, d_trace,
+                                   (const double *)(fuse ? d_x : nullptr), zv, zslot, (unsigned)zep, zerr);
                 if (tracing) {
                     long long h[64 * 16];
                     LSQ_HIP(hipStreamSynchronize(c->stream));

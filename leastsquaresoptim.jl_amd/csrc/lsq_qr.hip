@@ -1205,6 +1205,7 @@ struct TriPipe {
     unsigned long long epoch = 0;
     int *d_err = nullptr;
     int n = 0;
+    bool fwd_fused = false;                      // the forward half of the coming solve was run by the factorisation kernel
 };
 static void tripipe_free(void *p) {
     TriPipe *t = (TriPipe *)p;
@@ -1241,16 +1242,33 @@ double *lsq_tri_chol_diagbuf(lsq_solver *s, int n) {
     TriPipe *t = nullptr;
     return tri_chol_pipe(s, n, &t) == LSQ_OK ? t->Xd : nullptr;
 }
+// k_chol_chain runs U'z = b itself, block by block behind the factorisation (lsq_dense_mfma.hip): the operands of
+// k_tri_fsolve_t for the coming solve, whose epoch starts here; lsq_tri_chol_solve then launches the backward half only
+int lsq_tri_chol_fwd_operands(lsq_solver *s, int n, double **z, unsigned long long **slot, unsigned long long *epoch, int **err) {
+    TriPipe *t = nullptr;
+    if (tri_chol_pipe(s, n, &t) != LSQ_OK) return LSQ_EARG;
+    ++t->epoch;
+    t->fwd_fused = true;
+    *z = t->z;
+    *slot = t->slot_f;
+    *epoch = t->epoch;
+    *err = t->d_err;
+    return LSQ_OK;
+}
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
     lsq_ctx *c = s->ctx;
     const int nblk = lsq_div_up(n, 64);
     TriPipe *t = nullptr;
     if (tri_chol_pipe(s, n, &t) != LSQ_OK) return LSQ_EARG;
-    ++t->epoch;
-    if (!s->chol_have_diaginv)     // (the MFMA panel kernel of the blocked factorisation has already left inv(U_kk) in Xd)
-        hipLaunchKernelGGL(k_tri_diaginv, dim3(nblk), dim3(256), 0, c->stream, U, n, t->Xd, 64, (size_t)4096);
-    hipLaunchKernelGGL(k_tri_fsolve_t, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, d_bx, t->z, t->slot_f,
-                       t->epoch, t->d_err);
+    if (t->fwd_fused) {
+        t->fwd_fused = false;                    // z is in t->z already
+    } else {
+        ++t->epoch;
+        if (!s->chol_have_diaginv)     // (the MFMA panel kernel of the blocked factorisation has already left inv(U_kk) in Xd)
+            hipLaunchKernelGGL(k_tri_diaginv, dim3(nblk), dim3(256), 0, c->stream, U, n, t->Xd, 64, (size_t)4096);
+        hipLaunchKernelGGL(k_tri_fsolve_t, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, d_bx, t->z, t->slot_f,
+                           t->epoch, t->d_err);
+    }
     hipLaunchKernelGGL(k_tri_bsolve, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, t->z, d_bx, t->slot_b,
                        t->epoch, t->d_err);
     if (getenv("LSQ_TEST_EXCHANGE_TIMEOUT")) {   // test hook: pretend a wait gave up (and spoil the result it would have spoilt)

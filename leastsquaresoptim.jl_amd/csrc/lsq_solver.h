@@ -106,6 +106,7 @@ struct lsq_solver {
     bool last_chol_tiles = false;   // the last blocked factorisation was the one-launch one
 };
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx);
+int lsq_tri_chol_fwd_operands(lsq_solver *s, int n, double **z, unsigned long long **slot, unsigned long long *epoch, int **err);
 // buffer of the inverted 64 x 64 diagonal blocks of the pipelined solves (allocates the pipeline; nullptr when it is off)
 double *lsq_tri_chol_diagbuf(lsq_solver *s, int n);
 
