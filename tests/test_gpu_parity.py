@@ -306,7 +306,7 @@ def test_ldiv_cholesky(ctx, n):
     _, nmul = sv.ldiv_(dxo, dy, lsq.DeviceVector(ctx, n, damp))
     st, xr, _, _ = O.ldiv(O.CHOLESKY, O.Mat(dense=D), y, damp)
     assert nmul == 1 and np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
-    # n >= 128 (and at most one 64 x 64 upper tile per CU): the whole factorisation is one launch (k_chol_tiles)
+    # n >= 128 (and at most one 64 x 64 upper tile per CU): the whole factorisation is one launch (k_chol_chain; k_chol_tiles when tiles + 1 > CUs)
     assert sv.info()["chol_path"] == ("blocked-one-launch" if n >= 128 else "blocked" if n >= 32 else "one-workgroup")
     sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=False)  # pivoted (Dogleg)
     _, nmul = sv.ldiv_(dxo, dy)
@@ -315,7 +315,7 @@ def test_ldiv_cholesky(ctx, n):
 
 
 def test_cholesky_one_launch_is_repeatable(ctx):
-    """k_chol_tiles: workgroups hand tiles to each other inside ONE launch (epoch-tagged flags, bounded waits).  300 solves on
+    """k_chol_chain / k_chol_tiles: workgroups hand tiles to each other inside ONE launch (epoch-tagged flags, bounded waits).  300 solves on
     one solver: every result equals the first bit for bit and no wait ever gave up (the path would fall back to
     'blocked' and stay there).  tools/chol_stress.py runs the same check for thousands of solves."""
     rng = np.random.default_rng(5)

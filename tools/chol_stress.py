@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stress of the one-launch blocked Cholesky (k_chol_tiles): many damped solves on one solver; every result must equal the
+"""Stress of the one-launch blocked Cholesky (k_chol_chain; LSQ_CHOL_TILES_V1=1: k_chol_tiles): many damped solves on one solver; every result must equal the
 first one bit for bit, the path must stay 'blocked-one-launch' (a wait that gave up would switch it to 'blocked'), and
 the slowest solve is reported (a wait that limps shows up there).   python tools/chol_stress.py [n_solves] [m] [n]"""
 import os, sys, time
