@@ -1315,9 +1315,12 @@ static int model_f(double *out, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
     lsq_mat *J = md->J;
+    const bool have_tanh = md->tanh_x == x;   // the step kernel formed tanh(x) while it wrote x (model_trial_buffers)
     md->tanh_x = nullptr;
-    md->sfac_x = nullptr;
-    hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+    if (!have_tanh) {
+        md->sfac_x = nullptr;
+        hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+    }
     EpiResidual e{nullptr, 0, md->d_b, out, nullptr, nullptr};
     if (J->kind == LSQ_MAT_CSC && J->srows.active) {
         // the stored values themselves (fused: J's storage IS A; else A in the same layout), no column scale: r = A t - b
@@ -1339,7 +1342,7 @@ static int model_f(double *out, const double *x, void *user) {
 static void model_trial_buffers(void *user, const double *xt, double **t_out, double **s_out) {
     lsq_model *md = (lsq_model *)user;
     md->tanh_x = md->sfac_x = nullptr;
-    if (md->J->kind == LSQ_MAT_CSC && md->J->srows.active) {
+    if ((md->J->kind == LSQ_MAT_CSC && md->J->srows.active) || md->J->kind == LSQ_MAT_DENSE) {
         *t_out = md->d_t;
         *s_out = md->d_sspec;
         md->tanh_x = md->sfac_x = xt;
@@ -1369,8 +1372,10 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
 static int model_g(lsq_mat *J, const double *x, void *user) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
-    // s = 1 - tanh(x)^2: already there if x is the trial point the step kernel has just written
-    if (md->sfac_x == x) std::swap(md->d_s, md->d_sspec);
+    // s = 1 - tanh(x)^2: already there if x is the trial point the step kernel has just written (dense columns: k_scale_dense
+    // forms the factor of its column from x itself)
+    if (J->kind == LSQ_MAT_DENSE) {}
+    else if (md->sfac_x == x) std::swap(md->d_s, md->d_sspec);
     else hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_s);
     md->sfac_x = nullptr;
     md->tanh_x = nullptr;
