@@ -164,6 +164,8 @@ struct LsqSell {
     int spw = 0;                   // slices per block (every block is padded to the same count: block b starts at slice b * spw)
     long long nstore = 0;          // stored entries incl. padding
     int wrows = 0;                 // J*x: output rows per block
+    int ncw = 1, cwidth = 0;       // J*x, n > LSQ_LDS_X_MAX: column windows per row block (block b = row block * ncw + window),
+                                   // columns per window; the gather index of an entry is its column minus the window's first
     int ncb = 0, ccols = 0;        // J'*y: column blocks per gather window, columns per block
     int ngw = 0, grows = 0;        // J'*y: gather windows, rows per gather window
     int2 *d_smeta = nullptr;       // nslices x {entry offset, padded count}
@@ -173,6 +175,7 @@ struct LsqSell {
     double *d_val = nullptr;
     int *d_map = nullptr;          // stored entry -> CSC position (-1: padding)
     double *d_part = nullptr;      // J'*y: [gather window][2n] partials (dots | squares)
+    double *d_sx = nullptr;        // J*x with column windows: s .* x of a column-scaled handle (n doubles)
 };
 
 struct lsq_mat {

@@ -1393,7 +1393,7 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         double *rval = J->srows.active ? J->srows.d_val : J->csr.d_val;
         double *cval = J->scols.active ? J->scols.d_val : J->bcsc.d_val;
         const long long rlen = lsq_mirror_rows_len(J), clen = lsq_mirror_cols_len(J);
-        const bool lds_ok = J->n <= 12000 && J->nnz >= (1 << 20);
+        const bool lds_ok = J->n <= 12000 && J->nnz >= (1 << 20) && J->srows.ncw == 1;   // (window-relative indices otherwise)
         // big problems: every product (and colsumabs2) reads the mirrors, so only those are written; the
         // CSC-ordered copy is rebuilt on demand (lsq_ensure_csc)
         const bool lazy_csc = lds_ok && rcol && have_cols && ccol && lsq_can_fuse_grad_colsum(J);

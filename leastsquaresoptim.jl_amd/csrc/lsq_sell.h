@@ -33,6 +33,8 @@ constexpr int LSQ_SELL_ROWS_MAX = 4096;    // J*x: output rows per block
 // rows and half the columns of rounds 1-2 (8192 x 5120) -- same number of blocks, but a column's entries inside a window
 // double (C4: 7.8 -> 15.6), so the padding of the pair-interleaved slices halves (6.4 % -> 3 %), there are half as many
 // per-window partials to write and to combine (C4: 128 -> 64 per column) and half as many lane descriptors to read.
+constexpr int LSQ_SELL_CW_AUTO = 6;       // ... chosen by default up to this many (n <= 72960), see lsq_csc_create
+constexpr int LSQ_SELL_CW_MAX = 32;       // J*x with n > LSQ_LDS_X_MAX: at most this many column windows of x (k_sell_rows_wide)
 constexpr int LSQ_SELL_GROWS_MAX = 16384;
 constexpr int LSQ_SELL_CCOLS_MAX = 2560;
 
@@ -94,10 +96,9 @@ __device__ __forceinline__ void sell_batch_sum(SellBatch<U> &B, int p0, int np, 
 // index order.  A slice of the C4 workload holds 4-10 pairs per lane: one batch, one memory round trip (the round-1 loop paid one
 // per 4 pairs plus one per leftover pair, in sequence).
 template <bool SQ>
-__device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L, int len,
-                                              const double *xl, double &sum, double &sq) {
+__device__ __forceinline__ void sell_lane_sum_from(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int p0, int L,
+                                                   int len, const double *xl, double &sum, double &sq) {
     const int np = L >> 1;
-    int p0 = 0;
     for (; p0 + 8 <= np; p0 += 8) {
         SellBatch<8> B;
         sell_batch_load<8, false>(B, vp, ip, p0, np);
@@ -117,6 +118,12 @@ __device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, con
         sell_batch_load<2, true>(B, vp, ip, p0, np);
         sell_batch_sum<2, true, SQ>(B, p0, np, len, xl, sum, sq);
     }
+}
+
+template <bool SQ>
+__device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L, int len,
+                                              const double *xl, double &sum, double &sq) {
+    sell_lane_sum_from<SQ>(vp, ip, 0, L, len, xl, sum, sq);
 }
 
 // The slices of one wave (s0 + wave, + 16, ...), with the next slice's descriptor requested before the current slice's stream.
@@ -213,6 +220,124 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
     for (int e = blockIdx.x; e < epi.extra_blocks; e += gridDim.x)
         if (tid < LSQ_NT) epi.extra(e, racc);
     finish_block_nt<LSQ_BIG_NT>(epi, racc, sh);
+}
+
+// ---- J*x for n > LSQ_LDS_X_MAX: x passes through LDS one column window at a time --------------------
+// Block b = row block * ncw + window holds the rows' entries inside that window (rows without entries there have no
+// lane).  The row block's workgroup walks the windows in ascending order; a lane CONTINUES the row's running sum from the
+// output window in LDS (sum = yw[pos]; sum += products in column order; yw[pos] = sum), so every row is still one
+// left-to-right sum over its entries -- the reference's order, bit for bit, as in k_sell_rows.
+// A (row block, window) holds few entries per row (n = 50000, 10 per row: two), so its slices are short and a wave that
+// took them one after the other would spend its time in memory round trips with 1-2 KB in flight.  Instead a wave requests
+// the first two pairs of ALL its slices of the window (<= 4: 4096 rows = 64 slices over 16 waves) together with the window
+// of x, before the barrier that hands the window over; their descriptors were requested during the previous window.  Only
+// rows with more than four entries inside one window pay further round trips.
+// 512 threads (8 waves, one workgroup per CU: 256 VGPRs per lane) so that the heads of a wave's 8 slices, the window of x and
+// the next window's descriptors are all live in registers at once; with 1024 threads (128 VGPRs) the same code spilled.
+constexpr int LSQ_WIDE_NT = 512;
+constexpr int LSQ_SELL_WIDE_G = LSQ_SELL_ROWS_MAX / 64 / (LSQ_WIDE_NT / 64);   // slices per wave and (row block, window)
+
+template <class Epi>
+__global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int wrows, int m, int ncw, int cwidth,
+                                                                const double *__restrict__ x, int nx, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double sh[LSQ_WIDE_NT / 64];
+    constexpr int NW = LSQ_WIDE_NT / 64, G = LSQ_SELL_WIDE_G;
+    double *xl = smem;              // cwidth doubles (cwidth even)
+    double *yw = smem + cwidth;     // LSQ_SELL_ROWS_MAX doubles
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nrb = S.nblocks / ncw;
+    constexpr int XR = (LSQ_LDS_X_MAX + LSQ_WIDE_NT - 1) / LSQ_WIDE_NT;
+    constexpr int Q = LSQ_SELL_ROWS_MAX / LSQ_WIDE_NT;
+    SellSliceRef A[G];
+    double xr[XR];
+    auto refs_at = [&](int w, int cw) {   // descriptors of this wave's slices of (row block w, window cw)
+        const int sb = (w * ncw + cw) * S.spw;
+#pragma unroll
+        for (int g = 0; g < G; ++g) A[g] = sell_slice_ref(S, sb + wv + g * NW, sb + S.spw, lane);
+    };
+    auto fetch_x = [&](int cw) {
+        const int c0 = cw * cwidth;
+#pragma unroll
+        for (int q = 0; q < XR; ++q) xr[q] = x[min(c0 + tid + q * LSQ_WIDE_NT, nx - 1)];
+    };
+    if ((int)blockIdx.x < nrb) refs_at(blockIdx.x, 0);
+    const int dflag = epi.done ? *epi.done : 0;
+    if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
+    if constexpr (EpiHasPrepare<Epi>::value) epi.prepare();
+    if (dflag) return;   // launches queued behind a finished solve stop here
+    double racc = 0.0;
+    for (int w = blockIdx.x; w < nrb; w += gridDim.x) {
+        const int base = w * wrows, rows = min(wrows, m - base);
+        for (int cw = 0; cw < ncw; ++cw) {
+            // the window of x and the head of every slice of this window: requested before anything is waited for
+            // (measured and dropped: the NEXT window of x requested behind the LDS write, to travel during the sums -- its 48
+            //  registers live across the sums made the kernel spill 75, 45 us instead of 33 at n = 25000)
+            fetch_x(cw);
+            SellSliceRef a[G];
+            SellBatch<2> B[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                a[g] = A[g];
+                const size_t oa = (size_t)a[g].sm.x + lane * 2;   // (an empty slice: a valid address, nothing selected)
+                sell_batch_load<2, true>(B[g], S.val + oa, S.idx16 + oa, 0, max(a[g].sm.y >> 1, 1));
+            }
+            const bool more = cw + 1 < ncw, next_block = w + (int)gridDim.x < nrb;
+            if (more) refs_at(w, cw + 1);
+            else if (next_block) refs_at(w + gridDim.x, 0);
+            __syncthreads();   // the previous window's gathers / the previous block's epilogue are done with xl, yw
+#pragma unroll
+            for (int q = 0; q < XR; ++q)
+                if (tid + q * LSQ_WIDE_NT < cwidth) xl[tid + q * LSQ_WIDE_NT] = xr[q];
+            if (cw == 0) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) yw[tid + q * LSQ_WIDE_NT] = 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int np = a[g].sm.y >> 1, len = (int)(a[g].inf >> LSQ_SELL_POS_BITS);
+                const unsigned pos = a[g].inf & LSQ_SELL_POS_MASK;
+                if (np == 0) continue;   // (wave-uniform)
+                double sum = pos != LSQ_SELL_POS_MASK ? yw[pos] : 0.0, sq = 0.0;
+                sell_batch_sum<2, true, false>(B[g], 0, np, len, xl, sum, sq);
+                if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
+            }
+            // rows with more than four entries inside the window: the rest of their slices, one slice after the other
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (a[g].sm.y <= 4) continue;   // (wave-uniform)
+                const unsigned pos = a[g].inf & LSQ_SELL_POS_MASK;
+                const size_t oa = (size_t)a[g].sm.x + lane * 2;
+                double sum = pos != LSQ_SELL_POS_MASK ? yw[pos] : 0.0, sq = 0.0;
+                sell_lane_sum_from<false>(S.val + oa, S.idx16 + oa, 2, a[g].sm.y, (int)(a[g].inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
+                if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
+            }
+        }
+        double pre[Q];
+        if constexpr (EpiHasPre<Epi>::value) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) pre[q] = epi.pre(base + min(tid + q * LSQ_WIDE_NT, rows - 1));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int i = tid + q * LSQ_WIDE_NT;
+            if (i < rows) {
+                if constexpr (EpiHasPre<Epi>::value) epi.seg_pre(base + i, yw[i], pre[q], racc);
+                else epi.seg(base + i, yw[i], racc);
+            }
+        }
+    }
+    for (int e = blockIdx.x; e < epi.extra_blocks; e += gridDim.x)
+        if (tid < LSQ_NT) epi.extra(e, racc);
+    finish_block_nt<LSQ_WIDE_NT>(epi, racc, sh);
+}
+
+// out = a .* b (the gather vector of a column-scaled wide handle: s .* x, formed once instead of once per row block)
+static __global__ void __launch_bounds__(LSQ_NT) k_sell_vmul(int n, const double *__restrict__ a, const double *__restrict__ b,
+                                                      double *__restrict__ out) {
+    for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) out[i] = a[i] * b[i];
 }
 
 // ---- J'*y: per (gather window, column) partial sums; k_combine adds the windows ----------------

@@ -139,9 +139,10 @@ static void free_segs(LsqSegs &S) {
 // Segments [first, first+count) of `ptr` are the outputs of block b (first/count from seg_range);
 // entry e of a segment gathers with index idx16_of(e), comes from CSC position srcmap[e] and
 // belongs to column col_of(e) (only stored when want_col16).
+// skip_empty: segments without entries get no lane (the kernel must not rely on every output of a block being written).
 template <class SegRange, class Idx16, class ColOf>
 static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, const std::vector<int> &srcmap,
-                      SegRange seg_range, Idx16 idx16_of, ColOf col_of, bool want_col16) {
+                      SegRange seg_range, Idx16 idx16_of, ColOf col_of, bool want_col16, bool skip_empty = false) {
     std::vector<int> map;
     std::vector<int2> smeta;
     std::vector<unsigned> info;
@@ -151,16 +152,21 @@ static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, cons
     // every block gets the same number of slices (empty ones at the end of the shorter blocks): a kernel then knows
     // its first slice from its block index alone, one dependent load less at the head of every launch
     int spw = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        int first, count;
+    auto block_order = [&](int b, int &first) {   // the block's segments that get a lane, in their original order
+        int count;
         seg_range(b, first, count);
-        spw = std::max(spw, (count + 63) / 64);
+        ord.clear();
+        for (int i = 0; i < count; ++i)
+            if (!skip_empty || ptr[first + i + 1] > ptr[first + i]) ord.push_back(i);
+        return (int)ord.size();
+    };
+    for (int b = 0; b < nblocks; ++b) {
+        int first;
+        spw = std::max(spw, (block_order(b, first) + 63) / 64);
     }
     for (int b = 0; b < nblocks; ++b) {
-        int first, count;
-        seg_range(b, first, count);
-        ord.resize(count);
-        for (int i = 0; i < count; ++i) ord[i] = i;
+        int first;
+        const int count = block_order(b, first);
         std::stable_sort(ord.begin(), ord.end(), [&](int a, int c2) {
             return ptr[first + a + 1] - ptr[first + a] > ptr[first + c2 + 1] - ptr[first + c2];
         });
@@ -235,7 +241,7 @@ static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, cons
 
 static void free_sell(LsqSell &S) {
     hipFree(S.d_smeta); hipFree(S.d_info); hipFree(S.d_idx16); hipFree(S.d_col16);
-    hipFree(S.d_val); hipFree(S.d_map); hipFree(S.d_part);
+    hipFree(S.d_val); hipFree(S.d_map); hipFree(S.d_part); hipFree(S.d_sx);
     S = LsqSell();
 }
 
@@ -290,18 +296,60 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
     LSQ_HIP(hipMalloc(&J->d_colsum, (n > 0 ? n : 1) * sizeof(double)));
     const bool sell_force = getenv("LSQ_SELL_FORCE") != nullptr;   // tests: sliced layouts on small patterns too
     const bool sell_ok = !getenv("LSQ_NO_SELL") && (sell_force || nnz >= (1 << 20)) && nnz > 0;
-    // sliced rows for J*x: the whole gather vector must fit in LDS next to the 4096-row output window
-    if (sell_ok && J->csr.plan == LSQ_PLAN_STREAM && n <= LSQ_LDS_X_MAX && n >= 1) {
+    // sliced rows for J*x: the gather vector in LDS next to the 4096-row output window -- all of it when n <= LSQ_LDS_X_MAX,
+    // else one COLUMN WINDOW of it at a time (k_sell_rows_wide: a row block's workgroup walks the windows in ascending
+    // order and keeps the rows' running sums in the output window, so a row is still summed left to right)
+    int xmax = LSQ_LDS_X_MAX;
+    if (const char *e = getenv("LSQ_SELL_XMAX")) xmax = std::min(LSQ_LDS_X_MAX, std::max(64, atoi(e)));   // tests: narrow windows
+    const int ncw = n >= 1 ? (n + xmax - 1) / xmax : 1;
+    // a window pass costs a row block ~4 us whatever it holds (two barriers, one exposed round trip), so the windows pay while
+    // every pass still moves >= 60 KB per CU.  MI355X, nnz = 1e7, m = 1e6: n = 25000 (3 windows) 32.7 us against 49.6 us with
+    // the segment kernel (x gathered through L1/L2), n = 50000 (5) 40.7 against 51.9, n = 100000 (9) 56.0 against 53.2;
+    // 200000 x 50000 with nnz 2e6: 26 against 13 us.
+    const bool wide_pays = ncw <= LSQ_SELL_CW_AUTO && nnz / c->num_cus >= (long long)ncw * 6000;
+    const bool wide_ok = ncw <= LSQ_SELL_CW_MAX && (long long)ncw * m < 200000000LL && !getenv("LSQ_NO_SELL_WIDE") &&
+                         (wide_pays || sell_force || getenv("LSQ_SELL_WIDE"));
+    if (sell_ok && J->csr.plan == LSQ_PLAN_STREAM && n >= 1 && (ncw == 1 || wide_ok)) {
         int per_cu = (m + c->num_cus - 1) / c->num_cus;
         int rounds = (per_cu + LSQ_SELL_ROWS_MAX - 1) / LSQ_SELL_ROWS_MAX;
         int wrows = (m + rounds * c->num_cus - 1) / (rounds * c->num_cus);
         wrows = std::min(LSQ_SELL_ROWS_MAX, (wrows + 63) & ~63);
         if (const char *e = getenv("LSQ_SELL_ROWS")) wrows = std::min(LSQ_SELL_ROWS_MAX, std::max(64, atoi(e) & ~63));
-        const int nblocks = (m + wrows - 1) / wrows;
-        int st = build_sell(
-            J->srows, nblocks, rptr, map,
-            [&](int b, int &first, int &count) { first = b * wrows; count = std::min(wrows, m - first); },
-            [&](int e) { return (unsigned short)ridx[e]; }, [&](int e) { return (unsigned short)ridx[e]; }, false);
+        const int nrb = (m + wrows - 1) / wrows;
+        int st;
+        if (ncw == 1) {
+            st = build_sell(
+                J->srows, nrb, rptr, map,
+                [&](int b, int &first, int &count) { first = b * wrows; count = std::min(wrows, m - first); },
+                [&](int e) { return (unsigned short)ridx[e]; }, [&](int e) { return (unsigned short)ridx[e]; }, false);
+        } else {
+            // sub-rows (window, row): entries of a row keep their column order inside every window
+            const int cwidth = (((n + ncw - 1) / ncw) + 1) & ~1;
+            std::vector<int> wptr((size_t)ncw * m + 1, 0), widx(nnz), wmap(nnz);
+            for (int i = 0; i < m; ++i)
+                for (int e = rptr[i]; e < rptr[i + 1]; ++e) wptr[(size_t)(ridx[e] / cwidth) * m + i + 1]++;
+            for (size_t s2 = 0; s2 < (size_t)ncw * m; ++s2) wptr[s2 + 1] += wptr[s2];
+            {
+                std::vector<int> fill(wptr.begin(), wptr.end() - 1);
+                for (int i = 0; i < m; ++i)
+                    for (int e = rptr[i]; e < rptr[i + 1]; ++e) {
+                        int p = fill[(size_t)(ridx[e] / cwidth) * m + i]++;
+                        widx[p] = ridx[e] % cwidth;
+                        wmap[p] = map[e];
+                    }
+            }
+            st = build_sell(
+                J->srows, nrb * ncw, wptr, wmap,
+                [&](int b, int &first, int &count) {
+                    const int rb = b / ncw, cw = b % ncw;
+                    first = cw * m + rb * wrows;
+                    count = std::min(wrows, m - rb * wrows);
+                },
+                [&](int e) { return (unsigned short)widx[e]; }, [&](int e) { return (unsigned short)widx[e]; }, false, true);
+            J->srows.ncw = ncw;
+            J->srows.cwidth = cwidth;
+            if (st == LSQ_OK) LSQ_HIP(hipMalloc(&J->srows.d_sx, (size_t)n * sizeof(double)));
+        }
         if (st == LSQ_OK) {
             J->srows.wrows = wrows;
             hipFree(J->csr.d_val);   // the sliced layout carries the values; misuse of the mirror must fail loudly
@@ -953,24 +1001,31 @@ extern "C" int lsq_colsumabs2(lsq_mat *J, double *out) {
 // sliced rows: the lane that owns a row adds its squares left to right (the reference's order: the
 // CSC sweep reaches a row's entries in column order)
 __global__ void __launch_bounds__(256)
-k_sell_rowsq(SellDev S, int wrows, int m, double *__restrict__ out, const double *__restrict__ cscale) {
+k_sell_rowsq(SellDev S, int wrows, int m, int ncw, int cwidth, double *__restrict__ out, const double *__restrict__ cscale) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int w = blockIdx.x; w < S.nblocks; w += gridDim.x) {
+    const int nrb = S.nblocks / ncw;
+    for (int w = blockIdx.x; w < nrb; w += gridDim.x) {
         const int base = w * wrows;
-        for (int s = w * S.spw + wv; s < (w + 1) * S.spw; s += 4) {
-            const int2 sm = S.smeta[s];
-            const unsigned inf = S.info[(size_t)s * 64 + lane];
-            const unsigned pos = inf & LSQ_SELL_POS_MASK;
-            const int len = (int)(inf >> LSQ_SELL_POS_BITS);
-            const double *vp = S.val + (size_t)sm.x + lane * 2;
-            const unsigned short *ip = S.idx16 + (size_t)sm.x + lane * 2;
-            double acc = 0.0;
-            for (int j = 0; j < len; ++j) {
-                double a = vp[(size_t)(j / 2) * 128 + (j & 1)];
-                if (cscale) a *= cscale[ip[(size_t)(j / 2) * 128 + (j & 1)]];   // (column-scaled: the entry of J)
-                acc += a * a;
+        // column windows (ncw > 1, `out` zeroed by the caller): a row's sum continues where the previous window left it
+        for (int cw = 0; cw < ncw; ++cw) {
+            if (cw) __syncthreads();
+            const int b = w * ncw + cw;
+            for (int s = b * S.spw + wv; s < (b + 1) * S.spw; s += 4) {
+                const int2 sm = S.smeta[s];
+                const unsigned inf = S.info[(size_t)s * 64 + lane];
+                const unsigned pos = inf & LSQ_SELL_POS_MASK;
+                const int len = (int)(inf >> LSQ_SELL_POS_BITS);
+                const bool valid = pos != LSQ_SELL_POS_MASK && base + (int)pos < m;
+                const double *vp = S.val + (size_t)sm.x + lane * 2;
+                const unsigned short *ip = S.idx16 + (size_t)sm.x + lane * 2;
+                double acc = (ncw > 1 && valid) ? out[base + pos] : 0.0;
+                for (int j = 0; j < len; ++j) {
+                    double a = vp[(size_t)(j / 2) * 128 + (j & 1)];
+                    if (cscale) a *= cscale[cw * cwidth + ip[(size_t)(j / 2) * 128 + (j & 1)]];   // (column-scaled: the entry of J)
+                    acc += a * a;
+                }
+                if (valid) out[base + pos] = acc;
             }
-            if (pos != LSQ_SELL_POS_MASK && base + (int)pos < m) out[base + pos] = acc;
         }
     }
 }
@@ -1001,8 +1056,11 @@ extern "C" int lsq_rowsumabs2(lsq_mat *J, double *out) {
     } else {
         LSQ_TRY(lsq_ensure_csr(J));
         if (J->srows.active) {
-            int grid = std::max(1, std::min(J->srows.nblocks, c->num_cus * 4));
-            hipLaunchKernelGGL(k_sell_rowsq, dim3(grid), dim3(256), 0, c->stream, sell_dev(J->srows), J->srows.wrows, J->m, out, J->d_colscale);
+            const int ncw = J->srows.ncw;
+            int grid = std::max(1, std::min(J->srows.nblocks / ncw, c->num_cus * 4));
+            if (ncw > 1) LSQ_HIP(hipMemsetAsync(out, 0, (size_t)J->m * sizeof(double), c->stream));   // rows without entries
+            hipLaunchKernelGGL(k_sell_rowsq, dim3(grid), dim3(256), 0, c->stream, sell_dev(J->srows), J->srows.wrows, J->m, ncw,
+                               J->srows.cwidth, out, J->d_colscale);
         } else {
             EpiStore e{nullptr, 0, out, nullptr, nullptr};
             LSQ_TRY(launch_segs<true>(c, J->csr, nullptr, e));

@@ -857,6 +857,26 @@ template <class Epi>
 static inline int launch_sell_rows(lsq_mat *J, const double *xscale, const double *x, const Epi &epi, const double *val = nullptr) {
     lsq_ctx *c = J->ctx;
     const LsqSell &S = J->srows;
+    if (S.ncw > 1) {   // n > LSQ_LDS_X_MAX: one column window of x in LDS at a time
+        const size_t lds = (size_t)(S.cwidth + LSQ_SELL_ROWS_MAX) * sizeof(double);
+        auto kern = k_sell_rows_wide<Epi>;
+        LSQ_TRY(lsq_set_lds(c, (const void *)kern, (LSQ_LDS_X_MAX + 2 + LSQ_SELL_ROWS_MAX) * sizeof(double)));
+        if (xscale) {   // column-scaled handle: the gather vector s .* x once, not once per row block and window
+            hipLaunchKernelGGL(k_sell_vmul, dim3(std::min(lsq_div_up(J->n, LSQ_NT), c->num_cus * 4)), dim3(LSQ_NT), 0, c->stream,
+                               J->n, x, xscale, S.d_sx);
+            x = S.d_sx;
+        }
+        const int grid = std::max(1, std::min(S.nblocks / S.ncw, c->num_cus));
+        hipEvent_t e0, e1;
+        if (lsq_prof_take(c, &e0, &e1))
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_WIDE_NT), lds, c->stream, e0, e1, 0, sell_dev(S, val), S.wrows,
+                                  J->m, S.ncw, S.cwidth, x, J->n, epi);
+        else
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_WIDE_NT), lds, c->stream, sell_dev(S, val), S.wrows, J->m, S.ncw,
+                               S.cwidth, x, J->n, epi);
+        LSQ_HIP(hipGetLastError());
+        return LSQ_OK;
+    }
     const int nxpad = (J->n + 1) & ~1;
     const size_t lds = (size_t)(nxpad + LSQ_SELL_ROWS_MAX) * sizeof(double);
     auto kern = k_sell_rows<Epi>;

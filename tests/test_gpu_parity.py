@@ -141,6 +141,76 @@ def test_sliced_layouts(ctx, m, n, density, rows, grows):
         lsq.set_exact(None)
 
 
+@pytest.mark.parametrize("m,n,density,xmax,rows", [(3000, 200, 0.01, 64, None), (64, 3000, 0.02, 100, None),
+                                                   (9000, 6000, 0.001, 1000, 128), (20000, 300, 0.004, 77, 64),
+                                                   (5000, 400, 0.3, 128, 4096)])
+def test_sliced_rows_column_windows(ctx, m, n, density, xmax, rows):
+    """J*x of patterns wider than the LDS copy of x (n > 12160 in production; here the window is narrowed with
+    LSQ_SELL_XMAX): the row block's workgroup walks the column windows and continues every row's running sum, so the rows
+    must still match a sequential left-to-right evaluation BIT FOR BIT; rowsumabs2 likewise; column-scaled handles; values
+    written after creation; rows without entries in some or all windows."""
+    S = rand_csc(m, n, density, 2 * m + n).tolil()
+    S[5, :] = np.random.default_rng(0).standard_normal(n)
+    S[:, 1] = 0
+    S[3, :] = 0
+    S[7, : n // 2] = 0          # entries only in the upper windows
+    S[8, n // 3:] = 0           # ... only in the lower ones
+    S = S.tocsc()
+    S.sort_indices()
+    S.eliminate_zeros()
+    os.environ["LSQ_SELL_FORCE"], os.environ["LSQ_SELL_XMAX"] = "1", str(xmax)
+    if rows:
+        os.environ["LSQ_SELL_ROWS"] = str(rows)
+    try:
+        J = lsq.DeviceMatrix(ctx, S)
+    finally:
+        for k in ("LSQ_SELL_FORCE", "LSQ_SELL_ROWS", "LSQ_SELL_XMAX"):
+            os.environ.pop(k, None)
+    lsq.set_exact(False)
+    try:
+        A = O.Mat.from_scipy(S)
+        rng = np.random.default_rng(1)
+        x, y = rng.standard_normal(n), rng.standard_normal(m)
+        dx = lsq.DeviceVector(ctx, n, x)
+        scale = 1 + np.abs(S).sum(axis=1).max()
+        Sr = S.tocsr()
+
+        def seq_rows(vals, xx, idx):
+            out = {}
+            for i in idx:
+                dot = 0.0
+                for k in range(Sr.indptr[i], Sr.indptr[i + 1]):
+                    dot += vals[k] * xx[Sr.indices[k]]
+                out[i] = dot
+            return out
+        sample = [5, 3, 7, 8] + list(rng.integers(0, m, 60))
+        out = lsq.mul_(lsq.DeviceVector(ctx, m, y), J, dx, 1.5, -0.5).get()
+        assert np.max(np.abs(out - O.mul(A, x, 1.5, -0.5, y))) <= 1e-12 * scale
+        if S.nnz / m < 48:
+            for i, dot in seq_rows(Sr.data, x, sample).items():
+                assert out[i] == 1.5 * dot + -0.5 * y[i], i
+        out = lsq.mul_(lsq.DeviceVector(ctx, m, np.full(m, np.nan)), J, dx, 1.0, 0.0).get()
+        assert np.max(np.abs(out - O.mul(A, x))) <= 1e-12 * scale and out[3] == 0.0
+        # the adjoint product and colsumabs2 of the same handle
+        dy = lsq.DeviceVector(ctx, m, y)
+        outt = lsq.mul_(lsq.DeviceVector(ctx, n, x), J, dy, -2.0, 0.25, trans=True).get()
+        assert np.max(np.abs(outt - O.mulT(A, y, -2.0, 0.25, x))) <= 1e-12 * (1 + np.abs(S).sum(axis=0).max())
+        assert np.allclose(lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get(), O.colsumabs2(A), rtol=1e-13, atol=0)
+        # rowsumabs2: left-to-right sums of squares across the windows
+        rs = lsq.rowsumabs2_(lsq.DeviceVector(ctx, m, np.full(m, np.nan)), J).get()
+        ref = O.rowsumabs2(A)
+        assert np.allclose(rs, ref, rtol=1e-13, atol=0) and rs[3] == 0.0
+        if S.nnz / m < 48:
+            assert np.array_equal(rs, ref)
+        # values written after creation reach the sliced copy and read back unchanged
+        J.set_values(2.0 * S.data)
+        out = lsq.mul_(lsq.DeviceVector(ctx, m), J, dx, 1.0, 0.0).get()
+        assert np.max(np.abs(out - 2.0 * O.mul(A, x))) <= 1e-12 * scale
+        assert np.array_equal(J.values(), 2.0 * S.data)
+    finally:
+        lsq.set_exact(None)
+
+
 def test_sliced_layouts_random_patterns(ctx):
     """Twenty random shapes / densities / block sizes, with columns and rows emptied at random and duplicate-free
     ragged rows: J*x, J'*y and colsumabs2 of the sliced layouts against scipy."""
@@ -1458,7 +1528,8 @@ def test_nist_certified_values(key, exact):
 @pytest.mark.parametrize("sparse,opt,sol,big", [(True, "lm", "lsmr", False), (False, "lm", "cholesky", False),
                                                 (False, "dogleg", "qr", False), (True, "dogleg", "lsmr", False),
                                                 (True, "lm", "lsmr", True), (True, "dogleg", "lsmr", True),
-                                                (True, "lm", "lsmr", "segments"), (True, "dogleg", "lsmr", "segments")])
+                                                (True, "lm", "lsmr", "segments"), (True, "dogleg", "lsmr", "segments"),
+                                                (True, "lm", "lsmr", "wide"), (True, "dogleg", "lsmr", "wide")])
 def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big, monkeypatch):
     """Reduced-size C4/C2/C3 family: device f!/g! + device solver vs the oracle's C model.
     `big` is large enough (m > 131072 rows, nnz >= 2^20) to take the paths C4 takes: the sliced
@@ -1468,8 +1539,13 @@ def test_tanh_model_matches_oracle(ctx, sparse, opt, sol, big, monkeypatch):
         m, n, per_col = 300000, 2000, 600
     if big == "segments":   # the segment kernels (LDS-staged stream / row windows) instead of the sliced layouts
         monkeypatch.setenv("LSQ_NO_SELL", "1")
+    if big == "wide":       # J*v with x in four column windows (k_sell_rows_wide: what n > 12160 gets), column-scaled handle
+        monkeypatch.setenv("LSQ_SELL_XMAX", "500")
+        monkeypatch.setenv("LSQ_SELL_WIDE", "1")
     pr = lsq.synthetic.TanhProblem(m, n, sparse=sparse, per_col=per_col, seed=7, ctx=ctx)
     monkeypatch.delenv("LSQ_NO_SELL", raising=False)
+    monkeypatch.delenv("LSQ_SELL_XMAX", raising=False)
+    monkeypatch.delenv("LSQ_SELL_WIDE", raising=False)
     pr.reset()
     okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
     skind = {"lsmr": lsq._lib.LSMR, "cholesky": lsq._lib.CHOLESKY, "qr": lsq._lib.QR}[sol]
@@ -1588,7 +1664,7 @@ def test_device_g_values_stay_consistent(ctx, fused, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["sliced", "segments", "small", "dense"])
+@pytest.mark.parametrize("kind", ["sliced", "wide", "segments", "small", "dense"])
 def test_column_scaled_jacobian(ctx, kind, monkeypatch):
     """lsq_mat_set_colscale (include/lsqhip.h): a handle holding V with n factors s acts as J = V diag(s) in every operation of
     the hot path -- products, colsumabs2, rowsumabs2, the damped LSMR solve -- on the sliced layouts (fused, nothing multiplied
@@ -1596,11 +1672,13 @@ def test_column_scaled_jacobian(ctx, kind, monkeypatch):
     behind the handle).  Checked against the oracle on the multiplied-out matrix; then s changes (colscale_changed), then V
     changes (set_values), then the scale is removed."""
     rng = np.random.default_rng(11)
-    if kind in ("sliced", "segments"):
+    if kind in ("sliced", "segments", "wide"):
         m, n = 200000, 1500
         S = rand_csc(m, n, 0.004, 5)
         if kind == "segments":
             monkeypatch.setenv("LSQ_NO_SELL", "1")
+        if kind == "wide":     # x passes through LDS in four column windows (what n > 12160 gets)
+            monkeypatch.setenv("LSQ_SELL_XMAX", "400")
     elif kind == "small":
         m, n = 300, 20
         S = rand_csc(m, n, 0.3, 6)
@@ -1609,6 +1687,7 @@ def test_column_scaled_jacobian(ctx, kind, monkeypatch):
         S = rng.standard_normal((m, n))
     J = lsq.DeviceMatrix(ctx, S)
     monkeypatch.delenv("LSQ_NO_SELL", raising=False)
+    monkeypatch.delenv("LSQ_SELL_XMAX", raising=False)
     V = S.tocsc() if kind != "dense" else S
     x, y = rng.standard_normal(n), rng.standard_normal(m)
     damp = rng.uniform(0.5, 2.0, n)

@@ -7,6 +7,8 @@ ctx = lsq.Context(0)
 L = lsq._lib
 shapes = [(1000000, 10000, 1000), (100000, 1000, 1000), (1000000, 100, 20000), (200000, 50000, 40), (2000000, 20, 200000),
           (50000, 50000, 10), (1000000, 1000, 5000)]
+if len(sys.argv) > 1:      # m,n,per_col ...
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for m, n, pc in shapes:
     pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=lsq.synthetic.BASE_SEED, ctx=ctx)
     for oname, opt in (("LM", L.LEVENBERG_MARQUARDT), ("Dogleg", L.DOGLEG)):
