@@ -360,6 +360,8 @@ struct LsqSlotPublish {
 LsqSlotPublish lsq_slots_ticket(lsq_ctx *c, int first, int count);
 int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, double *h_out);
 int lsq_read_ints(lsq_ctx *c, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]);   // null pointers read as 0
+LsqSlotPublish lsq_ints_ticket(lsq_ctx *c);
+int lsq_wait_ints(lsq_ctx *c, unsigned long long seq, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]);
 
 static inline void lsq_run_idle_hook(lsq_ctx *c) {
     if (!c->idle_hook) return;
@@ -387,6 +389,13 @@ void lsq_workspace_free(void *workspace);
 // internal entry points shared between translation units
 int lsq_sparse_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);
 int lsq_dense_mul(lsq_mat *J, int trans, double alpha, const double *d_x, double beta, double *d_y);
+// gather windows of the dense J'y (0: one block per column, k_dense_t)
+static inline int lsq_dense_t_windows(const lsq_ctx *c, int m, int n) {
+    if (n <= 0 || n >= c->num_cus || m < 8192) return 0;
+    int nwin = (4 * c->num_cus + n - 1) / n;
+    nwin = std::min(nwin, std::max(1, m / 2048));
+    return nwin > 1 ? nwin : 0;
+}
 int lsq_dense_colsumabs2(lsq_mat *J, double *d_out);
 int lsq_dense_part(lsq_mat *J, int nwin);   // makes sure J->d_dpart holds nwin x n doubles
 int lsq_dense_part_elems(lsq_mat *J, size_t need);   // ... or `need` doubles

@@ -13,7 +13,8 @@
 #include "lsq_spmv.h"
 
 // allow_tiles: the one-launch factorisation (k_chol_tiles) may be used; the caller then handles info == -1 (a bounded wait gave up)
-int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax, bool allow_tiles = false);
+int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax, bool allow_tiles = false,
+                         const double *d_y = nullptr);
 int lsq_cholesky_blocked_solve(lsq_solver *s, int n, double *d_x);
 int lsq_tri_inv_fro2(lsq_solver *s, const double *U, int n, double *fro2_inv);   // lsq_qr.hip
 void lsq_tri_pipe_err_copy(lsq_solver *s, int *h_dst);                           // lsq_qr.hip
@@ -355,21 +356,26 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
     if (blocked && d_damp) {
         // MFMA SYRK + blocked Cholesky + pipelined solves (lsq_dense_mfma.hip); measured crossover against the
         // single-workgroup kernel: 200 x 16 0.15 vs 0.11 ms, 300 x 32 0.15 vs 0.18, 500 x 64 0.16 vs 0.32, 2000 x 127 0.24 vs 0.93
-        LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
-        LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, true));
-        s->last_chol_path = s->last_chol_tiles ? 4 : 2;
+        // mul!(x, J', y) rides in the SYRK launch of lsq_cholesky_blocked (d_y), or is launched by it
         // the two status words (PosDefException position / "a wait gave up", and the solve pipeline's flag) reach the host
         // through the pinned slot mirror and a spin, as the loops' scalars do: a hipStreamSynchronize wake-up here cost
-        // ~50 us of every 0.35 ms solve
+        // ~50 us of every 0.35 ms solve; the backward solve's last block stores them itself (pub_want)
         int st4[4] = {0, 0, 0, 0};
-        LSQ_TRY(lsq_read_ints(c, s->d_info, lsq_tri_pipe_err_ptr(s), nullptr, nullptr, st4));
+        auto factor_and_solve = [&](bool tiles) {
+            s->pub_want = true;
+            s->pub_seq = 0;
+            LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, tiles, d_y));
+            s->pub_want = false;
+            if (s->pub_seq) return lsq_wait_ints(c, s->pub_seq, s->d_info, lsq_tri_pipe_err_ptr(s), nullptr, nullptr, st4);
+            return lsq_read_ints(c, s->d_info, lsq_tri_pipe_err_ptr(s), nullptr, nullptr, st4);
+        };
+        LSQ_TRY(factor_and_solve(true));
+        s->last_chol_path = s->last_chol_tiles ? 4 : 2;
         int info = st4[0], perr = st4[1];
         if (info == -1) {                         // k_chol_tiles gave up on a wait: panel launches for a while, and redo
             s->fb_tiles.gave_up(c, LSQ_FB_CHOL_TILES);
             s->last_chol_path = 2;
-            LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));
-            LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, false));
-            LSQ_TRY(lsq_read_ints(c, s->d_info, lsq_tri_pipe_err_ptr(s), nullptr, nullptr, st4));
+            LSQ_TRY(factor_and_solve(false));
             info = st4[0];
             perr = st4[1];
         }

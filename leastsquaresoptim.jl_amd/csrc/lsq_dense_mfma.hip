@@ -27,11 +27,30 @@ constexpr int KS = KC + 2;    // LDS row stride in doubles: 68 dwords = 4 banks 
 template <int MODE>
 __global__ void __launch_bounds__(256)
 k_syrk_mfma(const double *__restrict__ A, int lda, int krows, int ncols, int col0, int kslices, double *__restrict__ W,
-            double *__restrict__ C, int ldc) {
+            double *__restrict__ C, int ldc, const double *__restrict__ jy = nullptr, double *__restrict__ jx = nullptr) {
     __shared__ double sA[MT * KS];
     __shared__ double sB[MT * KS];
     const int nt = (ncols + MT - 1) / MT;
     const int ntiles = nt * (nt + 1) / 2;
+    if constexpr (MODE == 0) {
+        // mul!(x, J', y) of the normal-equations solve rides in this launch: workgroups past the tiles take one column each
+        // (k_dense_t's arithmetic, sum for sum: the result does not depend on which launch formed it)
+        if ((int)blockIdx.x >= ntiles * kslices) {
+            const int b = (int)blockIdx.x - ntiles * kslices;
+            const double *col = A + (size_t)(col0 + b) * lda;
+            double a0 = 0.0, a1 = 0.0;
+            int i = threadIdx.x;
+            for (; i + LSQ_NT < krows; i += 2 * LSQ_NT) {
+                const double c0 = col[i], c1 = col[i + LSQ_NT];
+                a0 += c0 * jy[i];
+                a1 += c1 * jy[i + LSQ_NT];
+            }
+            if (i < krows) a0 += col[i] * jy[i];
+            const double sum = block_sum<LSQ_NT>(a0 + a1, sA);
+            if (threadIdx.x == 0) jx[b] = 1.0 * sum;
+            return;
+        }
+    }
     const int tile = blockIdx.x % ntiles, slice = blockIdx.x / ntiles;
     int t = tile, bi = 0;
     while (t >= nt - bi) { t -= nt - bi; ++bi; }
@@ -891,7 +910,9 @@ k_diag_max(const double *__restrict__ C, int n, double *__restrict__ out) {
 
 // dense_cholesky.jl:43-59: returns LSQ_ENOTPD through *info like the small kernel.  d_x == nullptr: factor only
 // (the caller decides about the solves); d_dmax != nullptr: also max_j (J'J + damp)_jj before the factorisation.
-int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax, bool allow_tiles) {
+// d_y: the right-hand side is J'y and d_x does not hold it yet (it is formed here, inside the SYRK launch where that applies)
+int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double *d_x, double *d_dmax, bool allow_tiles,
+                         const double *d_y) {
     lsq_ctx *c = s->ctx;
     const int m = J->m, n = J->n;
     const int nt = (n + MT - 1) / MT, ntiles = nt * (nt + 1) / 2;
@@ -906,7 +927,10 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         LSQ_HIP(hipMalloc(&s->d_T, need * sizeof(double)));
         s->work_elems = need;
     }
-    if (n <= SS_MAXN && m >= 16384) {
+    const bool small_syrk = n <= SS_MAXN && m >= 16384;
+    const bool jty_rides = d_y && d_x && !small_syrk && lsq_dense_t_windows(c, m, n) == 0 && !getenv("LSQ_CHOL_SEPARATE_JTY");
+    if (d_y && d_x && !jty_rides) LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
+    if (small_syrk) {
         // few columns, many rows: the pair kernel (one pass over J, no 64 x 64 tile of mostly padding)
         const int nwin = std::max(1, std::min(2 * c->num_cus, m / 1024));
         const int wrows = ((m + nwin - 1) / nwin + SS_ROWS - 1) / SS_ROWS * SS_ROWS;
@@ -922,8 +946,8 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
         hipLaunchKernelGGL(k_syrk_small_reduce, dim3((npairs + 255) / 256), dim3(256), 0, c->stream, s->d_T, n, nw, d_damp, s->d_chol,
                            s->d_info);
     } else {
-        hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices), dim3(256), 0, c->stream, J->d_dense, m, m, n, 0, kslices,
-                           s->d_T, (double *)nullptr, 0);
+        hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices + (jty_rides ? n : 0)), dim3(256), 0, c->stream, J->d_dense, m, m,
+                           n, 0, kslices, s->d_T, (double *)nullptr, 0, jty_rides ? d_y : nullptr, jty_rides ? d_x : nullptr);
         hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol, s->d_info);
     }
     if (d_dmax) hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);

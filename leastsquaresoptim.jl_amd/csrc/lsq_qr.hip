@@ -995,7 +995,9 @@ __global__ void k_tri_identity(int *__restrict__ jp, int n, int *__restrict__ ra
 __global__ void __launch_bounds__(256)
 k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int ldx, size_t bstride /* as k_tri_diaginv */,
              int n, const double *__restrict__ cvec, double *__restrict__ x,
-             unsigned long long *__restrict__ slot /* [nblk][64][2] */, unsigned long long epoch, int *__restrict__ err) {
+             unsigned long long *__restrict__ slot /* [nblk][64][2] */, unsigned long long epoch, int *__restrict__ err,
+             const int *pub_info = nullptr, double *pub_dst = nullptr, unsigned long long *pub_seq_word = nullptr,
+             unsigned long long pub_seq = 0) {
     __shared__ double sc[64], sz[64], sp[4][64];
     const int nblk = (n + 63) / 64;
     const int t = nblk - 1 - (int)blockIdx.x;
@@ -1058,6 +1060,16 @@ k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int ldx
         __hip_atomic_store(mine, hi | (unsigned)__double2loint(z), RLX_AGENT);
         __hip_atomic_store(mine + 1, hi | (unsigned)__double2hiint(z), RLX_AGENT);
         if (rin) x[r0 + tid] = z;
+        // block 0 is the last to finish (it has waited for every other block, and cannot finish cleanly if one of them gave
+        // up): it hands the solve's status words -- the factorisation's `info` and the pipeline's flag -- to the host itself,
+        // through the pinned mirror (k_publish_ints: one launch less at the end of every Cholesky solve)
+        if (pub_dst && t == 0 && tid == 0) {
+            __hip_atomic_store(pub_dst + 0, pub_info ? (double)*pub_info : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub_dst + 1, (double)__hip_atomic_load(err, RLX_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub_dst + 2, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub_dst + 3, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub_seq_word, pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1269,9 +1281,17 @@ int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
         hipLaunchKernelGGL(k_tri_fsolve_t, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, d_bx, t->z, t->slot_f,
                            t->epoch, t->d_err);
     }
+    // the caller wants the status words on the host after this solve: the last block publishes them (lsq_cholesky_solve)
+    const bool hook = getenv("LSQ_TEST_EXCHANGE_TIMEOUT") != nullptr;
+    LsqSlotPublish pub;
+    if (s->pub_want && !hook) {
+        pub = lsq_ints_ticket(c);
+        s->pub_seq = pub.seq;
+    }
+    s->pub_want = false;
     hipLaunchKernelGGL(k_tri_bsolve, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, t->z, d_bx, t->slot_b,
-                       t->epoch, t->d_err);
-    if (getenv("LSQ_TEST_EXCHANGE_TIMEOUT")) {   // test hook: pretend a wait gave up (and spoil the result it would have spoilt)
+                       t->epoch, t->d_err, (const int *)s->d_info, pub.dst, pub.seq_word, pub.seq);
+    if (hook) {   // test hook: pretend a wait gave up (and spoil the result it would have spoilt)
         static const int one = 1;
         LSQ_HIP(hipMemcpyAsync(t->d_err, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
         LSQ_HIP(hipMemsetAsync(d_bx, 0xff, (size_t)n * sizeof(double), c->stream));

@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int w
 }
 
 // out = a .* b (the gather vector of a column-scaled wide handle: s .* x, formed once instead of once per row block)
-static __global__ void __launch_bounds__(LSQ_NT) k_sell_vmul(int n, const double *__restrict__ a, const double *__restrict__ b,
+template <int = 0>
+__global__ void __launch_bounds__(LSQ_NT) k_sell_vmul(int n, const double *__restrict__ a, const double *__restrict__ b,
                                                       double *__restrict__ out) {
     for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) out[i] = a[i] * b[i];
 }

@@ -104,6 +104,8 @@ struct lsq_solver {
     LsqFallback fb_qrx;             // QR: slab exchange of the panel steps + pipelined certified solve (mirrors Qr2Work::no_exchange)
     LsqFallback fb_cholqr;          // QR: CholeskyQR2 panels (numerical breakdowns; mirrors Qr2Work::no_cholqr)
     bool last_chol_tiles = false;   // the last blocked factorisation was the one-launch one
+    bool pub_want = false;          // lsq_tri_chol_solve: let the backward solve's last block publish {info, pipeline flag}
+    unsigned long long pub_seq = 0; // ... sequence number of that hand-over (0: it was not launched, use lsq_read_ints)
 };
 int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx);
 int lsq_tri_chol_fwd_operands(lsq_solver *s, int n, double **z, unsigned long long **slot, unsigned long long *epoch, int **err);

@@ -760,12 +760,6 @@ __global__ void __launch_bounds__(LSQ_NT) k_dense_t_win(const double *__restrict
     if (threadIdx.x == 0) part[(size_t)w * n + j] = sum;
 }
 // window count for a dense m x n matrix (0: one block per column is fine)
-static inline int lsq_dense_t_windows(const lsq_ctx *c, int m, int n) {
-    if (n <= 0 || n >= c->num_cus || m < 8192) return 0;
-    int nwin = (4 * c->num_cus + n - 1) / n;
-    nwin = std::min(nwin, std::max(1, m / 2048));
-    return nwin > 1 ? nwin : 0;
-}
 
 // Per-window column sums -> d_bpart[w*n + j] (first pass of the window-blocked J'*y)
 struct EpiPart {
@@ -862,7 +856,7 @@ static inline int launch_sell_rows(lsq_mat *J, const double *xscale, const doubl
         auto kern = k_sell_rows_wide<Epi>;
         LSQ_TRY(lsq_set_lds(c, (const void *)kern, (LSQ_LDS_X_MAX + 2 + LSQ_SELL_ROWS_MAX) * sizeof(double)));
         if (xscale) {   // column-scaled handle: the gather vector s .* x once, not once per row block and window
-            hipLaunchKernelGGL(k_sell_vmul, dim3(std::min(lsq_div_up(J->n, LSQ_NT), c->num_cus * 4)), dim3(LSQ_NT), 0, c->stream,
+            hipLaunchKernelGGL(k_sell_vmul<0>, dim3(std::min(lsq_div_up(J->n, LSQ_NT), c->num_cus * 4)), dim3(LSQ_NT), 0, c->stream,
                                J->n, x, xscale, S.d_sx);
             x = S.d_sx;
         }

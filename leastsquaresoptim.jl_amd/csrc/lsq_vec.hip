@@ -277,10 +277,18 @@ __global__ void k_publish_ints(const int *a, const int *b, const int *c2, const 
     }
 }
 int lsq_read_ints(lsq_ctx *c, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]) {
-    constexpr int FIRST = LSQ_NSLOTS - 8;     // (slots 56..59: not used by any reduction)
-    LsqSlotPublish p = lsq_slots_ticket(c, FIRST, 4);
+    LsqSlotPublish p = lsq_ints_ticket(c);
     hipLaunchKernelGGL(k_publish_ints, dim3(1), dim3(64), 0, c->stream, d_a, d_b, d_c, d_d, p.dst, p.seq_word, p.seq);
     LSQ_HIP(hipGetLastError());
+    return lsq_wait_ints(c, p.seq, d_a, d_b, d_c, d_d, h_out);
+}
+// the ticket of a status hand-over a kernel of the caller performs itself (k_tri_bsolve's last workgroup: dst[0..3] as
+// doubles, then the sequence word with release semantics at system scope), and the host side of it
+LsqSlotPublish lsq_ints_ticket(lsq_ctx *c) { return lsq_slots_ticket(c, LSQ_NSLOTS - 8, 4); }   // (slots 56..59: no reduction uses them)
+int lsq_wait_ints(lsq_ctx *c, unsigned long long seq, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]) {
+    constexpr int FIRST = LSQ_NSLOTS - 8;
+    LsqSlotPublish p;
+    p.seq = seq;
     // (the fallback copy of lsq_wait_slots reads d_slots, which this kernel does not fill: only reached if the pinned word
     //  never becomes visible although the stream drained)
     double v[4];
