@@ -1796,12 +1796,15 @@ def test_c2_dense_lm_cholesky_full_size(ctx):
     pr.close()
 
 
-def test_c4_sparse_full_size_properties(ctx):
-    """C4: sparse 10^6 x 10^4, nnz = 10^7 -- the kernels the bench times, checked through
+@pytest.mark.parametrize("n,pc", [(10_000, 1000), (30_000, 333)])
+def test_c4_sparse_full_size_properties(ctx, n, pc):
+    """C4: sparse 10^6 x 10^4, nnz = 10^7 -- the kernels the bench times -- and the same entry count spread over n = 30000
+    columns (x no longer fits in LDS: J*v takes the column-windowed k_sell_rows_wide), checked through
     size-independent properties: linearity and adjointness of the two products
-    (<J x, y> == <x, J'y>), colsumabs2 against the product with unit vectors' squares, run-to-run
+    (<J x, y> == <x, J'y>), colsumabs2 against the product with unit vectors' squares, sampled rows of J*x bit for bit against
+    a sequential left-to-right sum, run-to-run
     determinism of a full LM+LSMR solve, and the reference's convergence on the tanh model."""
-    m, n, pc = 1_000_000, 10_000, 1000
+    m = 1_000_000
     pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=lsq.synthetic.BASE_SEED, ctx=ctx)
     L = lsq.lib()
     rng = np.random.default_rng(1)
@@ -1824,6 +1827,14 @@ def test_c4_sparse_full_size_properties(ctx):
     assert np.max(np.abs(jx1 - ref)) <= 1e-12 * (1 + np.max(np.abs(ref)))
     cs = lsq.colsumabs2_(out(n), _J).get()
     assert np.allclose(cs, np.add.reduceat(pr.A * pr.A, pr.colptr[:-1]), rtol=1e-12)
+    # one lane adds a row's products left to right (across the column windows when n > 12160): the reference's order
+    Sr = sp.csc_matrix((pr.A, pr.rowval, pr.colptr), shape=(m, n)).tocsr()
+    Sr.sort_indices()
+    for i in rng.integers(0, m, 200):
+        dot = 0.0
+        for k in range(Sr.indptr[i], Sr.indptr[i + 1]):
+            dot += Sr.data[k] * x1[Sr.indices[k]]
+        assert jx1[i] == dot, i
     # determinism + convergence of the whole loop
     runs = []
     for _ in range(2):
