@@ -354,20 +354,27 @@ __device__ __forceinline__ void sell_cols_stage_y(int b, int ncb, int grows, int
     for (int j = 0; j < YR; ++j)
         if (tid + j * LSQ_BIG_NT < grows) yl[tid + j * LSQ_BIG_NT] = (tid + j * LSQ_BIG_NT < rows) ? yr[j] : 0.0;
 }
-// the workgroup's blocks (blockIdx.x, + gridDim.x, ...); the y window of the first one is already on its way to LDS
-// (sell_cols_stage_y)
+// the workgroup's blocks: a CONTIGUOUS run of block indices (blocks of one gather window are consecutive, so a workgroup that
+// holds several blocks -- wide n: 1280 blocks at n = 50000 -- re-stages its 128 KB window of y only when the window changes,
+// not once per block); the y window of the first one is already on its way to LDS (sell_cols_stage_y)
+__device__ __forceinline__ int sell_cols_first(int nblocks) {
+    const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
+    return (int)blockIdx.x * per;
+}
 template <bool SQ>
 __device__ __forceinline__ void sell_cols_pass(const SellDev &S, int ncb, int ccols, int grows, int m, int n,
                                                const double *__restrict__ y, double *__restrict__ part, double *smem) {
     double *yl = smem;                          // LSQ_SELL_GROWS_MAX doubles
     double *ow = smem + LSQ_SELL_GROWS_MAX;     // LSQ_SELL_CCOLS_MAX doubles
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int b = blockIdx.x; b < S.nblocks; b += gridDim.x) {
+    const int per = (S.nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = (int)blockIdx.x * per, b1 = min(S.nblocks, b0 + per);
+    for (int b = b0; b < b1; ++b) {
         const int gw = b / ncb, cb = b - gw * ncb;
         const int cbase = cb * ccols, cols = min(ccols, n - cbase);
-        if (b != (int)blockIdx.x) {
-            __syncthreads();   // the previous block's output pass is done with ow / yl
-            sell_cols_stage_y(b, ncb, grows, m, y, yl, tid);
+        if (b != b0) {
+            __syncthreads();   // the previous block's output pass is done with ow (and its gathers with yl)
+            if (gw != (b - 1) / ncb) sell_cols_stage_y(b, ncb, grows, m, y, yl, tid);
         }
         const int s0 = b * S.spw, s1 = s0 + S.spw;
         double *dst = part + (size_t)gw * (SQ ? 2 : 1) * n + cbase;
@@ -389,7 +396,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_cols(SellDev S, int ncb, in
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the first window is fetched together with the `done` flag of a finished solve (one latency, not two in a row)
     const int dflag = done ? *done : 0;
-    if ((int)blockIdx.x < S.nblocks) sell_cols_stage_y(blockIdx.x, ncb, grows, m, y, smem, threadIdx.x);
+    if (sell_cols_first(S.nblocks) < S.nblocks) sell_cols_stage_y(sell_cols_first(S.nblocks), ncb, grows, m, y, smem, threadIdx.x);
     if (dflag) return;
     sell_cols_pass<SQ>(S, ncb, ccols, grows, m, n, y, part, smem);
 }
