@@ -281,6 +281,13 @@ def main():
         except Exception as e:   # noqa: BLE001
             dense = {"error": repr(e)}
 
+    wide = None
+    if not a.no_cpu and world == 1:
+        try:
+            wide = sparse_secondary(ctx, lsq)
+        except Exception as e:   # noqa: BLE001
+            wide = {"error": repr(e)}
+
     value = a.steps * world / dt
     out = {"metric": "lm_lsmr_outer_iterations_per_sec", "value": value, "unit": "LM outer iterations/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -300,7 +307,7 @@ def main():
                                   "multiplied-out copies of rounds 1-2)" if not os.environ.get("LSQ_NO_COLSCALE") else
                                   "multiplied out into both sliced copies by g!",
                       "final_ssr": r.ssr, "setup_seconds": t_setup},
-           "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense,
+           "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense, "sparse_secondary": wide,
            # bounded-wait give-ups of the fast paths that assume co-resident workgroups (include/lsqhip.h: lsq_solver_stats)
            "fallback_giveups": ctx.fallback_stats(),
            # LM+LSMR: solves whose follow-up kernels were queued behind a guessed last inner iteration, and wrong guesses
@@ -351,6 +358,46 @@ def dry_run(a, rank, world, real_stdout):
 
 
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense fp64 matrix peak
+
+
+def sparse_secondary(ctx, lsq):
+    """The sparse products where x no longer fits in LDS (n > 12160, DESIGN 4.1: column-windowed sliced rows): the C4 entry
+    count spread over n = 25000 columns -- J*v and J'u back to back (HIP events around 30 launches, lsq_bench_mul) against the
+    HBM roofline with the algorithmic bytes of SURVEY 8d, and the LM+LSMR outer iteration on the tanh model.  Not part of
+    `value`."""
+    import ctypes as C
+    import time
+    L = lsq.lib()
+    m, n, pc = 1_000_000, 25_000, 400
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=lsq.synthetic.BASE_SEED, ctx=ctx)
+    nnz = pr.nnz
+    pr.reset()
+    pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=2, fetch_x=False)   # (J = A diag(s))
+    best = None
+    for _ in range(3):
+        pr.reset()
+        t0 = time.perf_counter()
+        r = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=6, fetch_x=False)
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / max(r.iterations, 1) * 1e3
+        best = ms if best is None else min(best, ms)
+    import numpy as np
+    x = lsq.DeviceVector(ctx, n, np.ones(n))
+    y = lsq.DeviceVector(ctx, m, np.ones(m))
+    out = {"workload": "sparse CSC %dx%d, nnz=%d, tanh model" % (m, n, nnz),
+           "lm_lsmr_outer_iteration_ms": best, "lsmr_inner_per_outer": r.lsmr_iterations / max(r.iterations, 1)}
+    for trans, name in ((0, "jv"), (1, "jtu")):
+        ms = C.c_float(0)
+        if trans == 0:
+            lsq._lib.check(L.lsq_bench_mul(pr.J, 0, 30, x.ptr, y.ptr, 1.0, C.byref(ms)))
+        else:
+            lsq._lib.check(L.lsq_bench_mul(pr.J, 1, 30, y.ptr, x.ptr, 1.0, C.byref(ms)))
+        b = 12 * nnz + (4 * (m + 1) + 8 * n + 16 * m if trans == 0 else 4 * (n + 1) + 8 * m + 16 * n)
+        out[name] = {"ms": ms.value, "roofline": {"bound": "hbm", "achieved": b / (ms.value * 1e-3) / 1e9, "peak": 8000.0,
+                                                   "unit": "GB/s", "frac": b / (ms.value * 1e-3) / 1e9 / 8000.0,
+                                                   "algorithmic_bytes_per_launch": b}}
+    pr.close()
+    return out
 
 
 def dense_secondary(ctx, lsq):

@@ -364,8 +364,9 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
         auto factor_and_solve = [&](bool tiles) {
             s->pub_want = true;
             s->pub_seq = 0;
-            LSQ_TRY(lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, tiles, d_y));
-            s->pub_want = false;
+            const int rc = lsq_cholesky_blocked(s, J, d_damp, d_x, nullptr, tiles, d_y);
+            s->pub_want = false;     // (whatever happened: no later solve of this solver may publish on this call's behalf)
+            if (rc != LSQ_OK) return rc;
             if (s->pub_seq) return lsq_wait_ints(c, s->pub_seq, s->d_info, lsq_tri_pipe_err_ptr(s), nullptr, nullptr, st4);
             return lsq_read_ints(c, s->d_info, lsq_tri_pipe_err_ptr(s), nullptr, nullptr, st4);
         };
