@@ -212,12 +212,12 @@ def test_sliced_rows_column_windows(ctx, m, n, density, xmax, rows):
 
 
 def test_sliced_layouts_random_patterns(ctx):
-    """Twenty random shapes / densities / block sizes, with columns and rows emptied at random and duplicate-free
-    ragged rows: J*x, J'*y and colsumabs2 of the sliced layouts against scipy."""
+    """Forty random shapes / densities / block sizes (every other one with x cut into column windows), with columns and
+    rows emptied at random and duplicate-free ragged rows: J*x, J'*y, colsumabs2 and rowsumabs2 of the sliced layouts against scipy."""
     rng = np.random.default_rng(20260928)
     lsq.set_exact(False)
     try:
-        for case in range(20):
+        for case in range(40):
             m = int(rng.integers(1, 4000))
             n = int(rng.integers(1, 600))
             density = float(rng.choice([0.0005, 0.005, 0.05, 0.3]))
@@ -233,10 +233,12 @@ def test_sliced_layouts_random_patterns(ctx):
             os.environ["LSQ_SELL_FORCE"] = "1"
             os.environ["LSQ_SELL_ROWS"] = str(int(rng.choice([64, 128, 4096])))
             os.environ["LSQ_SELL_GROWS"] = str(int(rng.choice([64, 512, 8192])))
+            if case % 2:      # every other case: x in column windows narrower than n (k_sell_rows_wide)
+                os.environ["LSQ_SELL_XMAX"] = str(int(rng.integers(64, 300)))
             try:
                 J = lsq.DeviceMatrix(ctx, S)
             finally:
-                for k in ("LSQ_SELL_FORCE", "LSQ_SELL_ROWS", "LSQ_SELL_GROWS"):
+                for k in ("LSQ_SELL_FORCE", "LSQ_SELL_ROWS", "LSQ_SELL_GROWS", "LSQ_SELL_XMAX"):
                     os.environ.pop(k, None)
             x, y = rng.standard_normal(n), rng.standard_normal(m)
             dx, dy = lsq.DeviceVector(ctx, n, x), lsq.DeviceVector(ctx, m, y)
@@ -248,6 +250,8 @@ def test_sliced_layouts_random_patterns(ctx):
             assert np.max(np.abs(out - ref)) <= 1e-12 * (1 + np.abs(S).sum(axis=0).max() + np.abs(x).max()), (case, m, n, density)
             cs = lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get()
             assert np.allclose(cs, np.asarray(S.multiply(S).sum(axis=0)).ravel(), rtol=1e-13, atol=0), (case, m, n, density)
+            rs = lsq.rowsumabs2_(lsq.DeviceVector(ctx, m, np.full(m, np.nan)), J).get()
+            assert np.allclose(rs, np.asarray(S.multiply(S).sum(axis=1)).ravel(), rtol=1e-13, atol=0), (case, m, n, density)
             J.free()
     finally:
         lsq.set_exact(None)
