@@ -175,8 +175,9 @@ def main():
         run(a.warmup)
     # The timed region is EXACTLY K steps between barrier + synchronize; it is repeated --repeats times (each
     # repeat bracketed the same way) and `value` comes from the MEDIAN region, so the headline is not one sample
-    # of a few milliseconds.  Every third J*v launch of every region carries its own start/stop events.
-    stride = int(os.environ.get("LSQ_BENCH_PROF_STRIDE", "3"))
+    # of a few milliseconds.  Every twelfth J*v launch of every region carries its own start/stop events (250 samples
+    # per run; a timed launch costs ~9 us of pipeline gaps, so every third -- rounds 1-3 -- cost 1.5 % of the rate it measured).
+    stride = int(os.environ.get("LSQ_BENCH_PROF_STRIDE", "12"))
     L.lsq_prof_select(ctx.h, 1 | (stride << 8))     # bits 0-7: kernel mask; bits 8+: time every k-th launch
     L.lsq_prof_begin(ctx.h, 1 << 16)
     region_s, inner_local, r = [], 0, None

@@ -5,7 +5,7 @@ rows=[r for r in csv.DictReader(open(sys.argv[1]))]
 ev=sorted([(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows])
 names=[e[2] for e in ev]
 steps=int(sys.argv[2]) if len(sys.argv)>2 else 40
-damp=[i for i,n in enumerate(names) if n.startswith('k_lm_damp')]
+damp=[i for i,n in enumerate(names) if n.startswith('k_lm_damp') or n.startswith('k_lm_lsmr_setup')]
 # the timed region = the 40 steps after the 8 warm-up steps
 start=damp[8]; end=damp[8+steps] if len(damp)>8+steps else len(ev)-1
 seg=ev[start:end]

@@ -6,7 +6,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 ev = sorted([(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows])
 names = [e[2] for e in ev]
-damp = [i for i, n in enumerate(names) if n.startswith('k_lm_damp')]
+damp = [i for i, n in enumerate(names) if n.startswith('k_lm_damp') or n.startswith('k_lm_lsmr_setup')]
 seg = ev[damp[warm]:damp[warm + steps]]
 d = collections.defaultdict(list)
 for a, b, n in seg:
