@@ -268,6 +268,16 @@ __device__ __forceinline__ double wave_max(double v) {
     return fmax(fmax(lsq_readlane_f64(v, 0), lsq_readlane_f64(v, 16)), fmax(lsq_readlane_f64(v, 32), lsq_readlane_f64(v, 48)));
 }
 
+// XCD-aware placement.  Workgroup b of a launch runs on XCD b mod 8 and every XCD has its own L2, so workgroups that read the
+// same operand should have indices 8 apart, not adjacent.  lsq_xcd_block turns the hardware index into a LOGICAL index such that
+// each XCD owns one contiguous range of logical indices (XCD x: its slot-th workgroup, slot = b / 8, takes logical index
+// first(x) + slot): kernels whose neighbouring logical blocks share data (the column blocks of a gather window of J'u, the column
+// tiles of one split-K slice of V'B) then find it in their own L2 instead of fetching it once per XCD.
+__device__ __forceinline__ int lsq_xcd_block(int b, int G) {
+    const int q = G >> 3, r = G & 7, x = b & 7;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 // Sum over the block in a fixed order (deterministic); result valid in thread 0.
 template <int NT>
 __device__ __forceinline__ double block_sum(double v, double *sh /* NT/64 doubles */) {

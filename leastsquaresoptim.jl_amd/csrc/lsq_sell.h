@@ -357,14 +357,10 @@ __device__ __forceinline__ void sell_cols_stage_y(int b, int ncb, int grows, int
 // the workgroup's blocks: a CONTIGUOUS run of block indices (blocks of one gather window are consecutive, so a workgroup that
 // holds several blocks -- wide n: 1280 blocks at n = 50000 -- re-stages its 128 KB window of y only when the window changes,
 // not once per block); the y window of the first one is already on its way to LDS (sell_cols_stage_y)
-// XCD-aware placement: workgroup i of a launch runs on XCD i mod 8, and each XCD has its own L2.  The blocks of one gather
-// window (its column blocks) read the same 128 KB of y, so they should sit behind ONE L2: hardware workgroup (x, slot) takes the
-// slot-th run of the x-th eighth of the runs, instead of run blockIdx.x -- with runs dealt round-robin the four column blocks of a
-// C4 gather window landed on four XCDs and every window of y was fetched four times (32 MB instead of 8 per launch).
-__device__ __forceinline__ int sell_cols_wg() {
-    const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    return (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
-}
+// XCD-aware placement (lsq_xcd_block): the blocks of one gather window (its column blocks) read the same 128 KB of y, so they
+// should sit behind ONE L2 -- with runs dealt round-robin the four column blocks of a C4 gather window landed on four XCDs and
+// every window of y was fetched four times (32 MB instead of 8 per launch).
+__device__ __forceinline__ int sell_cols_wg() { return lsq_xcd_block((int)blockIdx.x, (int)gridDim.x); }
 __device__ __forceinline__ int sell_cols_first(int nblocks) {
     const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
     return sell_cols_wg() * per;
