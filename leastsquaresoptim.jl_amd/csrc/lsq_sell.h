@@ -10,8 +10,10 @@
 //
 // Layout, built once per pattern (lsq_sparse.hip: build_sell):
 //   * outputs are cut into blocks ("windows") that one 1024-thread workgroup owns:
-//       J*x : <= 4096 consecutive rows            (gather vector x: all n entries in LDS)
-//       J'*y: <= 5120 consecutive columns of one <= 8192-row gather window (y[window] in LDS)
+//       J*x : <= 4096 consecutive rows            (gather vector x: all n entries in LDS; n > 12160: one column window of
+//                                                   x at a time, k_sell_rows_wide, block = (row block, window))
+//       J'*y: <= 2560 consecutive columns of one <= 16384-row gather window (y[window] in LDS); blocks are placed XCD-aware
+//             (lsq_xcd_block: the column blocks of a window behind one L2)
 //   * inside a block the outputs are sorted by entry count and grouped 64 at a time (a slice,
 //     lane = output); a slice stores max-count (rounded up to even) entries per lane, interleaved
 //     in pairs:  slot(j, lane) = off + ((j/2)*64 + lane)*2 + (j%2)   -> a lane reads one 16-byte
