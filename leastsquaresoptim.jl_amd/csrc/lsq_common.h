@@ -318,6 +318,7 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
 // grid would spend 25 us in the fan-in alone).  All counters are left at zero.
 // Returns true in every thread of the last block (after fin has run).
 constexpr int LSQ_RGROUPS = 8;          // ticket groups (blocks b % 8: one per XCD)
+constexpr int LSQ_RFLAT = 64;           // up to this many workgroups: one counter instead of the two levels
 constexpr int LSQ_CTR_STRIDE = 32;      // unsigneds between counters (128-byte lines)
 constexpr int LSQ_CTR_SLOT = (LSQ_RGROUPS + 1) * LSQ_CTR_STRIDE;  // unsigneds per reduction slot
 template <int NT, bool IS_MAX = false, class Fin>
@@ -331,9 +332,15 @@ __device__ __forceinline__ bool grid_reduce(double block_val, double *partials, 
         const int g = b % LSQ_RGROUPS;
         const int ngroups = nblocks < LSQ_RGROUPS ? nblocks : LSQ_RGROUPS;
         const unsigned gsize = (unsigned)((nblocks - g + LSQ_RGROUPS - 1) / LSQ_RGROUPS);
-        unsigned t = __hip_atomic_fetch_add(counter + (1 + g) * LSQ_CTR_STRIDE, 1u, RLX_AGENT);
         int last = 0;
-        if (t == gsize - 1) {
+        if (nblocks <= LSQ_RFLAT) {
+            // few workgroups (the n-length kernels of C4: 40): ONE counter -- two dependent atomics in a row cost a second
+            // memory round trip on a latency-bound kernel, and 40 arrivals at ~12 ns each serialise for less than that
+            if (__hip_atomic_fetch_add(counter, 1u, RLX_AGENT) == (unsigned)(nblocks - 1)) {
+                __hip_atomic_store(counter, 0u, RLX_AGENT);
+                last = 1;
+            }
+        } else if (__hip_atomic_fetch_add(counter + (1 + g) * LSQ_CTR_STRIDE, 1u, RLX_AGENT) == gsize - 1) {
             __hip_atomic_store(counter + (1 + g) * LSQ_CTR_STRIDE, 0u, RLX_AGENT);
             unsigned t2 = __hip_atomic_fetch_add(counter, 1u, RLX_AGENT);
             if (t2 == (unsigned)(ngroups - 1)) {
