@@ -93,7 +93,7 @@ int lsq_mat_refresh(lsq_mat *J);
  * time.  A g! that changed s calls lsq_mat_colscale_changed(J) (instead of lsq_mat_refresh); lsq_mat_set_values /
  * lsq_mat_values / lsq_mat_get_values keep addressing V.  d_s = NULL turns J back into the plain matrix V.
  * Entry (i,j) of J is used as V_ij * s_j formed on the fly where the reference would have stored fl(V_ij s_j): results agree
- * with a multiplied-out J to a few ulp per product, not bit for bit (tests/test_gpu_parity.py::test_column_scaled_jacobian). */
+ * with a multiplied-out J to a few ulp per product, not bit for bit (tests/test_a_gpu_contract.py::test_column_scaled_jacobian). */
 int lsq_mat_set_colscale(lsq_mat *J, const double *d_s);
 int lsq_mat_colscale_changed(lsq_mat *J);
 
@@ -224,6 +224,10 @@ int lsq_solver_chol_path(const lsq_solver *s, int *path);
 int lsq_solver_stats(const lsq_solver *s, int h_giveups[4], int h_paused[4]);
 /* the same totals over every solver the context has run (the solver lsq_optimize keeps inside the context included) */
 int lsq_ctx_fallback_stats(const lsq_ctx *ctx, int h_giveups[4]);
+/* What the context's device looks like to the launch heuristics: compute units (256 on an unpartitioned MI355X, 32 in CPX mode:
+ * the slab exchanges of the QR panel need all 256 -- lsq_qr_stage1.hip), XCDs inferred from that (8 CUs x 4 per XCD -> num_cus / 32),
+ * and the architecture name (at most name_cap - 1 characters).  Any pointer may be null. */
+int lsq_ctx_device_info(const lsq_ctx *ctx, int *num_cus, int *num_xcds, char *arch_name, int name_cap);
 
 /* LM + LSMR with a device-side f!: the kernels that follow the inner solve (step, predicted residual, trial residual) are
  * enqueued behind the inner iteration at which the PREVIOUS solve stopped and skip themselves if this one is not over by then
@@ -328,6 +332,18 @@ int lsq_bench_occupy_wait(lsq_ctx *ctx);
  * restatement exactly even where LSMR's stop iteration depends on the last bit.
  * on = 1 / 0 forces it on / off, -1 restores the default (on; env LSQ_EXACT=0 turns it off). */
 int lsq_set_exact(int on);
+
+/* Debug modes, process-wide (the hazard / serialised build the reference gets from Julia's --check-bounds and a
+ * single thread; also environment LSQ_DEBUG_LAUNCH_JITTER=<us>, LSQ_DEBUG_SERIAL=<0|1|2>, read when the first context is made):
+ *   launch_jitter_us > 0  random host stalls of up to that many microseconds (one in 64: 20x) in front of one kernel launch in
+ *                         four -- any hand-off between kernels that holds only because the next launch follows at once breaks;
+ *   serial = 1            every launch is waited for before the host goes on: no side-stream concurrency, no LSMR look-ahead,
+ *                         no speculation -- SAME kernels and arithmetic, results must be bit-identical to the normal mode;
+ *   serial = 2            additionally without the in-kernel workgroup exchanges (QR slab exchange, pipelined triangular
+ *                         solves, one-launch Cholesky): the multi-launch fallbacks, equal to the fast paths to round-off.
+ * A negative argument leaves that setting alone.  lsq_debug_get also reports the number of stalls injected so far. */
+int lsq_debug_set(int launch_jitter_us, int serial);
+int lsq_debug_get(int *launch_jitter_us, int *serial, long long *stalls);
 
 /* HIP-event instrumentation of the two dominant kernels inside lsq_ldiv(_damped) with LSMR:
  * kernel 0 = K1 (u <- J t - cu u, the J*v product), kernel 1 = K2 (v <- J'u ..., the J'*u product).

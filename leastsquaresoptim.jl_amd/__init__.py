@@ -7,7 +7,7 @@ from .api import (axpy_, box_clip_, clamp_, copyto_, ediv_, fill_, first_nonfini
                   AllocatedSolver, Cholesky, Context, PinnedBuffer, DeviceMatrix, DeviceOperator, DeviceVector, Dogleg, LSMR,
                   LeastSquaresProblem, LeastSquaresProblemAllocated, LeastSquaresResult, LevenbergMarquardt, OptimizationState, QR,
                   colsumabs2_, rowsumabs2_, converged, default_context, default_optimizer, default_solver,
-                  maxabs, maxabs_projected_gradient, mul_, norm, optimize, optimize_, set_exact, sumsq, wdot,
+                  maxabs, maxabs_projected_gradient, mul_, norm, optimize, optimize_, set_exact, debug_set, debug_get, sumsq, wdot,
                   wnorm)
 from . import loops, rowshard, sharding, synthetic
 from .loops import optimize_operator_level

@@ -146,6 +146,7 @@ def lib():
         "lsq_solver_chol_path": (i, [vp, c_ip]),
         "lsq_solver_stats": (i, [vp, c_ip, c_ip]),
         "lsq_ctx_fallback_stats": (i, [vp, c_ip]),
+        "lsq_ctx_device_info": (i, [vp, c_ip, c_ip, C.c_char_p, i]),
         "lsq_ctx_tail_stats": (i, [vp, C.POINTER(C.c_longlong)]),
         "lsq_bench_occupy": (i, [vp, i, i, d]),
         "lsq_bench_occupy_wait": (i, [vp]),
@@ -161,6 +162,8 @@ def lib():
         "lsq_synth_uniform": (i, [i, C.c_ulonglong, d, d, c_dp]),
         "lsq_synth_normal": (i, [i, C.c_ulonglong, c_dp]),
         "lsq_set_exact": (i, [i]),
+        "lsq_debug_set": (i, [i, i]),
+        "lsq_debug_get": (i, [c_ip, c_ip, C.POINTER(C.c_longlong)]),
         "lsq_prof_begin": (i, [vp, i]),
         "lsq_prof_select": (i, [vp, i]),
         "lsq_prof_end": (i, [vp, c_dp, c_ip]),

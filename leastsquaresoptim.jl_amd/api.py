@@ -160,6 +160,17 @@ class Context:
     def sync(self):
         check(lib().lsq_ctx_sync(self.h))
 
+    def device_info(self):
+        """lsq_ctx_device_info: {'num_cus', 'num_xcds', 'arch'} -- what the launch heuristics see (256 CUs unpartitioned)."""
+        a, b = C.c_int(0), C.c_int(0)
+        name = C.create_string_buffer(128)
+        check(lib().lsq_ctx_device_info(self.h, C.byref(a), C.byref(b), name, 128))
+        return {"num_cus": a.value, "num_xcds": b.value, "arch": name.value.decode()}
+
+    @property
+    def num_cus(self):
+        return self.device_info()["num_cus"]
+
     def fallback_stats(self):
         """lsq_ctx_fallback_stats: how often the co-residency fast paths of this context's solvers gave up on a bounded wait."""
         g = (C.c_int * 4)()
@@ -446,6 +457,21 @@ def set_exact(on=None):
     """Reference-order arithmetic for small problems (include/lsqhip.h: lsq_set_exact).
     True / False force it on / off; None restores the default (on unless LSQ_EXACT=0)."""
     check(lib().lsq_set_exact(-1 if on is None else (1 if on else 0)))
+
+
+def debug_set(launch_jitter_us=None, serial=None):
+    """Process-wide debug modes of the library (include/lsqhip.h: lsq_debug_set): random host stalls in front of the
+    kernel launches / serialised launches (1: same kernels, bit-identical results; 2: also without the in-kernel
+    workgroup exchanges).  None leaves a setting alone."""
+    check(lib().lsq_debug_set(-1 if launch_jitter_us is None else int(launch_jitter_us), -1 if serial is None else int(serial)))
+
+
+def debug_get():
+    """(launch_jitter_us, serial, stalls injected so far)"""
+    import ctypes as _C
+    a, b, c = _C.c_int(0), _C.c_int(0), _C.c_longlong(0)
+    check(lib().lsq_debug_get(_C.byref(a), _C.byref(b), _C.byref(c)))
+    return a.value, b.value, c.value
 
 
 class DeviceOperator:

@@ -28,6 +28,35 @@ void lsq_set_error(const char *fmt, ...);
         if (s__ != LSQ_OK) return s__; \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// Debug modes (lsq_debug_set in include/lsqhip.h; environment LSQ_DEBUG_LAUNCH_JITTER=<us>, LSQ_DEBUG_SERIAL=<0|1|2>,
+// read when the first context is created).  Every kernel launch of the library goes through LSQ_LAUNCH:
+//   jitter  a random host stall (uniform in [0, us], before one launch in four; one in 64 is 20x longer) in front of the
+//           launch -- what a busy host does to the queue once per thousand launches, on every solve.  Any hand-off between
+//           kernels that holds only "because the next launch follows at once" fails under it.
+//   serial  1: the launch is waited for before the host goes on (nothing overlaps: no side-stream concurrency, no
+//           look-ahead, no speculation behind unfinished kernels) -- same kernels, same arithmetic, so the results
+//           must be bit-identical to the normal mode;  2: in addition the paths built on in-kernel exchanges between
+//           workgroups (QR slab exchange, pipelined triangular solves, one-launch Cholesky) are off -- other kernels,
+//           compared to a tolerance.
+// ---------------------------------------------------------------------------------------------
+extern int lsq_dbg_jitter_us;
+extern int lsq_dbg_serial;
+void lsq_dbg_init();
+void lsq_dbg_stall();
+#define LSQ_LAUNCH(kern, grid, block, lds, stream, ...)                         \
+    do {                                                                        \
+        if (lsq_dbg_jitter_us > 0) lsq_dbg_stall();                             \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);        \
+        if (lsq_dbg_serial) (void)hipStreamSynchronize(stream);                 \
+    } while (0)
+#define LSQ_LAUNCH_TIMED(kern, grid, block, lds, stream, e0, e1, ...)           \
+    do {                                                                        \
+        if (lsq_dbg_jitter_us > 0) lsq_dbg_stall();                             \
+        hipExtLaunchKernelGGL(kern, grid, block, lds, stream, e0, e1, __VA_ARGS__); \
+        if (lsq_dbg_serial) (void)hipStreamSynchronize(stream);                 \
+    } while (0)
+
 constexpr int LSQ_NT = 256;             // threads per block for streaming kernels (4 waves)
 constexpr int LSQ_MAX_PARTIALS = 1 << 16;
 constexpr int LSQ_NSLOTS = 64;          // device scalar slots / reduction counter slots

@@ -74,15 +74,15 @@ int lsq_dense_colsumabs2(lsq_mat *J, double *out) {  // utils.jl:139-144
     if (const int nwin = lsq_dense_t_windows(J->ctx, J->m, J->n)) {   // few columns: (window, column) blocks + combine
         LSQ_TRY(lsq_dense_part(J, nwin));
         const int wrows = ((J->m + nwin - 1) / nwin + 3) / 4 * 4;
-        hipLaunchKernelGGL((k_dense_t_win<true>), dim3(nwin * J->n), dim3(LSQ_NT), 0, J->ctx->stream, J->d_dense, J->m, J->n,
+        LSQ_LAUNCH((k_dense_t_win<true>), dim3(nwin * J->n), dim3(LSQ_NT), 0, J->ctx->stream, J->d_dense, J->m, J->n,
                            (const double *)nullptr, wrows, J->d_dpart, (const int *)nullptr);
         const int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
-        hipLaunchKernelGGL((k_combine<EpiStoreD>), dim3(nb), dim3(LSQ_NT), 0, J->ctx->stream, J->d_dpart, J->n, nwin, e, nb);
+        LSQ_LAUNCH((k_combine<EpiStoreD>), dim3(nb), dim3(LSQ_NT), 0, J->ctx->stream, J->d_dpart, J->n, nwin, e, nb);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }
     int grid = J->n > LSQ_MAX_GRID ? LSQ_MAX_GRID : J->n;
-    hipLaunchKernelGGL((k_dense_t<EpiStoreD, true>), dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream,
+    LSQ_LAUNCH((k_dense_t<EpiStoreD, true>), dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream,
                        J->d_dense, J->m, J->n, nullptr, e);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -398,15 +398,15 @@ int lsq_cholesky_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const doubl
         if (rc_cert != LSQ_OK) return rc_cert;
         s->last_chol_path = 1;
         const int nt = (n + SY_T - 1) / SY_T;
-        hipLaunchKernelGGL(k_syrk_upper, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, J->d_dense, m, n,
+        LSQ_LAUNCH(k_syrk_upper, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, J->d_dense, m, n,
                            s->d_chol, d_damp);
         LSQ_TRY(lsq_dense_mul(J, 1, 1.0, d_y, 0.0, d_x));  // mul!(x, J', y)
         int *piv = (int *)s->d_tau;
         if (d_damp)
-            hipLaunchKernelGGL((k_chol_solve<false>), dim3(1), dim3(CH_NT), 0, c->stream, s->d_chol, n, d_x,
+            LSQ_LAUNCH((k_chol_solve<false>), dim3(1), dim3(CH_NT), 0, c->stream, s->d_chol, n, d_x,
                                s->d_info, piv, s->d_work, s->d_work + 2 * n);
         else
-            hipLaunchKernelGGL((k_chol_solve<true>), dim3(1), dim3(CH_NT), 0, c->stream, s->d_chol, n, d_x,
+            LSQ_LAUNCH((k_chol_solve<true>), dim3(1), dim3(CH_NT), 0, c->stream, s->d_chol, n, d_x,
                                s->d_info, piv, s->d_work, s->d_work + 2 * n);
         LSQ_HIP(hipGetLastError());
         int info = 0;

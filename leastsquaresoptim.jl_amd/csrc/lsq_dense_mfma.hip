@@ -942,15 +942,15 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
             s->work_elems = need2;
         }
         const int nw = (m + wrows - 1) / wrows;
-        hipLaunchKernelGGL(k_syrk_small, dim3(nw), dim3(256), 0, c->stream, J->d_dense, m, n, wrows, s->d_T);
-        hipLaunchKernelGGL(k_syrk_small_reduce, dim3((npairs + 255) / 256), dim3(256), 0, c->stream, s->d_T, n, nw, d_damp, s->d_chol,
+        LSQ_LAUNCH(k_syrk_small, dim3(nw), dim3(256), 0, c->stream, J->d_dense, m, n, wrows, s->d_T);
+        LSQ_LAUNCH(k_syrk_small_reduce, dim3((npairs + 255) / 256), dim3(256), 0, c->stream, s->d_T, n, nw, d_damp, s->d_chol,
                            s->d_info);
     } else {
-        hipLaunchKernelGGL((k_syrk_mfma<0>), dim3(ntiles * kslices + (jty_rides ? n : 0)), dim3(256), 0, c->stream, J->d_dense, m, m,
+        LSQ_LAUNCH((k_syrk_mfma<0>), dim3(ntiles * kslices + (jty_rides ? n : 0)), dim3(256), 0, c->stream, J->d_dense, m, m,
                            n, 0, kslices, s->d_T, (double *)nullptr, 0, jty_rides ? d_y : nullptr, jty_rides ? d_x : nullptr);
-        hipLaunchKernelGGL(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol, s->d_info);
+        LSQ_LAUNCH(k_syrk_reduce, dim3(ntiles * 16), dim3(256), 0, c->stream, s->d_T, n, kslices, d_damp, s->d_chol, s->d_info);
     }
-    if (d_dmax) hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);
+    if (d_dmax) LSQ_LAUNCH(k_diag_max, dim3(1), dim3(256), 0, c->stream, s->d_chol, n, d_dmax);
     // one launch for the whole factorisation when every 64 x 64 upper tile gets a CU of its own (k_chol_tiles)
     if (allow_tiles && !s->fb_tiles.off() && ntiles <= c->num_cus && n >= 2 * NB && !getenv("LSQ_CHOL_PANELS")) {
         double *Xt = lsq_tri_chol_diagbuf(s, n);
@@ -978,7 +978,7 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
                 static const bool nofuse = getenv("LSQ_CHOL_NO_FUSED_FSOLVE") != nullptr;     // (A/B)
                 const bool fuse = d_x && !nofuse && ntiles + 1 + nt <= c->num_cus &&
                                   lsq_tri_chol_fwd_operands(s, n, &zv, &zslot, &zep, &zerr) == LSQ_OK;
-                hipLaunchKernelGGL(k_chol_chain, dim3(ntiles + 1 + (fuse ? nt : 0)), dim3(256), CHC_LDS, c->stream, s->d_chol, n, nt,
+                LSQ_LAUNCH(k_chol_chain, dim3(ntiles + 1 + (fuse ? nt : 0)), dim3(256), CHC_LDS, c->stream, s->d_chol, n, nt,
                                    s->d_info, Xt, (double *)((char *)s->d_chol_flags + FLAG_BYTES), s->d_chol_flags,
                                    s->d_chol_flags + 1024, s->chol_epoch, wait_epoch, inject ? 64 : CHT_SPIN_LIMIT, d_trace,
                                    (const double *)(fuse ? d_x : nullptr), zv, zslot, (unsigned)zep, zerr);
@@ -1001,14 +1001,14 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
                 }
             } else {
                 LSQ_TRY(lsq_set_lds(c, (const void *)k_chol_tiles, CHT_LDS));
-                hipLaunchKernelGGL(k_chol_tiles, dim3(ntiles), dim3(256), CHT_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
+                LSQ_LAUNCH(k_chol_tiles, dim3(ntiles), dim3(256), CHT_LDS, c->stream, s->d_chol, n, nt, s->d_info, Xt,
                                    s->d_chol_flags, s->chol_epoch, wait_epoch, inject ? 64 : CHT_SPIN_LIMIT);
             }
             s->chol_have_diaginv = true;
             s->last_chol_tiles = true;
             if (!d_x) { LSQ_HIP(hipGetLastError()); return LSQ_OK; }
             if (lsq_tri_chol_solve(s, s->d_chol, n, d_x) != LSQ_OK)
-                hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
+                LSQ_LAUNCH(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
             LSQ_HIP(hipGetLastError());
             return LSQ_OK;
         }
@@ -1025,23 +1025,23 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
     s->chol_have_diaginv = Xd != nullptr;
     for (int j0 = 0; j0 < n; j0 += NB) {
         const int nb = std::min(NB, n - j0), rest = n - j0 - nb;
-        hipLaunchKernelGGL(k_chol_panel_mfma, dim3(std::max(1, (rest + NB - 1) / NB)), dim3(256), CHP_LDS, c->stream, s->d_chol,
+        LSQ_LAUNCH(k_chol_panel_mfma, dim3(std::max(1, (rest + NB - 1) / NB)), dim3(256), CHP_LDS, c->stream, s->d_chol,
                            n, j0, s->d_info, Ds, Xd);
         merged = true;
         if (rest > 0) {
             const int nt2 = (rest + MT - 1) / MT;
             // A22 -= U12' U12 : "A" = rows j0..j0+nb of chol (lda n), columns from j0+nb
-            hipLaunchKernelGGL((k_syrk_mfma<1>), dim3(nt2 * (nt2 + 1) / 2), dim3(256), 0, c->stream, s->d_chol + j0, n, nb,
+            LSQ_LAUNCH((k_syrk_mfma<1>), dim3(nt2 * (nt2 + 1) / 2), dim3(256), 0, c->stream, s->d_chol + j0, n, nb,
                                rest, j0 + nb, 1, (double *)nullptr, s->d_chol, n);
         }
     }
     if (merged)
-        hipLaunchKernelGGL(k_chol_diag_restore, dim3((n + NB - 1) / NB), dim3(256), 0, c->stream, s->d_chol, n, Ds,
+        LSQ_LAUNCH(k_chol_diag_restore, dim3((n + NB - 1) / NB), dim3(256), 0, c->stream, s->d_chol, n, Ds,
                            (const int *)s->d_info);
     if (!d_x) { LSQ_HIP(hipGetLastError()); return LSQ_OK; }
     // U'z = b, U x = z: pipelined over the 64-blocks on several CUs; the single-workgroup kernel otherwise
     if (lsq_tri_chol_solve(s, s->d_chol, n, d_x) != LSQ_OK)
-        hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
+        LSQ_LAUNCH(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -1050,7 +1050,7 @@ int lsq_cholesky_blocked(lsq_solver *s, lsq_mat *J, const double *d_damp, double
 int lsq_cholesky_blocked_solve(lsq_solver *s, int n, double *d_x) {
     lsq_ctx *c = s->ctx;
     if (lsq_tri_chol_solve(s, s->d_chol, n, d_x) != LSQ_OK)
-        hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
+        LSQ_LAUNCH(k_chol_trsv, dim3(1), dim3(1024), 0, c->stream, s->d_chol, n, d_x);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

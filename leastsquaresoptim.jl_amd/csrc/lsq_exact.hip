@@ -117,17 +117,17 @@ int lsq_exact_mul(lsq_mat *J, int trans, double alpha, const double *x, double b
     if (J->kind == LSQ_MAT_CSC) {
         if (!trans) {
             LSQ_TRY(lsq_ensure_csr(J));
-            hipLaunchKernelGGL((k_seg_seq_ab<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, nseg, J->csr.d_ptr,
+            LSQ_LAUNCH((k_seg_seq_ab<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, nseg, J->csr.d_ptr,
                                J->csr.d_idx, J->csr.d_val, x, alpha, beta, y);
         } else {
-            hipLaunchKernelGGL((k_seg_seq_ab<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, nseg, J->csc.d_ptr,
+            LSQ_LAUNCH((k_seg_seq_ab<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, nseg, J->csc.d_ptr,
                                J->csc.d_idx, J->csc.d_val, x, alpha, beta, y);
         }
     } else if (!trans) {
-        hipLaunchKernelGGL((k_dense_seq_ab<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
+        LSQ_LAUNCH((k_dense_seq_ab<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
                            alpha, beta, y);
     } else {
-        hipLaunchKernelGGL((k_dense_seq_ab<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
+        LSQ_LAUNCH((k_dense_seq_ab<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
                            alpha, beta, y);
     }
     LSQ_HIP(hipGetLastError());
@@ -142,12 +142,12 @@ int lsq_exact_product(lsq_mat *J, int trans, const double *x, double *y) {
     if (J->kind == LSQ_MAT_CSC) {
         if (!trans) LSQ_TRY(lsq_ensure_csr(J));
         const LsqSegs &S = trans ? J->csc : J->csr;
-        hipLaunchKernelGGL((k_seg_seq<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, nseg, S.d_ptr, S.d_idx, S.d_val,
+        LSQ_LAUNCH((k_seg_seq<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, nseg, S.d_ptr, S.d_idx, S.d_val,
                            x, y);
     } else if (!trans) {
-        hipLaunchKernelGGL(k_dense_seq_n, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x, y);
+        LSQ_LAUNCH(k_dense_seq_n, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x, y);
     } else {
-        hipLaunchKernelGGL((k_dense_seq_t<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x, y);
+        LSQ_LAUNCH((k_dense_seq_t<false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x, y);
     }
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -158,10 +158,10 @@ int lsq_exact_colsumabs2(lsq_mat *J, double *out) {
     if (J->n <= 0) return LSQ_OK;
     const int grid = lsq_div_up(J->n, LSQ_NT);
     if (J->kind == LSQ_MAT_CSC)
-        hipLaunchKernelGGL((k_seg_seq<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, J->csc.d_idx,
+        LSQ_LAUNCH((k_seg_seq<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, J->csc.d_idx,
                            J->csc.d_val, (const double *)nullptr, out);
     else
-        hipLaunchKernelGGL((k_dense_seq_t<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n,
+        LSQ_LAUNCH((k_dense_seq_t<true>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n,
                            (const double *)nullptr, out);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_seq_reduce(int mode, int n, const doubl
     if (threadIdx.x == 0) *out = acc;
 }
 int lsq_seq_reduce(lsq_ctx *c, int mode, int n, const double *x, const double *y, const double *w, double *d_out) {
-    hipLaunchKernelGGL(k_seq_reduce, dim3(1), dim3(256), 0, c->stream, mode, n, x, y, w, d_out);
+    LSQ_LAUNCH(k_seq_reduce, dim3(1), dim3(256), 0, c->stream, mode, n, x, y, w, d_out);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -221,7 +221,7 @@ k_lm_damp_seq(int n, const double *__restrict__ colsum, double inv_delta, double
     }
 }
 int lsq_exact_lm_damp(lsq_ctx *c, int n, const double *colsum, double inv_delta, double *dtd) {
-    hipLaunchKernelGGL(k_lm_damp_seq, dim3(1), dim3(LSQ_NT), 0, c->stream, n, colsum, inv_delta, dtd);
+    LSQ_LAUNCH(k_lm_damp_seq, dim3(1), dim3(LSQ_NT), 0, c->stream, n, colsum, inv_delta, dtd);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -416,7 +416,7 @@ int lsq_lsmr_exact_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d
     ExactMat M{J->kind == LSQ_MAT_DENSE, m, n, J->d_dense, J->csr.d_ptr, J->csr.d_idx, J->csr.d_val,
                J->csc.d_ptr, J->csc.d_idx, J->csc.d_val};
     int *res = (int *)(s->d_red);  // reuse the reduction scratch for {iter, istop}
-    hipLaunchKernelGGL(k_lsmr_exact, dim3(1), dim3(EX_NT), 0, c->stream, M, d_y, colsum, d_damp, d_x, s->d_u, s->d_ux,
+    LSQ_LAUNCH(k_lsmr_exact, dim3(1), dim3(EX_NT), 0, c->stream, M, d_y, colsum, d_damp, d_x, s->d_u, s->d_ux,
                        s->d_v, s->d_h, s->d_hbar, s->d_t, s->d_dg /* tmp2 */, s->d_P, s->d_rhs, atol, btol,
                        1.0 / conlim, maxiter, res);
     LSQ_HIP(hipGetLastError());

@@ -454,8 +454,15 @@ struct EpiBuf {   // out[j] = dot
     __device__ void extra(int, double &) const {}
     __device__ void finalize(double) const {}
 };
-__global__ void __launch_bounds__(LSQ_NT) k_rowshard_sumsq(const double *pu, const int *npu, double *out, const int *done) {
-    if (done && *done) return;
+__global__ void __launch_bounds__(LSQ_NT) k_rowshard_sumsq(const double *pu, const int *npu, double *out, const int *done,
+                                                            double *xbuf, int n) {
+    if (done && *done) {
+        // an iteration queued behind the stop (the rest of a look-ahead chunk): its product returned at once and the buffer still
+        // holds the LAST all-reduced vector, which the coming collective would sum again (x world per queued iteration, for
+        // nobody to read -- but it must not run off to Inf): clear it
+        for (int i = threadIdx.x; i <= n; i += LSQ_NT) xbuf[i] = 0.0;
+        return;
+    }
     double a, b, c2;
     ordered_sum256x3(pu, npu, nullptr, nullptr, nullptr, nullptr, a, b, c2);
     if (threadIdx.x == 0) *out = a;
@@ -479,13 +486,34 @@ extern "C" int lsq_solver_set_row_allreduce(lsq_solver *s, lsq_device_allreduce_
     }
     return LSQ_OK;
 }
+// colsumabs2 of the whole Jacobian for a row-sharded solver (lsq_solver.h: d_colsum_g): one collective per Jacobian version,
+// issued by every rank at the same point of its call sequence; unsharded solvers get the handle's cache
+int lsq_rowshard_colsum(lsq_solver *s, lsq_mat *J, const double **out) {
+    const double *local = lsq_cached_colsum(J);
+    if (!local) return LSQ_EHIP;
+    *out = local;
+    if (!s->row_cb) return LSQ_OK;
+    lsq_ctx *c = s->ctx;
+    if (!s->d_colsum_g) LSQ_HIP(hipMalloc(&s->d_colsum_g, (size_t)(s->n > 0 ? s->n : 1) * sizeof(double)));
+    if (s->colsum_g_mat != J || s->colsum_g_version != J->version) {
+        LSQ_HIP(hipMemcpyAsync(s->d_colsum_g, local, (size_t)J->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (s->row_cb(s->d_colsum_g, J->n, (void *)c->stream, s->row_user) != 0) {
+            lsq_set_error("row all-reduce callback reported failure");
+            return LSQ_ECALLBACK;
+        }
+        s->colsum_g_mat = J;
+        s->colsum_g_version = J->version;
+    }
+    *out = s->d_colsum_g;
+    return LSQ_OK;
+}
 // v~ <- epilogue(sum over ranks of J_p'src_p) with beta from the summed sum(src.^2); `ev` is the unsharded epilogue
 static int rowshard_adjoint(lsq_solver *s, lsq_mat *J, const double *src, EpiV ev, const double *pu, const int *npu) {
     lsq_ctx *c = s->ctx;
     const int n = J->n;
     EpiBuf eb{ev.done, 0, s->d_xbuf, nullptr, nullptr};
     LSQ_TRY(launch_product(J, 1, src, eb));
-    hipLaunchKernelGGL(k_rowshard_sumsq, dim3(1), dim3(LSQ_NT), 0, c->stream, pu, npu, s->d_xbuf + n, ev.done);
+    LSQ_LAUNCH(k_rowshard_sumsq, dim3(1), dim3(LSQ_NT), 0, c->stream, pu, npu, s->d_xbuf + n, ev.done, s->d_xbuf, n);
     LSQ_HIP(hipGetLastError());
     if (s->row_cb(s->d_xbuf, n + 1, (void *)c->stream, s->row_user) != 0) {
         lsq_set_error("row all-reduce callback reported failure");
@@ -494,7 +522,7 @@ static int rowshard_adjoint(lsq_solver *s, lsq_mat *J, const double *src, EpiV e
     ev.pu = s->d_xbuf + n;
     ev.npu = s->d_one;
     const int nb = lsq_div_up(n, LSQ_CMB_COLS);
-    hipLaunchKernelGGL((k_combine<EpiV>), dim3(std::min(nb, 2048)), dim3(LSQ_NT), 0, c->stream, s->d_xbuf, n, 1, ev, nb);
+    LSQ_LAUNCH((k_combine<EpiV>), dim3(std::min(nb, 2048)), dim3(LSQ_NT), 0, c->stream, s->d_xbuf, n, 1, ev, nb);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -520,7 +548,7 @@ int lsq_lsmr_alloc(lsq_solver *s) {
 void lsq_lsmr_free(lsq_solver *s) {
     hipFree(s->d_state); hipFree(s->d_u); hipFree(s->d_ux); hipFree(s->d_v); hipFree(s->d_h);
     hipFree(s->d_hbar); hipFree(s->d_t); hipFree(s->d_P); hipFree(s->d_dg); hipFree(s->d_rhs); hipFree(s->d_red);
-    hipFree(s->d_xbuf); hipFree(s->d_one);
+    hipFree(s->d_xbuf); hipFree(s->d_one); hipFree(s->d_colsum_g);
 }
 
 static inline int nvec_grid(const lsq_ctx *c, int n) {
@@ -531,7 +559,10 @@ static inline int nvec_grid(const lsq_ctx *c, int n) {
 
 // d_damp == nullptr: undamped (Dogleg, atol = btol = 1e-6); else LM (btol = 0.5).
 bool lsq_lsmr_takes_lm_prep(const lsq_solver *s, const lsq_mat *J) {
-    return s->kind == LSQ_LSMR && J->n <= LSMR_LM_PREP_MAX_N && !lsq_small_mat(J) && !s->precond_cb && !s->gen_ldiv &&
+    // (row-sharded: every rank must take the same kernels -- their summation orders differ in the last bits, and ranks whose
+    //  replicated scalars differ stop at different inner iterations, i.e. issue different numbers of collectives; so the choice
+    //  may depend on n only, never on the size of this rank's row block)
+    return s->kind == LSQ_LSMR && J->n <= LSMR_LM_PREP_MAX_N && (s->row_cb || !lsq_small_mat(J)) && !s->precond_cb && !s->gen_ldiv &&
            !getenv("LSQ_LSMR_SEPARATE_SETUP");
 }
 
@@ -556,11 +587,12 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         LSQ_TRY(lsq_lsmr_exact_solve(s, J, d_y, d_damp, d_x, nmul));
         return tail && tail->fn ? tail->fn(nullptr, tail->user) : LSQ_OK;
     }
-    static const int lookahead = [] {
+    static const int lookahead_env = [] {
         const char *e = getenv("LSQ_LOOKAHEAD");
         int v = e ? atoi(e) : LSQ_LOOKAHEAD_DEFAULT;
         return v < 1 ? 1 : v;
     }();
+    const int lookahead = lsq_dbg_serial ? 1 : lookahead_env;   // (serial debug mode: nothing queued behind an undecided iteration)
     const bool damped = d_damp != nullptr;
     const double atol = 1e-6, btol = damped ? 0.5 : 1e-6, conlim = 1e8;  // lsmr.jl:54, il:255
     const long long rows = (sharded ? s->global_rows : (long long)m) + (damped ? n : 0);
@@ -576,8 +608,10 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     int *npxb[2] = {npu + 2, npu + 3};
 
     if (J->kind == LSQ_MAT_CSC) LSQ_TRY(lsq_ensure_csr(J));
-    const double *colsum = lsq_cached_colsum(J);  // computed once per Jacobian (reference: twice)
-    if (!colsum) return LSQ_EHIP;
+    // computed once per Jacobian (reference: twice); row-sharded: the sum over the ranks' blocks -- the preconditioner is a
+    // replicated n-vector and has to be the same on every rank
+    const double *colsum = nullptr;
+    LSQ_TRY(lsq_rowshard_colsum(s, J, &colsum));
     const int custom_p = s->precond_cb ? 1 : 0;
     if (custom_p) {   // preconditioner!(P, x, J, damp) on the host, damp still un-rooted (iterative_lsmr.jl:251-252)
         LSQ_HIP(hipStreamSynchronize(c->stream));
@@ -594,7 +628,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     auto launch_begin = [&]() {
         long long gb = std::min<long long>(lsq_div_up(m > 0 ? m : 1, LSQ_NT), (long long)c->num_cus * 8);
         if (gb > 4096) gb = 4096;
-        hipLaunchKernelGGL(k_lsmr_begin, dim3((int)gb), dim3(LSQ_NT), 0, c->stream, m, d_y, st, pu, npu, atol,
+        LSQ_LAUNCH(k_lsmr_begin, dim3((int)gb), dim3(LSQ_NT), 0, c->stream, m, d_y, st, pu, npu, atol,
                            btol, 1.0 / conlim, maxiter, epoch);
     };
     if (lm) {
@@ -602,23 +636,23 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             lsq_set_error("lsmr: LM preparation requested where it does not apply");
             return LSQ_EARG;
         }
-        hipLaunchKernelGGL(k_lm_lsmr_setup, dim3(lsq_div_up(n, 1024)), dim3(1024), 0, c->stream, n, *lm, d_damp, s->d_P, s->d_dg,
+        LSQ_LAUNCH(k_lm_lsmr_setup, dim3(lsq_div_up(n, 1024)), dim3(1024), 0, c->stream, n, *lm, d_damp, s->d_P, s->d_dg,
                            s->d_ux, d_Jty, s->d_v, st, pu, npu, y_sumsq, pv, npv, atol, btol, 1.0 / conlim, maxiter, epoch);
-        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
+        LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
                            s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
         LSQ_HIP(hipGetLastError());
     } else if (d_Jty) {
         if (!(y_sumsq >= 0.0)) launch_begin();
-        hipLaunchKernelGGL(k_lsmr_setup, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P, s->d_dg,
+        LSQ_LAUNCH(k_lsmr_setup, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P, s->d_dg,
                            s->d_ux, d_Jty, s->d_v, st, pu, npu, y_sumsq >= 0.0 ? y_sumsq : -1.0, pv, npv, atol, btol,
                            1.0 / conlim, maxiter, epoch, custom_p);
-        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
+        LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
                            s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
         LSQ_HIP(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(k_lsmr_prep, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P,
+        LSQ_LAUNCH(k_lsmr_prep, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P,
                            s->d_dg, s->d_ux, custom_p);
         launch_begin();
         LSQ_HIP(hipGetLastError());
@@ -626,7 +660,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         if (sharded) LSQ_TRY(rowshard_adjoint(s, J, d_y, ev, pu, npu));
         else LSQ_TRY(launch_product(J, 1, d_y, ev));
         // setup K3: u~x is still zero, so only sum(u~_y^2) enters beta_1; it already forms iteration 1's u~x
-        hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
+        LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
                            sharded ? (const double *)(s->d_xbuf + n) : (const double *)pu, sharded ? (const int *)s->d_one : (const int *)npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
                            s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
@@ -684,7 +718,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                 if (c->prof_ev[1].size() > before) prof_iter[1].push_back(enq + 1);
             }
             if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 1);
-            hipLaunchKernelGGL(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
+            LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
                                sharded ? (const double *)(s->d_xbuf + n) : (const double *)pu,
                                sharded ? (const int *)s->d_one : (const int *)npu,
                                pv, npv, (const double *)(damped ? pxb[cur] : nullptr), (const int *)npxb[cur],

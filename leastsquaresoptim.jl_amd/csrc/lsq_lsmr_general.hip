@@ -65,7 +65,7 @@ int lsq_lsmr_general_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double 
     // mul!(v, A', u, 1, bv) for A = PreconditionedMatrix(DampenedMatrix(J, dg), P): iterative_lsmr.jl:36-51 over :95-109
     auto At_u = [&](double bv) -> int {
         LSQ_TRY(lsq_mul(J, 1, 1.0, u, 0.0, tmp));                 // fill!(tmp, 0); mul!(tmp, J', u.y, 1, 1)
-        if (damped) hipLaunchKernelGGL(k_gen_muladd, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, 1.0, tmp, 1.0, ux, dg);
+        if (damped) LSQ_LAUNCH(k_gen_muladd, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, 1.0, tmp, 1.0, ux, dg);
         LSQ_TRY(P_ldiv(tmp2, tmp));
         if (bv == 0.0) LSQ_TRY(lsq_fill(c, n, 0.0, v));
         else if (bv != 1.0) LSQ_TRY(lsq_scal(c, n, bv, v));
@@ -75,7 +75,7 @@ int lsq_lsmr_general_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double 
     auto A_v = [&](double bu) -> int {
         LSQ_TRY(P_ldiv(tmp, v));
         LSQ_TRY(lsq_mul(J, 0, 1.0, tmp, bu, u));
-        if (damped) hipLaunchKernelGGL(k_gen_muladd, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, bu, ux, 1.0, (const double *)tmp, dg);
+        if (damped) LSQ_LAUNCH(k_gen_muladd, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, bu, ux, 1.0, (const double *)tmp, dg);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     };
@@ -90,7 +90,7 @@ int lsq_lsmr_general_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double 
         lsq_set_error("preconditioner! callback reported failure");
         return LSQ_ECALLBACK;
     }
-    if (damped) hipLaunchKernelGGL(k_gen_sqrt, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, d_damp);
+    if (damped) LSQ_LAUNCH(k_gen_sqrt, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, d_damp);
     const double atol = 1e-6, btol = damped ? 0.5 : 1e-6, ctol = 1e-8;
     const long long rows = (s->row_cb ? s->global_rows : (long long)m) + (damped ? n : 0);
     const int maxiter = (int)std::max<long long>(rows, n);

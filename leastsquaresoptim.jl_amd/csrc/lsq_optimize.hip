@@ -409,7 +409,7 @@ static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, i
     long long g = (n + LSQ_NT - 1) / LSQ_NT, cap = (long long)c->num_cus * 2;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_sumsq_slot, dim3((int)g), dim3(LSQ_NT), 0, c->stream, n, x, c->d_partials, lsq_ctr(c, ctr), d_out,
+    LSQ_LAUNCH(k_sumsq_slot, dim3((int)g), dim3(LSQ_NT), 0, c->stream, n, x, c->d_partials, lsq_ctr(c, ctr), d_out,
                        pub);
     return LSQ_OK;
 }
@@ -515,7 +515,7 @@ static int wdot_to_slot(lsq_ctx *c, bool exact, int n, const double *x, const do
                         double *d_out) {
     if (exact) return lsq_seq_reduce(c, 2, n, x, y, w, d_out);
     int g = lsq_div_up(n > 0 ? n : 1, LSQ_NT), cap = c->num_cus * 8;
-    hipLaunchKernelGGL(k_wdot_slot, dim3(g > cap ? cap : g), dim3(LSQ_NT), 0, c->stream, n, x, y, w, c->d_partials,
+    LSQ_LAUNCH(k_wdot_slot, dim3(g > cap ? cap : g), dim3(LSQ_NT), 0, c->stream, n, x, y, w, c->d_partials,
                        lsq_ctr(c, ctr), d_out);
     return LSQ_OK;
 }
@@ -695,7 +695,6 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
     const int gn = ngrid(c, n);
     // reference summation order for small problems (lsq_exact.hip); a general preconditioner runs the operator-level LSMR
     const bool exact = lsq_small_mat(J) && !sharded && !(sv->kind == LSQ_LSMR && sv->gen_ldiv);
-    unsigned long long colsum_global_version = ~0ull;   // (sharded) version of J whose cached colsumabs2 holds the ranks' sum
     int last_inner = 0;          // inner iterations of the previous LSMR solve of this run: the guess for the next one (LsmrTail)
     int local_done = 0;
     double gssr = ssr, ggr = maxabs_gr;
@@ -729,18 +728,16 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             LSQ_TRY(lsq_sparse_grad_colsum(J, fcur, b.grad));
             have_grad = true;
         }
-        const double *cs = lsq_cached_colsum(J);  // :82 (and reused by the LSMR preconditioner)
-        if (!cs) return LSQ_EHIP;
-        if (sharded && colsum_global_version != J->version) {   // colsumabs2(J) = sum_p colsumabs2(J_p): once per g!
-            LSQ_TRY(rows_sum(J->d_colsum, n));
-            colsum_global_version = J->version;
-        }
+        // :82 (and reused by the LSMR preconditioner); row-sharded: colsumabs2(J) = sum_p colsumabs2(J_p), once per g!, in the
+        // solver's buffer (the handle's cache keeps this rank's own block)
+        const double *cs = nullptr;
+        LSQ_TRY(lsq_rowshard_colsum(sv, J, &cs));
         const bool one_wg = !exact && n <= LSQ_ONE_WG_N;
         // (ssr = NaN, i.e. f(x) not finite: the fused preparation takes ssr as the norm of the right-hand side; the
         //  separate kernels re-form it and let the NaN travel to the reference's check_isfinite at the next iteration)
         const bool lm_prep = one_wg && sv->kind == LSQ_LSMR && ssr >= 0.0 && lsq_lsmr_takes_lm_prep(sv, J);
         if (exact) LSQ_TRY(lsq_exact_lm_damp(c, n, cs, 1.0 / delta, b.dtd));
-        else if (!one_wg) hipLaunchKernelGGL(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
+        else if (!one_wg) LSQ_LAUNCH(k_lm_damp, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd);
         {   // :102-104 gradient g = J'f at the pre-step x.  The reference forms it AFTER the solve
             // (into dtd); J and fcur do not change in between, so it is formed once, before the
             // solve, and LSMR's setup product A'b = P.*(J'f)/beta reuses it (saves one pass over J).
@@ -748,10 +745,10 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             if (sharded) LSQ_TRY(rows_sum(b.grad, n));                  // J'f = sum_p J_p'f_p
             if (lm_prep) {}   // (damping and gradient norm ride in the LSMR setup launch below)
             else if (one_wg)
-                hipLaunchKernelGGL(k_lm_damp_grad, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd, b.grad,
+                LSQ_LAUNCH(k_lm_damp_grad, dim3(1), dim3(1024), 0, c->stream, n, cs, 1.0 / delta, b.dtd, b.grad,
                                    x, b.lo, b.hi, c->d_slots + SL_GRAD);
             else
-                hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.grad, x, b.lo, b.hi,
+                LSQ_LAUNCH(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.grad, x, b.lo, b.hi,
                                    c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             mul_calls++;
         }
@@ -790,7 +787,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             lsq_ctx *c = t.c;
             double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
             if (t.is_model) model_trial_buffers(t.user, t.xt, &t_out, &s_out);
-            hipLaunchKernelGGL(k_step, dim3(t.gn), dim3(LSQ_NT), 0, c->stream, t.n, t.x, t.b->dx, t.xt, c->d_partials,
+            LSQ_LAUNCH(k_step, dim3(t.gn), dim3(LSQ_NT), 0, c->stream, t.n, t.x, t.b->dx, t.xt, c->d_partials,
                                lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out, skip);   // :106
             LSQ_HIP(hipGetLastError());
             LSQ_TRY(predicted_to_slot(c, false, t.J, t.b->dx, t.fcur, t.b->fpred, 8, c->d_slots + SL_PRED, LsqSlotPublish(), skip));
@@ -807,7 +804,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             const LsmrLmPrep prep{cs, 1.0 / delta, MIN_DIAGONAL, MAX_DIAGONAL, x, b.lo, b.hi, c->d_slots + SL_GRAD};
             // (speculation needs kernels that honour the skip flag: the device model on the sliced rows)
             static const bool no_spec = getenv("LSQ_NO_TAIL_SPECULATION") != nullptr;
-            const bool guardable = tc.is_model && J->kind == LSQ_MAT_CSC && J->srows.active && !no_spec;
+            const bool guardable = tc.is_model && J->kind == LSQ_MAT_CSC && J->srows.active && !no_spec && !lsq_dbg_serial;
             LsmrTail tail{guardable ? last_inner : 0, tail_fn, &tc};
             LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr, lm_prep ? &prep : nullptr,
                                    tail_ok ? &tail : nullptr));  // :87
@@ -827,7 +824,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
         double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
         if (!exact && f == model_f) model_trial_buffers(user, xt, &t_out, &s_out);
-        hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
+        LSQ_LAUNCH(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
                            lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out);   // :106
         LSQ_HIP(hipGetLastError());
         if (exact) {
@@ -875,7 +872,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             need_jac = true;
             nonfinite_at = trial_nonfinite;
         } else {
-            hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, xt, b.dx, x);  // :135
+            LSQ_LAUNCH(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, xt, b.dx, x);  // :135
             // a non-finite trial component stays non-finite through (x - dx) + dx: the reference's
             // check_isfinite(x) at the top of the next iteration then throws (utils.jl:70-75)
             nonfinite_at = trial_nonfinite;
@@ -955,7 +952,7 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
             }
             const double *cs = lsq_cached_colsum(J);                      // :85
             if (!cs) return LSQ_EHIP;
-            hipLaunchKernelGGL(k_dl_scale, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, cs, b.dtd);  // :90
+            LSQ_LAUNCH(k_dl_scale, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, cs, b.dtd);  // :90
             if (iter == 1) {                                              // :92-97
                 double wx2;
                 LSQ_TRY(lsq_wdot(c, n, x, x, b.dtd, &wx2));
@@ -964,7 +961,7 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
             }
             if (!have_grad) LSQ_TRY(gradient_into(c, exact, J, fcur, b.dgr));  // :99
             mul_calls++;
-            hipLaunchKernelGGL(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, x, b.lo, b.hi,
+            LSQ_LAUNCH(k_gradnorm, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, b.dgr, x, b.lo, b.hi,
                                c->d_partials, lsq_ctr(c, 4), c->d_slots + SL_GRAD);
             LSQ_TRY(lsq_ediv(c, n, b.dgr, b.dtd, b.dgr));                 // :105
             LSQ_TRY(wdot_to_slot(c, exact, n, b.dgr, b.dgr, b.dtd, 5, c->d_slots + SL_W0));     // :106
@@ -1003,7 +1000,7 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
             LSQ_TRY(lsq_d2d(c, b.dx, b.dgn, (size_t)n * sizeof(double)));
             wnorm_dx = wnorm_dgn;
         } else if (wnorm_dgr * alpha >= delta) {                          // :124 case 2
-            hipLaunchKernelGGL(k_lincomb, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, delta / wnorm_dgr, b.dgr, 0.0,
+            LSQ_LAUNCH(k_lincomb, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, delta / wnorm_dgr, b.dgr, 0.0,
                                (const double *)nullptr, b.dx);
             wnorm_dx = delta;
         } else {                                                          // :131 case 3
@@ -1013,7 +1010,7 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
             double cc = b_dot_a - a2;
             double d = std::sqrt(cc * cc + bma2 * (delta * delta - a2));
             double beta = (cc <= 0) ? (d - cc) / bma2 : (delta * delta - a2) / (d + cc);
-            hipLaunchKernelGGL(k_lincomb, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, beta, b.dgn, alpha * (1 - beta),
+            LSQ_LAUNCH(k_lincomb, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, beta, b.dgn, alpha * (1 - beta),
                                (const double *)b.dgr, b.dx);
             double w2;
             LSQ_TRY(lsq_wdot(c, n, b.dx, b.dx, b.dtd, &w2));              // :144
@@ -1022,7 +1019,7 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                 // :148-160
         double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
         if (!exact && f == model_f) model_trial_buffers(user, xt, &t_out, &s_out);
-        hipLaunchKernelGGL(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
+        LSQ_LAUNCH(k_step, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, x, b.dx, xt, c->d_partials,
                            lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out);    // :160
         LSQ_HIP(hipGetLastError());
         LSQ_TRY(f_then_sumsq(c, exact, f, user, m, ftrial, xt, 7, c->d_slots + SL_TRIAL));   // :164, :168
@@ -1046,7 +1043,7 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
             nonfinite_at = trial_nonfinite;
         } else {
             reuse = true;
-            hipLaunchKernelGGL(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, xt, b.dx, x);
+            LSQ_LAUNCH(k_revert, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, xt, b.dx, x);
             nonfinite_at = trial_nonfinite;   // (x - dx) + dx keeps a non-finite component non-finite (see optimize_lm)
         }
         if (rho < DECREASE_THRESHOLD) delta = std::max(MIN_DELTA, delta * 0.5);           // :193-197
@@ -1319,7 +1316,7 @@ static int model_f(double *out, const double *x, void *user) {
     md->tanh_x = nullptr;
     if (!have_tanh) {
         md->sfac_x = nullptr;
-        hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+        LSQ_LAUNCH(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     }
     EpiResidual e{nullptr, 0, md->d_b, out, nullptr, nullptr};
     if (J->kind == LSQ_MAT_CSC && J->srows.active) {
@@ -1362,7 +1359,7 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
     md->tanh_x = nullptr;
     if (!have_tanh) {
         md->sfac_x = nullptr;
-        hipLaunchKernelGGL(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
+        LSQ_LAUNCH(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     }
     if (launch_sell_rows(J, nullptr, md->d_t, e, md->fused ? nullptr : md->d_Acsr) != LSQ_OK) return 1;
     *done = true;
@@ -1376,7 +1373,7 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
     // forms the factor of its column from x itself)
     if (J->kind == LSQ_MAT_DENSE) {}
     else if (md->sfac_x == x) std::swap(md->d_s, md->d_sspec);
-    else hipLaunchKernelGGL(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_s);
+    else LSQ_LAUNCH(k_sfac, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_s);
     md->sfac_x = nullptr;
     md->tanh_x = nullptr;
     if (md->fused) {
@@ -1399,7 +1396,7 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         const bool lazy_csc = lds_ok && rcol && have_cols && ccol && lsq_can_fuse_grad_colsum(J);
         if (!lazy_csc) {
             int grid = J->n < c->num_cus * 16 ? (J->n > 0 ? J->n : 1) : c->num_cus * 16;
-            hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, md->d_Acsc,
+            LSQ_LAUNCH(k_scale_cols, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, md->d_Acsc,
                                x, J->csc.d_val);
         }
         J->csc_fresh = !lazy_csc;
@@ -1410,11 +1407,11 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         }
         if (J->nnz > 0) {
             if (lds_ok && rcol) {
-                hipLaunchKernelGGL(k_scale_lds<true>, dim3(c->num_cus), dim3(1024), lds, c->stream, (rlen + 3) / 4, rcol,
+                LSQ_LAUNCH(k_scale_lds<true>, dim3(c->num_cus), dim3(1024), lds, c->stream, (rlen + 3) / 4, rcol,
                                    md->d_Acsr, md->d_s, J->n, rval);
             } else if (!J->srows.active) {
                 long long g2 = std::min<long long>((J->nnz + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
-                hipLaunchKernelGGL(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
+                LSQ_LAUNCH(k_scale_csr, dim3((int)g2), dim3(LSQ_NT), 0, c->stream, J->nnz, J->csr.d_idx,
                                    md->d_Acsr, md->d_s, J->csr.d_val);
             } else {
                 // sliced rows without the LDS-staged scaling (forced onto a small pattern): rebuild from the CSC copy
@@ -1424,7 +1421,7 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         }
         if (have_cols) {
             if (lds_ok && ccol) {
-                hipLaunchKernelGGL(k_scale_lds<false>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
+                LSQ_LAUNCH(k_scale_lds<false>, dim3(c->num_cus), dim3(1024), lds, c->stream, (clen + 3) / 4,
                                    ccol, md->d_Ab, md->d_s, J->n, cval);
             } else if (J->scols.active) {
                 // no LDS-staged scaling: rebuild the sliced columns from the CSC copy instead
@@ -1433,12 +1430,12 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
             } else if (J->nnz < 16LL * J->bcsc.nseg) {
                 int nsegs = J->bcsc.nseg;
                 int g3 = std::min(lsq_div_up(nsegs, LSQ_NT), c->num_cus * 16);
-                hipLaunchKernelGGL(k_scale_bcsc_thread, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n,
+                LSQ_LAUNCH(k_scale_bcsc_thread, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n,
                                    J->bcsc.d_ptr, md->d_Ab, md->d_s, J->bcsc.d_val);
             } else {
                 int nsegs = J->bcsc.nseg;
                 int g3 = std::min(lsq_div_up(nsegs, LSQ_NT / 64), c->num_cus * 16);
-                hipLaunchKernelGGL(k_scale_bcsc, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n, J->bcsc.d_ptr,
+                LSQ_LAUNCH(k_scale_bcsc, dim3(g3), dim3(LSQ_NT), 0, c->stream, nsegs, J->n, J->bcsc.d_ptr,
                                    md->d_Ab, md->d_s, J->bcsc.d_val);
             }
         }
@@ -1449,7 +1446,7 @@ static int model_g(lsq_mat *J, const double *x, void *user) {
         const int chunks = std::max(1, (int)std::min<long long>((J->m + 4 * LSQ_NT - 1) / (4 * LSQ_NT),
                                                                std::max<long long>(1, (long long)c->num_cus * 16 / std::max(1, J->n))));
         if (tot > 0)
-            hipLaunchKernelGGL(k_scale_dense, dim3(J->n, chunks), dim3(LSQ_NT), 0, c->stream, J->m, md->d_Acsc, x, J->d_dense);
+            LSQ_LAUNCH(k_scale_dense, dim3(J->n, chunks), dim3(LSQ_NT), 0, c->stream, J->m, md->d_Acsc, x, J->d_dense);
     }
     J->version++;
     return hipGetLastError() == hipSuccess ? 0 : 1;

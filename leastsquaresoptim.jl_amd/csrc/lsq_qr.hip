@@ -1166,21 +1166,21 @@ static int qr2_certify_full_rank(lsq_solver *s, const double *R2, int n, double 
         LSQ_HIP(hipMalloc(&q->fro, 2 * FRO_BLOCKS * sizeof(double)));
         LSQ_HIP(hipHostMalloc(&q->h_fro, (2 * FRO_BLOCKS + 1) * sizeof(double)));
     }
-    hipLaunchKernelGGL(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, n, q->Xinv, n, (size_t)64 * n + 64);
+    LSQ_LAUNCH(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, n, q->Xinv, n, (size_t)64 * n + 64);
     for (long long sz = 64; sz < n; sz *= 2) {
         const int sb = (int)sz, npairs = (int)((n + 2 * sz - 1) / (2 * sz)), tps = sb / 64;
         const int grid = npairs * tps * tps;
-        hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, R2, q->Xinv, q->T2, n, sb, 0);
-        hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, R2, q->Xinv, q->T2, n, sb, 1);
+        LSQ_LAUNCH(k_tri_level, dim3(grid), dim3(256), 0, c->stream, R2, q->Xinv, q->T2, n, sb, 0);
+        LSQ_LAUNCH(k_tri_level, dim3(grid), dim3(256), 0, c->stream, R2, q->Xinv, q->T2, n, sb, 1);
     }
-    hipLaunchKernelGGL(k_tri_fro, dim3(FRO_BLOCKS), dim3(256), 0, c->stream, R2, q->Xinv, n, q->fro);
+    LSQ_LAUNCH(k_tri_fro, dim3(FRO_BLOCKS), dim3(256), 0, c->stream, R2, q->Xinv, n, q->fro);
     if (lsq_div_up(n, 64) <= 256 && !q->no_exchange) {   // speculative: used if certified
         if (!q->bslot) {
             LSQ_HIP(hipMalloc(&q->bslot, (size_t)256 * 64 * 2 * sizeof(unsigned long long)));
             LSQ_ZERO(q->bslot, 0, (size_t)256 * 64 * 2 * sizeof(unsigned long long));
         }
-        hipLaunchKernelGGL(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
-        hipLaunchKernelGGL(k_tri_bsolve, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, q->Xinv, n, (size_t)64 * n + 64, n,
+        LSQ_LAUNCH(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
+        LSQ_LAUNCH(k_tri_bsolve, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, R2, q->Xinv, n, (size_t)64 * n + 64, n,
                            rhs2, d_x, q->bslot, ++q->epoch, q->d_err);
         *solved = true;
     }
@@ -1277,8 +1277,8 @@ int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
     } else {
         ++t->epoch;
         if (!s->chol_have_diaginv)     // (the MFMA panel kernel of the blocked factorisation has already left inv(U_kk) in Xd)
-            hipLaunchKernelGGL(k_tri_diaginv, dim3(nblk), dim3(256), 0, c->stream, U, n, t->Xd, 64, (size_t)4096);
-        hipLaunchKernelGGL(k_tri_fsolve_t, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, d_bx, t->z, t->slot_f,
+            LSQ_LAUNCH(k_tri_diaginv, dim3(nblk), dim3(256), 0, c->stream, U, n, t->Xd, 64, (size_t)4096);
+        LSQ_LAUNCH(k_tri_fsolve_t, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, d_bx, t->z, t->slot_f,
                            t->epoch, t->d_err);
     }
     // the caller wants the status words on the host after this solve: the last block publishes them (lsq_cholesky_solve)
@@ -1289,7 +1289,7 @@ int lsq_tri_chol_solve(lsq_solver *s, const double *U, int n, double *d_bx) {
         s->pub_seq = pub.seq;
     }
     s->pub_want = false;
-    hipLaunchKernelGGL(k_tri_bsolve, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, t->z, d_bx, t->slot_b,
+    LSQ_LAUNCH(k_tri_bsolve, dim3(nblk), dim3(256), 0, c->stream, U, t->Xd, 64, (size_t)4096, n, t->z, d_bx, t->slot_b,
                        t->epoch, t->d_err, (const int *)s->d_info, pub.dst, pub.seq_word, pub.seq);
     if (hook) {   // test hook: pretend a wait gave up (and spoil the result it would have spoilt)
         static const int one = 1;
@@ -1329,14 +1329,14 @@ int lsq_tri_inv_fro2(lsq_solver *s, const double *U, int n, double *fro2_inv) {
         LSQ_HIP(hipMalloc(&s->tri_fro, 2 * FRO_BLOCKS * sizeof(double)));
         LSQ_HIP(hipHostMalloc(&s->tri_hfro, 2 * FRO_BLOCKS * sizeof(double)));
     }
-    hipLaunchKernelGGL(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, U, n, s->tri_X, n, (size_t)64 * n + 64);
+    LSQ_LAUNCH(k_tri_diaginv, dim3(lsq_div_up(n, 64)), dim3(256), 0, c->stream, U, n, s->tri_X, n, (size_t)64 * n + 64);
     for (long long sz = 64; sz < n; sz *= 2) {
         const int sb = (int)sz, npairs = (int)((n + 2 * sz - 1) / (2 * sz)), tps = sb / 64;
         const int grid = npairs * tps * tps;
-        hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, U, s->tri_X, s->tri_T, n, sb, 0);
-        hipLaunchKernelGGL(k_tri_level, dim3(grid), dim3(256), 0, c->stream, U, s->tri_X, s->tri_T, n, sb, 1);
+        LSQ_LAUNCH(k_tri_level, dim3(grid), dim3(256), 0, c->stream, U, s->tri_X, s->tri_T, n, sb, 0);
+        LSQ_LAUNCH(k_tri_level, dim3(grid), dim3(256), 0, c->stream, U, s->tri_X, s->tri_T, n, sb, 1);
     }
-    hipLaunchKernelGGL(k_tri_fro, dim3(FRO_BLOCKS), dim3(256), 0, c->stream, U, s->tri_X, n, s->tri_fro);
+    LSQ_LAUNCH(k_tri_fro, dim3(FRO_BLOCKS), dim3(256), 0, c->stream, U, s->tri_X, n, s->tri_fro);
     LSQ_HIP(hipMemcpyAsync(s->tri_hfro, s->tri_fro, 2 * FRO_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     double fx = 0.0;
@@ -1367,8 +1367,8 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
         }
         long long tot = (long long)M * n;
         int grid = (int)std::min<long long>((tot + LSQ_NT - 1) / LSQ_NT, (long long)c->num_cus * 16);
-        hipLaunchKernelGGL(k_stack, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, m, n, d_damp, s->d_qr);
-        hipLaunchKernelGGL(k_rhs, dim3(lsq_div_up(lu, LSQ_NT)), dim3(LSQ_NT), 0, c->stream, d_y, m, lu, s->d_qu);
+        LSQ_LAUNCH(k_stack, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, m, n, d_damp, s->d_qr);
+        LSQ_LAUNCH(k_rhs, dim3(lsq_div_up(lu, LSQ_NT)), dim3(LSQ_NT), 0, c->stream, d_y, m, lu, s->d_qu);
         const int mn = std::min(M, n);
         s->last_qr_path = 1;
         if (lsq_qr2_applies(M, n)) {
@@ -1391,11 +1391,11 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
             if (full_rank) {
                 // rank = n is certain: the unpivoted triangle gives the same (unique) solution, jp = identity
                 if (!solved) {
-                    hipLaunchKernelGGL(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
+                    LSQ_LAUNCH(k_tri_identity, dim3(lsq_div_up(n, 256)), dim3(256), 0, c->stream, jp, n, s->d_info);
                     if (n <= QRK_MAXN)
-                        hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
+                        LSQ_LAUNCH(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
                     else
-                        hipLaunchKernelGGL(k_tri_matvec, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, q->Xinv, n, rhs2, d_x);
+                        LSQ_LAUNCH(k_tri_matvec, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, q->Xinv, n, rhs2, d_x);
                 }
                 LSQ_HIP(hipGetLastError());
                 s->last_rank = -1;
@@ -1410,11 +1410,11 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
                 // one launch per column, lazy exchanges (k_qr2_step)
                 double *vn1[2] = {q->vn, q->vn + 2 * n}, *vn2[2] = {q->vn + n, q->vn + 3 * n};
                 int *colat[2] = {q->colat, q->colat + n};
-                hipLaunchKernelGGL(k_qr2_init, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, R2, n, vn1[0], vn2[0], colat[0]);
+                LSQ_LAUNCH(k_qr2_init, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, R2, n, vn1[0], vn2[0], colat[0]);
                 for (int i = 0; i < n; ++i) {
                     const int a = i & 1, b = a ^ 1;
                     auto go = [&](auto kern, int cpb) {
-                        hipLaunchKernelGGL(kern, dim3((n - i + cpb - 1) / cpb + 1), dim3(Q2S_NT), 0, c->stream, R2, n, i, rhs2,
+                        LSQ_LAUNCH(kern, dim3((n - i + cpb - 1) / cpb + 1), dim3(Q2S_NT), 0, c->stream, R2, n, i, rhs2,
                                            vn1[a], vn2[a], vn1[b], vn2[b], colat[a], colat[b], tau, ws + 7 * n, q->ice,
                                            (double)mn * DBL_EPSILON, s->d_info);
                     };
@@ -1425,49 +1425,49 @@ int lsq_qr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, const double *d_d
                 // the solve wants R in pivoted order: gather it into the (now free) factor buffer
                 long long tot = (long long)n * n;
                 int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 8);
-                hipLaunchKernelGGL(k_qr2_gather, dim3(g), dim3(256), 0, c->stream, R2, n, colat[n & 1], ws + 7 * n, s->d_qr, jp);
+                LSQ_LAUNCH(k_qr2_gather, dim3(g), dim3(256), 0, c->stream, R2, n, colat[n & 1], ws + 7 * n, s->d_qr, jp);
                 R2 = s->d_qr;
                 have_rank = true;
             } else {
                 double *vn1 = ws, *vn2 = ws + n;
-                hipLaunchKernelGGL(k_qr_norms, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, R2, n, n, vn1, vn2, jp);
+                LSQ_LAUNCH(k_qr_norms, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, R2, n, n, vn1, vn2, jp);
                 for (int i = 0; i < n; ++i) {
-                    hipLaunchKernelGGL(k_qr_pivot, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, i, vn1, vn2, jp, tau);
-                    hipLaunchKernelGGL(k_qr_apply, dim3(lsq_div_up(n - i, 4)), dim3(256), 0, c->stream, R2, n, n, i, rhs2, tau,
+                    LSQ_LAUNCH(k_qr_pivot, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, i, vn1, vn2, jp, tau);
+                    LSQ_LAUNCH(k_qr_apply, dim3(lsq_div_up(n - i, 4)), dim3(256), 0, c->stream, R2, n, n, i, rhs2, tau,
                                        vn1, vn2);
                 }
             }
             int ph = 0;
             if (n <= QRK_MAXN) {
                 if (!have_rank)
-                    hipLaunchKernelGGL(k_qr_rank, dim3(1), dim3(64), 0, c->stream, R2, n, n, (double)mn * DBL_EPSILON, s->d_info);
-                hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
+                    LSQ_LAUNCH(k_qr_rank, dim3(1), dim3(64), 0, c->stream, R2, n, n, (double)mn * DBL_EPSILON, s->d_info);
+                LSQ_LAUNCH(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, jp, s->d_info, d_x);
                 ph = 4;
             }
-            hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, n, d_x, s->d_work, jp,
+            LSQ_LAUNCH(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, R2, n, n, rhs2, n, d_x, s->d_work, jp,
                                s->d_T, (double)mn * DBL_EPSILON, s->d_info, ph);
         } else if (n >= 64 && (long long)M * n >= 65536) {
             // multi-CU column-pivoted Householder (BLAS-2 per column, the rhs rides along as column n)
             double *ws = s->d_work;
             double *vn1 = ws, *vn2 = ws + n, *tau = ws + 2 * n;
             int *jp = (int *)s->d_tau;
-            hipLaunchKernelGGL(k_qr_norms, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, s->d_qr, M, n, vn1, vn2, jp);
+            LSQ_LAUNCH(k_qr_norms, dim3(lsq_div_up(n, 4)), dim3(256), 0, c->stream, s->d_qr, M, n, vn1, vn2, jp);
             for (int i = 0; i < mn; ++i) {
-                hipLaunchKernelGGL(k_qr_pivot, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, i, vn1, vn2, jp, tau);
-                hipLaunchKernelGGL(k_qr_apply, dim3(lsq_div_up(n - i, 4)), dim3(256), 0, c->stream, s->d_qr, M, n, i,
+                LSQ_LAUNCH(k_qr_pivot, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, i, vn1, vn2, jp, tau);
+                LSQ_LAUNCH(k_qr_apply, dim3(lsq_div_up(n - i, 4)), dim3(256), 0, c->stream, s->d_qr, M, n, i,
                                    s->d_qu, tau, vn1, vn2);
             }
             int ph = 0;
             if (n <= QRK_MAXN && M >= n) {
-                hipLaunchKernelGGL(k_qr_rank, dim3(1), dim3(64), 0, c->stream, s->d_qr, M, mn, (double)mn * DBL_EPSILON, s->d_info);
-                hipLaunchKernelGGL(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, jp, s->d_info,
+                LSQ_LAUNCH(k_qr_rank, dim3(1), dim3(64), 0, c->stream, s->d_qr, M, mn, (double)mn * DBL_EPSILON, s->d_info);
+                LSQ_LAUNCH(k_qr_backsolve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, jp, s->d_info,
                                    d_x);
                 ph = 4;
             }
-            hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
+            LSQ_LAUNCH(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
                                s->d_work, jp, s->d_T, (double)mn * DBL_EPSILON, s->d_info, ph);
         } else {
-            hipLaunchKernelGGL(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
+            LSQ_LAUNCH(k_qrcp_solve, dim3(1), dim3(QR_NT), 0, c->stream, s->d_qr, M, n, s->d_qu, lu, d_x,
                                s->d_work, (int *)s->d_tau, s->d_T, (double)mn * DBL_EPSILON, s->d_info, 3);
         }
         LSQ_HIP(hipGetLastError());

@@ -8,6 +8,7 @@ struct CqrWork {
     double *R1 = nullptr;    // R1 (row-major 64 x 64)
     double *Binv = nullptr;  // inv(Q_top - S)
     double *S = nullptr;     // 64 signs
+    double *SR = nullptr;    // S R2 R1, the panel's part of the factor ([col][row]); k_cqr_tw moves it into A
     int max_slabs = 0;
     hipStream_t side = nullptr;           // the LU of Q_top runs here, beside the V'[A2 | b] product
     hipEvent_t ev_q = nullptr, ev_lu = nullptr;
@@ -16,9 +17,9 @@ struct CqrWork {
 int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M);
 void lsq_cqr_free(CqrWork *w);
 // Panel c0..c0+63 of A (column-major, leading dimension M, rows c0..M-1).  In stream order afterwards: Vb (ldv = M - c0)
-// holds Q, the panel's 64 x 64 triangle of A holds its part of R, and the kernel of the block reflector is on its way on
-// the side stream.  A breakdown (cond(panel) beyond ~1e7) sets bit 1 of *d_err.
+// holds Q, and the panel's part of R (w->SR) and the kernel of the block reflector are on their way on the side stream;
+// lsq_cqr_tw puts the former into A's 64 x 64 triangle.  A breakdown (cond(panel) beyond ~1e7) sets bit 1 of *d_err.
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err);
 // after W = Vb'[Vb | A2 | b] (k_qr1_vtb + k_qr1_wreduce):  W2 = T'W for the trailing columns and b; turns Vb into V = Q - [S; 0]
-int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, const double *A, int M, int c0, int cend, int n,
+int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, int M, int c0, int cend, int n,
                const double *rhs, double *Vb, int ldv, double *W2);

@@ -275,10 +275,13 @@ __global__ void __launch_bounds__(256) k_cqr_reduce(const double *__restrict__ G
 // ONE workgroup, on the side stream, beside pass 2 and the caller's V'[A2 | b] product: everything that hangs on the TOP
 // 64 rows only.  It repeats pass 2's factor and forms Q_top = Q1_top inv(R2) itself (so it needs nothing from pass 2),
 // then: modified LU of B = Q_top - S (S on the fly), inv(B) = inv(U) inv(L) and S -> global;
-// R = R2 R1 and the panel's part of the factor, S R, -> A's 64 x 64 triangle.
+// R = R2 R1 and the panel's part of the factor, S R, -> SRg (64 x 64, [col][row]).  It does NOT store into A: pass 2 runs
+// beside it on the main stream and its slab 0 reads Q1's top rows from exactly the elements S R belongs in (a write
+// after read with nothing ordering it -- the round-3 defect: a host stall between the two launches let the store win and
+// slab 0 built V's top rows from S R).  k_cqr_tw, behind both kernels, moves SRg into A's triangle.
 __global__ void __launch_bounds__(256)
-k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, double *__restrict__ A, int lda, int c0,
-          double *__restrict__ Binv, double *__restrict__ Sg, int *__restrict__ err) {
+k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, const double *__restrict__ A, int lda, int c0,
+          double *__restrict__ Binv, double *__restrict__ Sg, double *__restrict__ SRg, int *__restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *B0 = sm, *B1 = sm + S64_MAT, *B2 = sm + 2 * S64_MAT, *B3 = sm + 3 * S64_MAT, *T = sm + 4 * S64_MAT;
     __shared__ double sS[64], sR[64], s_red[4];
@@ -307,11 +310,11 @@ k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, double 
     double *M = B2, *Li = B0;
     s64_lu_modified(M, Li, sS, sR, tid);
     CQ_T(50);
-    // the panel's part of the factor: rows c0..c0+63 of columns c0..c0+63 <- S R (upper triangle)
+    // the panel's part of the factor, S R (upper triangle; zeros below), for k_cqr_tw to put into A
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int e = tid + 256 * q, col = e >> 6, row = e & 63;
-        if (row <= col) A[(size_t)(c0 + col) * lda + c0 + row] = sS[row] * B3[row * S64_LS + col];
+        SRg[e] = row <= col ? sS[row] * B3[row * S64_LS + col] : 0.0;
     }
     if (tid < 64) Sg[tid] = sS[tid];
     __syncthreads();
@@ -342,8 +345,8 @@ k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, double 
 // B-matrix column cb >= 64 is A(:, cend + cb - 64) or the right-hand side (last column); rows from c0.
 __global__ void __launch_bounds__(256)
 k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Binv, const double *__restrict__ Sg,
-         const double *__restrict__ A, int lda, int c0, int cend, int n, const double *__restrict__ rhs, double *__restrict__ Vb,
-         int ldv, double *__restrict__ W2) {
+         const double *__restrict__ SRg, double *A /* read: trailing columns' top rows; written: the panel's triangle */, int lda,
+         int c0, int cend, int n, const double *__restrict__ rhs, double *__restrict__ Vb, int ldv, double *__restrict__ W2) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *sBi = sm;                      // inv(B), row-major
     double *sRh = sm + S64_MAT;            // RHS[k][j]
@@ -365,7 +368,16 @@ k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Bi
             sRh[k * S64_LS + j] = j0 + j < ncols ? top[q] - sk * wq[q] : 0.0;
         }
     }
-    if (blockIdx.x == 0 && tid < 64) Vb[(size_t)tid * ldv + tid] -= Sg[tid];     // V = Q - [S; 0] for the update
+    if (blockIdx.x == 0) {
+        if (tid < 64) Vb[(size_t)tid * ldv + tid] -= Sg[tid];     // V = Q - [S; 0] for the update
+        // the panel's part of R -> A (this launch is ordered behind pass 2, the last reader of Q1's top rows, by the
+        // stream and behind k_cqr_top by ev_lu; nothing in this kernel reads the panel's columns of A)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, col = e >> 6, row = e & 63;
+            if (row <= col) A[(size_t)(c0 + col) * lda + c0 + row] = SRg[e];
+        }
+    }
     __syncthreads();
     const int ij = lane & 15, kq = lane >> 4;
     for (int q = wv; q < 16; q += 4) {
@@ -395,6 +407,7 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
     LSQ_HIP(hipMalloc(&w->G2, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->Binv, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->S, 64 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->SR, 4096 * sizeof(double)));
     {   // highest priority: its single workgroup (141 KB of LDS) must get a CU before the caller's V'[A2 | b] grid fills them
         int lo = 0, hi = 0;
         LSQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -413,7 +426,7 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
 
 void lsq_cqr_free(CqrWork *w) {
     if (!w || !w->ready) return;
-    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->S);
+    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->S); hipFree(w->SR);
     hipEventDestroy(w->ev_q); hipEventDestroy(w->ev_lu);
     hipStreamDestroy(w->side);
     w->ready = false;
@@ -422,32 +435,32 @@ void lsq_cqr_free(CqrWork *w) {
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err) {
     const int rows = M - c0, nslab = (rows + CQ_RS - 1) / CQ_RS;
     hipStream_t ps = c->stream;
-    hipLaunchKernelGGL(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
+    LSQ_LAUNCH(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
                        w->R1, Vb, ldv, d_err);
-    hipLaunchKernelGGL(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G);
-    hipLaunchKernelGGL(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G, w->Gp,
+    LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G);
+    LSQ_LAUNCH(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G, w->Gp,
                        w->R1, Vb, ldv, d_err);
-    hipLaunchKernelGGL(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G2);
+    LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G2);
     LSQ_HIP(hipGetLastError());
     // everything that hangs on the top 64 rows (the 64-step LU among it) runs on the side stream from here on, beside
     // pass 2 and the caller's V'[A2 | b] product
     LSQ_HIP(hipEventRecord(w->ev_q, ps));
     LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
-    hipLaunchKernelGGL(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1, A, M, c0,
-                       w->Binv, w->S, d_err);
+    LSQ_LAUNCH(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1,
+                       (const double *)A, M, c0, w->Binv, w->S, w->SR, d_err);
     LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
-    hipLaunchKernelGGL(k_cqr_pass<2>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G2, w->Gp,
+    LSQ_LAUNCH(k_cqr_pass<2>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G2, w->Gp,
                        w->R1, Vb, ldv, d_err);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 
-int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, const double *A, int M, int c0, int cend, int n,
+int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, int M, int c0, int cend, int n,
                const double *rhs, double *Vb, int ldv, double *W2) {
     LSQ_HIP(hipStreamWaitEvent(c->stream, w->ev_lu, 0));
     const int ncols = ncolsB - 64;
-    hipLaunchKernelGGL(k_cqr_tw, dim3(std::max(1, (ncols + 63) / 64)), dim3(256), CQ_LDS_TW, c->stream, W, ncolsB,
-                       (const double *)w->Binv, (const double *)w->S, A, M, c0, cend, n, rhs, Vb, ldv, W2);
+    LSQ_LAUNCH(k_cqr_tw, dim3(std::max(1, (ncols + 63) / 64)), dim3(256), CQ_LDS_TW, c->stream, W, ncolsB,
+                       (const double *)w->Binv, (const double *)w->S, (const double *)w->SR, A, M, c0, cend, n, rhs, Vb, ldv, W2);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

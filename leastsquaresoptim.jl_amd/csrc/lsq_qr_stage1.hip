@@ -785,7 +785,7 @@ static int qr2_factor(lsq_solver *s, int M, int n, double **R_out, double **rhs_
             }
             double *So = q->tsS[level & 1], *ro = q->tsr[level & 1];
             auto go = [&](auto kern, int slabs_per_block) {
-                hipLaunchKernelGGL(kern, dim3(lsq_div_up(S, slabs_per_block)), dim3(256), 0, c->stream, Acur, Mcur, n, 0, n, q->tau1,
+                LSQ_LAUNCH(kern, dim3(lsq_div_up(S, slabs_per_block)), dim3(256), 0, c->stream, Acur, Mcur, n, 0, n, q->tau1,
                                    q->lazy, q->lazy + n, S, q->xslot, ++q->epoch, q->d_err, q->Pn, 0, bcur, So, Ms, ro);
             };
             if (n <= 8) go(k_qr1_step_multi<256, 8, 8, 1, true>, 4);
@@ -833,6 +833,8 @@ static int qr2_workspace(lsq_solver *s, int M, int n) {
         LSQ_HIP(hipMalloc(&q->colat, (2 * (size_t)n + 8) * sizeof(int)));
         s->qr2 = q;
         s->qr2_free = qr2_free;
+        q->no_exchange = s->fb_qrx.off();
+        q->no_cholqr = s->fb_cholqr.off();
     }
     return LSQ_OK;
 }
@@ -855,17 +857,17 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
             const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
             int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
-            hipLaunchKernelGGL(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
+            LSQ_LAUNCH(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
                                q->Wp);
             {
                 long long tot = (long long)ntile * Q2_NB * Q2_NB;
                 int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
-                hipLaunchKernelGGL(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
+                LSQ_LAUNCH(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
             }
             LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
             {
                 const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
-                hipLaunchKernelGGL(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M,
+                LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M,
                                    c0, cend, n, rhs, ncols, q->W2);
             }
             continue;
@@ -876,15 +878,15 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
         const bool ride = cend == n;
         bool rode = false;
         auto steps = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(1), dim3(QR_NT), 0, c->stream, A, M, cend, c0, 1, q->tau1);
+            LSQ_LAUNCH(kern, dim3(1), dim3(QR_NT), 0, c->stream, A, M, cend, c0, 1, q->tau1);
             for (int i = c0; i + 1 < cend; ++i)
-                hipLaunchKernelGGL(kern, dim3(cend - i - 1), dim3(QR_NT), 0, c->stream, A, M, cend, i, 0, q->tau1);
+                LSQ_LAUNCH(kern, dim3(cend - i - 1), dim3(QR_NT), 0, c->stream, A, M, cend, i, 0, q->tau1);
         };
         auto steps_multi = [&](auto kern, int nt, int K, int S) {
             for (int i = c0; i < cend; i += K) {
                 const int kk = std::min(K, cend - i), G = std::max(1, cend - i - kk + (ride ? 1 : 0));
                 const int grid = S >= 64 ? G * S : S > 1 ? 8 * S * ((G + 7) / 8) : G;
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), 0, c->stream, A, M, cend, i, kk, q->tau1, q->lazy, q->lazy + n, G,
+                LSQ_LAUNCH(kern, dim3(grid), dim3(nt), 0, c->stream, A, M, cend, i, kk, q->tau1, q->lazy, q->lazy + n, G,
                                    q->xslot, ++q->epoch, q->d_err, q->Pn, c0, ride ? rhs : (double *)nullptr,
                                    (double *)nullptr, 0, (double *)nullptr);
             }
@@ -911,7 +913,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
         else if (prow <= 40 * 512) steps_multi(k_qr1_step_multi<512, 40, 2, 1>, 512, 2, 1);
         else steps(k_qr1_step);     // (taller than 20480 rows with the slab exchange off: the plain per-column loop)
         if (rode) {
-            hipLaunchKernelGGL(k_qr1_fin, dim3(1), dim3(256), 0, c->stream, A, M, c0, nb, (const double *)q->lazy,
+            LSQ_LAUNCH(k_qr1_fin, dim3(1), dim3(256), 0, c->stream, A, M, c0, nb, (const double *)q->lazy,
                                side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
             continue;
         }
@@ -922,31 +924,31 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
         {
             long long tot = (long long)rows * Q2_NB;
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 8);
-            hipLaunchKernelGGL(k_qr1_vbuf, dim3(g), dim3(256), 0, c->stream, A, M, c0, nb, q->Vb, ldv,
+            LSQ_LAUNCH(k_qr1_vbuf, dim3(g), dim3(256), 0, c->stream, A, M, c0, nb, q->Vb, ldv,
                                lazy ? (const double *)q->lazy : (const double *)nullptr,
                                lazy ? (const double *)(q->lazy + n) : (const double *)nullptr,
                                side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
         }
         int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
-        hipLaunchKernelGGL(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
+        LSQ_LAUNCH(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
                            q->Wp);
         {
             long long tot = (long long)ntile * Q2_NB * Q2_NB;
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
-            hipLaunchKernelGGL(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
+            LSQ_LAUNCH(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
         }
-        hipLaunchKernelGGL(k_qr1_tw_mfma, dim3(std::max(1, lsq_div_up(ncols, Q2_NB))), dim3(256), 0, c->stream, q->W, ncolsB,
+        LSQ_LAUNCH(k_qr1_tw_mfma, dim3(std::max(1, lsq_div_up(ncols, Q2_NB))), dim3(256), 0, c->stream, q->W, ncolsB,
                                q->tau1, c0, nb, q->W2);
         {
             const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
-            hipLaunchKernelGGL(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols,
+            LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols,
                                q->W2);
         }
     }
     {
         long long tot = (long long)n * n;
         int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 8);
-        hipLaunchKernelGGL(k_qr1_extract, dim3(g), dim3(256), 0, c->stream, A, M, n, rhs, q->R, q->rhs2);
+        LSQ_LAUNCH(k_qr1_extract, dim3(g), dim3(256), 0, c->stream, A, M, n, rhs, q->R, q->rhs2);
     }
     LSQ_HIP(hipGetLastError());
     s->last_qr_panel = q->cholqr_used ? 2 : 1;

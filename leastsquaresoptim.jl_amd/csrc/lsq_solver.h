@@ -31,7 +31,8 @@ struct LsqFallback {
     int giveups = 0;        // how often a bounded wait of this path gave up (lsq_solver_stats)
     int cooldown = 0;       // solves left before the path is armed again (0: armed)
     int next_pause = 16;
-    bool off() const { return cooldown > 0; }
+    bool exchange = true;   // false: the path has no in-kernel exchange (fb_cholqr: a numerical fallback) -- LSQ_DEBUG_SERIAL=2 leaves it on
+    bool off() const { return cooldown > 0 || (exchange && lsq_dbg_serial >= 2); }
     void gave_up(lsq_ctx *c, int which) {
         giveups++;
         c->fallback_giveups[which]++;
@@ -66,6 +67,12 @@ struct lsq_solver {
     void *row_user = nullptr;
     long long global_rows = 0;
     double *d_xbuf = nullptr;  // n + 2
+    // colsumabs2 of the WHOLE Jacobian (sum over the ranks of the row blocks' column sums) for the default Jacobi
+    // preconditioner and LM's damping: solver-owned, keyed on the handle and its version -- the handle's own cache keeps
+    // the LOCAL block's sums, which is what lsq_colsumabs2(J) and any unsharded solve on the same handle must see
+    double *d_colsum_g = nullptr;
+    const lsq_mat *colsum_g_mat = nullptr;
+    unsigned long long colsum_g_version = ~0ull;
     int *d_one = nullptr;      // the constant 1 (partial count of a sum that is already complete)
     // --- dense Cholesky (dense_cholesky.jl:7-21) ---
     double *d_chol = nullptr;  // n*n
@@ -102,7 +109,7 @@ struct lsq_solver {
     unsigned chol_epoch = 0;
     LsqFallback fb_tiles;           // one-launch factorisation k_chol_tiles (else launch-per-panel)
     LsqFallback fb_qrx;             // QR: slab exchange of the panel steps + pipelined certified solve (mirrors Qr2Work::no_exchange)
-    LsqFallback fb_cholqr;          // QR: CholeskyQR2 panels (numerical breakdowns; mirrors Qr2Work::no_cholqr)
+    LsqFallback fb_cholqr{0, 0, 16, false};   // QR: CholeskyQR2 panels (numerical breakdowns; mirrors Qr2Work::no_cholqr)
     bool last_chol_tiles = false;   // the last blocked factorisation was the one-launch one
     bool pub_want = false;          // lsq_tri_chol_solve: let the backward solve's last block publish {info, pipeline flag}
     unsigned long long pub_seq = 0; // ... sequence number of that hand-over (0: it was not launched, use lsq_read_ints)
@@ -193,6 +200,7 @@ struct LsmrTail {
     int (*fn)(const int *skip, void *user) = nullptr;
     void *user = nullptr;
 };
+int lsq_rowshard_colsum(lsq_solver *s, lsq_mat *J, const double **out);   // colsumabs2 of the whole J (row-sharded: summed over the ranks)
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
                    const double *d_Jty = nullptr, double y_sumsq = -1.0, const LsmrLmPrep *lm = nullptr,
                    const LsmrTail *tail = nullptr);

@@ -595,8 +595,8 @@ k_permute_pad(long long nstore, const int *__restrict__ map, const double *__res
 static int permute_launch(lsq_mat *J, long long count, const int *map, const double *src, double *dst, bool pad) {
     if (count <= 0) return LSQ_OK;
     int grid = (int)std::min<long long>((count + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
-    if (pad) hipLaunchKernelGGL(k_permute_pad, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, map, src, dst);
-    else hipLaunchKernelGGL(k_permute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, map, src, dst);
+    if (pad) LSQ_LAUNCH(k_permute_pad, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, map, src, dst);
+    else LSQ_LAUNCH(k_permute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, map, src, dst);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -639,10 +639,10 @@ int lsq_ensure_csc(lsq_mat *J) {
         const long long count = J->srows.active ? J->srows.nstore : J->nnz;
         int grid = (int)std::min<long long>((count + LSQ_NT - 1) / LSQ_NT, (long long)J->ctx->num_cus * 16);
         if (J->srows.active)
-            hipLaunchKernelGGL(k_unpermute_pad, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, J->srows.d_map,
+            LSQ_LAUNCH(k_unpermute_pad, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, J->srows.d_map,
                                J->srows.d_val, J->csc.d_val);
         else
-            hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, J->d_map,
+            LSQ_LAUNCH(k_unpermute, dim3(grid), dim3(LSQ_NT), 0, J->ctx->stream, count, J->d_map,
                                J->csr.d_val, J->csc.d_val);
         LSQ_HIP(hipGetLastError());
     }
@@ -682,10 +682,10 @@ static int colscale_multiply_out(lsq_mat *J) {
     lsq_ctx *c = J->ctx;
     const int grid = std::max(1, std::min(J->n, c->num_cus * 16));
     if (J->kind == LSQ_MAT_DENSE)
-        hipLaunchKernelGGL(k_colscale_apply, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, (const int *)nullptr, J->m,
+        LSQ_LAUNCH(k_colscale_apply, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, (const int *)nullptr, J->m,
                            J->d_cs_base, J->d_cs_user, J->d_dense);
     else
-        hipLaunchKernelGGL(k_colscale_apply, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, J->d_cs_base,
+        LSQ_LAUNCH(k_colscale_apply, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->n, J->csc.d_ptr, 0, J->d_cs_base,
                            J->d_cs_user, J->csc.d_val);
     LSQ_HIP(hipGetLastError());
     if (J->kind == LSQ_MAT_CSC) {
@@ -918,7 +918,7 @@ int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {
         EpiGradCs e{nullptr, 0, g, J->d_colsum, J->d_colscale, J->d_colsum_base, nullptr, nullptr};
         int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
         int grid = std::min(nb, c->num_cus * 8);
-        hipLaunchKernelGGL((k_combine<EpiGradCs>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, J->n, J->scols.ngw,
+        LSQ_LAUNCH((k_combine<EpiGradCs>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, J->n, J->scols.ngw,
                            e, nb, J->d_colscale);
         LSQ_HIP(hipGetLastError());
         J->colsum_version = J->version;
@@ -929,7 +929,7 @@ int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {
         EpiGradSq e{nullptr, 0, J->n, g, J->d_colsum, nullptr, nullptr};
         int nb = lsq_div_up(2 * J->n, LSQ_CMB_COLS);
         int grid = std::min(nb, c->num_cus * 8);
-        hipLaunchKernelGGL((k_combine<EpiGradSq>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, 2 * J->n,
+        LSQ_LAUNCH((k_combine<EpiGradSq>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, 2 * J->n,
                            J->scols.ngw, e, nb);
         LSQ_HIP(hipGetLastError());
         J->colsum_version = J->version;
@@ -938,12 +938,12 @@ int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {
     const size_t lds = (size_t)(LSQ_WIN_ROWS_MAX + 2 * LSQ_BIG_WINDOW) * sizeof(double);
     auto kern = J->bcsc.d_idx16 ? k_bcsc_lds<true, true> : k_bcsc_lds<false, true>;
     int g2 = std::max(1, std::min(J->bcsc.nwin, c->num_cus));
-    hipLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc), (const int4 *)J->bcsc.d_big,
+    LSQ_LAUNCH(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc), (const int4 *)J->bcsc.d_big,
                        J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m, J->n, f, J->d_bpart, (const int *)nullptr);
     EpiGradSq e{nullptr, 0, J->n, g, J->d_colsum, nullptr, nullptr};
     int nb = lsq_div_up(2 * J->n, LSQ_CMB_COLS);
     int grid = std::min(nb, c->num_cus * 8);
-    hipLaunchKernelGGL((k_combine<EpiGradSq>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_bpart, 2 * J->n, J->nwin,
+    LSQ_LAUNCH((k_combine<EpiGradSq>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_bpart, 2 * J->n, J->nwin,
                        e, nb);
     LSQ_HIP(hipGetLastError());
     J->colsum_version = J->version;
@@ -964,7 +964,7 @@ const double *lsq_cached_colsum(lsq_mat *J) {
     }
     if (J->d_colscale && J->colsum_version != J->version) {
         if (colsum_base_ready(J) != LSQ_OK) return nullptr;
-        hipLaunchKernelGGL(k_colsum_scaled, dim3(std::max(1, std::min(lsq_div_up(J->n, LSQ_NT), J->ctx->num_cus * 4))), dim3(LSQ_NT),
+        LSQ_LAUNCH(k_colsum_scaled, dim3(std::max(1, std::min(lsq_div_up(J->n, LSQ_NT), J->ctx->num_cus * 4))), dim3(LSQ_NT),
                            0, J->ctx->stream, J->n, J->d_colscale, J->d_colsum_base, J->d_colsum);
         if (hipGetLastError() != hipSuccess) return nullptr;
         J->colsum_version = J->version;
@@ -1052,14 +1052,14 @@ extern "C" int lsq_rowsumabs2(lsq_mat *J, double *out) {
     if (J->m <= 0) return LSQ_OK;
     if (J->kind == LSQ_MAT_DENSE) {
         int grid = std::min(lsq_div_up(J->m, LSQ_NT), c->num_cus * 8);
-        hipLaunchKernelGGL(k_dense_rowsq, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, out);
+        LSQ_LAUNCH(k_dense_rowsq, dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, out);
     } else {
         LSQ_TRY(lsq_ensure_csr(J));
         if (J->srows.active) {
             const int ncw = J->srows.ncw;
             int grid = std::max(1, std::min(J->srows.nblocks / ncw, c->num_cus * 4));
             if (ncw > 1) LSQ_HIP(hipMemsetAsync(out, 0, (size_t)J->m * sizeof(double), c->stream));   // rows without entries
-            hipLaunchKernelGGL(k_sell_rowsq, dim3(grid), dim3(256), 0, c->stream, sell_dev(J->srows), J->srows.wrows, J->m, ncw,
+            LSQ_LAUNCH(k_sell_rowsq, dim3(grid), dim3(256), 0, c->stream, sell_dev(J->srows), J->srows.wrows, J->m, ncw,
                                J->srows.cwidth, out, J->d_colscale);
         } else {
             EpiStore e{nullptr, 0, out, nullptr, nullptr};

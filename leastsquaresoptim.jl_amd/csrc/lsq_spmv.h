@@ -600,29 +600,29 @@ static inline int launch_segs(lsq_ctx *ctx, const LsqSegs &segs, const double *x
             int grid = std::max(1, std::min(segs.nbig, ctx->num_cus));
             hipEvent_t e0, e1;
             if (lsq_prof_take(ctx, &e0, &e1))
-                hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, e0, e1, 0, S,
+                LSQ_LAUNCH_TIMED(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, e0, e1, 0, S,
                                       (const int4 *)segs.d_big, segs.nbig, x, segs.nx, nxpad, epi);
             else
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, (const int4 *)segs.d_big,
+                LSQ_LAUNCH(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, ctx->stream, S, (const int4 *)segs.d_big,
                                    segs.nbig, x, segs.nx, nxpad, epi);
             break;
         }
         int grid = cap((long long)segs.ntiles + epi.extra_blocks);
         if (grid > 0)
-            hipLaunchKernelGGL((k_seg_stream<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi);
+            LSQ_LAUNCH((k_seg_stream<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi);
         break;
     }
     case LSQ_PLAN_WAVE: {
         int nb = lsq_div_up(segs.nseg, LSQ_NT / 64);
         int grid = cap((long long)nb + epi.extra_blocks);
         if (grid > 0)
-            hipLaunchKernelGGL((k_seg_wave<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi, nb);
+            LSQ_LAUNCH((k_seg_wave<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi, nb);
         break;
     }
     default: {
         int grid = cap((long long)segs.nseg + epi.extra_blocks);
         if (grid > 0)
-            hipLaunchKernelGGL((k_seg_block<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi);
+            LSQ_LAUNCH((k_seg_block<Epi, SQ>), dim3(grid), dim3(LSQ_NT), 0, ctx->stream, S, x, epi);
         break;
     }
     }
@@ -856,17 +856,17 @@ static inline int launch_sell_rows(lsq_mat *J, const double *xscale, const doubl
         auto kern = k_sell_rows_wide<Epi>;
         LSQ_TRY(lsq_set_lds(c, (const void *)kern, (LSQ_LDS_X_MAX + 2 + LSQ_SELL_ROWS_MAX) * sizeof(double)));
         if (xscale) {   // column-scaled handle: the gather vector s .* x once, not once per row block and window
-            hipLaunchKernelGGL(k_sell_vmul<0>, dim3(std::min(lsq_div_up(J->n, LSQ_NT), c->num_cus * 4)), dim3(LSQ_NT), 0, c->stream,
+            LSQ_LAUNCH(k_sell_vmul<0>, dim3(std::min(lsq_div_up(J->n, LSQ_NT), c->num_cus * 4)), dim3(LSQ_NT), 0, c->stream,
                                J->n, x, xscale, S.d_sx);
             x = S.d_sx;
         }
         const int grid = std::max(1, std::min(S.nblocks / S.ncw, c->num_cus));
         hipEvent_t e0, e1;
         if (lsq_prof_take(c, &e0, &e1))
-            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_WIDE_NT), lds, c->stream, e0, e1, 0, sell_dev(S, val), S.wrows,
+            LSQ_LAUNCH_TIMED(kern, dim3(grid), dim3(LSQ_WIDE_NT), lds, c->stream, e0, e1, 0, sell_dev(S, val), S.wrows,
                                   J->m, S.ncw, S.cwidth, x, J->n, epi);
         else
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_WIDE_NT), lds, c->stream, sell_dev(S, val), S.wrows, J->m, S.ncw,
+            LSQ_LAUNCH(kern, dim3(grid), dim3(LSQ_WIDE_NT), lds, c->stream, sell_dev(S, val), S.wrows, J->m, S.ncw,
                                S.cwidth, x, J->n, epi);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
@@ -878,10 +878,10 @@ static inline int launch_sell_rows(lsq_mat *J, const double *xscale, const doubl
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
     hipEvent_t e0, e1;
     if (lsq_prof_take(c, &e0, &e1))
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S, val), S.wrows,
+        LSQ_LAUNCH_TIMED(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S, val), S.wrows,
                               J->m, x, xscale, J->n, nxpad, epi);
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S, val), S.wrows, J->m, x, xscale,
+        LSQ_LAUNCH(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S, val), S.wrows, J->m, x, xscale,
                            J->n, nxpad, epi);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -898,10 +898,10 @@ static inline int launch_sell_cols(lsq_mat *J, const double *y, const int *done)
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
     hipEvent_t e0, e1;
     if (lsq_prof_take(c, &e0, &e1))
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.ncb, S.ccols,
+        LSQ_LAUNCH_TIMED(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.ncb, S.ccols,
                               S.grows, J->m, J->n, y, S.d_part, done);
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.ncb, S.ccols, S.grows,
+        LSQ_LAUNCH(kern, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.ncb, S.ccols, S.grows,
                            J->m, J->n, y, S.d_part, done);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -925,7 +925,7 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
         int nb = lsq_div_up(len, LSQ_CMB_COLS);
         int grid = cap((long long)nb + epi.extra_blocks);
         if (grid > 0)
-            hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_optmp, len, 1, epi, nb);
+            LSQ_LAUNCH((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_optmp, len, 1, epi, nb);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }
@@ -940,7 +940,7 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
             LSQ_TRY(launch_sell_cols<false>(J, x, epi.done));
             int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
             int grid = cap((long long)nb + epi.extra_blocks);
-            hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, J->n,
+            LSQ_LAUNCH((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, J->n,
                                J->scols.ngw, epi, nb, J->d_colscale);
             LSQ_HIP(hipGetLastError());
             return LSQ_OK;
@@ -955,11 +955,11 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
                 int g2 = std::max(1, std::min(J->bcsc.nwin, c->num_cus));
                 hipEvent_t e0, e1;
                 if (lsq_prof_take(c, &e0, &e1))
-                    hipExtLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, segs_dev(J->bcsc),
+                    LSQ_LAUNCH_TIMED(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, segs_dev(J->bcsc),
                                           (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m,
                                           J->n, x, J->d_bpart, epi.done);
                 else
-                    hipLaunchKernelGGL(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc),
+                    LSQ_LAUNCH(kern, dim3(g2), dim3(LSQ_BIG_NT), lds, c->stream, segs_dev(J->bcsc),
                                        (const int4 *)J->bcsc.d_big, J->bcsc.d_wtile, J->bcsc.nwin, J->bcsc.rw, J->m,
                                        J->n, x, J->d_bpart, epi.done);
             } else {
@@ -968,7 +968,7 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
             }
             int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
             int grid = cap((long long)nb + epi.extra_blocks);
-            hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_bpart, J->n,
+            LSQ_LAUNCH((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_bpart, J->n,
                                J->nwin, epi, nb);
             LSQ_HIP(hipGetLastError());
             return LSQ_OK;
@@ -980,29 +980,29 @@ static inline int launch_product(lsq_mat *J, int trans, const double *x, const E
         const int nch = lsq_dense_n_chunks(c, J->m, J->n), nrb = lsq_div_up(J->m, LSQ_NT);
         const int ccols = ((J->n + nch - 1) / nch + 7) / 8 * 8, nchunks = (J->n + ccols - 1) / ccols;
         LSQ_TRY(lsq_dense_part_elems(J, (size_t)nchunks * J->m));
-        hipLaunchKernelGGL(k_dense_n_win<0>, dim3(nrb * nchunks), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x, ccols, nrb,
+        LSQ_LAUNCH(k_dense_n_win<0>, dim3(nrb * nchunks), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x, ccols, nrb,
                            J->d_dpart, epi.done);
         int nb = lsq_div_up(J->m, LSQ_CMB_COLS);
         int grid = cap((long long)nb + epi.extra_blocks);
-        hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dpart, J->m, nchunks, epi, nb);
+        LSQ_LAUNCH((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dpart, J->m, nchunks, epi, nb);
     } else if (!trans) {
         int nb = lsq_div_up(J->m, LSQ_NT);
         int grid = cap((long long)nb + epi.extra_blocks);
         if (grid > 0)
-            hipLaunchKernelGGL((k_dense_n<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m,
+            LSQ_LAUNCH((k_dense_n<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m,
                                J->n, x, epi, nb);
     } else if (const int nwin = lsq_dense_t_windows(c, J->m, J->n)) {
         LSQ_TRY(lsq_dense_part(J, nwin));
         const int wrows = ((J->m + nwin - 1) / nwin + 3) / 4 * 4;
-        hipLaunchKernelGGL((k_dense_t_win<false>), dim3(nwin * J->n), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
+        LSQ_LAUNCH((k_dense_t_win<false>), dim3(nwin * J->n), dim3(LSQ_NT), 0, c->stream, J->d_dense, J->m, J->n, x,
                            wrows, J->d_dpart, epi.done);
         int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
         int grid = cap((long long)nb + epi.extra_blocks);
-        hipLaunchKernelGGL((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dpart, J->n, nwin, epi, nb);
+        LSQ_LAUNCH((k_combine<Epi>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dpart, J->n, nwin, epi, nb);
     } else {
         int grid = cap((long long)J->n + epi.extra_blocks);
         if (grid > 0)
-            hipLaunchKernelGGL((k_dense_t<Epi, false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense,
+            LSQ_LAUNCH((k_dense_t<Epi, false>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->d_dense,
                                J->m, J->n, x, epi);
     }
     LSQ_HIP(hipGetLastError());

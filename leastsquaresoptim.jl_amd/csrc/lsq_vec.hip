@@ -19,6 +19,46 @@ void lsq_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *lsq_last_error(void) { return g_err; }
+
+// ---- debug modes (lsq_common.h: LSQ_LAUNCH) --------------------------------------------------
+int lsq_dbg_jitter_us = 0;
+int lsq_dbg_serial = 0;
+static unsigned long long g_dbg_rng = 0x9e3779b97f4a7c15ull;
+static unsigned long long g_dbg_stalls = 0;
+void lsq_dbg_init() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char *e = getenv("LSQ_DEBUG_LAUNCH_JITTER")) lsq_dbg_jitter_us = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = getenv("LSQ_DEBUG_SERIAL")) lsq_dbg_serial = atoi(e) > 0 ? atoi(e) : 0;
+}
+void lsq_dbg_stall() {
+    // xorshift64*: a fixed sequence per process (a failing interleaving can be replayed); one launch in four is held back
+    g_dbg_rng ^= g_dbg_rng >> 12; g_dbg_rng ^= g_dbg_rng << 25; g_dbg_rng ^= g_dbg_rng >> 27;
+    const unsigned long long r = g_dbg_rng * 0x2545f4914f6cdd1dull;
+    if ((r & 3) != 0) return;
+    unsigned long long us = (r >> 8) % (unsigned long long)(lsq_dbg_jitter_us + 1);
+    if (((r >> 2) & 63) == 0) us *= 20;            // the occasional long stall (30-70 ms observed in the wild)
+    g_dbg_stalls++;
+    timespec t0, t1;                               // busy wait: usleep's granularity (~60 us) would hide the short stalls
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    do { clock_gettime(CLOCK_MONOTONIC, &t1); }
+    while ((unsigned long long)(t1.tv_sec - t0.tv_sec) * 1000000ull + (unsigned long long)(t1.tv_nsec - t0.tv_nsec) / 1000ull < us
+           && (t1.tv_sec > t0.tv_sec || t1.tv_nsec >= t0.tv_nsec));
+}
+extern "C" int lsq_debug_set(int launch_jitter_us, int serial) {
+    lsq_dbg_init();                                // (so that a later first context does not overwrite this from the environment)
+    if (launch_jitter_us >= 0) lsq_dbg_jitter_us = launch_jitter_us;
+    if (serial >= 0) lsq_dbg_serial = serial;
+    return LSQ_OK;
+}
+extern "C" int lsq_debug_get(int *launch_jitter_us, int *serial, long long *stalls) {
+    lsq_dbg_init();
+    if (launch_jitter_us) *launch_jitter_us = lsq_dbg_jitter_us;
+    if (serial) *serial = lsq_dbg_serial;
+    if (stalls) *stalls = (long long)g_dbg_stalls;
+    return LSQ_OK;
+}
 extern "C" int lsq_version(void) { return 100; }
 
 extern "C" int lsq_ctx_create(int device, void *stream, lsq_ctx **out) {
@@ -31,6 +71,7 @@ extern "C" int lsq_ctx_create(int device, void *stream, lsq_ctx **out) {
         return LSQ_EHIP;
     }
     LSQ_HIP(hipSetDevice(device));
+    lsq_dbg_init();
     lsq_ctx *c = new lsq_ctx();
     c->device = device;
     c->mail_epoch = 0;
@@ -133,7 +174,7 @@ extern "C" int lsq_prof_overhead(lsq_ctx *c, int pairs, double *h_ms) {
     for (auto &e : ev) LSQ_HIP(hipEventCreate(&e));
     // a small kernel before each pair so the first marker waits for real work, like in the solve
     for (int i = 0; i < pairs; ++i) {
-        hipLaunchKernelGGL(k_fill, dim3(1), dim3(LSQ_NT), 0, c->stream, 1, 0.0, c->d_slots + LSQ_NSLOTS - 1);
+        LSQ_LAUNCH(k_fill, dim3(1), dim3(LSQ_NT), 0, c->stream, 1, 0.0, c->d_slots + LSQ_NSLOTS - 1);
         LSQ_HIP(hipEventRecord(ev[2 * i], c->stream));
         LSQ_HIP(hipEventRecord(ev[2 * i + 1], c->stream));
     }
@@ -207,12 +248,12 @@ extern "C" int lsq_d2d(lsq_ctx *c, void *dst, const void *src, size_t bytes) {
     if (a16) {
         size_t n = bytes / 16;
         size_t g = (n + LSQ_NT - 1) / LSQ_NT, cap = (size_t)c->num_cus * 8;
-        hipLaunchKernelGGL(k_copy16, dim3((unsigned)(g > cap ? cap : g)), dim3(LSQ_NT), 0, c->stream, n,
+        LSQ_LAUNCH(k_copy16, dim3((unsigned)(g > cap ? cap : g)), dim3(LSQ_NT), 0, c->stream, n,
                            (const double2 *)src, (double2 *)dst);
     } else if (a8) {
         size_t n = bytes / 8;
         size_t g = (n + LSQ_NT - 1) / LSQ_NT, cap = (size_t)c->num_cus * 8;
-        hipLaunchKernelGGL(k_copy8, dim3((unsigned)(g > cap ? cap : g)), dim3(LSQ_NT), 0, c->stream, n,
+        LSQ_LAUNCH(k_copy8, dim3((unsigned)(g > cap ? cap : g)), dim3(LSQ_NT), 0, c->stream, n,
                            (const double *)src, (double *)dst);
     } else {
         LSQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -278,7 +319,7 @@ __global__ void k_publish_ints(const int *a, const int *b, const int *c2, const 
 }
 int lsq_read_ints(lsq_ctx *c, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]) {
     LsqSlotPublish p = lsq_ints_ticket(c);
-    hipLaunchKernelGGL(k_publish_ints, dim3(1), dim3(64), 0, c->stream, d_a, d_b, d_c, d_d, p.dst, p.seq_word, p.seq);
+    LSQ_LAUNCH(k_publish_ints, dim3(1), dim3(64), 0, c->stream, d_a, d_b, d_c, d_d, p.dst, p.seq_word, p.seq);
     LSQ_HIP(hipGetLastError());
     return lsq_wait_ints(c, p.seq, d_a, d_b, d_c, d_d, h_out);
 }
@@ -318,7 +359,7 @@ int lsq_wait_ints(lsq_ctx *c, unsigned long long seq, const int *d_a, const int 
 
 int lsq_read_slots(lsq_ctx *c, int first, int count, double *h_out) {
     LsqSlotPublish p = lsq_slots_ticket(c, first, count);
-    hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(64), 0, c->stream, p.src, p.count, p.dst, p.seq_word, p.seq);
+    LSQ_LAUNCH(k_publish_slots, dim3(1), dim3(64), 0, c->stream, p.src, p.count, p.dst, p.seq_word, p.seq);
     LSQ_HIP(hipGetLastError());
     return lsq_wait_slots(c, first, count, p.seq, h_out);
 }
@@ -428,7 +469,7 @@ k_first_nonfinite(int n, const double *__restrict__ x, double *partials, unsigne
 #define LSQ_LAUNCH_EW(kernel, n, ...)                                                     \
     do {                                                                                  \
         if ((n) > 0)                                                                      \
-            hipLaunchKernelGGL(kernel, dim3(ew_grid(c, (n))), dim3(LSQ_NT), 0, c->stream, \
+            LSQ_LAUNCH(kernel, dim3(ew_grid(c, (n))), dim3(LSQ_NT), 0, c->stream, \
                                __VA_ARGS__);                                              \
         LSQ_HIP(hipGetLastError());                                                       \
     } while (0)
@@ -482,7 +523,7 @@ static int reduce_to_host(lsq_ctx *c, int n, const double *x, const double *y, c
         return lsq_read_slots(c, 0, 1, h_out);
     }
     int grid = ew_grid(c, n);
-    hipLaunchKernelGGL(k_reduce<MODE>, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x, y, w, lo, hi,
+    LSQ_LAUNCH(k_reduce<MODE>, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x, y, w, lo, hi,
                        c->d_partials, lsq_ctr(c, 0), c->d_slots + 0);
     LSQ_HIP(hipGetLastError());
     LSQ_TRY(lsq_read_slots(c, 0, 1, h_out));
@@ -521,7 +562,7 @@ extern "C" int lsq_first_nonfinite(lsq_ctx *c, int n, const double *x, int *h_in
         return LSQ_OK;
     }
     int grid = ew_grid(c, n);
-    hipLaunchKernelGGL(k_first_nonfinite, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x,
+    LSQ_LAUNCH(k_first_nonfinite, dim3(grid), dim3(LSQ_NT), 0, c->stream, n, x,
                        c->d_partials, lsq_ctr(c, 0), c->d_slots + 0);
     LSQ_HIP(hipGetLastError());
     double v;
@@ -554,12 +595,23 @@ extern "C" int lsq_bench_occupy(lsq_ctx *c, int workgroups, int lds_bytes, doubl
     int rate_khz = 100000;   // wall_clock64 ticks at 100 MHz on gfx9
     (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c->device);
     const long long ticks = (long long)(milliseconds * (double)rate_khz);
-    hipLaunchKernelGGL(k_occupy, dim3(workgroups), dim3(256), (size_t)lds_bytes, c->occupy_stream, ticks, c->d_slots + LSQ_NSLOTS - 2);
+    LSQ_LAUNCH(k_occupy, dim3(workgroups), dim3(256), (size_t)lds_bytes, c->occupy_stream, ticks, c->d_slots + LSQ_NSLOTS - 2);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 extern "C" int lsq_bench_occupy_wait(lsq_ctx *c) {
     if (c && c->occupy_stream) LSQ_HIP(hipStreamSynchronize(c->occupy_stream));
+    return LSQ_OK;
+}
+extern "C" int lsq_ctx_device_info(const lsq_ctx *c, int *num_cus, int *num_xcds, char *arch_name, int name_cap) {
+    if (!c) return LSQ_EARG;
+    if (num_cus) *num_cus = c->num_cus;
+    if (num_xcds) *num_xcds = std::max(1, c->num_cus / 32);
+    if (arch_name && name_cap > 0) {
+        hipDeviceProp_t prop;
+        LSQ_HIP(hipGetDeviceProperties(&prop, c->device));
+        snprintf(arch_name, (size_t)name_cap, "%s", prop.gcnArchName);
+    }
     return LSQ_OK;
 }
 extern "C" int lsq_ctx_fallback_stats(const lsq_ctx *c, int h_giveups[4]) {

@@ -5,7 +5,7 @@ This is what runs when the Julia shim of INTEGRATION.md plugs `HipVector` / `Hip
 `HipAllocatedSolver` into the reference's OWN `optimize!` (levenberg_marquardt.jl:39-144,
 dogleg.jl:41-203): every statement below is one statement of those loops, each array operation one
 C-ABI call on device memory.  It exists to show that the operator-level boundary is sufficient and
-is checked against the fused loop-level entry point `lsq_optimize` (tests/test_gpu_parity.py).
+is checked against the fused loop-level entry point `lsq_optimize` (tests/test_a_gpu_contract.py).
 It costs one host synchronisation per returned scalar, which is why the loop-level call exists.
 """
 import numpy as np

@@ -15,7 +15,7 @@ reduction, including the sparse products and wdot that the reference writes as s
 the wavefront reductions of the HIP fast path use.  `robust` further requires the same signature under 16 random
 summation orders (modes 100..115) and 32 random last-bit perturbations of every reduction result (modes 1000..1031: the
 effect of any algebraically equivalent reformulation, e.g. the 1/beta the fast kernels fold into the next product).
-The fast-path parity test (tests/test_gpu_parity.py::test_minpack_fast_kernels) compares counts on the robust set.
+The fast-path parity test (tests/test_a_gpu_contract.py::test_minpack_fast_kernels) compares counts on the robust set.
 
 Run from the repo root:  python tests/golden/make_count_stable.py
 """

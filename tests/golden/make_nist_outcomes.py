@@ -12,7 +12,7 @@ the reference's algorithms run onto.  The plateaus themselves are pinned indepen
 the minima of LIMIT MODELS (nist_cases.LIMIT_MODELS), fitted here by scipy (`plateaus`).
 
 (2) is produced by the oracle, NOT by a Julia run (there is no Julia here): tests/test_oracle.py re-derives every class
-with its evidence each time and compares; tests/test_gpu_parity.py holds the HIP path to the same table.  The oracle
+with its evidence each time and compares; tests/test_a_gpu_contract.py holds the HIP path to the same table.  The oracle
 is additionally run under every summation-order model of the stdlib reductions (orc_set_sum_mode 1..5) and under
 one-rounding-error perturbations of every reduction result: a class that changes there is a round-off accident, not a
 property of the algorithm; `order_dependent` lists those runs with every class seen, and an implementation whose sums

@@ -1,0 +1,233 @@
+"""GPU parity, LAST tier -- stress: shape sweeps around every launch-path threshold, bit-for-bit repeatability, launch
+jitter (lsq_debug_set), injected exchange time-outs, a busy neighbour on the device.  A failure here must not hide the
+contract (test_a_*) or the kernels (test_b_*): pytest collects files in name order and the driver runs `-x`."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import problems as P
+from oracle import oracle as O
+from gpu_common import GRID, OPT, SOL, compare, gpu_run, lsq, oracle_run, rand_csc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m,n,rank,solver", [(700, 200, 1, "qr"), (3000, 130, 130, "qr"), (9000, 200, 200, "qr"),
+                                             (700, 200, 200, "chol"), (3000, 500, 500, "chol")])
+def test_dense_solves_are_repeatable(ctx, m, n, rank, solver, monkeypatch):
+    """Every reduction of the dense factorisations runs in a fixed order (block reductions, slab exchanges,
+    split-K slices, pipelined block solves), so repeated solves must agree BIT FOR BIT -- which also makes this
+    the detector for races between workgroups or between the rounds of a panel launch (an unsynchronised
+    hand-off shows up as a result that changes from run to run)."""
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n)) if rank < n else rng.standard_normal((m, n))
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    cases = [()] if solver == "chol" else [("LSQ_QR_TWO_STAGE",), ("LSQ_QR_TWO_STAGE", "LSQ_QR_ALWAYS_PIVOT")]
+    for envs in cases:
+        for env in envs:
+            monkeypatch.setenv(env, "1")
+        first = None
+        for rep in range(12):
+            if solver == "chol":
+                sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+                sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+            else:
+                sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+                sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+            x = dxo.get()
+            if first is None:
+                first = x
+            assert np.array_equal(x, first), (envs, rep, np.abs(x - first).max())
+        for env in envs:
+            monkeypatch.delenv(env)
+
+
+def _sweep_shapes():
+    rng = np.random.default_rng(2026)
+    ms = [16, 17, 63, 65, 129, 257, 1000, 2047, 2049, 4097, 8193, 16385, 20481, 32769, 50000, 131073]
+    ns = [1, 2, 3, 8, 9, 13, 15, 16, 17, 21, 25, 29, 32, 33, 63, 64, 65, 100, 129, 200]
+    shapes = set()
+    while len(shapes) < 70:
+        n = int(rng.choice(ns))
+        m = max(int(rng.choice(ms)), n + int(rng.integers(0, 40)))
+        if m * n <= 6e6:
+            shapes.add((m, n))
+    return sorted(shapes)
+
+
+def _diagnosis(ctx, sv, **kw):
+    """Everything needed to tell WHICH launch sequence produced a wrong answer (the round-3 record lacked it); a plain
+    string, so that pytest's assertion rewriting cannot abbreviate it."""
+    d = dict(kw)
+    d.update(info=sv.info(), solver_stats=sv.stats() if hasattr(sv, "stats") else None, fallback=ctx.fallback_stats(),
+             device=ctx.device_info(), debug=lsq.debug_get())
+    return repr(d)
+
+
+def _dense_case(ctx, m, n, seed, check):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.05
+    J = lsq.DeviceMatrix(ctx, A)
+    x = lsq.DeviceVector(ctx, n)
+    ref0 = np.linalg.lstsq(A, y, rcond=None)[0]
+    refd = np.linalg.solve(A.T @ A + np.diag(damp), A.T @ y)
+    cond = np.linalg.cond(A) if m * n <= 2e5 else 10.0
+    for solver in (lsq.QR(), lsq.Cholesky()):
+        for for_lm in (False, True):
+            sv = lsq.AllocatedSolver(J, solver, for_lm=for_lm)
+            if for_lm:
+                sv.ldiv_(x, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+            else:
+                sv.ldiv_(x, lsq.DeviceVector(ctx, m, y))
+            ref = refd if for_lm else ref0
+            tol = 1e-9 * max(1.0, cond * cond if (isinstance(solver, lsq.Cholesky) and not for_lm) else cond)
+            got = x.get()
+            err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            check(got, err, tol, lambda: _diagnosis(ctx, sv, m=m, n=n, solver=type(solver).__name__, for_lm=for_lm, rel_err=err, tol=tol))
+            sv.free()
+    J.free()
+
+
+@pytest.mark.parametrize("m,n", _sweep_shapes())
+def test_dense_shape_sweep(ctx, m, n):
+    """The dense launch sequence depends on the shape in many ways (one-workgroup / two-stage / TSQR levels, 1-256
+    row slabs, ragged panels, pair kernel vs MFMA tiles for J'J): shapes around every threshold, all four
+    solver variants, against LAPACK through numpy (full-rank operands: the solution is unique, so any
+    stable method is the oracle here; tools/dense_fuzz.py is the long version).  One test per shape: a failure names its
+    shape and leaves the others with a result."""
+    def check(got, err, tol, diag):
+        if not (np.isfinite(err) and err <= tol):
+            pytest.fail(diag(), pytrace=False)
+    _dense_case(ctx, m, n, 2026 + 7 * m + n, check)
+
+
+@pytest.mark.parametrize("m,n", [(2049, 129), (2049, 200), (4097, 129), (1000, 129), (8193, 65), (16385, 200), (50000, 33),
+                                 (700, 200), (3000, 500)])
+def test_dense_solves_under_launch_jitter(ctx, m, n):
+    """Hand-offs between kernels that are not plain stream order (the CholeskyQR2 panel's side stream, slab exchanges, the
+    pipelined solves' status words) must not depend on the next launch following at once.  lsq_debug_set(jitter) puts
+    random host stalls (up to 150 us, one in 64 up to 3 ms) in front of the launches; every solve is repeated and must
+    give THE SAME BITS as the undisturbed solve and agree with LAPACK.  (2049 x 129, QR, damped is the round-3 failure:
+    round 3's panel fails this test within a few dozen solves -- tools/repro/qr_race.py, profiles/r04/qr_race.md.)"""
+    clean = []
+
+    def record(got, err, tol, diag):
+        if not (np.isfinite(err) and err <= tol):
+            pytest.fail("undisturbed solve wrong: " + diag(), pytrace=False)
+        clean.append(got)
+    seed = 99 + m + n
+    _dense_case(ctx, m, n, seed, record)
+    reps = 25 if m * n <= 1e6 else 8
+    try:
+        lsq.debug_set(150, None)
+        for rep in range(reps):
+            k = [0]
+
+            def same(got, err, tol, diag):
+                if not np.array_equal(got, clean[k[0]]):
+                    pytest.fail("solve %d differs under launch jitter (repeat %d, max diff %.3e): %s"
+                                % (k[0], rep, float(np.abs(got - clean[k[0]]).max()), diag()), pytrace=False)
+                k[0] += 1
+            _dense_case(ctx, m, n, seed, same)
+    finally:
+        lsq.debug_set(0, None)
+    assert lsq.debug_get()[2] > 0          # (stalls were actually injected)
+
+
+def test_dense_exchange_timeout_falls_back(ctx, monkeypatch):
+    """The in-kernel exchanges (row slabs of the QR panel steps, pipelined block solves) wait with a bound; when a wait
+    gives up, the same synchronisation that carries the solver's decision reports it and the solve is repeated
+    without exchanges -- from then on for that solver.  LSQ_TEST_EXCHANGE_TIMEOUT makes the library pretend (and
+    spoil the result the way a real timeout would): answers must still be the oracle's."""
+    monkeypatch.setenv("LSQ_TEST_EXCHANGE_TIMEOUT", "1")
+    rng = np.random.default_rng(99)
+    m, n = 9000, 200                       # slabs in the panel steps, 4 blocks in the solves
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    xr, rk, *_ = O.qr_solve(A, y)
+    sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+    for k in range(2):                     # first solve: timeout + retry; second: exchanges paused
+        sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+        assert sv.info()["qr_rank"] == rk == n
+        assert np.allclose(dxo.get(), xr, rtol=1e-9, atol=1e-12)
+        st = sv.stats()["qr_exchange"]     # counted once, and paused (16 solves) rather than switched off for good
+        assert st["giveups"] == 1 and st["paused"] == 16 - (k + 1), st
+    for for_lm in (True, False):
+        svc = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=for_lm)
+        for _ in range(2):
+            if for_lm:
+                svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+                xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y, damp)[1]
+                assert svc.info()["chol_path"] == "blocked"      # the one-launch factorisation gave up and is paused
+                assert svc.stats()["chol_one_launch"]["giveups"] == 1 and svc.stats()["chol_one_launch"]["paused"] > 0
+                assert svc.stats()["tri_pipeline"]["giveups"] == 1
+            else:
+                svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+                xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y)[1]
+            assert np.allclose(dxo.get(), xc, rtol=1e-9, atol=1e-12), for_lm
+
+
+def test_fast_paths_are_rearmed_after_a_pause(ctx, monkeypatch):
+    """A give-up pauses a co-residency fast path for 16 solves, then it is armed again (no one-way latches): with
+    the fault injector on for the first solve only, solve 1 falls back, solves 2..17 run the launch-per-panel path, solve 18
+    is the one-launch factorisation again -- and every answer is the oracle's."""
+    rng = np.random.default_rng(5)
+    m, n = 4096, 512
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y, damp = rng.standard_normal(m), rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    sv = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+    xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y, damp)[1]
+    dxo = lsq.DeviceVector(ctx, n)
+    paths = []
+    for k in range(19):
+        if k == 0:
+            monkeypatch.setenv("LSQ_TEST_EXCHANGE_TIMEOUT", "1")
+        sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+        monkeypatch.delenv("LSQ_TEST_EXCHANGE_TIMEOUT", raising=False)
+        assert np.allclose(dxo.get(), xc, rtol=1e-9, atol=1e-12), k
+        paths.append(sv.info()["chol_path"])
+    assert paths[0] == "blocked" and set(paths[1:16]) == {"blocked"}
+    assert paths[-1] == "blocked-one-launch", paths
+    st = sv.stats()
+    assert st["chol_one_launch"] == {"giveups": 1, "paused": 0}
+    assert ctx.fallback_stats()["chol_one_launch"] >= 1
+
+
+def test_dense_solves_next_to_a_busy_neighbour(ctx):
+    """The situation a sharded run creates (an RCCL kernel, or any other tenant, holding CUs while the solvers' one-launch /
+    pipelined paths assume their workgroups are co-resident): C2-sized Cholesky and a QR solve while a second stream keeps
+    224 workgroups x 96 KB of LDS busy for 30 ms at a time.  Results must be the oracle's whatever the fast paths decide;
+    how often they gave up is reported (and bounded: a give-up pauses the path)."""
+    rng = np.random.default_rng(6)
+    m, n = 4096, 512
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y, damp = rng.standard_normal(m), rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    svc = lsq.AllocatedSolver(J, lsq.Cholesky(), for_lm=True)
+    svq = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+    xc = O.ldiv(O.CHOLESKY, O.Mat(dense=A), y, damp)[1]
+    xq = O.qr_solve(A, y)[0]
+    dxo = lsq.DeviceVector(ctx, n)
+    before = ctx.fallback_stats()
+    for k in range(6):
+        ctx.occupy(224, 96 * 1024, 30.0)
+        svc.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+        assert np.allclose(dxo.get(), xc, rtol=1e-9, atol=1e-12), k
+        svq.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+        assert np.allclose(dxo.get(), xq, rtol=1e-9, atol=1e-12), k
+        ctx.occupy_wait()
+    after = ctx.fallback_stats()
+    fired = {k: after[k] - before[k] for k in after}
+    print("fallbacks fired next to a busy neighbour:", fired, svc.stats(), svq.stats())
+    assert all(v <= 2 for v in fired.values()), fired          # a path that gave up is paused, not retried every solve

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import problems as P  # noqa: E402
 import lsq_amd as lsq  # noqa: E402
-from test_gpu_parity import OPT, SOL, gpu_run, oracle_run  # noqa: E402
+from gpu_common import OPT, SOL, gpu_run, oracle_run  # noqa: E402
 
 cs = json.load(open(os.path.join(ROOT, "tests", "golden", "count_stable.json")))
 probs = {P.label(p): p for p in P.minpack_all()}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How far the fast (tree-reduction) kernels drift from the oracle on the NON-robust runs of the MINPACK grid (the ones whose
 counts the oracle itself does not keep under reordered sums): iteration difference and distance of the minimisers.  Input for the
-bounds in tests/test_gpu_parity.py::test_minpack_fast_kernels."""
+bounds in tests/test_a_gpu_contract.py::test_minpack_fast_kernels."""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import lsq_amd as lsq  # noqa: E402
 import problems as P  # noqa: E402
-import test_gpu_parity as T  # noqa: E402
+import test_a_gpu_contract as T  # noqa: E402
 
 cs = json.load(open(os.path.join(ROOT, "tests", "golden", "count_stable.json")))
 stable = {(r["problem"], r["optimizer"], r["solver"], r["sparse"]): r["robust"] for r in cs["runs"]}
