@@ -542,6 +542,16 @@ class AllocatedSolver:
             self._pc = _precond_trampoline(solver.preconditioner, J.ctx, J)
             check(lib().lsq_solver_set_preconditioner(self.h, self._pc, None))
 
+    def set_row_allreduce(self, hook, global_rows):
+        """lsq_solver_set_row_allreduce: J (and y) of the coming ldiv! calls are this rank's ROW BLOCK of one problem with
+        `global_rows` residuals; `hook` (rowshard.RcclRowAllreduce / HostStagedRowAllreduce, or None to switch it off) sums
+        the replicated n-vectors over the ranks.  LSMR() only."""
+        self._row_hook = hook       # (keeps the ctypes callback alive)
+        if hook is None:
+            check(lib().lsq_solver_set_row_allreduce(self.h, _lib.ROW_ALLREDUCE_CALLBACK(), None, 0))
+        else:
+            check(lib().lsq_solver_set_row_allreduce(self.h, hook.callback, hook.user, int(global_rows)))
+
     def ldiv_(self, x, y, damp=None):
         """ldiv!(x, J, y[, damp], A) -> (x, nmul)"""
         n = C.c_int(0)

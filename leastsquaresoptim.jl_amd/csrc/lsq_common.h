@@ -57,6 +57,16 @@ void lsq_dbg_stall();
         if (lsq_dbg_serial) (void)hipStreamSynchronize(stream);                 \
     } while (0)
 
+// roctx ranges at the C-ABI entries: a trace taken with `rocprofv3 --marker-trace --kernel-trace` can be read per
+// ldiv! / optimize! / product.  The marker library is bound at run time (librocprofiler-sdk-roctx.so, else libroctx64.so) and
+// only when LSQ_ROCTX=1 is set: without it a range is one predictable branch.
+struct LsqRange {
+    bool on;
+    explicit LsqRange(const char *name);
+    ~LsqRange();
+};
+#define LSQ_RANGE(name) LsqRange lsq_range__(name)
+
 constexpr int LSQ_NT = 256;             // threads per block for streaming kernels (4 waves)
 constexpr int LSQ_MAX_PARTIALS = 1 << 16;
 constexpr int LSQ_NSLOTS = 64;          // device scalar slots / reduction counter slots

@@ -650,7 +650,7 @@ k_chol_chain(double *C, int n, int nt, int *info, double *Xd, double *Wd, unsign
                 unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
                 int spins = 0;
                 while ((unsigned)(w0 >> 32) != zep || (unsigned)(w1 >> 32) != zep) {
-                    if (++spins > spin_limit) { atomicOr(zerr, 1); break; }
+                    if (++spins > spin_limit) { atomicOr(zerr, 1); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); break; }
                     __builtin_amdgcn_s_sleep(1);
                     w0 = __hip_atomic_load(f, RLX_AGENT);
                     w1 = __hip_atomic_load(f + 1, RLX_AGENT);

@@ -21,6 +21,7 @@ enum { SL_GRAD = 8, SL_DX = 9, SL_NONFIN = 10, SL_TRIAL = 11, SL_PRED = 12, SL_S
 // solver objects
 // ---------------------------------------------------------------------------------------------
 extern "C" int lsq_solver_create(lsq_ctx *c, lsq_mat *J, int kind, int for_lm, lsq_solver **out) {
+    LSQ_RANGE("lsq_solver_create");
     if (!c || !J || !out) return LSQ_EARG;
     if (kind == LSQ_QR && J->kind != LSQ_MAT_DENSE) {
         lsq_set_error("solver QR() is not available for sparse Jacobians. Choose between Cholesky() and LSMR()");
@@ -57,6 +58,7 @@ extern "C" int lsq_solver_destroy(lsq_solver *s) {
 }
 
 extern "C" int lsq_ldiv(lsq_solver *s, lsq_mat *J, const double *y, double *x, int *nmul) {
+    LSQ_RANGE("lsq_ldiv");
     if (!s || !J || !y || !x) return LSQ_EARG;
     if (s->for_lm && s->kind == LSQ_QR) {
         lsq_set_error("ldiv!: this QR solver was allocated for LevenbergMarquardt (damped)");
@@ -70,6 +72,7 @@ extern "C" int lsq_ldiv(lsq_solver *s, lsq_mat *J, const double *y, double *x, i
 }
 
 extern "C" int lsq_ldiv_damped(lsq_solver *s, lsq_mat *J, const double *y, double *damp, double *x, int *nmul) {
+    LSQ_RANGE("lsq_ldiv_damped");
     if (!s || !J || !y || !x || !damp) return LSQ_EARG;
     switch (s->kind) {
     case LSQ_LSMR: return lsq_lsmr_solve(s, J, y, damp, x, nmul);
@@ -1062,6 +1065,7 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
 
 extern "C" int lsq_optimize(lsq_ctx *c, int optimizer, int solver_kind, lsq_mat *J, double *x, double *fcur,
                             lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *opt, lsq_result *res) {
+    LSQ_RANGE("lsq_optimize");
     if (!c || !J || !x || !fcur || !f || !g || !opt || !res) {
         lsq_set_error("lsq_optimize: null argument");
         return LSQ_EARG;

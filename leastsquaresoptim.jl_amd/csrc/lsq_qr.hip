@@ -1038,7 +1038,7 @@ k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int ldx
             unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
             int spins = 0;
             while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
-                if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); break; }
+                if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); break; }
                 __builtin_amdgcn_s_sleep(1);
                 w0 = __hip_atomic_load(f, RLX_AGENT);
                 w1 = __hip_atomic_load(f + 1, RLX_AGENT);
@@ -1064,6 +1064,9 @@ k_tri_bsolve(const double *__restrict__ R, const double *__restrict__ X, int ldx
         // up): it hands the solve's status words -- the factorisation's `info` and the pipeline's flag -- to the host itself,
         // through the pinned mirror (k_publish_ints: one launch less at the end of every Cholesky solve)
         if (pub_dst && t == 0 && tid == 0) {
+            // (a workgroup whose wait gave up raised the flag, fenced, and only then published the slots this workgroup has
+            //  consumed: with the acquire below the flag read here cannot be older than those slots)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __hip_atomic_store(pub_dst + 0, pub_info ? (double)*pub_info : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(pub_dst + 1, (double)__hip_atomic_load(err, RLX_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(pub_dst + 2, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1105,7 +1108,7 @@ k_tri_fsolve_t(const double *__restrict__ U, const double *__restrict__ X, int l
             unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
             int spins = 0;
             while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
-                if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); break; }
+                if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); break; }
                 __builtin_amdgcn_s_sleep(1);
                 w0 = __hip_atomic_load(f, RLX_AGENT);
                 w1 = __hip_atomic_load(f + 1, RLX_AGENT);

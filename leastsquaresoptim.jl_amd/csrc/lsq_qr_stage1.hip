@@ -267,7 +267,7 @@ k_qr1_step_multi(double *__restrict__ A, int M, int cend, int i, int kk /* live 
                     unsigned long long w0 = __hip_atomic_load(f, RLX_AGENT), w1 = __hip_atomic_load(f + 1, RLX_AGENT);
                     int spins = 0;
                     while ((unsigned)(w0 >> 32) != ep || (unsigned)(w1 >> 32) != ep) {
-                        if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); break; }
+                        if (++spins > QR1_SPIN_LIMIT) { atomicOr(err, 1); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); break; }
                         __builtin_amdgcn_s_sleep(1);
                         w0 = __hip_atomic_load(f, RLX_AGENT);
                         w1 = __hip_atomic_load(f + 1, RLX_AGENT);

@@ -245,7 +245,22 @@ static void free_sell(LsqSell &S) {
     S = LsqSell();
 }
 
+static int csc_create_impl(lsq_ctx *c, int m, int n, const int *colptr, const int *rowval, lsq_mat **out);
 extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const int *rowval, lsq_mat **out) {
+    LSQ_RANGE("lsq_csc_create");
+    // the layouts are built in host vectors of up to a few hundred MB: an allocation failure must come back as a status, not
+    // as a C++ exception through the C ABI
+    try {
+        return csc_create_impl(c, m, n, colptr, rowval, out);
+    } catch (const std::bad_alloc &) {
+        lsq_set_error("lsq_csc_create: out of host memory while building the layouts of a %d x %d matrix", m, n);
+        return LSQ_EHIP;
+    } catch (const std::exception &e) {
+        lsq_set_error("lsq_csc_create: %s", e.what());
+        return LSQ_EHIP;
+    }
+}
+static int csc_create_impl(lsq_ctx *c, int m, int n, const int *colptr, const int *rowval, lsq_mat **out) {
     if (!c || !out || m < 0 || n < 0 || !colptr) {
         lsq_set_error("lsq_csc_create: bad arguments");
         return LSQ_EARG;
@@ -307,7 +322,7 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
     // the segment kernel (x gathered through L1/L2), n = 50000 (5) 40.7 against 51.9, n = 100000 (9) 56.0 against 53.2;
     // 200000 x 50000 with nnz 2e6: 26 against 13 us.
     const bool wide_pays = ncw <= LSQ_SELL_CW_AUTO && nnz / c->num_cus >= (long long)ncw * 6000;
-    const bool wide_ok = ncw <= LSQ_SELL_CW_MAX && (long long)ncw * m < 200000000LL && !getenv("LSQ_NO_SELL_WIDE") &&
+    const bool wide_ok = ncw <= LSQ_SELL_CW_MAX && (long long)ncw * m < 64000000LL && !getenv("LSQ_NO_SELL_WIDE") &&
                          (wide_pays || sell_force || getenv("LSQ_SELL_WIDE"));
     if (sell_ok && J->csr.plan == LSQ_PLAN_STREAM && n >= 1 && (ncw == 1 || wide_ok)) {
         int per_cu = (m + c->num_cus - 1) / c->num_cus;
@@ -329,14 +344,17 @@ extern "C" int lsq_csc_create(lsq_ctx *c, int m, int n, const int *colptr, const
             for (int i = 0; i < m; ++i)
                 for (int e = rptr[i]; e < rptr[i + 1]; ++e) wptr[(size_t)(ridx[e] / cwidth) * m + i + 1]++;
             for (size_t s2 = 0; s2 < (size_t)ncw * m; ++s2) wptr[s2 + 1] += wptr[s2];
-            {
-                std::vector<int> fill(wptr.begin(), wptr.end() - 1);
-                for (int i = 0; i < m; ++i)
-                    for (int e = rptr[i]; e < rptr[i + 1]; ++e) {
-                        int p = fill[(size_t)(ridx[e] / cwidth) * m + i]++;
-                        widx[p] = ridx[e] % cwidth;
-                        wmap[p] = map[e];
-                    }
+            // (a row's entries are sorted by column, so its entries of one window are consecutive: a running offset per
+            //  (row, window) instead of a second ncw * m array of fill positions)
+            for (int i = 0; i < m; ++i) {
+                int w_cur = -1, off = 0;
+                for (int e = rptr[i]; e < rptr[i + 1]; ++e) {
+                    const int w = ridx[e] / cwidth;
+                    if (w != w_cur) { w_cur = w; off = 0; }
+                    const int p = wptr[(size_t)w * m + i] + off++;
+                    widx[p] = ridx[e] % cwidth;
+                    wmap[p] = map[e];
+                }
             }
             st = build_sell(
                 J->srows, nrb * ncw, wptr, wmap,
@@ -739,6 +757,7 @@ extern "C" int lsq_mat_set_colscale(lsq_mat *J, const double *d_s) {
 }
 
 extern "C" int lsq_mat_refresh(lsq_mat *J) {
+    LSQ_RANGE("lsq_mat_refresh");
     J->version++;
     J->base_version++;
     if (J->d_cs_base) LSQ_TRY(colscale_multiply_out(J));   // (the caller wrote V: multiply out again)
@@ -750,6 +769,7 @@ extern "C" int lsq_mat_refresh(lsq_mat *J) {
 }
 
 extern "C" int lsq_mat_set_values(lsq_mat *J, const double *h) {
+    LSQ_RANGE("lsq_mat_set_values");
     if (J->kind == LSQ_MAT_OP) {
         lsq_set_error("a matrix-free operator has no stored values");
         return LSQ_EARG;
@@ -980,6 +1000,7 @@ const double *lsq_cached_colsum(lsq_mat *J) {
 }
 
 extern "C" int lsq_mul(lsq_mat *J, int trans, double alpha, const double *x, double beta, double *y) {
+    LSQ_RANGE("lsq_mul");
     if (!J || !x || !y) {
         lsq_set_error("lsq_mul: null argument");
         return LSQ_EARG;
@@ -991,6 +1012,7 @@ extern "C" int lsq_mul(lsq_mat *J, int trans, double alpha, const double *x, dou
 }
 
 extern "C" int lsq_colsumabs2(lsq_mat *J, double *out) {
+    LSQ_RANGE("lsq_colsumabs2");
     if (!J || !out) return LSQ_EARG;
     const double *cs = lsq_cached_colsum(J);
     if (!cs) return LSQ_EHIP;
@@ -1043,6 +1065,7 @@ k_dense_rowsq(const double *__restrict__ A, int m, int n, double *__restrict__ o
 }
 
 extern "C" int lsq_rowsumabs2(lsq_mat *J, double *out) {
+    LSQ_RANGE("lsq_rowsumabs2");
     if (!J || !out) return LSQ_EARG;
     if (J->kind == LSQ_MAT_OP) {
         lsq_set_error("rowsumabs2 of a matrix-free operator: not provided by its callbacks");

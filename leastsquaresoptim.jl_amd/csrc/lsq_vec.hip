@@ -7,9 +7,32 @@
 
 #include <algorithm>
 
+#include <dlfcn.h>
+
 #include "lsq_common.h"
 
 static thread_local char g_err[512] = "";
+
+// ---- roctx ranges (lsq_common.h: LSQ_RANGE) ----------------------------------------------------
+static int (*g_roctx_push)(const char *) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static int g_roctx_state = 0;   // 0: not looked at, 1: bound, -1: off
+static bool roctx_bind() {
+    if (g_roctx_state) return g_roctx_state > 0;
+    g_roctx_state = -1;
+    const char *e = getenv("LSQ_ROCTX");
+    if (!e || atoi(e) <= 0) return false;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) { g_roctx_state = 1; return true; }
+    }
+    return false;
+}
+LsqRange::LsqRange(const char *name) : on(roctx_bind()) { if (on) g_roctx_push(name); }
+LsqRange::~LsqRange() { if (on) g_roctx_pop(); }
 
 void lsq_set_error(const char *fmt, ...) {
     va_list ap;

@@ -226,6 +226,97 @@ def test_row_sharded_host_driver_on_device_world2():
         assert ssr == pytest.approx(ro.ssr, rel=1e-10) and np.max(np.abs(x - ro.minimizer)) <= 1e-8
 
 
+def _worker_ldiv(rank, world, port, q, damped):
+    """Operator-level row sharding (include/lsqhip.h: lsq_solver_set_row_allreduce + lsq_ldiv / lsq_ldiv_damped): this rank's
+    row block of J and y, one ldiv!, then colsumabs2 of the handle (must still be the LOCAL block's) and an unsharded solve
+    on the same handle (must not see the ranks' sum)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, n, S, y, damp = _ldiv_problem()
+    lo, hi = RS.row_slice(m, rank, world)
+    Sp = S.tocsr()[lo:hi].tocsc()
+    Sp.sort_indices()
+    ctx = lsq.Context(0)
+    J = lsq.DeviceMatrix(ctx, Sp)
+    sv = lsq.AllocatedSolver(J, lsq.LSMR(), for_lm=damped)
+    hook = RS.HostStagedRowAllreduce(ctx, dist)
+    sv.set_row_allreduce(hook, m)
+    x = lsq.DeviceVector(ctx, n)
+    dy = lsq.DeviceVector(ctx, hi - lo, y[lo:hi])
+    if damped:
+        dd = lsq.DeviceVector(ctx, n, damp)
+        _, nmul = sv.ldiv_(x, dy, dd)
+    else:
+        _, nmul = sv.ldiv_(x, dy)
+    xs = x.get()
+    calls = hook.stats()[0]
+    cs_local = lsq.colsumabs2_(lsq.DeviceVector(ctx, n), J).get()
+    # the same handle, unsharded afterwards: this block alone
+    sv.set_row_allreduce(None, 0)
+    if damped:
+        _, nmul_own = sv.ldiv_(x, dy, lsq.DeviceVector(ctx, n, damp))
+    else:
+        _, nmul_own = sv.ldiv_(x, dy)
+    q.put((rank, xs, nmul, calls, cs_local, x.get(), nmul_own, sv.info()["lsmr_iter"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _ldiv_problem():
+    rng = np.random.default_rng(5)
+    m, n = 9000, 300            # (beyond the reference-order kernels' size: the fast LSMR path)
+    S = sp.random(m, n, density=0.02, format="csc", random_state=rng, data_rvs=rng.standard_normal)
+    S.sort_indices()
+    # rows with very different weights in the two halves: the blocks' own column sums differ a lot from their total
+    S = sp.diags(np.where(np.arange(m) < m // 2, 3.0, 0.2)) @ S
+    S = S.tocsc()
+    S.sort_indices()
+    return m, n, S, rng.standard_normal(m), rng.random(n) + 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("damped", [True, False])
+def test_row_sharded_operator_level_ldiv_world2_equals_oracle(damped):
+    """a row-sharded ldiv! built its default Jacobi preconditioner from the LOCAL block's colsumabs2, so
+    the replicated vectors diverged between the ranks.  Two ranks (gloo, host-staged hook), one damped / undamped LSMR solve
+    of a row-split J against the ORACLE on the whole J: same mul count, same x on both ranks bit for bit; the handle's own
+    colsumabs2 stays the block's; the same solver un-sharded afterwards equals the oracle on the block alone."""
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    ps = [mpc.Process(target=_worker_ldiv, args=(r, 2, port, q, damped)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rec = q.get(timeout=240)
+        res[rec[0]] = rec[1:]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    m, n, S, y, damp = _ldiv_problem()
+    if damped:
+        st, xr, nmul_r, _ = O.ldiv(O.LSMR, O.Mat.from_scipy(S), y, damp)
+    else:
+        st, xr, nmul_r = O.ldiv(O.LSMR, O.Mat.from_scipy(S), y)
+    assert np.array_equal(res[0][0], res[1][0])                    # replicated x: the same bits on both ranks
+    for rank in (0, 1):
+        xs, nmul, calls, cs_local, x_own, nmul_own, it_own = res[rank]
+        assert nmul == nmul_r and nmul > 0, (nmul, nmul_r)
+        assert np.allclose(xs, xr, rtol=1e-8, atol=1e-10)
+        lo, hi = RS.row_slice(m, rank, 2)
+        Sp = S.tocsr()[lo:hi].tocsc()
+        assert np.allclose(cs_local, np.asarray(Sp.multiply(Sp).sum(axis=0)).ravel(), rtol=1e-12)
+        if damped:
+            _, xo, nmul_o, _ = O.ldiv(O.LSMR, O.Mat.from_scipy(Sp), y[lo:hi], damp)
+        else:
+            _, xo, nmul_o = O.ldiv(O.LSMR, O.Mat.from_scipy(Sp), y[lo:hi])
+        assert nmul_own == nmul_o and np.allclose(x_own, xo, rtol=1e-8, atol=1e-10)
+    assert res[0][2] == res[1][2]                                   # the same number of collectives on both ranks
+
+
 def test_rccl_shim_exports_its_header():
     """include/lsqrccl.h vs liblsqrccl.so: every declared symbol is exported (no RCCL call without a GPU)."""
     import ctypes as C
