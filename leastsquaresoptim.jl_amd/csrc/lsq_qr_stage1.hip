@@ -403,11 +403,13 @@ __device__ __forceinline__ const double *q2_bcol(const double *Vb, int ldv, cons
 // Wp[slice][tile][64 x 64] = V(rows of the slice)' * B(rows of the slice, 64 columns of tile)   (fp64 MFMA)
 __global__ void __launch_bounds__(256)
 k_qr1_vtb(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, int M, int c0, int cend, int n,
-          const double *__restrict__ rhs, int ncolsB, int kslices, double *__restrict__ Wp) {
+          const double *__restrict__ rhs, int ncolsB, int kslices, double *__restrict__ Wp, int tile0 /* first tile formed: 1
+          skips V'V, which only the Householder-step panels' T factor needs */) {
     __shared__ double sA[Q2_NB * Q2_KS];
     __shared__ double sB[Q2_NB * Q2_KS];
     const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
-    const int tile = blockIdx.x % ntile, slice = blockIdx.x / ntile;
+    const int nt = ntile - tile0;
+    const int tile = tile0 + blockIdx.x % nt, slice = blockIdx.x / nt;
     const int rows = M - c0;
     const int kper = ((rows + kslices - 1) / kslices + Q2_KC - 1) / Q2_KC * Q2_KC;
     const int kb = slice * kper, ke = min(rows, kb + kper);
@@ -857,14 +859,11 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
             const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
             int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
-            LSQ_LAUNCH(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
-                               q->Wp);
-            {
-                long long tot = (long long)ntile * Q2_NB * Q2_NB;
-                int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
-                LSQ_LAUNCH(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
-            }
-            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
+            // (V'V, tile 0, is not formed: the basis-kernel form needs V'[A2 | b] only; the sum over the k slices is taken by
+            //  k_cqr_tw itself, in the same order as k_qr1_wreduce would)
+            LSQ_LAUNCH(k_qr1_vtb, dim3((ntile - 1) * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
+                               q->Wp, 1);
+            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->Wp, ncolsB, ks, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
             {
                 const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
                 LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M,
@@ -931,7 +930,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
         }
         int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
         LSQ_LAUNCH(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
-                           q->Wp);
+                           q->Wp, 0);
         {
             long long tot = (long long)ntile * Q2_NB * Q2_NB;
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
