@@ -307,7 +307,10 @@ def main():
                                   "no Jacobian copy is multiplied out (lsq_mat_set_colscale; LSQ_NO_COLSCALE=1 restores the "
                                   "multiplied-out copies of rounds 1-2)" if not os.environ.get("LSQ_NO_COLSCALE") else
                                   "multiplied out into both sliced copies by g!",
-                      "final_ssr": r.ssr, "setup_seconds": t_setup},
+                      "final_ssr": r.ssr, "setup_seconds": t_setup,
+                      # what the launch heuristics saw: 256 CUs / 8 XCDs = an unpartitioned MI355X (SPX); a partitioned device
+                      # (CPX: 32 CUs) takes other kernels in the dense solvers (no slab exchange) and fewer workgroups everywhere
+                      "device": ctx.device_info(), "debug_modes": dict(zip(("launch_jitter_us", "serial", "stalls"), lsq.debug_get()))},
            "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense, "sparse_secondary": wide,
            # bounded-wait give-ups of the fast paths that assume co-resident workgroups (include/lsqhip.h: lsq_solver_stats)
            "fallback_giveups": ctx.fallback_stats(),

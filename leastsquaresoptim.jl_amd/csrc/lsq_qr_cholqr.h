@@ -20,7 +20,6 @@ void lsq_cqr_free(CqrWork *w);
 // holds Q, and the panel's part of R (w->SR) and the kernel of the block reflector are on their way on the side stream;
 // lsq_cqr_tw puts the former into A's 64 x 64 triangle.  A breakdown (cond(panel) beyond ~1e7) sets bit 1 of *d_err.
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err);
-// after Wp = the k-slice partials of Vb'[. | A2 | b] (k_qr1_vtb; their sum over the slices is taken here):  W2 = T'W for the
-// trailing columns and b; turns Vb into V = Q - [S; 0]
-int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *Wp, int ncolsB, int kslices, double *A, int M, int c0, int cend, int n,
+// after W = Vb'[Vb | A2 | b] (k_qr1_vtb + k_qr1_wreduce):  W2 = T'W for the trailing columns and b; turns Vb into V = Q - [S; 0]
+int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, int M, int c0, int cend, int n,
                const double *rhs, double *Vb, int ldv, double *W2);

@@ -341,12 +341,10 @@ k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, const d
     CQ_T(52);
 }
 
-// W2(:, 64 columns of the workgroup) = inv(B) (A2_top - S W_Q)   [W = V'[A2 | b] with V = Q: the sum over the k slices of
-// k_qr1_vtb's partials Wp[slice][tile][col][row], taken HERE in slice order (what k_qr1_wreduce did in a launch of its own:
-// 10 us per panel for a 1 MB read per workgroup that hides behind the loads of inv(B) and A2_top)]
+// W2(:, 64 columns of the workgroup) = inv(B) (A2_top - S W_Q)   [W = V'[V | A2 | b] with V = Q, from k_qr1_vtb + wreduce]
 // B-matrix column cb >= 64 is A(:, cend + cb - 64) or the right-hand side (last column); rows from c0.
 __global__ void __launch_bounds__(256)
-k_cqr_tw(const double *__restrict__ Wp, int ncolsB, int kslices, const double *__restrict__ Binv, const double *__restrict__ Sg,
+k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Binv, const double *__restrict__ Sg,
          const double *__restrict__ SRg, double *A /* read: trailing columns' top rows; written: the panel's triangle */, int lda,
          int c0, int cend, int n, const double *__restrict__ rhs, double *__restrict__ Vb, int ldv, double *__restrict__ W2) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -354,7 +352,6 @@ k_cqr_tw(const double *__restrict__ Wp, int ncolsB, int kslices, const double *_
     double *sRh = sm + S64_MAT;            // RHS[k][j]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ncols = ncolsB - 64, j0 = blockIdx.x * 64;
-    const int ntile = (ncolsB + 63) / 64;
     cq_load64(sBi, Binv, tid);
     {
         double top[16], wq[16];
@@ -363,26 +360,7 @@ k_cqr_tw(const double *__restrict__ Wp, int ncolsB, int kslices, const double *_
         for (int q = 0; q < 16; ++q) {
             const int e = tid + 256 * q, j = e >> 6, k = e & 63, col = min(j0 + j, ncols - 1), a = cend + col;
             top[q] = a < n ? A[(size_t)a * lda + c0 + k] : rhs[c0 + k];
-            wq[q] = 0.0;
-        }
-        // tile 1 + blockIdx.x of the partials: entry [col - j0][k] at offset e = tid + 256 q (64 columns x 64 rows, as stored)
-        const double *wp = Wp + (size_t)(1 + blockIdx.x) * 4096 + tid;
-        const size_t sstride = (size_t)ntile * 4096;
-        int sl = 0;
-        for (; sl + 4 <= kslices; sl += 4) {
-            double t[4][16];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) t[u][q] = wp[(size_t)(sl + u) * sstride + 256 * q];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) wq[q] += t[u][q];
-        }
-        for (; sl < kslices; ++sl) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) wq[q] += wp[(size_t)sl * sstride + 256 * q];
+            wq[q] = W[(size_t)(64 + col) * 64 + k];
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -477,11 +455,11 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
     return LSQ_OK;
 }
 
-int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *Wp, int ncolsB, int kslices, double *A, int M, int c0, int cend, int n,
+int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, int M, int c0, int cend, int n,
                const double *rhs, double *Vb, int ldv, double *W2) {
     LSQ_HIP(hipStreamWaitEvent(c->stream, w->ev_lu, 0));
     const int ncols = ncolsB - 64;
-    LSQ_LAUNCH(k_cqr_tw, dim3(std::max(1, (ncols + 63) / 64)), dim3(256), CQ_LDS_TW, c->stream, Wp, ncolsB, kslices,
+    LSQ_LAUNCH(k_cqr_tw, dim3(std::max(1, (ncols + 63) / 64)), dim3(256), CQ_LDS_TW, c->stream, W, ncolsB,
                        (const double *)w->Binv, (const double *)w->S, (const double *)w->SR, A, M, c0, cend, n, rhs, Vb, ldv, W2);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;

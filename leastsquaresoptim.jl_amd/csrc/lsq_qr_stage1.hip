@@ -484,10 +484,10 @@ k_qr1_vtb(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, 
 
 // W[cb][0:64] = sum over slices (fixed order)
 __global__ void __launch_bounds__(256)
-k_qr1_wreduce(const double *__restrict__ Wp, int ncolsB, int kslices, double *__restrict__ W) {
+k_qr1_wreduce(const double *__restrict__ Wp, int ncolsB, int kslices, double *__restrict__ W, int tile0 /* first tile formed by k_qr1_vtb */) {
     const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
     const long long tot = (long long)ntile * Q2_NB * Q2_NB;
-    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+    for (long long e = (long long)tile0 * Q2_NB * Q2_NB + blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
         double s = 0.0;
         for (int sl = 0; sl < kslices; ++sl) s += Wp[(size_t)sl * tot + e];
         W[e] = s;   // layout [tile][col][row] == [cb][row]
@@ -859,11 +859,17 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
             const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
             int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
-            // (V'V, tile 0, is not formed: the basis-kernel form needs V'[A2 | b] only; the sum over the k slices is taken by
-            //  k_cqr_tw itself, in the same order as k_qr1_wreduce would)
+            // (V'V, tile 0, is not formed: the basis-kernel form needs V'[A2 | b] only.  Measured and dropped in round 4: the sum
+            //  over the k slices taken by k_cqr_tw itself instead of the k_qr1_wreduce launch -- 32 workgroups reading 1 MB of
+            //  partials each take longer than the 10 us launch over 256: C3 7.83 against 7.60 ms, profiles/r04/ab_c3_tw.txt)
             LSQ_LAUNCH(k_qr1_vtb, dim3((ntile - 1) * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
                                q->Wp, 1);
-            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->Wp, ncolsB, ks, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
+            {
+                long long tot = (long long)(ntile - 1) * Q2_NB * Q2_NB;
+                int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
+                LSQ_LAUNCH(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W, 1);
+            }
+            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
             {
                 const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
                 LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M,
@@ -934,7 +940,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
         {
             long long tot = (long long)ntile * Q2_NB * Q2_NB;
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
-            LSQ_LAUNCH(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W);
+            LSQ_LAUNCH(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W, 0);
         }
         LSQ_LAUNCH(k_qr1_tw_mfma, dim3(std::max(1, lsq_div_up(ncols, Q2_NB))), dim3(256), 0, c->stream, q->W, ncolsB,
                                q->tau1, c0, nb, q->W2);

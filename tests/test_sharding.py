@@ -126,6 +126,62 @@ def test_two_ranks_lm_with_exchange():
     assert ssr0 == pytest.approx(s0 + s1, rel=1e-12) and ssr1 == pytest.approx(ssr0, rel=1e-15)
 
 
+def _worker_shared_device(rank, world, port, q):
+    """Rank 0: a sparse LM+LSMR problem (sliced layouts, look-ahead, speculative tail); rank 1: a C2-sized dense LM+Cholesky
+    problem (4096 x 512: the one-launch Cholesky and the pipelined triangular solves, which assume co-resident workgroups).
+    Both processes drive the ONE device of the box at the same time and meet in the per-iteration exchange."""
+    _init(rank, world, port)
+    ctx = lsq.Context(0)
+    if rank == 0:
+        pr = lsq.synthetic.TanhProblem(400_000, 4000, sparse=True, per_col=400, seed=21, ctx=ctx)
+        sol = lsq._lib.LSMR
+    else:
+        pr = lsq.synthetic.TanhProblem(4096, 512, sparse=False, seed=22, ctx=ctx)
+        sol = lsq._lib.CHOLESKY
+    cb = lsq.sharding.make_allreduce_callback(dist, rank, world, "cpu")
+    runs = []
+    for rep in range(3):                      # (several runs: the neighbour's kernels land differently every time)
+        pr.reset()
+        r = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, sol, iterations=12, allreduce=cb, x_tol=0, f_tol=0, g_tol=0)
+        runs.append((r.iterations, r.ssr, r.minimizer))
+    dist.barrier()                            # the neighbour is done: the device is this process's own
+    pr.reset()
+    r1 = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, sol, iterations=12, x_tol=0, f_tol=0, g_tol=0)
+    q.put((rank, [(it, ssr, float(np.max(np.abs(x - r1.minimizer)) / max(1.0, np.max(np.abs(r1.minimizer))))) for it, ssr, x in runs],
+           r1.iterations, r1.ssr, ctx.fallback_stats()))
+    pr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_device_lsmr_beside_dense_cholesky():
+    """C5 readiness without an 8-GPU node: two ranks of the independent-problem LM loop on the ONE device
+    of the box -- a sparse LM+LSMR run beside a C2-sized LM+Cholesky run, exchanging once per outer iteration.  The other
+    rank's kernels are exactly the neighbour that breaks the co-residency assumptions of the dense fast paths (DESIGN 4.6
+    rows 5, 7): whatever they do -- run clean, or give up on a bounded wait and fall back -- every run must reproduce the
+    rank's own undisturbed run (LSMR: same kernels, to round-off of nothing: equal bits; Cholesky: to 1e-9, the fall-back
+    factors in another order), with the global ssr in every rank's result."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_shared_device, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rec = q.get(timeout=600)
+        res[rec[0]] = rec[1:]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for rep in range(3):
+        (it0, ssr0, d0), (it1, ssr1, d1) = res[0][0][rep], res[1][0][rep]
+        assert it0 == it1 == 12
+        assert ssr0 == pytest.approx(res[0][2] + res[1][2], rel=1e-9) and ssr1 == pytest.approx(ssr0, rel=1e-15)
+        assert d0 == 0.0, ("sparse LM+LSMR beside a neighbour", rep, d0)
+        assert d1 <= 1e-9, ("dense LM+Cholesky beside a neighbour", rep, d1, res[1][3])
+
+
 def _worker_lm_failing(rank, world, port, q, fail_at_f_call, iterations):
     """Rank 1's f! fails at its `fail_at_f_call`-th call (call 1 = f(x0), call k+1 = the trial point of iteration k)."""
     import ctypes as C
