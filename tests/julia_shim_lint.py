@@ -96,7 +96,7 @@ JULIA_CLASS = {"Cint": {"int"}, "Cdouble": {"double"}, "Csize_t": {"size_t"}, "C
                "Ptr{Cdouble}": {"ptr:double"}, "Ref{Cdouble}": {"ptr:double"},
                "Ptr{Cint}": {"ptr:int"}, "Ref{Cint}": {"ptr:int"}, "Ptr{Cfloat}": {"ptr:float"}, "Ref{Cfloat}": {"ptr:float"},
                "Ref{Ptr{Cvoid}}": {"ptrptr"}, "Ref{LsqOptions}": {"ptr:lsq_options"}, "Ref{LsqResult}": {"ptr:lsq_result"},
-               "Ptr{UInt8}": {"ptr:uchar"}, "Ptr{Clonglong}": {"ptr:longlong"}, "Ref{Clonglong}": {"ptr:longlong"}}
+               "Ptr{UInt8}": {"ptr:uchar", "ptr:char"}, "Ptr{Clonglong}": {"ptr:longlong"}, "Ref{Clonglong}": {"ptr:longlong"}}
 
 
 def julia_blocks():
