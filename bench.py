@@ -258,7 +258,7 @@ def main():
 
     # HBM traffic of that kernel comes from rocprofv3 PMC passes (it cannot be read inside this
     # process): the committed measurement for exactly this workload, newest round first
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))
             if tr["config"] == {"m": m, "n": n, "nnz": nnz}:
