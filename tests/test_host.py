@@ -1,11 +1,15 @@
 """CPU tests of the product's host side: the C-ABI library loads and exports every symbol
 include/lsqhip.h declares, fails loudly without a GPU, the default-selection rules of
 types.jl:114-127 hold, and the synthetic generator is deterministic.  No compute calls."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
 
 import lsq_amd as lsq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -145,3 +149,41 @@ def test_julia_shim_defines_what_the_reference_loops_call():
     m = re.search(r"const HipProblem = LeastSquaresProblem\{(.*)\}", src)
     assert m and m.group(1).count(",") == 4          # LeastSquaresProblem{Tx, Ty, Tf, TJ, Tg}: types.jl:7
     assert "<:HipVector,<:HipVector,<:Any,<:HipJacobian" in m.group(1)
+
+
+def _build_abi_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_demo")
+    libdir = os.path.join(ROOT, "leastsquaresoptim.jl_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_demo.c"), "-o", exe, "-L", libdir, "-llsqhip", "-lm",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_header_is_plain_c_and_agrees_with_the_library(tmp_path):
+    """The boundary is a C ABI: include/lsqhip.h and include/lsqrccl.h compile as C99 (-pedantic -Werror) in a plain C
+    program that links liblsqhip.so, reads the reference's default options through it, and sees the same struct sizes as
+    the ctypes mirrors the Python host side uses (no device needed)."""
+    import ctypes as C
+    import subprocess
+    import lsq_amd
+    lsq_amd.build()
+    exe = _build_abi_demo(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    sizes = dict(l.rsplit(" ", 1) for l in out.stdout.strip().splitlines())
+    assert int(sizes["sizeof lsq_options"]) == C.sizeof(lsq_amd._lib.Options)
+    assert int(sizes["sizeof lsq_result"]) == C.sizeof(lsq_amd._lib.Result)
+    assert int(sizes["lsq_version"]) == lsq_amd.lib().lsq_version()
+
+
+@pytest.mark.gpu
+def test_c_program_solves_through_the_abi(tmp_path):
+    """The same C program on the device: lsq_ldiv of QR, Cholesky and LSMR on a small dense problem, checked by the
+    normal equations -- the boundary used from C, with no Python in the data path."""
+    import subprocess
+    exe = _build_abi_demo(tmp_path)
+    out = subprocess.run([exe, "--gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert out.stdout.count("max|J'(Jx - y)|") == 3
