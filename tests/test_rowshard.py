@@ -146,15 +146,16 @@ BIG = (300000, 2000, 600, 4)     # nnz 1.2e6, m > 131072: the sliced layouts and
 MID = (120000, 400, 300, 3)      # segment kernels, g! multiplies J out
 
 
-def _worker_device(rank, world, port, q, mode, shape):
+def _worker_device(rank, world, port, q, mode, shape, device_per_rank=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL between processes needs it on this driver
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # (carries RCCL's unique id only)
     m, n, colptr, rowval, A, S, b = _problem(*shape)
     (mp_, cp, rv, nz), bp = _local_rows_csc(S, b, rank, world)
-    ctx = lsq.Context(0)
+    ctx = lsq.Context(rank if device_per_rank else 0)
     pr = lsq.synthetic.TanhProblem(mp_, n, sparse=True, ctx=ctx, inputs=(cp, rv, nz), b=bp)
     pr.reset()
     hook = RS.RcclRowAllreduce(rank, world, dist if world > 1 else None) if mode == "rccl" else \
@@ -170,11 +171,11 @@ def _worker_device(rank, world, port, q, mode, shape):
         dist.destroy_process_group()
 
 
-def _run_device(world, mode, shape):
+def _run_device(world, mode, shape, device_per_rank=False):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker_device, args=(r, world, port, q, mode, shape)) for r in range(world)]
+    ps = [ctx.Process(target=_worker_device, args=(r, world, port, q, mode, shape, device_per_rank)) for r in range(world)]
     for p in ps:
         p.start()
     res = {}
@@ -198,6 +199,35 @@ def test_row_sharded_device_loop_through_rccl_equals_oracle(shape):
     m, n, colptr, rowval, A, S, b = _problem(*shape)
     ro = _oracle(m, n, colptr, rowval, A, b, 40)
     _check_against_oracle(ro, res[0], n)
+
+
+def _visible_devices():
+    """GPUs of the box, from the KFD topology (no HIP runtime is initialised at collection time)."""
+    import glob
+    count = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split() for l in open(f) if len(l.split()) == 2)
+            count += int(props.get("simd_count", "0")) > 0
+        except OSError:
+            pass
+    return count
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_visible_devices() < 2, reason="needs two GPUs: RCCL cannot put two ranks on one device")
+def test_row_sharded_device_loop_through_rccl_world2_equals_oracle():
+    """the direct-RCCL hook with MORE than one rank (one device per rank, xGMI between them): every rank must
+    issue the same number of ncclAllReduce calls (chunking by the look-ahead, the `reported` gate, the unique id carried by
+    the launcher's group), walk the unsharded oracle's trajectory, and end with a bit-identical replicated minimizer.
+    Skipped on the one-GPU boxes of this pool; written for the 8-GPU tier."""
+    res = _run_device(2, "rccl", BIG, device_per_rank=True)
+    m, n, colptr, rowval, A, S, b = _problem(*BIG)
+    ro = _oracle(m, n, colptr, rowval, A, b, 40)
+    for rank in (0, 1):
+        _check_against_oracle(ro, res[rank], n)
+    assert np.array_equal(res[0][7], res[1][7])
+    assert res[0][8:10] == res[1][8:10]                 # hook.stats(): the same collectives, the same payload
 
 
 @pytest.mark.gpu
