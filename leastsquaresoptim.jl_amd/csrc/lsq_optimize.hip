@@ -421,6 +421,10 @@ static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, i
 static int model_f(double *out, const double *x, void *user);
 static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done,
                          const int *skip = nullptr);
+// predicted residual |J dx - f|^2 AND f!(x_trial) with its sum of squares in ONE pass over the model's matrix
+// (k_sell_rows_pair, lsq_sell.h); *done tells whether it applied (else nothing was launched: the caller takes the two passes)
+static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const double *fcur, double *ftrial, const double *xt,
+                           double *slot_pred, double *slot_trial, LsqSlotPublish pub, const int *skip, bool *done);
 // buffers for tanh(xt) and 1 - tanh(xt)^2 when the model's next f!(., xt) can take them from the step kernel (else nulls)
 static void model_trial_buffers(void *user, const double *xt, double **t_out, double **s_out);
 static int f_then_sumsq(lsq_ctx *c, bool exact, lsq_f_callback f, void *user, long long m, double *out, const double *x, int ctr,
@@ -793,10 +797,18 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             LSQ_LAUNCH(k_step, dim3(t.gn), dim3(LSQ_NT), 0, c->stream, t.n, t.x, t.b->dx, t.xt, c->d_partials,
                                lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out, skip);   // :106
             LSQ_HIP(hipGetLastError());
-            LSQ_TRY(predicted_to_slot(c, false, t.J, t.b->dx, t.fcur, t.b->fpred, 8, c->d_slots + SL_PRED, LsqSlotPublish(), skip));
             // the last kernel of the iteration hands the scalars to the host
             t.pub = lsq_slots_ticket(c, SL_GRAD, 5);
-            LSQ_TRY(f_then_sumsq(c, false, t.f, t.user, t.m, t.ftrial, t.xt, 7, c->d_slots + SL_TRIAL, t.pub, skip));
+            bool pair = false;
+            if (t.is_model && model_pair_tail(t.user, t.J, t.b->dx, t.fcur, t.ftrial, t.xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL,
+                                              t.pub, skip, &pair) != 0) {
+                lsq_set_error("user callback reported failure");
+                return LSQ_ECALLBACK;
+            }
+            if (!pair) {
+                LSQ_TRY(predicted_to_slot(c, false, t.J, t.b->dx, t.fcur, t.b->fpred, 8, c->d_slots + SL_PRED, LsqSlotPublish(), skip));
+                LSQ_TRY(f_then_sumsq(c, false, t.f, t.user, t.m, t.ftrial, t.xt, 7, c->d_slots + SL_TRIAL, t.pub, skip));
+            }
             LSQ_HIP(hipGetLastError());
             t.launched++;
             return LSQ_OK;
@@ -847,10 +859,15 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             LSQ_TRY(rows_sum(c->d_slots + SL_TRIAL, 2));
             LSQ_TRY(lsq_read_slots(c, SL_GRAD, 5, sl));
         } else {
-            LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));
-            // f!(x_trial) and sum(abs2, ftrial) (:107, :111); the last kernel of the iteration hands the scalars to the host
+            // the predicted residual (:114-117), f!(x_trial) and sum(abs2, ftrial) (:107, :111); the last kernel of the iteration
+            // hands the scalars to the host.  The built-in model on a column-scaled handle takes all of it in one pass over A.
             LsqSlotPublish pub = lsq_slots_ticket(c, SL_GRAD, 5);
-            LSQ_TRY(f_then_sumsq(c, exact, f, user, m, ftrial, xt, 7, c->d_slots + SL_TRIAL, pub));
+            bool pair = false;
+            if (f == model_f) CB(model_pair_tail(user, J, b.dx, fcur, ftrial, xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL, pub, nullptr, &pair));
+            if (!pair) {
+                LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));
+                LSQ_TRY(f_then_sumsq(c, exact, f, user, m, ftrial, xt, 7, c->d_slots + SL_TRIAL, pub));
+            }
             f_calls++;
             LSQ_HIP(hipGetLastError());
             LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, pub.seq, sl));
@@ -1366,6 +1383,29 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
         LSQ_LAUNCH(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
     }
     if (launch_sell_rows(J, nullptr, md->d_t, e, md->fused ? nullptr : md->d_Acsr) != LSQ_OK) return 1;
+    *done = true;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const double *fcur, double *ftrial, const double *xt,
+                           double *slot_pred, double *slot_trial, LsqSlotPublish pub, const int *skip, bool *done) {
+    lsq_model *md = (lsq_model *)user;
+    lsq_ctx *c = md->ctx;
+    *done = false;
+    // the column-scaled handle on the one-window sliced rows (J = A diag(s): both products stream the same A), both gather
+    // vectors resident in LDS, tanh(x_trial) already formed by the step kernel
+    if (!(md->fused && J == md->J && J->kind == LSQ_MAT_CSC && J->srows.active && J->srows.ncw == 1 && J->d_colscale &&
+          J->n <= LSQ_PAIR_X_MAX && md->tanh_x == xt) || getenv("LSQ_NO_PAIR_TAIL"))
+        return 0;
+    const LsqSell &S = J->srows;
+    const int nxpad = (J->n + 1) & ~1;
+    const size_t lds = (size_t)2 * nxpad * sizeof(double);
+    if (lsq_set_lds(c, (const void *)k_sell_rows_pair<0>, (size_t)2 * LSQ_PAIR_X_MAX * sizeof(double)) != LSQ_OK) return 0;
+    md->tanh_x = nullptr;     // (consumed, as model_f_sumsq does)
+    const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
+    SellPairEpi e{skip, fcur, md->d_b, ftrial, c->d_partials, c->d_partials + 4096, lsq_ctr(c, 7), slot_pred, slot_trial, pub};
+    LSQ_LAUNCH(k_sell_rows_pair<0>, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.wrows, J->m, dx, J->d_colscale,
+               (const double *)md->d_t, J->n, nxpad, e);
     *done = true;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -224,6 +224,148 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows(SellDev S, int wrows, 
     finish_block_nt<LSQ_BIG_NT>(epi, racc, sh);
 }
 
+// ---- TWO products with the same stored values in ONE pass: rows of V*(s .* xa) and of V*xb --------------------------
+// The tail of an LM iteration on a model r(x) = V phi(x) - b with the column-scaled Jacobian J = V diag(s) streams V twice:
+// the predicted residual |J dx - f|^2 (levenberg_marquardt.jl:114-117) and the trial residual f!(x_trial) = V phi(x_trial) - b
+// with its sum of squares (:107, :111) -- 2 x 107 MB at C4 for 16 MB of vectors.  Here every (value, index) pair is loaded
+// once and multiplied into both gather vectors.  Both vectors must be resident in LDS (2 x 8n bytes: n <= 10200 with the
+// 160 KB of a CU), which leaves no room for the output window of k_sell_rows: a lane applies the epilogue to its row itself
+// (f[i], b[i] requested at the head of the slice, the trial residual stored straight from the lane -- 8-byte accesses inside
+// the block's 32 KB window, merged in L2).  A row's two sums are formed left to right by one lane, as everywhere: the bits
+// of J dx and of V phi(x_trial) are those of the two separate launches; the two sums of squares are added per lane in slice
+// order, then wave tree / 16 waves / blocks in index order (deterministic; another association than the row-order pass of
+// the separate launches, i.e. equal to it to round-off).
+template <int U, bool CLAMP>
+__device__ __forceinline__ void sell_batch_sum2(SellBatch<U> &B, int p0, int np, int len, const double *xa, const double *xb,
+                                                double &sa, double &sb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned i0 = B.c[u] & 0xffffu, i1 = B.c[u] >> 16;
+        double a0 = B.a[u].x * xa[i0], a1 = B.a[u].y * xa[i1], b0 = B.a[u].x * xb[i0], b1 = B.a[u].y * xb[i1];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));   // (the products exist here: see sell_batch_sum)
+        const int j = 2 * (p0 + u);
+        const bool in0 = j < len, in1 = j + 1 < len;
+        const double ta0 = sa + a0;
+        sa = in0 ? ta0 : sa;
+        const double ta1 = sa + a1;
+        sa = in1 ? ta1 : sa;
+        const double tb0 = sb + b0;
+        sb = in0 ? tb0 : sb;
+        const double tb1 = sb + b1;
+        sb = in1 ? tb1 : sb;
+    }
+}
+__device__ __forceinline__ void sell_lane_sum2(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L, int len,
+                                               const double *xa, const double *xb, double &sa, double &sb) {
+    const int np = L >> 1;
+    int p0 = 0;
+    for (; p0 + 8 <= np; p0 += 8) {
+        SellBatch<8> B;
+        sell_batch_load<8, false>(B, vp, ip, p0, np);
+        sell_batch_sum2<8, false>(B, p0, np, len, xa, xb, sa, sb);
+    }
+    const int rem = np - p0;
+    if (rem > 4) {
+        SellBatch<8> B;
+        sell_batch_load<8, true>(B, vp, ip, p0, np);
+        sell_batch_sum2<8, true>(B, p0, np, len, xa, xb, sa, sb);
+    } else if (rem > 2) {
+        SellBatch<4> B;
+        sell_batch_load<4, true>(B, vp, ip, p0, np);
+        sell_batch_sum2<4, true>(B, p0, np, len, xa, xb, sa, sb);
+    } else if (rem > 0) {
+        SellBatch<2> B;
+        sell_batch_load<2, true>(B, vp, ip, p0, np);
+        sell_batch_sum2<2, true>(B, p0, np, len, xa, xb, sa, sb);
+    }
+}
+constexpr int LSQ_PAIR_X_MAX = 10200;      // doubles per gather vector: 2 x 10200 x 8 B + the kernel's static LDS (~140 B) <= 160 KB
+struct SellPairEpi {
+    const int *done;            // skip flag of a launch queued behind an undecided LSMR solve (LsmrTail), or null
+    const double *fa;           // f (current residual):  ra = (V (s .* xa))_i - fa_i,  sum ra^2 -> *slot_a
+    const double *fb;           // b (model constant):    rb = (V xb)_i - fb_i -> out_b[i],  sum rb^2 -> *slot_b
+    double *out_b;
+    double *part_a, *part_b;    // block partials (gridDim.x each)
+    unsigned *counter;          // ticket slot of grid_reduce
+    double *slot_a, *slot_b;
+    LsqSlotPublish pub;         // the iteration's scalars -> host once both sums are final
+};
+template <int = 0>     // (a template so that the header can be included by several translation units)
+__global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows_pair(SellDev S, int wrows, int m, const double *__restrict__ xa,
+                                                               const double *__restrict__ sa_scale, const double *__restrict__ xb,
+                                                               int nx, int nxpad, SellPairEpi e) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double sh[LSQ_BIG_NT / 64];
+    double *la = smem, *lb = smem + nxpad;
+    constexpr int NW = LSQ_BIG_NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int XR = (LSQ_PAIR_X_MAX + LSQ_BIG_NT - 1) / LSQ_BIG_NT;
+    {   // both gather vectors and the factors: one memory latency at the head
+        double ra[XR], rs[XR], rb[XR];
+#pragma unroll
+        for (int q = 0; q < XR; ++q) {
+            const int i = min(tid + q * LSQ_BIG_NT, nx - 1);
+            ra[q] = xa[i];
+            rs[q] = sa_scale ? sa_scale[i] : 1.0;
+            rb[q] = xb[i];
+        }
+        const int dflag = e.done ? *e.done : 0;
+#pragma unroll
+        for (int q = 0; q < XR; ++q)
+            if (tid + q * LSQ_BIG_NT < nx) {
+                la[tid + q * LSQ_BIG_NT] = ra[q] * rs[q];
+                lb[tid + q * LSQ_BIG_NT] = rb[q];
+            }
+        if (dflag) return;
+    }
+    double acc_a = 0.0, acc_b = 0.0;
+    for (int w = blockIdx.x; w < S.nblocks; w += gridDim.x) {
+        const int base = w * wrows;
+        const int s0 = w * S.spw, s1 = s0 + S.spw;
+        int s = s0 + wv;
+        SellSliceRef A = sell_slice_ref(S, s, s1, lane);
+        __syncthreads();                      // the gather vectors are staged (first block) -- nothing else is shared
+        for (; s < s1; s += NW) {
+            const SellSliceRef a = A;
+            A = sell_slice_ref(S, s + NW, s1, lane);
+            const unsigned pos = a.inf & LSQ_SELL_POS_MASK;
+            const bool valid = pos != LSQ_SELL_POS_MASK;
+            const int row = base + (valid ? (int)pos : 0);
+            const double fa = e.fa[row], fb = e.fb[row];          // (in flight during the stream)
+            const size_t oa = (size_t)a.sm.x + lane * 2;
+            double sum_a = 0.0, sum_b = 0.0;
+            sell_lane_sum2(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), la, lb, sum_a, sum_b);
+            if (valid) {
+                const double r_a = sum_a - fa, r_b = sum_b - fb;
+                e.out_b[row] = r_b;
+                acc_a += r_a * r_a;
+                acc_b += r_b * r_b;
+            }
+        }
+    }
+    const double ba = block_sum<LSQ_BIG_NT>(acc_a, sh);
+    const double bb = block_sum<LSQ_BIG_NT>(acc_b, sh);
+    if (tid == 0) __hip_atomic_store(&e.part_b[blockIdx.x], bb, RLX_AGENT);   // (drained with part_a's store inside grid_reduce)
+    double total_a = 0.0;
+    const bool last = grid_reduce<LSQ_BIG_NT>(ba, e.part_a, e.counter, gridDim.x, sh, [&](double t) { total_a = t; });
+    if (!last) return;
+    double pb = 0.0;
+    for (int i = tid; i < (int)gridDim.x; i += LSQ_BIG_NT) pb += __hip_atomic_load(&e.part_b[i], RLX_AGENT);
+    const double total_b = block_sum<LSQ_BIG_NT>(pb, sh);
+    if (tid == 0) {
+        *e.slot_a = total_a;
+        *e.slot_b = total_b;
+        if (e.pub.count > 0) {
+            for (int i = 0; i < e.pub.count; ++i) {
+                const double *src = e.pub.src + i;
+                const double v = src == e.slot_a ? total_a : (src == e.slot_b ? total_b : *src);
+                __hip_atomic_store(e.pub.dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(e.pub.seq_word, e.pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ---- J*x for n > LSQ_LDS_X_MAX: x passes through LDS one column window at a time --------------------
 // Block b = row block * ncw + window holds the rows' entries inside that window (rows without entries there have no
 // lane).  The row block's workgroup walks the windows in ascending order; a lane CONTINUES the row's running sum from the

@@ -195,6 +195,34 @@ def test_lm_fused_setup_matches_separate_kernels(ctx, big, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,n,per_col", [(300000, 2000, 600), (1_000_000, 10_000, 1000)], ids=["300000x2000", "C4"])
+def test_lm_pair_tail_matches_the_two_passes(ctx, m, n, per_col, monkeypatch):
+    """Round 4: the predicted residual |J dx - f|^2 (levenberg_marquardt.jl:114-117) and f!(x_trial) + sum(abs2, .) (:107,
+    :111) of the built-in model as ONE pass over A (k_sell_rows_pair: every value/index pair feeds both gather vectors)
+    against the two launches it replaces (LSQ_NO_PAIR_TAIL=1).  Every row's two sums are the same left-to-right sums, so the
+    trial residual is identical bit for bit; the two sums of squares are associated differently (per lane in slice order
+    instead of per row in window order): identical counts, accept pattern, inner counts; ssr / iterates to 1e-12."""
+    runs = []
+    for env in ({}, {"LSQ_NO_PAIR_TAIL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=13, ctx=ctx)
+        pr.reset()
+        r = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, trace=True, iterations=8, x_tol=0, f_tol=0, g_tol=0)
+        fc = pr.fcur.get()
+        for k in env:
+            monkeypatch.delenv(k)
+        runs.append((r, fc))
+        pr.close()
+    (a, fa), (b, fb) = runs
+    assert a.iterations == b.iterations == 8 and a.mul_calls == b.mul_calls and a.f_calls == b.f_calls
+    assert np.array_equal(a.trace["inner"], b.trace["inner"]) and np.array_equal(a.trace["accept"], b.trace["accept"])
+    assert np.allclose(a.trace["ssr"], b.trace["ssr"], rtol=1e-12, atol=0)
+    assert np.max(np.abs(np.array(a.trace["x"]) - np.array(b.trace["x"]))) <= 1e-12
+    assert np.max(np.abs(fa - fb)) <= 1e-12 * max(1.0, np.max(np.abs(fb)))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("opt", ["lm", "dogleg"])
 def test_tanh_model_column_scaled_vs_multiplied_out(ctx, opt, monkeypatch):
     """The built-in model keeps J = A diag(1 - tanh(x)^2) as a COLUMN-SCALED handle on big sparse patterns (nothing is
