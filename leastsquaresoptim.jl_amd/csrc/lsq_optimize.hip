@@ -1178,7 +1178,16 @@ struct lsq_model {
     double *d_sspec = nullptr; // the same at the latest trial point (written by the step kernel)
     const double *tanh_x = nullptr;   // device vector whose tanh the step kernel has already put into d_t
     const double *sfac_x = nullptr;   // device vector whose 1 - tanh^2 the step kernel has already put into d_sspec
+    // k_sell_rows_pair reads its two m-vectors in the SLICE ORDER of J's sliced rows (lsq_sell.h): b once, and two mirrors of
+    // residual vectors, each valid for the row-order device vector named in perm_of (nullptr: stale)
+    double *d_b_perm = nullptr;
+    double *d_perm[2] = {nullptr, nullptr};
+    const double *perm_of[2] = {nullptr, nullptr};
 };
+static void model_perm_invalidate(lsq_model *md, const double *vec) {   // vec == nullptr: all
+    for (int k = 0; k < 2; ++k)
+        if (!vec || md->perm_of[k] == vec) md->perm_of[k] = nullptr;
+}
 
 __global__ void __launch_bounds__(LSQ_NT) k_tanh(int n, const double *__restrict__ x, double *__restrict__ t) {
     for (int i = blockIdx.x * LSQ_NT + threadIdx.x; i < n; i += gridDim.x * LSQ_NT) t[i] = tanh(x[i]);
@@ -1335,6 +1344,7 @@ static int model_f(double *out, const double *x, void *user) {
     lsq_mat *J = md->J;
     const bool have_tanh = md->tanh_x == x;   // the step kernel formed tanh(x) while it wrote x (model_trial_buffers)
     md->tanh_x = nullptr;
+    model_perm_invalidate(md, out);           // (a slice-order mirror of `out` is stale from here on)
     if (!have_tanh) {
         md->sfac_x = nullptr;
         LSQ_LAUNCH(k_tanh, dim3(ngrid(c, J->n)), dim3(LSQ_NT), 0, c->stream, J->n, x, md->d_t);
@@ -1375,6 +1385,7 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
     lsq_mat *J = md->J;
     *done = false;
     if (!(J->kind == LSQ_MAT_CSC && J->srows.active)) return model_f(out, x, user);
+    model_perm_invalidate(md, out);
     EpiResidualSq e{skip, 0, md->d_b, out, c->d_partials, lsq_ctr(c, ctr), d_out, pub};
     const bool have_tanh = md->tanh_x == x;   // k_step formed tanh(x) while it wrote x
     md->tanh_x = nullptr;
@@ -1401,9 +1412,30 @@ static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const doubl
     const int nxpad = (J->n + 1) & ~1;
     const size_t lds = (size_t)2 * nxpad * sizeof(double);
     if (lsq_set_lds(c, (const void *)k_sell_rows_pair<0>, (size_t)2 * LSQ_PAIR_X_MAX * sizeof(double)) != LSQ_OK) return 0;
+    // slice-order mirrors: b once; f from the slot that mirrors fcur (filled by an earlier launch of this kernel if the step that
+    // produced fcur was accepted, else permuted now); the other slot takes this launch's trial residual
+    const size_t plen = (size_t)S.nslices * 64;
+    const int pgrid = std::max(1, std::min(lsq_div_up((long long)plen, LSQ_NT), c->num_cus * 8));
+    if (!md->d_b_perm) {
+        if (hipMalloc(&md->d_b_perm, plen * sizeof(double)) != hipSuccess || hipMalloc(&md->d_perm[0], plen * sizeof(double)) != hipSuccess ||
+            hipMalloc(&md->d_perm[1], plen * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        LSQ_LAUNCH(k_sell_perm_rows<0>, dim3(pgrid), dim3(LSQ_NT), 0, c->stream, sell_dev(S), S.wrows, S.nslices, (const double *)md->d_b,
+                   md->d_b_perm);
+    }
+    int k = md->perm_of[0] == fcur ? 0 : (md->perm_of[1] == fcur ? 1 : -1);
+    if (k < 0) {
+        k = 0;
+        LSQ_LAUNCH(k_sell_perm_rows<0>, dim3(pgrid), dim3(LSQ_NT), 0, c->stream, sell_dev(S), S.wrows, S.nslices, fcur, md->d_perm[k]);
+        md->perm_of[k] = fcur;
+    }
+    md->perm_of[1 - k] = ftrial;
     md->tanh_x = nullptr;     // (consumed, as model_f_sumsq does)
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
-    SellPairEpi e{skip, fcur, md->d_b, ftrial, c->d_partials, c->d_partials + 4096, lsq_ctr(c, 7), slot_pred, slot_trial, pub};
+    SellPairEpi e{skip, md->d_perm[k], md->d_b_perm, ftrial, md->d_perm[1 - k], c->d_partials, c->d_partials + 4096, lsq_ctr(c, 7),
+                  slot_pred, slot_trial, pub};
     LSQ_LAUNCH(k_sell_rows_pair<0>, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.wrows, J->m, dx, J->d_colscale,
                (const double *)md->d_t, J->n, nxpad, e);
     *done = true;
@@ -1548,6 +1580,7 @@ extern "C" int lsq_model_destroy(lsq_model *md) {
     hipStreamSynchronize(md->ctx->stream);
     if (md->fused && md->J) lsq_mat_set_colscale(md->J, nullptr);   // (the factor vector goes away with the model)
     hipFree(md->d_Acsc); hipFree(md->d_Acsr); hipFree(md->d_Ab); hipFree(md->d_b); hipFree(md->d_t); hipFree(md->d_s); hipFree(md->d_sspec);
+    hipFree(md->d_b_perm); hipFree(md->d_perm[0]); hipFree(md->d_perm[1]);
     delete md;
     return LSQ_OK;
 }

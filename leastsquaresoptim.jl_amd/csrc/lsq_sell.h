@@ -282,14 +282,30 @@ __device__ __forceinline__ void sell_lane_sum2(const double *__restrict__ vp, co
 constexpr int LSQ_PAIR_X_MAX = 10200;      // doubles per gather vector: 2 x 10200 x 8 B + the kernel's static LDS (~140 B) <= 160 KB
 struct SellPairEpi {
     const int *done;            // skip flag of a launch queued behind an undecided LSMR solve (LsmrTail), or null
-    const double *fa;           // f (current residual):  ra = (V (s .* xa))_i - fa_i,  sum ra^2 -> *slot_a
-    const double *fb;           // b (model constant):    rb = (V xb)_i - fb_i -> out_b[i],  sum rb^2 -> *slot_b
-    double *out_b;
+    // the two m-vectors the epilogue reads come in SLICE ORDER (element s * 64 + lane = the row that lane of slice s owns;
+    // k_sell_perm_rows): a lane's 8-byte access to its row's own position is one cache line per lane -- 64 line requests per
+    // wave instruction, as many as the whole value + index stream of the slice; measured 42.7 us with f, b and the output all
+    // in row order, 35.6 us with f and b in slice order, 30.8 us with the output in slice order too (profiles/r04)
+    const double *fa;           // f (current residual), slice order:  ra = (V (s .* xa))_i - fa_i,  sum ra^2 -> *slot_a
+    const double *fb;           // b (model constant), slice order:    rb = (V xb)_i - fb_i,  sum rb^2 -> *slot_b
+    double *out_b;              // rb in row order (what the gather of J'f and the caller read)
+    double *out_b_perm;         // rb in slice order (the next iteration's fa if the step is accepted)
     double *part_a, *part_b;    // block partials (gridDim.x each)
     unsigned *counter;          // ticket slot of grid_reduce
     double *slot_a, *slot_b;
     LsqSlotPublish pub;         // the iteration's scalars -> host once both sums are final
 };
+// dst[s * 64 + lane] = src[row owned by lane of slice s] (0 for lanes without a row): an m-vector in slice order
+template <int = 0>
+__global__ void __launch_bounds__(LSQ_NT) k_sell_perm_rows(SellDev S, int wrows, int nslices, const double *__restrict__ src,
+                                                           double *__restrict__ dst) {
+    for (long long i = blockIdx.x * (long long)LSQ_NT + threadIdx.x; i < (long long)nslices * 64; i += (long long)gridDim.x * LSQ_NT) {
+        const unsigned inf = S.info[i];
+        const unsigned pos = inf & LSQ_SELL_POS_MASK;
+        const int w = (int)(i >> 6) / S.spw;
+        dst[i] = pos != LSQ_SELL_POS_MASK ? src[(size_t)w * wrows + pos] : 0.0;
+    }
+}
 template <int = 0>     // (a template so that the header can be included by several translation units)
 __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows_pair(SellDev S, int wrows, int m, const double *__restrict__ xa,
                                                                const double *__restrict__ sa_scale, const double *__restrict__ xb,
@@ -331,13 +347,15 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows_pair(SellDev S, int wr
             const unsigned pos = a.inf & LSQ_SELL_POS_MASK;
             const bool valid = pos != LSQ_SELL_POS_MASK;
             const int row = base + (valid ? (int)pos : 0);
-            const double fa = e.fa[row], fb = e.fb[row];          // (in flight during the stream)
+            const size_t pidx = (size_t)s * 64 + lane;
+            const double fa = e.fa[pidx], fb = e.fb[pidx];        // (coalesced; in flight during the stream)
             const size_t oa = (size_t)a.sm.x + lane * 2;
             double sum_a = 0.0, sum_b = 0.0;
             sell_lane_sum2(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), la, lb, sum_a, sum_b);
             if (valid) {
                 const double r_a = sum_a - fa, r_b = sum_b - fb;
                 e.out_b[row] = r_b;
+                e.out_b_perm[pidx] = r_b;
                 acc_a += r_a * r_a;
                 acc_b += r_b * r_b;
             }
