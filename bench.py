@@ -307,6 +307,9 @@ def main():
                                   "no Jacobian copy is multiplied out (lsq_mat_set_colscale; LSQ_NO_COLSCALE=1 restores the "
                                   "multiplied-out copies of rounds 1-2)" if not os.environ.get("LSQ_NO_COLSCALE") else
                                   "multiplied out into both sliced copies by g!",
+                      "lm_tail": ("predicted residual and trial residual in ONE pass over A (k_sell_rows_pair, n <= 10200; LSQ_NO_PAIR_TAIL=1 "
+                                  "restores the two launches)" if n <= 10200 and not os.environ.get("LSQ_NO_PAIR_TAIL")
+                                  and not os.environ.get("LSQ_NO_COLSCALE") else "two passes over A (predicted residual, trial residual)"),
                       "final_ssr": r.ssr, "setup_seconds": t_setup,
                       # what the launch heuristics saw: 256 CUs / 8 XCDs = an unpartitioned MI355X (SPX); a partitioned device
                       # (CPX: 32 CUs) takes other kernels in the dense solvers (no slab exchange) and fewer workgroups everywhere
