@@ -474,7 +474,7 @@ def dense_secondary(ctx, lsq):
                      "roofline": {"bound": "mfma", "useful_flops": flops, "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS, "dominant_kernels": dom,
                                   "note": "whole ldiv! (factorisation + solve) over the useful flops of SURVEY 8d; per-kernel "
-                                          "split and MFMA counters: profiles/r03/dense_kernel_summary.md"},
+                                          "split and MFMA counters: profiles/r04/dense_kernel_summary.md"},
                      "path": {k: info.get(k) for k in ("qr_path", "qr_panel", "chol_path")}}
         J.free()
     # time per OUTER iteration of the dense tanh problems (f!, g! and the trust-region bookkeeping included)
