@@ -352,6 +352,22 @@ k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Bi
     double *sRh = sm + S64_MAT;            // RHS[k][j]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ncols = ncolsB - 64, j0 = blockIdx.x * 64;
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+        // ONE EXTRA workgroup, beside the ones that form W2: V = Q - [S; 0] for the update, and the panel's part of R -> A.
+        // (This launch is ordered behind pass 2 -- the last reader of Q1's top rows -- by the stream and behind k_cqr_top by
+        //  ev_lu; nothing in this kernel reads the panel's columns of A.  In workgroup 0, as first written in round 4, the
+        //  copy put a memory round trip in front of that workgroup's product: 11.2 instead of 7.7 us per launch.)
+        if (tid < 64) Vb[(size_t)tid * ldv + tid] -= Sg[tid];
+        double t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = SRg[tid + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, col = e >> 6, row = e & 63;
+            if (row <= col) A[(size_t)(c0 + col) * lda + c0 + row] = t[q];
+        }
+        return;
+    }
     cq_load64(sBi, Binv, tid);
     {
         double top[16], wq[16];
@@ -366,16 +382,6 @@ k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Bi
         for (int q = 0; q < 16; ++q) {
             const int e = tid + 256 * q, j = e >> 6, k = e & 63;
             sRh[k * S64_LS + j] = j0 + j < ncols ? top[q] - sk * wq[q] : 0.0;
-        }
-    }
-    if (blockIdx.x == 0) {
-        if (tid < 64) Vb[(size_t)tid * ldv + tid] -= Sg[tid];     // V = Q - [S; 0] for the update
-        // the panel's part of R -> A (this launch is ordered behind pass 2, the last reader of Q1's top rows, by the
-        // stream and behind k_cqr_top by ev_lu; nothing in this kernel reads the panel's columns of A)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q, col = e >> 6, row = e & 63;
-            if (row <= col) A[(size_t)(c0 + col) * lda + c0 + row] = SRg[e];
         }
     }
     __syncthreads();
@@ -459,7 +465,7 @@ int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, i
                const double *rhs, double *Vb, int ldv, double *W2) {
     LSQ_HIP(hipStreamWaitEvent(c->stream, w->ev_lu, 0));
     const int ncols = ncolsB - 64;
-    LSQ_LAUNCH(k_cqr_tw, dim3(std::max(1, (ncols + 63) / 64)), dim3(256), CQ_LDS_TW, c->stream, W, ncolsB,
+    LSQ_LAUNCH(k_cqr_tw, dim3(std::max(1, (ncols + 63) / 64) + 1), dim3(256), CQ_LDS_TW, c->stream, W, ncolsB,
                        (const double *)w->Binv, (const double *)w->S, (const double *)w->SR, A, M, c0, cend, n, rhs, Vb, ldv, W2);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
