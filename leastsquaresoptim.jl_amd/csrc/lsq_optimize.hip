@@ -1417,11 +1417,14 @@ static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const doubl
     const size_t plen = (size_t)S.nslices * 64;
     const int pgrid = std::max(1, std::min(lsq_div_up((long long)plen, LSQ_NT), c->num_cus * 8));
     if (!md->d_b_perm) {
-        if (hipMalloc(&md->d_b_perm, plen * sizeof(double)) != hipSuccess || hipMalloc(&md->d_perm[0], plen * sizeof(double)) != hipSuccess ||
-            hipMalloc(&md->d_perm[1], plen * sizeof(double)) != hipSuccess) {
+        double *pb = nullptr, *p0 = nullptr, *p1 = nullptr;     // (all three or none: a partial set must not look initialised)
+        if (hipMalloc(&pb, plen * sizeof(double)) != hipSuccess || hipMalloc(&p0, plen * sizeof(double)) != hipSuccess ||
+            hipMalloc(&p1, plen * sizeof(double)) != hipSuccess) {
             (void)hipGetLastError();
-            return 0;
+            hipFree(pb); hipFree(p0); hipFree(p1);
+            return 0;                                           // (the caller takes the two-pass tail)
         }
+        md->d_b_perm = pb; md->d_perm[0] = p0; md->d_perm[1] = p1;
         LSQ_LAUNCH(k_sell_perm_rows<0>, dim3(pgrid), dim3(LSQ_NT), 0, c->stream, sell_dev(S), S.wrows, S.nslices, (const double *)md->d_b,
                    md->d_b_perm);
     }
