@@ -496,7 +496,7 @@ int lsq_rowshard_colsum(lsq_solver *s, lsq_mat *J, const double **out) {
     lsq_ctx *c = s->ctx;
     if (!s->d_colsum_g) LSQ_HIP(hipMalloc(&s->d_colsum_g, (size_t)(s->n > 0 ? s->n : 1) * sizeof(double)));
     if (s->colsum_g_mat != J || s->colsum_g_version != J->version) {
-        LSQ_HIP(hipMemcpyAsync(s->d_colsum_g, local, (size_t)J->n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        LSQ_TRY(lsq_d2d(c, s->d_colsum_g, local, (size_t)J->n * sizeof(double)));   // (a copy kernel: no runtime-side staging hole)
         if (s->row_cb(s->d_colsum_g, J->n, (void *)c->stream, s->row_user) != 0) {
             lsq_set_error("row all-reduce callback reported failure");
             return LSQ_ECALLBACK;
