@@ -467,6 +467,9 @@ long long lsq_mirror_cols_len(const lsq_mat *J);
 bool lsq_can_fuse_grad_colsum(const lsq_mat *J);
 bool lsq_colscale_fusable(const lsq_mat *J);   // lsq_mat_set_colscale would take the fused (never multiplied out) mode
 int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g);  // g = J'f, fills the colsum cache
+int lsq_sparse_grad_colsum_spec(lsq_mat *J, const double *f, double *g, const double *s_new, const int *gate);  // see lsq_sparse.hip
+void lsq_sparse_grad_colsum_adopt(lsq_mat *J);   // the speculative pass ran for the handle's present factors: its colsumabs2 is current
+void lsq_sparse_colsum_forget(lsq_mat *J);       // ... or must not be trusted (it ran for factors that were never installed)
 const double *lsq_cached_colsum(lsq_mat *J);  // nullptr on failure (error set)
 // reads slot values to host (synchronises the stream)
 int lsq_read_slots(lsq_ctx *ctx, int first, int count, double *h_out);

@@ -423,8 +423,17 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
                          const int *skip = nullptr);
 // predicted residual |J dx - f|^2 AND f!(x_trial) with its sum of squares in ONE pass over the model's matrix
 // (k_sell_rows_pair, lsq_sell.h); *done tells whether it applied (else nothing was launched: the caller takes the two passes)
+// sg (optional): also queue the NEXT iteration's gradient + colsumabs2 pass behind it, guarded by the acceptance test the
+// kernel takes on the device (lsq_sparse_grad_colsum_spec); sg->launched tells whether that pass was queued
+struct SpecGrad {
+    int *gate;          // this pass's skip word (non-zero until the pair kernel clears it)
+    double ssr;         // the current sum of squares (what the host will test rho against)
+    double *grad;       // where the gradient goes
+    bool launched;
+};
 static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const double *fcur, double *ftrial, const double *xt,
-                           double *slot_pred, double *slot_trial, LsqSlotPublish pub, const int *skip, bool *done);
+                           double *slot_pred, double *slot_trial, LsqSlotPublish pub, const int *skip, bool *done,
+                           SpecGrad *sg = nullptr);
 // buffers for tanh(xt) and 1 - tanh(xt)^2 when the model's next f!(., xt) can take them from the step kernel (else nulls)
 static void model_trial_buffers(void *user, const double *xt, double **t_out, double **s_out);
 static int f_then_sumsq(lsq_ctx *c, bool exact, lsq_f_callback f, void *user, long long m, double *out, const double *x, int ctr,
@@ -456,7 +465,13 @@ struct LoopBuffers {
     double *dx = nullptr, *dtd = nullptr, *xt = nullptr, *ftrial = nullptr;
     double *dgn = nullptr, *dgr = nullptr, *grad = nullptr, *fpred = nullptr;
     double *lo = nullptr, *hi = nullptr;
+    // skip words of gradient passes queued before the host knows whether their step is accepted (k_sell_rows_pair writes 0 for
+    // "accepted"): one int per queued pass, handed out in order; every word is non-zero (= skip) until then
+    int *gate_ring = nullptr;
+    int gate_next = 0;
+    static constexpr int GATE_RING = 1024;
     ~LoopBuffers() {
+        hipFree(gate_ring);
         hipFree(dx); hipFree(dtd); hipFree(xt); hipFree(ftrial); hipFree(dgn); hipFree(dgr); hipFree(grad); hipFree(fpred); hipFree(lo);
         hipFree(hi);
     }
@@ -489,6 +504,9 @@ static int alloc_loop(LoopBuffers &b, lsq_ctx *c, int m, int n, const lsq_option
     LSQ_HIP(hipMalloc(&b.grad, nb));
     LSQ_HIP(hipMalloc(&b.fpred, mb));
     LSQ_HIP(hipMemsetAsync(b.dx, 0, nb, c->stream));
+    LSQ_HIP(hipMalloc(&b.gate_ring, LoopBuffers::GATE_RING * sizeof(int)));
+    LSQ_HIP(hipMemsetAsync(b.gate_ring, 1, LoopBuffers::GATE_RING * sizeof(int), c->stream));   // (every word non-zero: skip)
+    b.gate_next = 0;
     if (dogleg) {
         LSQ_HIP(hipMalloc(&b.dgn, nb));
         LSQ_HIP(hipMalloc(&b.dgr, nb));
@@ -573,6 +591,17 @@ static int check_start(const double *hx, int n, const lsq_options *o) {
         if (o->h_upper && !(hx[i] <= o->h_upper[i])) return LSQ_EBOUNDS;
     }
     return LSQ_OK;
+}
+
+// the next skip word of the gate ring (all words are non-zero until a pair kernel clears one; a wrapped ring is re-armed in
+// stream order: every pass that read the old words was queued before the memset)
+static int *next_gate(lsq_ctx *c, LoopBuffers &b) {
+    if (!b.gate_ring) return nullptr;
+    if (b.gate_next >= LoopBuffers::GATE_RING) {
+        if (hipMemsetAsync(b.gate_ring, 1, LoopBuffers::GATE_RING * sizeof(int), c->stream) != hipSuccess) return nullptr;
+        b.gate_next = 0;
+    }
+    return b.gate_ring + b.gate_next++;
 }
 
 // One global exchange per outer iteration for sharded problems.
@@ -703,6 +732,13 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
     // reference summation order for small problems (lsq_exact.hip); a general preconditioner runs the operator-level LSMR
     const bool exact = lsq_small_mat(J) && !sharded && !(sv->kind == LSQ_LSMR && sv->gen_ldiv);
     int last_inner = 0;          // inner iterations of the previous LSMR solve of this run: the guess for the next one (LsmrTail)
+    // The gradient + colsumabs2 pass of the NEXT Jacobian queued behind the tail of this iteration, before the host has seen the
+    // iteration's scalars (the ~12 us in which the host reads them, decides and launches used to be idle device time): the built-in
+    // model on a column-scaled handle with LSMR, no exchange.  spec_grad_ready: that pass has run for the factors g! is about to
+    // install -- adopted at the head of the next iteration, or forgotten if the loop is left before (SpecGuard).
+    const bool no_spec_grad = getenv("LSQ_NO_SPEC_GRADIENT") != nullptr;       // (read per run: the tests flip it)
+    bool spec_launched = false, spec_grad_ready = false;
+    struct SpecGuard { lsq_mat *J; bool &ready; ~SpecGuard() { if (ready) lsq_sparse_colsum_forget(J); } } spec_guard{J, spec_grad_ready};
     int local_done = 0;
     double gssr = ssr, ggr = maxabs_gr;
     long long inner_total = 0;
@@ -731,6 +767,15 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         }
         // a fresh Jacobian needs colsumabs2 (:82) and J'f (:102): one pass over J gives both
         bool have_grad = false;
+        if (spec_grad_ready) {      // ... and that pass has already run behind the previous iteration's tail
+            lsq_sparse_grad_colsum_adopt(J);
+            have_grad = true;
+            spec_grad_ready = false;
+        }
+        // (is a pass for the NEXT Jacobian worth queueing behind this iteration's tail?  not in the last allowed iteration)
+        const bool spec_ok = !no_spec_grad && !exact && !sharded && !o->allreduce && sv->kind == LSQ_LSMR && f == model_f &&
+                             iter < o->iterations && !lsq_dbg_serial;
+        spec_launched = false;
         if (!exact && J->colsum_version != J->version && lsq_can_fuse_grad_colsum(J)) {
             LSQ_TRY(lsq_sparse_grad_colsum(J, fcur, b.grad));
             have_grad = true;
@@ -788,7 +833,8 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             lsq_ctx *c; lsq_mat *J; LoopBuffers *b; lsq_f_callback f; void *user;
             const double *x, *fcur; double *xt, *ftrial;
             int m, n, gn; bool is_model; LsqSlotPublish pub; int launched;
-        } tc{c, J, &b, f, user, x, fcur, xt, ftrial, m, n, gn, !exact && f == model_f, LsqSlotPublish(), 0};
+            bool want_spec; double ssr; bool spec_launched;
+        } tc{c, J, &b, f, user, x, fcur, xt, ftrial, m, n, gn, !exact && f == model_f, LsqSlotPublish(), 0, spec_ok, ssr, false};
         auto tail_fn = [](const int *skip, void *u) -> int {
             TailCtx &t = *(TailCtx *)u;
             lsq_ctx *c = t.c;
@@ -800,11 +846,13 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             // the last kernel of the iteration hands the scalars to the host
             t.pub = lsq_slots_ticket(c, SL_GRAD, 5);
             bool pair = false;
+            SpecGrad sg{t.want_spec ? next_gate(c, *t.b) : nullptr, t.ssr, t.b->grad, false};
             if (t.is_model && model_pair_tail(t.user, t.J, t.b->dx, t.fcur, t.ftrial, t.xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL,
-                                              t.pub, skip, &pair) != 0) {
+                                              t.pub, skip, &pair, &sg) != 0) {
                 lsq_set_error("user callback reported failure");
                 return LSQ_ECALLBACK;
             }
+            t.spec_launched = sg.launched;      // (of the LAST time the tail was queued: an earlier one skipped itself)
             if (!pair) {
                 LSQ_TRY(predicted_to_slot(c, false, t.J, t.b->dx, t.fcur, t.b->fpred, 8, c->d_slots + SL_PRED, LsqSlotPublish(), skip));
                 LSQ_TRY(f_then_sumsq(c, false, t.f, t.user, t.m, t.ftrial, t.xt, 7, c->d_slots + SL_TRIAL, t.pub, skip));
@@ -834,6 +882,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         double sl[5];
         if (tail_done) {
             f_calls++;
+            spec_launched = tc.spec_launched;
             LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, tc.pub.seq, sl));
         } else {
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
@@ -863,7 +912,9 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             // hands the scalars to the host.  The built-in model on a column-scaled handle takes all of it in one pass over A.
             LsqSlotPublish pub = lsq_slots_ticket(c, SL_GRAD, 5);
             bool pair = false;
-            if (f == model_f) CB(model_pair_tail(user, J, b.dx, fcur, ftrial, xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL, pub, nullptr, &pair));
+            SpecGrad sg{spec_ok ? next_gate(c, b) : nullptr, ssr, b.grad, false};
+            if (f == model_f) CB(model_pair_tail(user, J, b.dx, fcur, ftrial, xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL, pub, nullptr, &pair, &sg));
+            spec_launched = sg.launched;
             if (!pair) {
                 LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));
                 LSQ_TRY(f_then_sumsq(c, exact, f, user, m, ftrial, xt, 7, c->d_slots + SL_TRIAL, pub));
@@ -881,6 +932,8 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         const double pred_red = std::fabs(ssr - predicted_ssr);
         const double rho = pred_red > 0 ? (ssr - trial_ssr) / pred_red : 0.0;   // :118-119
         const bool accepted = rho > MIN_STEP_QUALITY;                           // :122 (strict)
+        // the gradient + colsumabs2 pass of the next Jacobian was queued behind the tail and took the same decision on the device
+        spec_grad_ready = spec_launched && accepted;
         converged = assess(maxabs_dx, maxabs_gr, ssr, trial_ssr, o->x_tol, o->f_tol, o->g_tol, accepted, &xc, &fc, &gc);
         if (accepted) {
             std::swap(fcur, ftrial);                                            // copyto!(fcur, ftrial)
@@ -1399,7 +1452,7 @@ static int model_f_sumsq(void *user, double *out, const double *x, int ctr, doub
 }
 
 static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const double *fcur, double *ftrial, const double *xt,
-                           double *slot_pred, double *slot_trial, LsqSlotPublish pub, const int *skip, bool *done) {
+                           double *slot_pred, double *slot_trial, LsqSlotPublish pub, const int *skip, bool *done, SpecGrad *sg) {
     lsq_model *md = (lsq_model *)user;
     lsq_ctx *c = md->ctx;
     *done = false;
@@ -1437,12 +1490,20 @@ static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const doubl
     md->perm_of[1 - k] = ftrial;
     md->tanh_x = nullptr;     // (consumed, as model_f_sumsq does)
     const int grid = std::max(1, std::min(S.nblocks, c->num_cus));
+    // (the step kernel has put 1 - tanh^2(x_trial) into d_sspec: the factors g! will install if the step is accepted)
+    const bool spec = sg && sg->gate && md->sfac_x == xt;
     SellPairEpi e{skip, md->d_perm[k], md->d_b_perm, ftrial, md->d_perm[1 - k], c->d_partials, c->d_partials + 4096, lsq_ctr(c, 7),
-                  slot_pred, slot_trial, pub};
+                  slot_pred, slot_trial, pub, spec ? sg->gate : nullptr, spec ? sg->ssr : 0.0, MIN_STEP_QUALITY};
     LSQ_LAUNCH(k_sell_rows_pair<0>, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.wrows, J->m, dx, J->d_colscale,
                (const double *)md->d_t, J->n, nxpad, e);
     *done = true;
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    if (hipGetLastError() != hipSuccess) return 1;
+    if (spec) {
+        const int st = lsq_sparse_grad_colsum_spec(J, ftrial, sg->grad, md->d_sspec, sg->gate);
+        if (st == LSQ_OK) sg->launched = true;
+        else if (st != LSQ_EARG) return 1;
+    }
+    return 0;
 }
 
 static int model_g(lsq_mat *J, const double *x, void *user) {

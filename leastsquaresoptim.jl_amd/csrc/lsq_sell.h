@@ -294,6 +294,11 @@ struct SellPairEpi {
     unsigned *counter;          // ticket slot of grid_reduce
     double *slot_a, *slot_b;
     LsqSlotPublish pub;         // the iteration's scalars -> host once both sums are final
+    // LM's acceptance test taken on the device as well (levenberg_marquardt.jl:118-122, the host's own expression on the same
+    // doubles): *gate = 0 if the step will be accepted, 1 if not -- the skip word of the NEXT iteration's gradient pass, which
+    // is queued behind this kernel before the host has seen the scalars (null: no such pass is queued)
+    int *gate;
+    double ssr, min_quality;
 };
 // dst[s * 64 + lane] = src[row owned by lane of slice s] (0 for lanes without a row): an m-vector in slice order
 template <int = 0>
@@ -373,6 +378,11 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows_pair(SellDev S, int wr
     if (tid == 0) {
         *e.slot_a = total_a;
         *e.slot_b = total_b;
+        if (e.gate) {
+            const double pred_red = fabs(e.ssr - total_a);
+            const double rho = pred_red > 0 ? (e.ssr - total_b) / pred_red : 0.0;
+            *e.gate = rho > e.min_quality ? 0 : 1;
+        }
         if (e.pub.count > 0) {
             for (int i = 0; i < e.pub.count; ++i) {
                 const double *src = e.pub.src + i;

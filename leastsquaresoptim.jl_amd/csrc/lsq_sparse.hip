@@ -970,6 +970,27 @@ int lsq_sparse_grad_colsum(lsq_mat *J, const double *f, double *g) {
     return LSQ_OK;
 }
 
+// The same pass for the NEXT Jacobian of a column-scaled handle, queued before the host knows whether there will be one: the
+// handle's stored values with the factor vector `s_new` (what g! at the trial point would hand to lsq_mat_set_colscale) and
+// every kernel skipping itself when *gate != 0.  Nothing of the handle's bookkeeping changes here; when the step is accepted
+// and g! has installed s_new, lsq_sparse_grad_colsum_adopt marks the cache (J->d_colsum, written by this pass) as current.
+// Returns LSQ_EARG when the pass does not apply (the caller then runs the ordinary one later).
+int lsq_sparse_grad_colsum_spec(lsq_mat *J, const double *f, double *g, const double *s_new, const int *gate) {
+    lsq_ctx *c = J->ctx;
+    if (!(J->kind == LSQ_MAT_CSC && J->d_colscale && J->scols.active && J->srows.active && s_new && gate) ||
+        J->colsum_base_version != J->base_version)
+        return LSQ_EARG;
+    LSQ_TRY(launch_sell_cols<false>(J, f, gate));
+    EpiGradCs e{gate, 0, g, J->d_colsum, s_new, J->d_colsum_base, nullptr, nullptr};
+    int nb = lsq_div_up(J->n, LSQ_CMB_COLS);
+    int grid = std::min(nb, c->num_cus * 8);
+    LSQ_LAUNCH((k_combine<EpiGradCs>), dim3(grid), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, J->n, J->scols.ngw, e, nb, s_new);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+void lsq_sparse_grad_colsum_adopt(lsq_mat *J) { J->colsum_version = J->version; }
+void lsq_sparse_colsum_forget(lsq_mat *J) { J->colsum_version = ~0ull; }
+
 const double *lsq_cached_colsum(lsq_mat *J) {
     if (J->kind == LSQ_MAT_OP) {   // the operator owns its state: ask every time a new version is announced
         if (J->colsum_version != J->version) {

@@ -223,6 +223,49 @@ def test_lm_pair_tail_matches_the_two_passes(ctx, m, n, per_col, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("delta,noise", [(None, 1e-3), (1e6, 0.5), (1e-3, 0.5)], ids=["default", "rejections", "small_radius"])
+def test_lm_speculative_gradient_pass_changes_nothing(ctx, delta, noise, monkeypatch):
+    """Round 4: the next Jacobian's gradient + colsumabs2 pass is queued behind the tail of the current iteration, guarded by
+    the acceptance test taken on the device (k_sell_rows_pair writes the skip word), and adopted by the host when its own test
+    agrees (levenberg_marquardt.jl:118-122).  Same kernels on the same data in either order: the run must be BIT-IDENTICAL to
+    the run without speculation (LSQ_NO_SPEC_GRADIENT=1) -- also through rejected steps (a huge initial radius on a noisy
+    problem: the Gauss-Newton-like first steps are refused) and the handle's colsumabs2 must be the current one afterwards."""
+    m, n, per_col = 300000, 2000, 600
+    runs = []
+    for env in ({}, {"LSQ_NO_SPEC_GRADIENT": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=17, ctx=ctx)
+        if noise != 1e-3:      # a noisier right-hand side: larger residual, more curvature, steps get refused
+            rng = np.random.default_rng(3)
+            pr.close()
+            cp, rv, nz = lsq.synthetic.sparse_inputs(m, n, per_col, 17)
+            xt_true = lsq.synthetic.uniform(n, 17 + 101, -3.0, 3.0)
+            bvec = lsq.synthetic.csc_matvec(m, cp, rv, nz, np.tanh(xt_true)) + noise * rng.standard_normal(m)
+            pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=17, ctx=ctx, inputs=(cp, rv, nz), b=bvec)
+        pr.reset()
+        r = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, trace=True, iterations=14, delta=delta, x_tol=0, f_tol=0, g_tol=0)
+
+        class _J:
+            h = pr.J
+            ctx_ = ctx
+        cs = lsq.colsumabs2_(lsq.DeviceVector(ctx, n), _J).get()
+        for k in env:
+            monkeypatch.delenv(k)
+        runs.append((r, cs, pr.fcur.get()))
+        pr.close()
+    (a, csa, fa), (b, csb, fb) = runs
+    assert a.iterations == b.iterations == 14 and a.mul_calls == b.mul_calls and a.f_calls == b.f_calls and a.g_calls == b.g_calls
+    assert np.array_equal(a.trace["accept"], b.trace["accept"]) and np.array_equal(a.trace["inner"], b.trace["inner"])
+    if delta == 1e6:
+        assert not np.all(a.trace["accept"]), "this case is meant to contain rejected steps"
+    assert np.array_equal(a.trace["ssr"], b.trace["ssr"]) and np.array_equal(a.trace["gnorm"], b.trace["gnorm"])
+    assert np.array_equal(np.array(a.trace["x"]), np.array(b.trace["x"]))
+    assert np.array_equal(a.minimizer, b.minimizer) and np.array_equal(fa, fb)
+    assert np.array_equal(csa, csb)          # the handle's colsumabs2 cache: current, not a speculative leftover
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("opt", ["lm", "dogleg"])
 def test_tanh_model_column_scaled_vs_multiplied_out(ctx, opt, monkeypatch):
     """The built-in model keeps J = A diag(1 - tanh(x)^2) as a COLUMN-SCALED handle on big sparse patterns (nothing is
