@@ -844,7 +844,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
                                lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out, skip);   // :106
             LSQ_HIP(hipGetLastError());
             // the last kernel of the iteration hands the scalars to the host
-            t.pub = lsq_slots_ticket(c, SL_GRAD, 5);
+            t.pub = lsq_slots_ticket(c, SL_GRAD, 6);      // (the sixth: the device's own acceptance decision, k_sell_rows_pair)
             bool pair = false;
             SpecGrad sg{t.want_spec ? next_gate(c, *t.b) : nullptr, t.ssr, t.b->grad, false};
             if (t.is_model && model_pair_tail(t.user, t.J, t.b->dx, t.fcur, t.ftrial, t.xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL,
@@ -879,11 +879,11 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         if (o->allreduce && c->idle_status != LSQ_OK) return c->idle_status;
         mul_calls += lmiter;
         inner_total += lmiter / 2;
-        double sl[5];
+        double sl[6] = {0, 0, 0, 0, 0, 0};
         if (tail_done) {
             f_calls++;
             spec_launched = tc.spec_launched;
-            LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, tc.pub.seq, sl));
+            LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 6, tc.pub.seq, sl));
         } else {
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
         double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
@@ -910,7 +910,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         } else {
             // the predicted residual (:114-117), f!(x_trial) and sum(abs2, ftrial) (:107, :111); the last kernel of the iteration
             // hands the scalars to the host.  The built-in model on a column-scaled handle takes all of it in one pass over A.
-            LsqSlotPublish pub = lsq_slots_ticket(c, SL_GRAD, 5);
+            LsqSlotPublish pub = lsq_slots_ticket(c, SL_GRAD, 6);
             bool pair = false;
             SpecGrad sg{spec_ok ? next_gate(c, b) : nullptr, ssr, b.grad, false};
             if (f == model_f) CB(model_pair_tail(user, J, b.dx, fcur, ftrial, xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL, pub, nullptr, &pair, &sg));
@@ -921,7 +921,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             }
             f_calls++;
             LSQ_HIP(hipGetLastError());
-            LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 5, pub.seq, sl));
+            LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 6, pub.seq, sl));
         }
         }
         mul_calls++;
@@ -933,7 +933,11 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         const double rho = pred_red > 0 ? (ssr - trial_ssr) / pred_red : 0.0;   // :118-119
         const bool accepted = rho > MIN_STEP_QUALITY;                           // :122 (strict)
         // the gradient + colsumabs2 pass of the next Jacobian was queued behind the tail and took the same decision on the device
-        spec_grad_ready = spec_launched && accepted;
+        // -- adopted only if the device's decision (the sixth scalar) is the host's; should they ever differ, a pass that ran for a
+        // step the host refuses has overwritten the handle's colsumabs2 with another Jacobian's: forget it
+        const bool dev_accepted = spec_launched && sl[5] != 0.0;
+        spec_grad_ready = spec_launched && accepted && dev_accepted;
+        if (spec_launched && dev_accepted && !accepted) lsq_sparse_colsum_forget(J);
         converged = assess(maxabs_dx, maxabs_gr, ssr, trial_ssr, o->x_tol, o->f_tol, o->g_tol, accepted, &xc, &fc, &gc);
         if (accepted) {
             std::swap(fcur, ftrial);                                            // copyto!(fcur, ftrial)
@@ -1493,7 +1497,8 @@ static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const doubl
     // (the step kernel has put 1 - tanh^2(x_trial) into d_sspec: the factors g! will install if the step is accepted)
     const bool spec = sg && sg->gate && md->sfac_x == xt;
     SellPairEpi e{skip, md->d_perm[k], md->d_b_perm, ftrial, md->d_perm[1 - k], c->d_partials, c->d_partials + 4096, lsq_ctr(c, 7),
-                  slot_pred, slot_trial, pub, spec ? sg->gate : nullptr, spec ? sg->ssr : 0.0, MIN_STEP_QUALITY};
+                  slot_pred, slot_trial, pub, spec ? sg->gate : nullptr, spec ? sg->ssr : 0.0, MIN_STEP_QUALITY,
+                  c->d_slots + SL_SSR};
     LSQ_LAUNCH(k_sell_rows_pair<0>, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.wrows, J->m, dx, J->d_colscale,
                (const double *)md->d_t, J->n, nxpad, e);
     *done = true;

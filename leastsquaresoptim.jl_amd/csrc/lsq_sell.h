@@ -299,6 +299,8 @@ struct SellPairEpi {
     // is queued behind this kernel before the host has seen the scalars (null: no such pass is queued)
     int *gate;
     double ssr, min_quality;
+    double *slot_gate;          // the decision as a scalar (1.0 accepted / 0.0 not) among the published ones: the host adopts the
+                                // queued pass only if the device took the decision the host takes
 };
 // dst[s * 64 + lane] = src[row owned by lane of slice s] (0 for lanes without a row): an m-vector in slice order
 template <int = 0>
@@ -381,7 +383,9 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows_pair(SellDev S, int wr
         if (e.gate) {
             const double pred_red = fabs(e.ssr - total_a);
             const double rho = pred_red > 0 ? (e.ssr - total_b) / pred_red : 0.0;
-            *e.gate = rho > e.min_quality ? 0 : 1;
+            const bool acc = rho > e.min_quality;
+            *e.gate = acc ? 0 : 1;
+            *e.slot_gate = acc ? 1.0 : 0.0;
         }
         if (e.pub.count > 0) {
             for (int i = 0; i < e.pub.count; ++i) {
