@@ -773,7 +773,9 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             spec_grad_ready = false;
         }
         // (is a pass for the NEXT Jacobian worth queueing behind this iteration's tail?  not in the last allowed iteration)
-        const bool spec_ok = !no_spec_grad && !exact && !sharded && !o->allreduce && sv->kind == LSQ_LSMR && f == model_f &&
+        // (independent problems with their per-iteration exchange, C5, take it too: the exchange neither reads nor decides anything
+        //  the pass depends on; a rank frozen after convergence never adopts -- SpecGuard forgets the pass when the loop is left)
+        const bool spec_ok = !no_spec_grad && !exact && !sharded && sv->kind == LSQ_LSMR && f == model_f &&
                              iter < o->iterations && !lsq_dbg_serial;
         spec_launched = false;
         if (!exact && J->colsum_version != J->version && lsq_can_fuse_grad_colsum(J)) {
