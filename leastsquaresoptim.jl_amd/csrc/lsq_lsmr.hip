@@ -672,7 +672,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
 
     int enq = 0, it = 0, istop = 0;
     bool finished = false;
-    const bool spec = tail && tail->fn && tail->predict > 0 && !sharded && !c->idle_hook;
+    const bool spec = tail && tail->fn && tail->predict > 0 && !sharded;
     int tail_at = 0;             // iteration behind which the speculative tail was enqueued (0: not yet)
     const size_t prof_base[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
     std::vector<int> prof_iter[2];   // iteration number of every timed launch of this solve

@@ -863,7 +863,10 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             t.launched++;
             return LSQ_OK;
         };
-        const bool tail_ok = !exact && !sharded && !o->allreduce && sv->kind == LSQ_LSMR && !b.lo && !b.hi;
+        // (with the per-iteration exchange of independent problems too: the hook is issued by the LSMR driver while the device
+        //  works off the queued iterations and the tail; LSQ_NO_TAIL_WITH_EXCHANGE=1 restores the round-3 exclusion)
+        const bool tail_ok = !exact && !sharded && (!o->allreduce || !getenv("LSQ_NO_TAIL_WITH_EXCHANGE")) && sv->kind == LSQ_LSMR &&
+                             !b.lo && !b.hi;
         bool tail_done = false;
         if (sv->kind == LSQ_LSMR) {
             const LsmrLmPrep prep{cs, 1.0 / delta, MIN_DIAGONAL, MAX_DIAGONAL, x, b.lo, b.hi, c->d_slots + SL_GRAD};
