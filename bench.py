@@ -49,8 +49,10 @@ def parse():
     ap.add_argument("--no-dense", action="store_true", help="skip the secondary dense-path timings (C2/C3 ldiv!)")
     ap.add_argument("--repeats", type=int, default=25,
                     help="how many times the K-step timed region is repeated (value = median region)")
-    ap.add_argument("--exchange", choices=("nccl", "gloo"), default=os.environ.get("LSQ_EXCHANGE_BACKEND", "nccl"),
-                    help="backend of the per-outer-iteration ||r|| exchange of sharded runs (nccl = RCCL over xGMI)")
+    ap.add_argument("--exchange", choices=("rccl", "nccl", "gloo"), default=os.environ.get("LSQ_EXCHANGE_BACKEND", "rccl"),
+                    help="the per-outer-iteration ||r|| exchange of sharded runs: rccl = served in C (liblsqrccl.so: a direct "
+                         "ncclAllReduce over xGMI on a side stream, torch only carries the unique id); nccl / gloo = the "
+                         "Python hook over that torch.distributed backend (A/B)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch-path check without a GPU: spawn the ranks, build the process group (gloo), run the "
                          "exchange protocol on made-up scalars and print the JSON line with value = null")
@@ -120,7 +122,7 @@ def main():
         # The per-outer-iteration exchange {sum ssr, max |g|, all-converged} is ONE RCCL all-reduce over xGMI
         # (north_star).  --exchange gloo / LSQ_EXCHANGE_BACKEND=gloo is an opt-in A/B (the payload is 80
         # bytes of host scalars, and an RCCL kernel has to find a CU next to the persistent product kernels).
-        xgroup, xdev, exchange_backend = None, "cuda", "nccl"
+        xgroup, xdev, exchange_backend = None, "cuda", "rccl-c" if a.exchange == "rccl" else "nccl"
         if a.exchange == "gloo":
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the container hostname may not resolve
             xgroup, xdev, exchange_backend = dist.new_group(backend="gloo"), "cpu", "gloo"
@@ -142,10 +144,28 @@ def main():
 
     # one scalar all-reduce per outer iteration for the sharded (C5) case (sharding.py): sum of ssr,
     # max of the gradient norms, all-converged -- ONE RCCL all-reduce of world+2 doubles.
-    allreduce = None
+    allreduce = xchg_c = None
     if world > 1 or force_x:
         from lsq_amd import sharding
-        allreduce = sharding.make_allreduce_callback(dist, rank, world, xdev, group=xgroup)
+        if exchange_backend == "rccl-c":
+            # the exchange in C: its own RCCL communicator (unique id broadcast over the process group), one ncclAllReduce of
+            # world + 3 doubles per outer iteration on a side stream, no Python on the thread that feeds the launches
+            try:
+                allreduce = xchg_c = sharding.RcclScalarExchange(rank, world, dist if world > 1 else None)
+            except Exception as e:   # noqa: BLE001  (plumbing must not cost the run: the Python hook over the same RCCL)
+                print("bench: rank %d: C exchange unavailable (%s); falling back to the Python hook over nccl" % (rank, e),
+                      file=sys.stderr)
+                exchange_backend = "nccl (fallback from rccl-c)"
+            # every rank must take the same path: a collective mismatch would hang the job
+            if world > 1:
+                okt = torch.tensor([1.0 if xchg_c is not None else 0.0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                if okt.item() < 0.5 and xchg_c is not None:
+                    xchg_c.close()
+                    allreduce = xchg_c = None
+                    exchange_backend = "nccl (fallback from rccl-c)"
+        if allreduce is None:
+            allreduce = sharding.make_allreduce_callback(dist, rank, world, xdev, group=xgroup)
 
     LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
 
@@ -206,10 +226,17 @@ def main():
     ev_ovh = C.c_double(0.0)   # what an EMPTY event pair measures on this stream (marker overhead)
     L.lsq_prof_overhead(ctx.h, 50, C.byref(ev_ovh))
     region_s_local = list(region_s)
+    own_srt = sorted(region_s_local)
+    own_rate = a.steps / own_srt[len(own_srt) // 2]
+    rank_rates = [own_rate]
     if dist is not None:
         tt = torch.tensor(region_s, dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)       # every region: the slowest rank's time
         region_s = [float(v) for v in tt.tolist()]
+        rr = torch.zeros(world, dtype=torch.float64, device="cuda")
+        rr[rank] = own_rate
+        dist.all_reduce(rr)                             # every rank's own median rate, for the line (a straggler shows)
+        rank_rates = [float(v) for v in rr.tolist()]
         it = torch.tensor([float(inner_local)], dtype=torch.float64, device="cuda")
         dist.all_reduce(it)
         inner_total = float(it.item())
@@ -231,10 +258,17 @@ def main():
     ms_t = C.c_float(0)
     lsq._lib.check(L.lsq_bench_mul(pr.J, 1, 50, yv.ptr, xv.ptr, 1.0, C.byref(ms_t)))
 
-    if rank != 0:
+    def leave_group():
         if dist is not None:
+            from lsq_amd import sharding as _sh
+            _sh.drain_all()
+            if xchg_c is not None:
+                xchg_c.close()          # (the exchange's own communicator goes before the process group does)
             dist.barrier()
             dist.destroy_process_group()
+
+    if rank != 0:
+        leave_group()
         return
 
     bytes_jv = 12 * nnz + 4 * (m + 1) + 8 * n + 16 * m      # SURVEY 8d (CSR mirror, beta != 0)
@@ -269,12 +303,22 @@ def main():
             pass
 
     # (the headline measurement is complete at this point: a failure in the reported-alongside legs must not lose it)
-    cpu = None
+    cpu = parity = None
     if not a.no_cpu and a.cpu_steps > 0 and world == 1:   # reported at N = 1 only
         try:
-            cpu = cpu_baseline(a, pr, inputs)
+            # the solve the timed region repeats, once more with its trace kept: the CPU leg's first solve is the same
+            # problem on the same schedule, so the two trajectories are compared instead of thrown away
+            pr.reset()
+            rgt = pr.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=a.iters_per_solve, trace=True)
+            cpu, parity = cpu_baseline(a, pr, inputs, rgt)
         except Exception as e:   # noqa: BLE001
             cpu = {"value": None, "unit": "LM outer iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    generic = None
+    if not a.no_cpu and world == 1:
+        try:
+            generic = generic_g(a, ctx, lsq, inputs, pr.b)
+        except Exception as e:   # noqa: BLE001
+            generic = {"error": repr(e)}
     dense = None
     if not a.no_cpu and world == 1 and not a.no_dense:
         try:
@@ -300,6 +344,9 @@ def main():
                                   "1 problem per GPU" % (m, n, nnz, 100.0 * nnz / (m * n)),
                       "m": m, "n": n, "nnz": nnz, "seed": lsq.synthetic.BASE_SEED, "problems": world,
                       "exchange_backend": exchange_backend, "rccl_ranks": rccl_ranks,
+                      "exchange": (dict(xchg_c.stats(), served_by="liblsqrccl.so lsq_rccl_xchg_* (C, direct ncclAllReduce)")
+                                   if xchg_c is not None else None),
+                      "per_rank_it_per_s": rank_rates,
                       "lsmr_inner_iterations_total": inner_total,
                       "lsmr_inner_per_outer": inner_total / (a.steps * world),
                       "lsmr_inner_iterations_per_sec": inner_total / dt, "iters_per_solve": a.iters_per_solve,
@@ -314,16 +361,21 @@ def main():
                       # what the launch heuristics saw: 256 CUs / 8 XCDs = an unpartitioned MI355X (SPX); a partitioned device
                       # (CPX: 32 CUs) takes other kernels in the dense solvers (no slab exchange) and fewer workgroups everywhere
                       "device": ctx.device_info(), "debug_modes": dict(zip(("launch_jitter_us", "serial", "stalls"), lsq.debug_get()))},
-           "roofline": roof, "cpu_baseline": cpu, "dense_secondary": dense, "sparse_secondary": wide,
+           "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu": parity, "generic_g": generic,
+           "dense_secondary": dense, "sparse_secondary": wide,
            # bounded-wait give-ups of the fast paths that assume co-resident workgroups (include/lsqhip.h: lsq_solver_stats)
            "fallback_giveups": ctx.fallback_stats(),
            # LM+LSMR: solves whose follow-up kernels were queued behind a guessed last inner iteration, and wrong guesses
            "tail_speculation": dict(zip(("guesses", "wrong"), ctx.tail_stats()))}
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    leave_group()
+    if parity is not None and not parity["ok"]:
+        # a rate measured on a trajectory that is not the reference's is not a measurement of this path: the line fails
+        out["invalid"] = "parity_vs_cpu failed: the HIP run of the timed solve does not follow the oracle's trajectory"
+        out["value_unchecked"], out["value"] = out["value"], None
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + "\n").encode())   # fd 1 stays on stderr: RCCL prints its banner at exit
+    if out.get("invalid"):
+        raise SystemExit(3)
 
 
 def dry_run(a, rank, world, real_stdout):
@@ -339,7 +391,8 @@ def dry_run(a, rank, world, real_stdout):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo")
-        cb = sharding.make_allreduce_callback(dist, rank, world, "cpu")
+        # the protocol the GPU runs use (liblsqrccl.so: lsq_rccl_xchg_*), here over a gloo transport
+        cb = sharding.TorchTransportExchange(dist, rank, world)
         t0 = time.perf_counter()
         seen = []
         for it in range(a.steps):
@@ -360,7 +413,8 @@ def dry_run(a, rank, world, real_stdout):
         out = {"metric": "lm_lsmr_outer_iterations_per_sec", "value": None, "unit": "LM outer iterations/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True,
                "config": {"workload": "dry run: launch path only, no hot-path work", "problems": world,
-                          "exchange_backend": "gloo", "rccl_ranks": 0, "process_group_ranks": ranks}}
+                          "exchange_backend": "c-protocol (liblsqrccl.so) over gloo", "rccl_ranks": 0,
+                          "process_group_ranks": ranks}}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
@@ -404,6 +458,117 @@ def sparse_secondary(ctx, lsq):
                                                    "unit": "GB/s", "frac": b / (ms.value * 1e-3) / 1e9 / 8000.0,
                                                    "algorithmic_bytes_per_launch": b}}
     pr.close()
+    return out
+
+
+def generic_g(a, ctx, lsq, inputs, b):
+    """The SAME C4 problem and schedule with a g! that does what the reference's general sparse g! does -- rewrite every stored
+    value of J (test/nonlinearleastsquares.jl:47-86) -- instead of the headline's column-scaled handle, which only a model
+    of the form r = V phi(x) - b can use.  Two legs, each as LM outer iterations / s and ms per step (median of 5 regions of
+    --steps steps), reported NEXT TO the headline, never as `value`:
+      device_g_all_nnz        g! on the device multiplies A diag(1 - tanh(x)^2) out into both sliced copies (the layouts
+                              J*v and J'u read): 2 x (read 8 B + index 2 B, write 8 B) per stored entry per accepted step;
+                              predicted and trial residual as two passes (no shared stream of A);
+      host_g_pinned_async     g! on the HOST, in C + OpenMP (tools/hostg/hostg.c, a consumer of include/lsqhip.h): x comes
+                              down (80 KB), nnz values are written into a page-locked buffer and go up through
+                              lsq_mat_set_values_async (80 MB over PCIe per accepted step), the device re-sorts them into
+                              its two layouts; f! stays on the device.  What a Julia g! over the shim would cost at best."""
+    import ctypes as C
+    import numpy as np
+    L = lsq.lib()
+    m, n, pc = a.m, a.n, a.per_col
+    LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
+    colptr, rowval, nzval = inputs
+    out = {"workload": "same C4 problem and schedule as the headline (solves of %d iterations from x0 = 0, zero tolerances)"
+                       % a.iters_per_solve,
+           "headline_g": "column-scaled handle: g! writes n factors (model-specific)"}
+    saved = {k: os.environ.get(k) for k in ("LSQ_NO_COLSCALE", "LSQ_NO_PAIR_TAIL")}
+    os.environ["LSQ_NO_COLSCALE"] = "1"     # (read when the model is created: it keeps A aside and J gets multiplied out)
+    os.environ["LSQ_NO_PAIR_TAIL"] = "1"
+    try:
+        pr2 = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=0, ctx=ctx, inputs=inputs, b=b)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def timed(optimize, regions=5):
+        def run(iters):
+            done = 0
+            r = None
+            while done < iters:
+                k = min(a.iters_per_solve, iters - done)
+                pr2.reset()
+                r = optimize(k)
+                assert r.iterations == k, (r.iterations, k)
+                done += k
+            return r
+        run(a.iters_per_solve)
+        ts = []
+        for _ in range(regions):
+            ctx.sync()
+            t0 = time.perf_counter()
+            r = run(a.steps)
+            ctx.sync()
+            ts.append(time.perf_counter() - t0)
+        dt = sorted(ts)[len(ts) // 2]
+        return {"value": a.steps / dt, "unit": "LM outer iterations/s", "ms_per_step": dt / a.steps * 1e3,
+                "final_ssr": r.ssr, "g_calls_per_solve": r.g_calls}
+
+    leg = timed(lambda k: pr2.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, fetch_x=False))
+    leg["g"] = "device kernel, every stored value of both sliced copies rewritten (LSQ_NO_COLSCALE=1, two-pass tail)"
+    out["device_g_all_nnz"] = leg
+
+    try:
+        here = os.path.join(ROOT, "tools", "hostg")
+        so = os.path.join(here, "libhostg.so")
+        if not os.path.exists(so):
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", here])
+        H = C.CDLL(so)
+
+        class HostG(C.Structure):
+            _fields_ = [("ctx", C.c_void_p), ("inner_f", C.c_void_p), ("inner_user", C.c_void_p), ("n", C.c_int),
+                        ("nnz", C.c_longlong), ("colptr", C.c_void_p), ("A", C.c_void_p), ("stage", C.c_void_p),
+                        ("xh", C.c_void_p), ("threads", C.c_int), ("g_calls", C.c_int), ("fill_seconds", C.c_double),
+                        ("g_seconds", C.c_double)]
+        assert H.hostg_sizeof() == C.sizeof(HostG), (H.hostg_sizeof(), C.sizeof(HostG))
+        H.hostg_f_ptr.restype = C.c_void_p
+        H.hostg_g_ptr.restype = C.c_void_p
+        stage = C.c_void_p()
+        lsq._lib.check(L.lsq_host_alloc(ctx.h, len(nzval) * 8, C.byref(stage)))
+        xh = np.zeros(n)
+        thr = max(1, min(32, H.hostg_max_threads(), (os.cpu_count() or 1)))
+        hg = HostG(ctx.h, C.cast(L.lsq_model_f(), C.c_void_p), pr2.model, n, len(nzval), colptr.ctypes.data, nzval.ctypes.data,
+                   stage, xh.ctypes.data, thr, 0, 0.0, 0.0)
+        fcb = C.cast(H.hostg_f_ptr(), lsq._lib.F_CALLBACK)
+        gcb = C.cast(H.hostg_g_ptr(), lsq._lib.G_CALLBACK)
+
+        class _H:
+            h = pr2.J
+
+        def opt_host(k):
+            from lsq_amd.api import LeastSquaresResult, _run_native
+            st, res, _ = _run_native(ctx, LM, LSMR, _H, pr2.x, pr2.fcur, fcb, gcb, C.cast(C.pointer(hg), C.c_void_p),
+                                     0.0, 0.0, 0.0, k, None, None, None, False, n)
+            lsq._lib.check(st)
+            r = LeastSquaresResult()
+            r.iterations, r.ssr, r.g_calls = res.iterations, float(res.ssr), res.g_calls
+            return r
+        leg = timed(opt_host, regions=3)
+        lsq._lib.check(L.lsq_mat_upload_wait(pr2.J))
+        leg.update({"g": "host C + OpenMP producer (tools/hostg/hostg.c) -> page-locked buffer -> lsq_mat_set_values_async",
+                    "host_threads": thr, "host_fill_ms_per_g": hg.fill_seconds / max(hg.g_calls, 1) * 1e3,
+                    "host_g_ms_per_g": hg.g_seconds / max(hg.g_calls, 1) * 1e3,
+                    "upload_bytes_per_g": len(nzval) * 8})
+        out["host_g_pinned_async"] = leg
+        ctx.sync()
+        L.lsq_host_free(ctx.h, stage)
+    except Exception as e:   # noqa: BLE001
+        out["host_g_pinned_async"] = {"error": repr(e)}
+    pr2.close()
     return out
 
 
@@ -497,9 +662,32 @@ def dense_secondary(ctx, lsq):
     return out
 
 
-def cpu_baseline(a, pr, inputs):
+def parity_vs_cpu(rg, ro):
+    """The HIP run of the timed region's solve against the oracle's run of the same solve (same inputs, same schedule):
+    levenberg_marquardt.jl:72-140 / iterative_lsmr.jl:238-259.  `ok` = identical LSMR inner counts per outer iteration,
+    identical accept pattern, identical mul_calls, iterates within 1e-8 max(1, |x|_inf), ssr within 1e-9 relative."""
+    import numpy as np
+    k = min(rg.iterations, ro.iterations)
+    inner_eq = bool(rg.iterations == ro.iterations and np.array_equal(rg.trace["inner"], ro.trace["inner"]))
+    acc_eq = bool(rg.iterations == ro.iterations and np.array_equal(rg.trace["accept"], ro.trace["accept"]))
+    dx = max(float(np.max(np.abs(np.asarray(rg.trace["x"][i]) - ro.trace["x"][i]))) for i in range(k)) if k else None
+    xs = max(1.0, float(np.max(np.abs(ro.trace["x"][:k])))) if k else 1.0
+    ssr_rel = float(np.max(np.abs(np.asarray(rg.trace["ssr"][:k]) - ro.trace["ssr"][:k]) / ro.trace["ssr"][:k])) if k else None
+    ok = bool(inner_eq and acc_eq and rg.mul_calls == ro.mul_calls and dx is not None and dx <= 1e-8 * xs and ssr_rel <= 1e-9)
+    return {"ok": ok, "inner_equal": inner_eq, "accept_equal": acc_eq, "mul_calls": [int(rg.mul_calls), int(ro.mul_calls)],
+            "max_abs_dx": dx, "ssr_rel": ssr_rel, "iterations": [int(rg.iterations), int(ro.iterations)],
+            "inner_per_outer": [int(v) // 2 for v in ro.trace["inner"]], "accept": [int(v) for v in ro.trace["accept"]],
+            "checker": "oracle/lsq_oracle.c (CPU restatement of the reference), first solve of the cpu_baseline leg",
+            "tolerances": {"max_abs_dx": "1e-8*max(1,|x|inf)", "ssr_rel": 1e-9}}
+
+
+def cpu_baseline(a, pr, inputs, gpu_run=None):
     """The oracle (scalar C port of the reference, 1 thread -- the reference's sparse products and vector loops ARE serial,
-    SURVEY 8d) on the SAME inputs and schedule, bounded sample, one warm-up solve first.  Next to it, labelled, the
+    SURVEY 8d) on the SAME inputs and schedule, bounded sample, one warm-up solve first -- whose trajectory is compared
+    with the HIP run of the same solve (`parity_vs_cpu`).  NB the CPU leg's g! multiplies J = A diag(1 - tanh(x)^2) out
+    entry by entry (orc_tanh_g: what a generic g! of the reference does, test/nonlinearleastsquares.jl:47-86); the headline
+    GPU leg keeps a column-scaled handle (n factors) -- `generic_g` in the same line is the GPU doing what the CPU leg does.
+    Next to it, labelled, the
     "generous CPU" figure BASELINE.md promises: the same algorithm restructured for all host cores with OpenMP
     (oracle/lsq_oracle_omp.c: CSR mirror for J*v, both copies written by g!, parallel reductions)."""
     import numpy as np
@@ -519,7 +707,10 @@ def cpu_baseline(a, pr, inputs):
             done += k
             inner += int(ro.trace["inner"].sum()) // 2
         return inner
-    solves(min(a.iters_per_solve, a.cpu_steps))          # warm-up (page faults, caches)
+    # warm-up (page faults, caches) = the solve whose trajectory is checked against the GPU's
+    ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=a.iters_per_solve, x_tol=0.0, f_tol=0.0,
+                    g_tol=0.0, trace=True, trace_x=True)
+    parity = parity_vs_cpu(gpu_run, ro) if gpu_run is not None else None
     t0 = time.perf_counter()
     inner = solves(a.cpu_steps)
     dt = time.perf_counter() - t0
@@ -533,8 +724,9 @@ def cpu_baseline(a, pr, inputs):
     nnz = len(nzval)
     out = {"value": a.cpu_steps / dt, "unit": "LM outer iterations/s", "cores": 1, "kind": "port",
            "sample": "%d LM outer iterations (%d LSMR inner; solves of %d iterations from x0=0) of the same C4 "
-                     "problem with oracle/lsq_oracle.c, 1 thread, after one warm-up solve, %.1f s"
-                     % (a.cpu_steps, inner, a.iters_per_solve, dt),
+                     "problem with oracle/lsq_oracle.c, 1 thread, after one warm-up solve, %.1f s; its g! multiplies "
+                     "J = A diag(1 - tanh(x)^2) out entry by entry (compare with generic_g.device_g_all_nnz, not only with "
+                     "the column-scaled headline)" % (a.cpu_steps, inner, a.iters_per_solve, dt),
            "lsmr_inner_iterations_per_sec": inner / dt, "host_cores_available": os.cpu_count(),
            "jv_GBps": (12 * nnz + 4 * (m + 1) + 8 * n + 16 * m) / t_mv / 1e9}
     try:   # the all-cores figure (a restructured, OpenMP-parallel port: labelled, not the reference's serial path)
@@ -560,7 +752,7 @@ def cpu_baseline(a, pr, inputs):
         out["all_cores"] = dict(best, unit="LM outer iterations/s", kind="port (OpenMP, best thread count of those tried)")
     except Exception as e:   # noqa: BLE001
         out["all_cores"] = {"value": None, "sample": "failed: %r" % (e,)}
-    return out
+    return out, parity
 
 
 def guarded_main():

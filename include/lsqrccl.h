@@ -1,6 +1,7 @@
 /*
- * lsqrccl.h -- the row-sharded runs' all-reduce as a DIRECT RCCL call (include/lsqhip.h:
- * lsq_options.row_allreduce / lsq_solver_set_row_allreduce).
+ * lsqrccl.h -- the collectives of sharded runs as DIRECT RCCL calls: the row-sharded single problem's in-stream all-reduce
+ * (include/lsqhip.h: lsq_options.row_allreduce / lsq_solver_set_row_allreduce) and, below it, the one scalar
+ * exchange per outer iteration of independent problems (lsq_options.allreduce).
  *
  * liblsqrccl.so is a thin shim: it binds librccl.so at run time (dlopen -- the copy the host process already uses, e.g.
  * PyTorch's, so that there is one RCCL in the process), owns an ncclComm_t per handle and exports a callback of the
@@ -30,6 +31,38 @@ int lsq_rccl_comm_destroy(void *comm);
 void *lsq_rccl_allreduce_callback(void);
 /* how many collectives / doubles this comm handle has enqueued (diagnostics for the tests) */
 int lsq_rccl_comm_stats(void *comm, long long *calls, long long *doubles);
+
+/* ---- the one exchange of INDEPENDENT problems (north_star: "a single RCCL all-reduce over xGMI for the global
+ * ||r|| stopping test"; extends the reference's per-problem stop test, levenberg_marquardt.jl:123-124, to the whole job) ----
+ * lsq_options.allreduce (include/lsqhip.h) served in C: per OUTER iteration ONE ncclAllReduce(sum) of world + 3 doubles
+ * {sum of ssr, converged count, leaving count, one gradient-norm slot per rank} on a side stream of its own, staged through
+ * page-locked memory; every rank recovers {sum ssr, max |g|, all converged}.  Semantics (the contract written at
+ * lsq_allreduce_callback): a rank that reports converged or leaving, and every rank's first call, waits for its exchange
+ * and gets this iteration's values; an ACTIVE rank gets the PREVIOUS exchange's values and leaves the new one in flight
+ * under its iteration's device work (it never acts on "all converged": it is not converged itself); a rank that sees a
+ * non-zero leaving count returns 2 (-> LSQ_ERCCL) and issues no further collective, so every rank issues the same number.
+ * A wait is bounded by LSQ_EXCHANGE_TIMEOUT_S (default 120 s).
+ *     void *comm, *x;  lsq_rccl_comm_create(id, rank, world, &comm);  lsq_rccl_xchg_create(comm, rank, world, &x);
+ *     opt.allreduce = (lsq_allreduce_callback)lsq_rccl_xchg_callback();  opt.allreduce_user = x;
+ *     lsq_optimize(...);  lsq_rccl_xchg_drain(x);  (before a barrier / before destroying the communicator)
+ * The communicator stays the caller's (destroy the exchange first). */
+int lsq_rccl_xchg_create(void *comm, int rank, int world, void **xchg_out);
+int lsq_rccl_xchg_destroy(void *xchg);
+/* the function to put into lsq_options.allreduce, with the exchange handle as allreduce_user
+ * (signature of lsq_allreduce_callback: (double *h_vals, int count, void *user) -> 0 ok, 1 failed, 2 a peer has left) */
+void *lsq_rccl_xchg_callback(void);
+/* completes the exchange an active rank left in flight */
+int lsq_rccl_xchg_drain(void *xchg);
+/* collectives issued, how many of them were waited for on the spot, and whether an abort has been seen */
+int lsq_rccl_xchg_stats(void *xchg, long long *collectives, long long *synchronous, int *aborted);
+/* The same protocol over ANY transport -- what the CPU tests use to run it over gloo next to its Python twin
+ * (leastsquaresoptim.jl_amd/sharding.py), and what an MPI host would plug MPI_Iallreduce / MPI_Wait into:
+ *   issue(h_buf, count, slot, user)   start a SUM all-reduce of h_buf[0..count) in place (may return before it is complete);
+ *   finish(slot, user)                return once the all-reduce started for `slot` (0 or 1) is complete and h_buf holds it. */
+typedef int (*lsq_xchg_issue_fn)(double *h_buf, int count, int slot, void *user);
+typedef int (*lsq_xchg_finish_fn)(int slot, void *user);
+int lsq_rccl_xchg_create_custom(int rank, int world, lsq_xchg_issue_fn issue, lsq_xchg_finish_fn finish, void *user,
+                                void **xchg_out);
 
 #ifdef __cplusplus
 }

@@ -718,7 +718,11 @@ def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_
         opt.h_upper = hi.ctypes.data_as(_lib.c_dp)
         keep.append(hi)
     if allreduce is not None:
-        opt.allreduce = allreduce
+        if hasattr(allreduce, "callback"):      # an exchange served in C (sharding.RcclScalarExchange): function + handle
+            opt.allreduce = allreduce.callback
+            opt.allreduce_user = allreduce.user
+        else:                                   # a ctypes callback (sharding.make_allreduce_callback)
+            opt.allreduce = allreduce
         keep.append(allreduce)
     if preconditioner is not None:
         opt.preconditioner = preconditioner

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of liblsqhip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdarg>
 #include <cstdint>
@@ -217,6 +218,10 @@ struct LsqSell {
     double *d_sx = nullptr;        // J*x with column windows: s .* x of a column-scaled handle (n doubles)
 };
 
+inline unsigned long long lsq_next_mat_uid() {
+    static std::atomic<unsigned long long> next{1};
+    return next.fetch_add(1, std::memory_order_relaxed);
+}
 struct lsq_mat {
     lsq_ctx *ctx;
     int kind;
@@ -259,6 +264,9 @@ struct lsq_mat {
     void *op_user = nullptr;
     double *d_optmp = nullptr;
     unsigned long long version = 0;  // bumps whenever values change
+    // process-unique id of this handle: caches keyed on (handle, version) must not confuse a handle with one that was
+    // destroyed and re-created at the same address
+    unsigned long long uid = lsq_next_mat_uid();
     // cached colsumabs2 (utils.jl:139-151 is called twice per LM iteration by the reference)
     double *d_colsum = nullptr;
     unsigned long long colsum_version = ~0ull;

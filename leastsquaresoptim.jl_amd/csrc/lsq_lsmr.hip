@@ -475,6 +475,8 @@ extern "C" int lsq_solver_set_row_allreduce(lsq_solver *s, lsq_device_allreduce_
     s->row_cb = cb;
     s->row_user = user;
     s->global_rows = cb ? global_rows : 0;
+    s->colsum_g_uid = 0;                // (another hook = another group of ranks: the summed colsumabs2 is theirs, not ours)
+    s->colsum_g_version = ~0ull;
     if (cb && !s->d_xbuf) {
         // (n + 1 doubles travel; the slot behind them is read as a partial-sum array of count 1, and ordered_sum256x3
         //  fetches the first 256 entries of such an array before it looks at the count)
@@ -495,13 +497,13 @@ int lsq_rowshard_colsum(lsq_solver *s, lsq_mat *J, const double **out) {
     if (!s->row_cb) return LSQ_OK;
     lsq_ctx *c = s->ctx;
     if (!s->d_colsum_g) LSQ_HIP(hipMalloc(&s->d_colsum_g, (size_t)(s->n > 0 ? s->n : 1) * sizeof(double)));
-    if (s->colsum_g_mat != J || s->colsum_g_version != J->version) {
+    if (s->colsum_g_uid != J->uid || s->colsum_g_version != J->version) {
         LSQ_TRY(lsq_d2d(c, s->d_colsum_g, local, (size_t)J->n * sizeof(double)));   // (a copy kernel: no runtime-side staging hole)
         if (s->row_cb(s->d_colsum_g, J->n, (void *)c->stream, s->row_user) != 0) {
             lsq_set_error("row all-reduce callback reported failure");
             return LSQ_ECALLBACK;
         }
-        s->colsum_g_mat = J;
+        s->colsum_g_uid = J->uid;
         s->colsum_g_version = J->version;
     }
     *out = s->d_colsum_g;

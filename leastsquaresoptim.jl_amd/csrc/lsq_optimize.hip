@@ -419,6 +419,7 @@ static int sumsq_to_slot(lsq_ctx *c, bool exact, long long n, const double *x, i
 // f!(out, x) followed by sum(out.^2) -> slot.  When f! is the library's own device-side model on the sliced-row layout the
 // sum rides in the residual kernel's epilogue (no second pass over the m-vector: 8 MB and a launch less per iteration at C4)
 static int model_f(double *out, const double *x, void *user);
+static int model_g(lsq_mat *J, const double *x, void *user);
 static int model_f_sumsq(void *user, double *out, const double *x, int ctr, double *d_out, LsqSlotPublish pub, bool *done,
                          const int *skip = nullptr);
 // predicted residual |J dx - f|^2 AND f!(x_trial) with its sum of squares in ONE pass over the model's matrix
@@ -737,8 +738,11 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
     // model on a column-scaled handle with LSMR, no exchange.  spec_grad_ready: that pass has run for the factors g! is about to
     // install -- adopted at the head of the next iteration, or forgotten if the loop is left before (SpecGuard).
     const bool no_spec_grad = getenv("LSQ_NO_SPEC_GRADIENT") != nullptr;       // (read per run: the tests flip it)
-    bool spec_launched = false, spec_grad_ready = false;
-    struct SpecGuard { lsq_mat *J; bool &ready; ~SpecGuard() { if (ready) lsq_sparse_colsum_forget(J); } } spec_guard{J, spec_grad_ready};
+    // spec_pending: a pass has been QUEUED and the host has not yet ruled on it (an error return between the two --
+    // a departed C5 peer, a failed wait, a callback failure -- must not leave another Jacobian's colsumabs2 marked current)
+    bool spec_launched = false, spec_grad_ready = false, spec_pending = false;
+    struct SpecGuard { lsq_mat *J; bool &ready; bool &pending; ~SpecGuard() { if (ready || pending) lsq_sparse_colsum_forget(J); } }
+        spec_guard{J, spec_grad_ready, spec_pending};
     int local_done = 0;
     double gssr = ssr, ggr = maxabs_gr;
     long long inner_total = 0;
@@ -775,7 +779,9 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         // (is a pass for the NEXT Jacobian worth queueing behind this iteration's tail?  not in the last allowed iteration)
         // (independent problems with their per-iteration exchange, C5, take it too: the exchange neither reads nor decides anything
         //  the pass depends on; a rank frozen after convergence never adopts -- SpecGuard forgets the pass when the loop is left)
-        const bool spec_ok = !no_spec_grad && !exact && !sharded && sv->kind == LSQ_LSMR && f == model_f &&
+        // (f AND g must be the built-in model's: the pass assumes that g! installs the factors the step kernel has put into
+        //  d_sspec -- lsq_model_f() is a public export and may be paired with somebody else's g!)
+        const bool spec_ok = !no_spec_grad && !exact && !sharded && sv->kind == LSQ_LSMR && f == model_f && g == model_g &&
                              iter < o->iterations && !lsq_dbg_serial;
         spec_launched = false;
         if (!exact && J->colsum_version != J->version && lsq_can_fuse_grad_colsum(J)) {
@@ -835,8 +841,9 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             lsq_ctx *c; lsq_mat *J; LoopBuffers *b; lsq_f_callback f; void *user;
             const double *x, *fcur; double *xt, *ftrial;
             int m, n, gn; bool is_model; LsqSlotPublish pub; int launched;
-            bool want_spec; double ssr; bool spec_launched;
-        } tc{c, J, &b, f, user, x, fcur, xt, ftrial, m, n, gn, !exact && f == model_f, LsqSlotPublish(), 0, spec_ok, ssr, false};
+            bool want_spec; double ssr; bool spec_launched; bool *spec_pending;
+        } tc{c, J, &b, f, user, x, fcur, xt, ftrial, m, n, gn, !exact && f == model_f, LsqSlotPublish(), 0, spec_ok, ssr, false,
+             &spec_pending};
         auto tail_fn = [](const int *skip, void *u) -> int {
             TailCtx &t = *(TailCtx *)u;
             lsq_ctx *c = t.c;
@@ -855,6 +862,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
                 return LSQ_ECALLBACK;
             }
             t.spec_launched = sg.launched;      // (of the LAST time the tail was queued: an earlier one skipped itself)
+            if (sg.launched) *t.spec_pending = true;
             if (!pair) {
                 LSQ_TRY(predicted_to_slot(c, false, t.J, t.b->dx, t.fcur, t.b->fpred, 8, c->d_slots + SL_PRED, LsqSlotPublish(), skip));
                 LSQ_TRY(f_then_sumsq(c, false, t.f, t.user, t.m, t.ftrial, t.xt, 7, c->d_slots + SL_TRIAL, t.pub, skip));
@@ -920,6 +928,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             SpecGrad sg{spec_ok ? next_gate(c, b) : nullptr, ssr, b.grad, false};
             if (f == model_f) CB(model_pair_tail(user, J, b.dx, fcur, ftrial, xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL, pub, nullptr, &pair, &sg));
             spec_launched = sg.launched;
+            if (sg.launched) spec_pending = true;
             if (!pair) {
                 LSQ_TRY(predicted_to_slot(c, exact, J, b.dx, fcur, b.fpred, 8, c->d_slots + SL_PRED));
                 LSQ_TRY(f_then_sumsq(c, exact, f, user, m, ftrial, xt, 7, c->d_slots + SL_TRIAL, pub));
@@ -943,6 +952,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         const bool dev_accepted = spec_launched && sl[5] != 0.0;
         spec_grad_ready = spec_launched && accepted && dev_accepted;
         if (spec_launched && dev_accepted && !accepted) lsq_sparse_colsum_forget(J);
+        spec_pending = false;       // (ruled on: adopted at the head of the next iteration, forgotten, or never run on the device)
         converged = assess(maxabs_dx, maxabs_gr, ssr, trial_ssr, o->x_tol, o->f_tol, o->g_tol, accepted, &xc, &fc, &gc);
         if (accepted) {
             std::swap(fcur, ftrial);                                            // copyto!(fcur, ftrial)

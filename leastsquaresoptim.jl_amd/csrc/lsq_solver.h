@@ -71,7 +71,7 @@ struct lsq_solver {
     // preconditioner and LM's damping: solver-owned, keyed on the handle and its version -- the handle's own cache keeps
     // the LOCAL block's sums, which is what lsq_colsumabs2(J) and any unsharded solve on the same handle must see
     double *d_colsum_g = nullptr;
-    const lsq_mat *colsum_g_mat = nullptr;
+    unsigned long long colsum_g_uid = 0;     // lsq_mat::uid of the handle the buffer belongs to (0: none)
     unsigned long long colsum_g_version = ~0ull;
     int *d_one = nullptr;      // the constant 1 (partial count of a sum that is already complete)
     // --- dense Cholesky (dense_cholesky.jl:7-21) ---

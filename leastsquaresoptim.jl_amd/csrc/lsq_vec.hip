@@ -16,20 +16,21 @@ static thread_local char g_err[512] = "";
 // ---- roctx ranges (lsq_common.h: LSQ_RANGE) ----------------------------------------------------
 static int (*g_roctx_push)(const char *) = nullptr;
 static int (*g_roctx_pop)() = nullptr;
-static int g_roctx_state = 0;   // 0: not looked at, 1: bound, -1: off
 static bool roctx_bind() {
-    if (g_roctx_state) return g_roctx_state > 0;
-    g_roctx_state = -1;
-    const char *e = getenv("LSQ_ROCTX");
-    if (!e || atoi(e) <= 0) return false;
-    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
-        void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
-        if (!h) continue;
-        g_roctx_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
-        g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
-        if (g_roctx_push && g_roctx_pop) { g_roctx_state = 1; return true; }
-    }
-    return false;
+    // contexts may be driven from several host threads: bound exactly once (C++11 static initialisation is thread-safe)
+    static const bool bound = [] {
+        const char *e = getenv("LSQ_ROCTX");
+        if (!e || atoi(e) <= 0) return false;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_roctx_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (g_roctx_push && g_roctx_pop) return true;
+        }
+        return false;
+    }();
+    return bound;
 }
 LsqRange::LsqRange(const char *name) : on(roctx_bind()) { if (on) g_roctx_push(name); }
 LsqRange::~LsqRange() { if (on) g_roctx_pop(); }
@@ -46,8 +47,8 @@ extern "C" const char *lsq_last_error(void) { return g_err; }
 // ---- debug modes (lsq_common.h: LSQ_LAUNCH) --------------------------------------------------
 int lsq_dbg_jitter_us = 0;
 int lsq_dbg_serial = 0;
-static unsigned long long g_dbg_rng = 0x9e3779b97f4a7c15ull;
-static unsigned long long g_dbg_stalls = 0;
+static thread_local unsigned long long g_dbg_rng = 0x9e3779b97f4a7c15ull;   // (per host thread: contexts may be driven from several)
+static std::atomic<unsigned long long> g_dbg_stalls{0};
 void lsq_dbg_init() {
     static bool done = false;
     if (done) return;
@@ -62,12 +63,14 @@ void lsq_dbg_stall() {
     if ((r & 3) != 0) return;
     unsigned long long us = (r >> 8) % (unsigned long long)(lsq_dbg_jitter_us + 1);
     if (((r >> 2) & 63) == 0) us *= 20;            // the occasional long stall (30-70 ms observed in the wild)
-    g_dbg_stalls++;
+    g_dbg_stalls.fetch_add(1, std::memory_order_relaxed);
     timespec t0, t1;                               // busy wait: usleep's granularity (~60 us) would hide the short stalls
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    do { clock_gettime(CLOCK_MONOTONIC, &t1); }
-    while ((unsigned long long)(t1.tv_sec - t0.tv_sec) * 1000000ull + (unsigned long long)(t1.tv_nsec - t0.tv_nsec) / 1000ull < us
-           && (t1.tv_sec > t0.tv_sec || t1.tv_nsec >= t0.tv_nsec));
+    long long elapsed_ns;                          // signed: tv_nsec wraps when the wait crosses a second boundary
+    do {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        elapsed_ns = (long long)(t1.tv_sec - t0.tv_sec) * 1000000000ll + ((long long)t1.tv_nsec - (long long)t0.tv_nsec);
+    } while (elapsed_ns < (long long)us * 1000ll);
 }
 extern "C" int lsq_debug_set(int launch_jitter_us, int serial) {
     lsq_dbg_init();                                // (so that a later first context does not overwrite this from the environment)
@@ -79,7 +82,7 @@ extern "C" int lsq_debug_get(int *launch_jitter_us, int *serial, long long *stal
     lsq_dbg_init();
     if (launch_jitter_us) *launch_jitter_us = lsq_dbg_jitter_us;
     if (serial) *serial = lsq_dbg_serial;
-    if (stalls) *stalls = (long long)g_dbg_stalls;
+    if (stalls) *stalls = (long long)g_dbg_stalls.load(std::memory_order_relaxed);
     return LSQ_OK;
 }
 extern "C" int lsq_version(void) { return 100; }
@@ -121,6 +124,14 @@ extern "C" int lsq_ctx_create(int device, void *stream, lsq_ctx **out) {
     hipDeviceProp_t prop;
     LSQ_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
+    // LSQ_DEBUG_NUM_CUS=<k>: let the launch heuristics see a device of k compute units (e.g. 32 = one CPX partition of an
+    // MI355X): the branches a partitioned device takes -- no slab exchange in the QR panel, launch-per-panel Cholesky when the
+    // tiles do not fit, fewer workgroups everywhere -- run on an unpartitioned box (tests/test_b_gpu_kernels.py).  Only ever
+    // lowers the count: every co-residency assumption made for k CUs holds on the real device.
+    if (const char *e = getenv("LSQ_DEBUG_NUM_CUS")) {
+        const int k = atoi(e);
+        if (k >= 1 && k < c->num_cus) c->num_cus = k;
+    }
     LSQ_HIP(hipDeviceSynchronize());
     *out = c;
     return LSQ_OK;

@@ -160,3 +160,165 @@ def make_allreduce_callback(dist, rank, world, device, group=None):
 
     _DRAINS.append(_drain)
     return _lib.ALLREDUCE_CALLBACK(_cb)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the same exchange served in C (liblsqrccl.so: lsq_rccl_xchg_*, include/lsqrccl.h) -- what bench.py --gpus N uses and what a
+# Julia host binds with ccall.  The Python hook above stays as its test double: tests/test_sharding.py
+# runs both over gloo (world 2) on the same made-up scalars and asserts the same sequence of results and return codes.
+# ------------------------------------------------------------------------------------------------------------------------
+_RL = None
+XCHG_ISSUE_FN = None
+XCHG_FINISH_FN = None
+
+
+def rccl_shim():
+    """ctypes handle of liblsqrccl.so with the signatures of include/lsqrccl.h."""
+    global _RL, XCHG_ISSUE_FN, XCHG_FINISH_FN
+    if _RL is not None:
+        return _RL
+    import ctypes as C
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "liblsqrccl.so")
+    if not os.path.exists(path):
+        raise RuntimeError("liblsqrccl.so is not built (make -C leastsquaresoptim.jl_amd/csrc)")
+    L = C.CDLL(path)
+    vp, i, pvp, pll = C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)
+    XCHG_ISSUE_FN = C.CFUNCTYPE(i, C.POINTER(C.c_double), i, i, vp)
+    XCHG_FINISH_FN = C.CFUNCTYPE(i, i, vp)
+    L.lsq_rccl_last_error.restype = C.c_char_p
+    L.lsq_rccl_load.argtypes = [C.c_char_p]
+    L.lsq_rccl_unique_id.argtypes = [C.c_char_p]
+    L.lsq_rccl_comm_create.argtypes = [C.c_char_p, i, i, pvp]
+    L.lsq_rccl_comm_destroy.argtypes = [vp]
+    L.lsq_rccl_comm_stats.argtypes = [vp, pll, pll]
+    L.lsq_rccl_xchg_create.argtypes = [vp, i, i, pvp]
+    L.lsq_rccl_xchg_create_custom.argtypes = [i, i, XCHG_ISSUE_FN, XCHG_FINISH_FN, vp, pvp]
+    L.lsq_rccl_xchg_destroy.argtypes = [vp]
+    L.lsq_rccl_xchg_drain.argtypes = [vp]
+    L.lsq_rccl_xchg_callback.restype = vp
+    L.lsq_rccl_xchg_stats.argtypes = [vp, pll, pll, C.POINTER(i)]
+    _RL = L
+    return L
+
+
+def _librccl_path():
+    # ONE RCCL and ONE HIP runtime per process (see rowshard.RcclRowAllreduce): PyTorch's bundled copy if PyTorch is loaded
+    cands = []
+    if "torch" in sys.modules:
+        cands.append(os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "librccl.so"))
+    cands.append(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "librccl.so"))
+    return next((c for c in cands if os.path.exists(c)), None)
+
+
+class _XchgBase:
+    """Common part: .callback / .user go into lsq_options.allreduce / allreduce_user (api._run_native takes the object)."""
+
+    def _bind(self, L, h):
+        import ctypes as C
+        self._L, self.h = L, h
+        self.callback = C.cast(L.lsq_rccl_xchg_callback(), _lib.ALLREDUCE_CALLBACK)
+        self.user = h
+        _DRAINS.append(self.drain)
+
+    def drain(self):
+        if self.h and self._L.lsq_rccl_xchg_drain(self.h) != 0:
+            raise RuntimeError("exchange: " + self._L.lsq_rccl_last_error().decode())
+
+    def stats(self):
+        import ctypes as C
+        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+        self._L.lsq_rccl_xchg_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"collectives": a.value, "synchronous": b.value, "aborted": bool(c.value)}
+
+    def __call__(self, vals, count, user=None):       # (so that tests can drive it like the Python hook)
+        return self.callback(vals, count, self.user)
+
+    def close(self):
+        if self.h:
+            if self.drain in _DRAINS:
+                _DRAINS.remove(self.drain)
+            self._L.lsq_rccl_xchg_destroy(self.h)
+            self.h = None
+
+
+class RcclScalarExchange(_XchgBase):
+    """lsq_options.allreduce as a direct RCCL call from C (lsq_rccl_xchg_create): one communicator of `world` ranks over the
+    current HIP device; `dist` (any initialised torch.distributed group, or None when world == 1) only carries the 128-byte
+    unique id from rank 0 to the others.  The HIP device must be current before construction."""
+
+    def __init__(self, rank=0, world=1, dist=None, librccl=None):
+        import ctypes as C
+        L = rccl_shim()
+        librccl = librccl or _librccl_path()
+        if L.lsq_rccl_load(librccl.encode() if librccl else None) != 0:
+            raise RuntimeError("RCCL: " + L.lsq_rccl_last_error().decode())
+        idbuf = C.create_string_buffer(128)
+        if rank == 0 and L.lsq_rccl_unique_id(idbuf) != 0:
+            raise RuntimeError("RCCL: " + L.lsq_rccl_last_error().decode())
+        if world > 1:
+            box = [idbuf.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            idbuf = C.create_string_buffer(box[0], 128)
+        comm = C.c_void_p()
+        if L.lsq_rccl_comm_create(idbuf, rank, world, C.byref(comm)) != 0:
+            raise RuntimeError("RCCL: " + L.lsq_rccl_last_error().decode())
+        self.comm, self.rank, self.world = comm, rank, world
+        h = C.c_void_p()
+        if L.lsq_rccl_xchg_create(comm, rank, world, C.byref(h)) != 0:
+            L.lsq_rccl_comm_destroy(comm)
+            raise RuntimeError("RCCL: " + L.lsq_rccl_last_error().decode())
+        self._bind(L, h)
+
+    def comm_stats(self):
+        import ctypes as C
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self._L.lsq_rccl_comm_stats(self.comm, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        super().close()
+        if self.comm:
+            self._L.lsq_rccl_comm_destroy(self.comm)
+            self.comm = None
+
+
+class TorchTransportExchange(_XchgBase):
+    """The C protocol (lsq_rccl_xchg_create_custom) over a torch.distributed group as its transport: issue =
+    dist.all_reduce(async_op=True) on a tensor that aliases the C side's staging buffer, finish = work.wait().  CPU tests
+    (gloo); `world == 1` without a process group completes at once."""
+
+    def __init__(self, dist, rank, world, group=None):
+        import ctypes as C
+        import numpy as np
+        import torch
+        L = rccl_shim()
+        works = [None, None]
+        timeout_s = float(os.environ.get("LSQ_EXCHANGE_TIMEOUT_S", "120"))
+
+        def issue(h_buf, count, slot, _user):
+            try:
+                if world > 1:
+                    t = torch.from_numpy(np.ctypeslib.as_array(h_buf, (count,)))
+                    works[slot] = (dist.all_reduce(t, async_op=True, group=group), t)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("exchange transport (issue) failed:", e, file=sys.stderr)
+                return 1
+
+        def finish(slot, _user):
+            try:
+                w = works[slot]
+                works[slot] = None
+                if w is not None and not w[0].wait(datetime.timedelta(seconds=timeout_s)):
+                    return 1
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("exchange transport (finish) failed:", e, file=sys.stderr)
+                return 1
+
+        self._keep = (XCHG_ISSUE_FN(issue), XCHG_FINISH_FN(finish))
+        h = C.c_void_p()
+        if L.lsq_rccl_xchg_create_custom(rank, world, self._keep[0], self._keep[1], None, C.byref(h)) != 0:
+            raise RuntimeError("exchange: " + L.lsq_rccl_last_error().decode())
+        self._bind(L, h)

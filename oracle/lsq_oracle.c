@@ -717,7 +717,15 @@ static double larfg(int n, double *alpha, double *x, int incx) {
 
 /* LAPACK dgeqp3 semantics via the unblocked dlaqp2 recurrence (qr!(qrm, ColumnNorm()),
  * dense_qr.jl:37,83). */
+/* Large shapes (C3: 16384 x 2048 = 1.3e11 flops, minutes in this scalar loop): tests may hand the factorisation -- and
+ * only the factorisation; rank decision, Q'b, triangular solve and minimum-norm completion stay here -- to the very LAPACK
+ * routine Julia dispatches to (scipy's dgeqp3), through this hook.  Same output convention: reflectors below the
+ * diagonal, tau, 0-based jpvt.  NULL (default) = the restatement below. */
+static orc_geqp3_fn g_geqp3_backend = 0;
+void orc_set_geqp3_backend(orc_geqp3_fn fn) { g_geqp3_backend = fn; }
+
 void orc_geqp3(double *A, int m, int n, int *jpvt, double *tau) {
+    if (g_geqp3_backend) { g_geqp3_backend(A, m, n, jpvt, tau); return; }
     int mn = m < n ? m : n;
     double *vn1 = malloc(n * sizeof(double)), *vn2 = malloc(n * sizeof(double));
     double *w = malloc(n * sizeof(double));

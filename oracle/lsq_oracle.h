@@ -122,6 +122,10 @@ int orc_lsmr(double *x, const orc_mat *J, const double *diag, const double *P, d
 int orc_potrf_upper(double *A, int n);                         /* 0 ok, k>0 not PD at k */
 int orc_pstrf_upper(double *A, int n, int *piv, int *rank, double tol);
 void orc_geqp3(double *A, int m, int n, int *jpvt, double *tau);
+/* test hook: serve orc_geqp3 (and with it the QR solvers' factorisation) from LAPACK's dgeqp3 at sizes the scalar
+ * restatement needs minutes for; NULL restores the restatement */
+typedef void (*orc_geqp3_fn)(double *A, int m, int n, int *jpvt, double *tau);
+void orc_set_geqp3_backend(orc_geqp3_fn fn);
 int orc_qrp_solve(double *A, int m, int n, const int *jpvt, const double *tau, double *b, int lenb,
                   double rcond);                               /* returns rank; b[0:n] = solution */
 

@@ -232,6 +232,35 @@ def qr_solve(A, b, rcond=None):
     return u[:n].copy(), rank, jp, a.reshape((m, n), order="F"), tau
 
 
+GEQP3_CB = C.CFUNCTYPE(None, c_dp, C.c_int, C.c_int, c_ip, c_dp)
+_geqp3_keep = None
+
+
+def use_lapack_geqp3(on=True):
+    """Serve the oracle's geqp3 (inside orc_ldiv_qr / orc_ldiv_qr_damped and so inside optimize(.., QR, ..)) from scipy's
+    LAPACK dgeqp3 -- the routine Julia's qr!(A, ColumnNorm()) dispatches to (dense_qr.jl:37,83) -- for shapes where the
+    scalar restatement needs minutes (C3: 16384 x 2048).  Everything after the factorisation stays the oracle's."""
+    global _geqp3_keep
+    if not on:
+        lib().orc_set_geqp3_backend(C.cast(None, GEQP3_CB))
+        _geqp3_keep = None
+        return
+    from scipy.linalg import lapack
+
+    def _cb(ap, m, n, jp, taup):
+        a = np.ctypeslib.as_array(ap, (m * n,)).reshape((m, n), order="F")
+        qr, jpvt, tau, _, info = lapack.dgeqp3(a, overwrite_a=0)
+        assert info == 0
+        a[:, :] = qr
+        np.ctypeslib.as_array(jp, (n,))[:] = jpvt - 1
+        k = min(m, n)
+        if k:
+            np.ctypeslib.as_array(taup, (k,))[:] = tau[:k]
+
+    _geqp3_keep = GEQP3_CB(_cb)
+    lib().orc_set_geqp3_backend(_geqp3_keep)
+
+
 def potrf_upper(A):
     a = np.asfortranarray(np.asarray(A, dtype=np.float64)).reshape(-1, order="F").copy()
     n = A.shape[0]

@@ -32,7 +32,7 @@ def c_class(ctype):
     base = t.replace("*", "").strip()
     callbacks = {"lsq_f_callback", "lsq_g_callback", "lsq_allreduce_callback", "lsq_precond_callback", "lsq_device_allreduce_callback",
                  "lsq_precond_update_callback", "lsq_precond_ldiv_callback",
-                 "lsq_op_mul_callback", "lsq_op_colsum_callback"}
+                 "lsq_op_mul_callback", "lsq_op_colsum_callback", "lsq_xchg_issue_fn", "lsq_xchg_finish_fn"}
     handles = {"lsq_ctx", "lsq_mat", "lsq_solver", "lsq_model", "void"}
     if base in callbacks and stars == 0:
         return "ptr:void"

@@ -103,6 +103,69 @@ def test_c4_sparse_full_size_properties(ctx, n, pc):
     pr.close()
 
 
+@pytest.mark.parametrize("n,pc", [(10_000, 1000), (30_000, 333)], ids=["C4", "n30000_wide"])
+def test_c4_full_size_matches_oracle(ctx, n, pc):
+    """C4 AT FULL SIZE against the oracle: 8 LevenbergMarquardt(LSMR()) iterations of the bench's own
+    problem (10^6 x 10^4, nnz 10^7, BASE_SEED, zero tolerances = the bench schedule) -- the kernels the headline times
+    (k_sell_rows<EpiU>, k_sell_cols + k_combine, k_sell_rows_pair, the speculative gradient pass) -- and the same entry
+    count over n = 30000 columns (k_sell_rows_wide, two-launch tail) vs O.optimize on the same inputs:
+    levenberg_marquardt.jl:72-140, iterative_lsmr.jl:238-259.  Identical iteration / f / g / mul counts, LSMR inner counts
+    per outer iteration and accept pattern; every iterate to 1e-8 max(1, |x|_inf); ssr to 1e-9; Delta to 1e-12."""
+    m = 1_000_000
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=pc, seed=lsq.synthetic.BASE_SEED, ctx=ctx)
+    pr.reset()
+    rg = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, trace=True, iterations=8, x_tol=0.0, f_tol=0.0, g_tol=0.0)
+    A = O.Mat(csc=(m, n, pr.colptr, pr.rowval, pr.A))
+    J = O.Mat(csc=(m, n, pr.colptr, pr.rowval, np.zeros_like(pr.A)))
+    f, g, ud, keep = O.tanh_model(A, pr.b)
+    ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=8, x_tol=0.0, f_tol=0.0, g_tol=0.0)
+    assert rg.iterations == ro.iterations == 8
+    assert (rg.f_calls, rg.g_calls, rg.mul_calls) == (ro.f_calls, ro.g_calls, ro.mul_calls)
+    assert np.array_equal(rg.trace["inner"], ro.trace["inner"]), (rg.trace["inner"], ro.trace["inner"])
+    assert np.array_equal(rg.trace["accept"], ro.trace["accept"])
+    assert np.sum(ro.trace["accept"]) >= 5                       # (a trajectory, not eight refusals)
+    np.testing.assert_allclose(rg.trace["ssr"], ro.trace["ssr"], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(rg.trace["delta"], ro.trace["delta"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(rg.trace["gnorm"], ro.trace["gnorm"], rtol=1e-8, atol=1e-14)
+    for k in range(8):
+        xr = ro.trace["x"][k]
+        assert np.max(np.abs(rg.trace["x"][k] - xr)) <= 1e-8 * max(1.0, np.max(np.abs(xr))), k
+    assert np.max(np.abs(rg.minimizer - ro.minimizer)) <= 1e-8 * max(1.0, np.max(np.abs(ro.minimizer)))
+    fc = pr.fcur.get()                                            # the residual the loop carries == the oracle's
+    assert np.max(np.abs(fc - ro.fcur)) <= 1e-9 * max(1.0, np.max(np.abs(ro.fcur)))
+    pr.close()
+
+
+def test_c3_full_size_dogleg_qr_matches_oracle(ctx):
+    """C3 AT FULL SIZE against the oracle: 2 Dogleg(QR()) iterations on the 16384 x 2048 tanh problem,
+    dogleg.jl:77-199 + dense_qr.jl:30-42.  The oracle's loop, dense products, rank decision (dlaic1), Q'b and triangular solve
+    are its own; only its dgeqp3 is served by LAPACK (O.use_lapack_geqp3: scipy's dgeqp3, the routine Julia calls -- the
+    scalar restatement of it needs minutes at 1.3e11 flops).  Identical counts / accept pattern; iterates to 1e-9; Delta and
+    rho to 1e-8 (a ratio of differences of sums over 16384 rows)."""
+    m, n = 16384, 2048
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=False, seed=lsq.synthetic.BASE_SEED + 3, ctx=ctx)
+    pr.reset()
+    rg = pr.optimize(lsq._lib.DOGLEG, lsq._lib.QR, trace=True, iterations=2, x_tol=0.0, f_tol=0.0, g_tol=0.0)
+    A = O.Mat(dense=pr.A.reshape((m, n), order="F"))
+    J = O.Mat(dense=np.zeros((m, n)))
+    f, g, ud, keep = O.tanh_model(A, pr.b)
+    O.use_lapack_geqp3(True)
+    try:
+        ro = O.optimize(O.DOGLEG, O.QR, J, np.zeros(n), f, g, ud=ud, iterations=2, x_tol=0.0, f_tol=0.0, g_tol=0.0)
+    finally:
+        O.use_lapack_geqp3(False)
+    assert rg.iterations == ro.iterations == 2
+    assert (rg.f_calls, rg.g_calls, rg.mul_calls) == (ro.f_calls, ro.g_calls, ro.mul_calls)
+    assert np.array_equal(rg.trace["accept"], ro.trace["accept"]) and np.array_equal(rg.trace["inner"], ro.trace["inner"])
+    np.testing.assert_allclose(rg.trace["ssr"], ro.trace["ssr"], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(rg.trace["delta"], ro.trace["delta"], rtol=1e-8, atol=0)
+    np.testing.assert_allclose(rg.trace["rho"], ro.trace["rho"], rtol=1e-8, atol=0)
+    for k in range(2):
+        xr = ro.trace["x"][k]
+        assert np.max(np.abs(rg.trace["x"][k] - xr)) <= 1e-9 * max(1.0, np.max(np.abs(xr))), k
+    pr.close()
+
+
 def test_c3_dense_dogleg_qr_full_size(ctx):
     """C3: dense 16384 x 2048, Dogleg(QR()).  The CPU oracle's plain-C pivoted QR needs minutes at
     this size, so the full-size checks are properties: the QR least-squares solve agrees with

@@ -986,13 +986,16 @@ def test_matrix_free_operator(ctx):
 def _bits_both_ways(run):
     """run() in the normal mode and with every launch waited for (lsq_debug_set(serial=1): no side-stream concurrency, no
     look-ahead, no speculation; same kernels): the two must agree bit for bit."""
-    normal = run()
-    try:
+    prev = lsq.debug_get()          # (a suite run under LSQ_DEBUG_SERIAL / LSQ_DEBUG_LAUNCH_JITTER goes on in ITS mode afterwards,
+    try:                            #  and "normal" means serial = 0 here whatever the environment says: ADVICE r4)
+        lsq.debug_set(None, 0)
+        normal = run()
         lsq.debug_set(None, 1)
         serial = run()
-    finally:
         lsq.debug_set(None, 0)
-    again = run()
+        again = run()
+    finally:
+        lsq.debug_set(prev[0], prev[1])
     return normal, serial, again
 
 
@@ -1069,11 +1072,88 @@ def test_serial_mode_single_solves(ctx, m, n, solver, for_lm):
     assert np.linalg.norm(x0 - ref) <= 1e-9 * np.linalg.norm(ref), (i0,)
     assert np.array_equal(x0, x2), ("normal mode twice", float(np.abs(x0 - x2).max()), i0)
     assert np.array_equal(x0, x1), ("normal vs serialised", float(np.abs(x0 - x1).max()), i0, i1)
+    prev = lsq.debug_get()
     try:
         lsq.debug_set(None, 2)
         x3, i3 = run()
     finally:
-        lsq.debug_set(None, 0)
+        lsq.debug_set(None, prev[1])
     assert np.linalg.norm(x3 - ref) <= 1e-9 * np.linalg.norm(ref), (i3,)
     assert np.linalg.norm(x3 - x0) <= 1e-11 * np.linalg.norm(x0), (i0, i3)
     J.free()
+
+
+# ------------------------------------------------------- partitioned device
+@pytest.fixture(scope="module")
+def ctx_cpx(ctx):
+    """A context whose launch heuristics see 32 compute units -- one CPX partition of an MI355X (LSQ_DEBUG_NUM_CUS, read by
+    lsq_ctx_create): no slab exchange in the QR panel, launch-per-panel Cholesky when the tiles do not fit, fewer workgroups
+    and other split factors everywhere.  The device underneath is whatever the box has (>= 32 CUs), so every co-residency
+    assumption made for 32 CUs holds."""
+    os.environ["LSQ_DEBUG_NUM_CUS"] = "32"
+    try:
+        c = lsq.Context(ctx.device)
+    finally:
+        del os.environ["LSQ_DEBUG_NUM_CUS"]
+    assert c.device_info()["num_cus"] == 32
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("m,n", [(2049, 129), (4096, 512), (700, 200), (8193, 65), (3000, 700), (300, 17)])
+def test_partitioned_device_dense_solvers(ctx_cpx, m, n):
+    """The dense solvers on a 32-CU view of the device (dense_qr.jl:30-88, dense_cholesky.jl:29-59): all four variants against
+    LAPACK (full-rank operands) AND against the oracle's own ldiv!, with the paths that were taken reported -- the one-launch
+    Cholesky cannot apply at n = 512 / 700 (36 / 66 tiles + chain > 32 CUs), the QR panel runs without slabs."""
+    rng = np.random.default_rng(31 * m + n)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.05
+    J = lsq.DeviceMatrix(ctx_cpx, A)
+    x = lsq.DeviceVector(ctx_cpx, n)
+    Jo = O.Mat(dense=A)
+    small = m * n <= 3e5                     # (the oracle's scalar QR at the larger shapes: LAPACK stands in)
+    for solver, okind in ((lsq.QR(), O.QR), (lsq.Cholesky(), O.CHOLESKY)):
+        for for_lm in (False, True):
+            sv = lsq.AllocatedSolver(J, solver, for_lm=for_lm)
+            if for_lm:
+                sv.ldiv_(x, lsq.DeviceVector(ctx_cpx, m, y), lsq.DeviceVector(ctx_cpx, n, damp))
+                ref = np.linalg.solve(A.T @ A + np.diag(damp), A.T @ y)
+            else:
+                sv.ldiv_(x, lsq.DeviceVector(ctx_cpx, m, y))
+                ref = np.linalg.lstsq(A, y, rcond=None)[0]
+            got, info = x.get(), sv.info()
+            assert np.linalg.norm(got - ref) <= 1e-9 * np.linalg.norm(ref), (type(solver).__name__, for_lm, info)
+            if small or okind == O.CHOLESKY:
+                ro = O.ldiv(okind, Jo, y, damp if for_lm else None)
+                assert ro[0] == 0 and np.linalg.norm(got - ro[1]) <= 1e-9 * np.linalg.norm(ro[1]), (type(solver).__name__, for_lm, info)
+            if isinstance(solver, lsq.Cholesky) and for_lm and n >= 512:
+                assert info.get("chol_path") != "blocked-one-launch", info   # (one resident workgroup per tile needs more than 32 CUs)
+            sv.free()
+    J.free()
+    assert sum(ctx_cpx.fallback_stats().values()) == 0
+
+
+@pytest.mark.parametrize("opt,sol,sparse", [("lm", "lsmr", True), ("dogleg", "lsmr", True), ("lm", "cholesky", False),
+                                            ("dogleg", "qr", False)])
+def test_partitioned_device_trajectories(ctx_cpx, opt, sol, sparse):
+    """Whole trust-region runs on the 32-CU view against the oracle (levenberg_marquardt.jl:39-144, dogleg.jl:41-203): the sliced
+    layouts are built for 32 CUs (other block sizes, other partial-sum groupings), the dense factorisations take their
+    partitioned-device branches -- same counts, same inner counts, iterates to 1e-8."""
+    m, n, per_col = (300000, 2000, 600) if sparse else (1500, 48, None)
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=sparse, per_col=per_col, seed=7, ctx=ctx_cpx)
+    pr.reset()
+    okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
+    skind = {"lsmr": lsq._lib.LSMR, "cholesky": lsq._lib.CHOLESKY, "qr": lsq._lib.QR}[sol]
+    rg = pr.optimize(okind, skind, trace=True, iterations=50)
+    A = (O.Mat(csc=(m, n, pr.colptr, pr.rowval, pr.A)) if sparse else O.Mat(dense=pr.A.reshape((m, n), order="F")))
+    J = (O.Mat(csc=(m, n, pr.colptr, pr.rowval, np.zeros_like(pr.A))) if sparse else O.Mat(dense=np.zeros((m, n))))
+    f, g, ud, keep = O.tanh_model(A, pr.b)
+    ro = O.optimize(O.LM if opt == "lm" else O.DOGLEG, {"lsmr": O.LSMR, "cholesky": O.CHOLESKY, "qr": O.QR}[sol], J, np.zeros(n),
+                    f, g, ud=ud, iterations=50)
+    assert rg.iterations == ro.iterations and rg.mul_calls == ro.mul_calls and rg.converged == ro.converged
+    assert np.array_equal(rg.trace["inner"], ro.trace["inner"]) and np.array_equal(rg.trace["accept"], ro.trace["accept"])
+    for k in range(ro.iterations):
+        xr = ro.trace["x"][k]
+        assert np.max(np.abs(rg.trace["x"][k] - xr)) <= 1e-8 * max(1.0, np.max(np.abs(xr)))
+    pr.close()

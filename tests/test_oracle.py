@@ -492,3 +492,39 @@ def test_openmp_variant_agrees_with_the_oracle():
     assert inner == int(ro.trace["inner"].sum()) // 2 and threads == 2
     assert ssr == pytest.approx(ro.ssr, rel=1e-10)
     assert np.max(np.abs(x - ro.minimizer)) <= 1e-7
+
+
+def test_lapack_geqp3_backend_equals_the_restatement():
+    """The hook the full-size C3 trajectory test uses (O.use_lapack_geqp3: the oracle's QR factorisation served by scipy's
+    dgeqp3, everything behind it the oracle's own) against the scalar restatement on shapes the latter finishes at once:
+    full rank, rank-deficient (minimum-norm completion), wide, damped; and a Dogleg(QR) trajectory with identical counts."""
+    rng = np.random.default_rng(11)
+    cases = []
+    A = rng.standard_normal((300, 40)); cases.append(A)
+    B = A.copy(); B[:, 5] = 2 * B[:, 3] - B[:, 7]; cases.append(B)
+    cases.append(rng.standard_normal((20, 35)))
+    for A in cases:
+        y = rng.standard_normal(A.shape[0])
+        damp = rng.random(A.shape[1]) + 0.01
+        ref = O.ldiv(O.QR, O.Mat(dense=A), y)[1], O.ldiv(O.QR, O.Mat(dense=A), y, damp)[1]
+        O.use_lapack_geqp3(True)
+        try:
+            got = O.ldiv(O.QR, O.Mat(dense=A), y)[1], O.ldiv(O.QR, O.Mat(dense=A), y, damp)[1]
+        finally:
+            O.use_lapack_geqp3(False)
+        for r, g in zip(ref, got):
+            assert np.max(np.abs(r - g)) <= 1e-11 * max(1.0, np.max(np.abs(r)))
+    m, n = 600, 30
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    b = A @ np.tanh(rng.uniform(-1, 1, n)) + 1e-3 * rng.standard_normal(m)
+    runs = []
+    for on in (False, True):
+        f, g, ud, keep = O.tanh_model(O.Mat(dense=A), b)
+        O.use_lapack_geqp3(on)
+        try:
+            runs.append(O.optimize(O.DOGLEG, O.QR, O.Mat(dense=np.zeros((m, n))), np.zeros(n), f, g, ud=ud, iterations=30))
+        finally:
+            O.use_lapack_geqp3(False)
+    a, b_ = runs
+    assert a.iterations == b_.iterations and a.mul_calls == b_.mul_calls and np.array_equal(a.trace["accept"], b_.trace["accept"])
+    assert np.max(np.abs(a.minimizer - b_.minimizer)) <= 1e-10

@@ -86,6 +86,92 @@ def test_exchange_gloo_world2():
     assert res[0][4] == [0, 0, 0, 2]         # its peer: told at the next call, no further collective
 
 
+def _scripts(rank):
+    """Made-up per-iteration inputs {ssr, |g|, state} of rank `rank` (state: 0 active, 1 converged, -1 leaving)."""
+    a = [(10.0 * it + rank, float(it + rank), c) for it, c in enumerate([0.0, 0.0, 0.0, 1.0])]
+    # the ranks converge at different iterations: rank 0 freezes at call 2, rank 1 at call 5
+    b = [(1.0 / (it + 1) + rank, 3.0 - 0.5 * it + rank, 1.0 if it >= (2 if rank == 0 else 5) else 0.0) for it in range(7)]
+    # rank 1 leaves with an error at its 3rd call
+    c = [(1.0, 1.0 + rank, -1.0 if (rank == 1 and it == 2) else 0.0) for it in range(5)]
+    # rank 0 leaves at the very first call
+    d = [(2.0, 0.5, -1.0 if (rank == 0 and it == 0) else 0.0) for it in range(3)]
+    return [a, b, c, d]
+
+
+def _drive(cb, script):
+    import ctypes as C
+    seq = []
+    for ssr, gn, state in script:
+        vals = (C.c_double * 3)(ssr, gn, state)
+        rc = cb(vals, 3, None)
+        seq.append((rc, vals[0], vals[1], vals[2]))
+        if state < -0.5 or rc != 0:
+            break
+    return seq
+
+
+def _worker_c_vs_python(rank, world, port, q):
+    _init(rank, world, port)
+    out = []
+    for script in _scripts(rank):
+        py = _drive(lsq.sharding.make_allreduce_callback(dist, rank, world, "cpu"), script)
+        lsq.sharding.drain_all()
+        dist.barrier()
+        x = lsq.sharding.TorchTransportExchange(dist, rank, world)
+        cc = _drive(x, script)
+        x.drain()
+        st = x.stats()
+        x.close()
+        dist.barrier()
+        out.append((py, cc, st))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_c_exchange_equals_python_hook_gloo_world2():
+    """lsq_options.allreduce served in C (liblsqrccl.so: lsq_rccl_xchg_*, here over a gloo transport through
+    lsq_rccl_xchg_create_custom) against its Python twin (sharding.make_allreduce_callback) on the same made-up scalars,
+    world 2: the same return code and the same three values at EVERY call -- first call synchronous, active ranks get the
+    previous exchange, frozen ranks this one, a leaving rank stops everybody with the same number of collectives."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_c_vs_python, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        for k, (py, cc, st) in enumerate(res[r]):
+            assert py == cc, (r, k, py, cc)
+            assert st["collectives"] <= len(cc)
+    # script a, both ranks: sums over ranks {0,1}: iteration it contributes 20*it + 1, max gnorm it + 1
+    assert [v[1:] for v in res[0][0][1]] == [(1.0, 1.0, 0.0), (1.0, 1.0, 0.0), (21.0, 2.0, 0.0), (61.0, 4.0, 1.0)]
+    # script c: the leaving rank's last call succeeds, its peer is told at its next call; both issued 3 collectives
+    assert [v[0] for v in res[1][2][1]] == [0, 0, 0] and [v[0] for v in res[0][2][1]] == [0, 0, 0, 2]
+    assert res[0][2][2]["collectives"] == res[1][2][2]["collectives"] == 3 and res[0][2][2]["aborted"]
+    # script d: rank 0 leaves at once (rc 0), rank 1's synchronous first call sees it: rc 2, one collective each
+    assert [v[0] for v in res[0][3][1]] == [0] and [v[0] for v in res[1][3][1]] == [2]
+    assert res[0][3][2]["collectives"] == res[1][3][2]["collectives"] == 1
+
+
+def test_c_exchange_symbols_and_one_rank_protocol():
+    """include/lsqrccl.h's exchange entry points are exported, and the protocol at world 1 over the built-in transport double
+    (no process group): first call and frozen calls synchronous, active calls return the previous exchange."""
+    import ctypes as C
+    L = lsq.sharding.rccl_shim()
+    for name in ("lsq_rccl_xchg_create", "lsq_rccl_xchg_create_custom", "lsq_rccl_xchg_destroy", "lsq_rccl_xchg_callback",
+                 "lsq_rccl_xchg_drain", "lsq_rccl_xchg_stats"):
+        assert hasattr(L, name), name
+    x = lsq.sharding.TorchTransportExchange(None, 0, 1)
+    seq = _drive(x, [(2.5, 0.3, 0.0), (1.5, 0.2, 0.0), (1.25, 0.1, 0.0), (1.0, 0.05, 1.0)])
+    assert seq == [(0, 2.5, 0.3, 0.0), (0, 2.5, 0.3, 0.0), (0, 1.5, 0.2, 0.0), (0, 1.0, 0.05, 1.0)]
+    assert x.stats() == {"collectives": 4, "synchronous": 2, "aborted": False}
+    x.close()
+
+
 def _worker_lm(rank, world, port, q):
     _init(rank, world, port)
     ctx = lsq.Context(0)
@@ -280,6 +366,84 @@ def test_lm_with_rccl_exchange_world1():
     assert d == 0.0 and ssr == pytest.approx(ssr1, rel=1e-15)
 
 
+def _worker_lm_c_exchange(rank, world, port, q, backend):
+    """The real LM loop with the exchange served in C: backend "gloo" = the C protocol over a gloo transport (two ranks on the
+    one device of the box), "rccl" = lsq_rccl_xchg_create over an RCCL communicator (rank r on device r)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = rank if backend == "rccl" and torch.cuda.device_count() >= world else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = lsq.Context(dev)
+    m, n = (4000, 40) if rank == 0 else (6000, 60)
+    pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=100, seed=11 + rank, ctx=ctx)
+    x = (lsq.sharding.RcclScalarExchange(rank, world, dist) if backend == "rccl" else
+         lsq.sharding.TorchTransportExchange(dist, rank, world))
+    pr.reset()
+    r = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, iterations=60, allreduce=x)
+    x.drain()
+    st = x.stats()
+    dist.barrier()
+    pr.reset()
+    r1 = pr.optimize(lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR, iterations=60)
+    q.put((rank, r.iterations, r.converged, r.ssr, r1.iterations, r1.ssr, float(np.max(np.abs(r.minimizer - r1.minimizer))), st))
+    x.close()
+    pr.close()
+    dist.destroy_process_group()
+
+
+def _run_c_exchange(world, backend):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_lm_c_exchange, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rec = q.get(timeout=600)
+        res[rec[0]] = rec[1:]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.gpu
+def test_lm_with_c_rccl_exchange_world1():
+    """lsq_rccl_xchg_* on hardware: a one-rank RCCL communicator (what a one-GPU box offers), ncclAllReduce of 4 doubles per
+    outer iteration on the exchange's side stream.  The run equals the unsharded run; every iteration issued one collective."""
+    res = _run_c_exchange(1, "rccl")
+    it, conv, ssr, it1, ssr1, d, st = res[0]
+    assert conv and it in (it1, it1 + 1) and d == 0.0 and ssr == pytest.approx(ssr1, rel=1e-15)
+    assert st["collectives"] == it and not st["aborted"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_lm_with_c_exchange_over_gloo():
+    """Two ranks of the real LM loop on the one device, the exchange served by the C protocol (gloo transport): both leave in
+    the same outer iteration, local trajectories untouched, global ssr in both results -- as with the Python hook."""
+    res = _run_c_exchange(2, "gloo")
+    (it0, c0, ssr0, alone0, s0, d0, st0), (it1, c1, ssr1, alone1, s1, d1, st1) = res[0], res[1]
+    assert c0 and c1 and it0 == it1 and it0 in (max(alone0, alone1), max(alone0, alone1) + 1)
+    assert d0 == 0.0 and d1 == 0.0
+    assert ssr0 == pytest.approx(s0 + s1, rel=1e-12) and ssr1 == pytest.approx(ssr0, rel=1e-15)
+    assert st0["collectives"] == st1["collectives"] == it0
+
+
+@pytest.mark.gpu
+def test_two_ranks_lm_with_c_rccl_exchange_world2():
+    """C5 over RCCL with N = 2 ranks, one per GPU (runs by itself wherever the box has two devices; skipped on a one-GPU
+    lease -- RCCL refuses two ranks on one device)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL: one rank per device)")
+    res = _run_c_exchange(2, "rccl")
+    (it0, c0, ssr0, alone0, s0, d0, st0), (it1, c1, ssr1, alone1, s1, d1, st1) = res[0], res[1]
+    assert c0 and c1 and it0 == it1 and d0 == 0.0 and d1 == 0.0
+    assert ssr0 == pytest.approx(s0 + s1, rel=1e-12) and ssr1 == pytest.approx(ssr0, rel=1e-15)
+    assert st0["collectives"] == st1["collectives"] == it0
+
+
 def _bench_line(args, env=None, timeout=900):
     import json
     import subprocess
@@ -320,5 +484,6 @@ def test_bench_forced_exchange_runs_on_rccl():
     """bench.py's sharded protocol with its default exchange backend on hardware (one rank: LSQ_BENCH_FORCE_EXCHANGE)."""
     j = _bench_line(["--steps", "8", "--warmup", "8", "--repeats", "3", "--m", "20000", "--n", "200", "--per-col", "100",
                      "--no-cpu"], env={"LSQ_BENCH_FORCE_EXCHANGE": "1"})
-    assert j["n_gpus"] == 1 and j["config"]["exchange_backend"] == "nccl" and j["config"]["rccl_ranks"] == 1
+    assert j["n_gpus"] == 1 and j["config"]["exchange_backend"] == "rccl-c" and j["config"]["rccl_ranks"] == 1
+    assert j["config"]["exchange"]["collectives"] > 0
     assert j["value"] > 0 and j["repeats"] == 3 and j["region_ms"]["min"] <= j["region_ms"]["median"] <= j["region_ms"]["max"]

@@ -125,6 +125,7 @@ def test_dense_solves_under_launch_jitter(ctx, m, n):
     seed = 99 + m + n
     _dense_case(ctx, m, n, seed, record)
     reps = 25 if m * n <= 1e6 else 8
+    prev = lsq.debug_get()
     try:
         lsq.debug_set(150, None)
         for rep in range(reps):
@@ -137,7 +138,7 @@ def test_dense_solves_under_launch_jitter(ctx, m, n):
                 k[0] += 1
             _dense_case(ctx, m, n, seed, same)
     finally:
-        lsq.debug_set(0, None)
+        lsq.debug_set(prev[0], None)
     assert lsq.debug_get()[2] > 0          # (stalls were actually injected)
 
 
