@@ -416,7 +416,8 @@ def test_lm_with_c_rccl_exchange_world1():
     res = _run_c_exchange(1, "rccl")
     it, conv, ssr, it1, ssr1, d, st = res[0]
     assert conv and it in (it1, it1 + 1) and d == 0.0 and ssr == pytest.approx(ssr1, rel=1e-15)
-    assert st["collectives"] == it and not st["aborted"]
+    # one collective per outer iteration + the frozen rank's call that sees "all converged" and leaves
+    assert st["collectives"] in (it, it + 1) and not st["aborted"]
 
 
 @pytest.mark.gpu
@@ -428,7 +429,7 @@ def test_two_ranks_lm_with_c_exchange_over_gloo():
     assert c0 and c1 and it0 == it1 and it0 in (max(alone0, alone1), max(alone0, alone1) + 1)
     assert d0 == 0.0 and d1 == 0.0
     assert ssr0 == pytest.approx(s0 + s1, rel=1e-12) and ssr1 == pytest.approx(ssr0, rel=1e-15)
-    assert st0["collectives"] == st1["collectives"] == it0
+    assert st0["collectives"] == st1["collectives"] and st0["collectives"] in (it0, it0 + 1)
 
 
 @pytest.mark.gpu
@@ -441,7 +442,7 @@ def test_two_ranks_lm_with_c_rccl_exchange_world2():
     (it0, c0, ssr0, alone0, s0, d0, st0), (it1, c1, ssr1, alone1, s1, d1, st1) = res[0], res[1]
     assert c0 and c1 and it0 == it1 and d0 == 0.0 and d1 == 0.0
     assert ssr0 == pytest.approx(s0 + s1, rel=1e-12) and ssr1 == pytest.approx(ssr0, rel=1e-15)
-    assert st0["collectives"] == st1["collectives"] == it0
+    assert st0["collectives"] == st1["collectives"] and st0["collectives"] in (it0, it0 + 1)
 
 
 def _bench_line(args, env=None, timeout=900):
