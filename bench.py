@@ -712,11 +712,15 @@ def parity_vs_cpu(rg, ro, ssr0):
             elif int(rg.trace["inner"][k]) != int(ro.trace["inner"][k]):
                 inner_eq = False
         prev_g, prev_o = sg, so
-    dx = max(float(np.max(np.abs(np.asarray(rg.trace["x"][i]) - ro.trace["x"][i]))) for i in range(k_all)) if k_all else None
     xs = max(1.0, float(np.max(np.abs(ro.trace["x"][:k_all])))) if k_all else 1.0
+    # iterates: 1e-8 max(1, |x|inf) up to the first round-off-decided iteration; from there on one run has taken a step the other
+    # refused (|dx| of such a step is itself ~1e-8 here): 5e-8
+    dxs = [float(np.max(np.abs(np.asarray(rg.trace["x"][i]) - ro.trace["x"][i]))) for i in range(k_all)]
+    dx = max(dxs) if dxs else None
+    dx_ok = all(d <= (1e-8 if (excused is None or i < excused) else 5e-8) * xs for i, d in enumerate(dxs))
     ssr_rel = float(np.max(np.abs(np.asarray(rg.trace["ssr"][:k_all]) - ro.trace["ssr"][:k_all]) / ro.trace["ssr"][:k_all])) if k_all else None
     ok = bool(same_len and inner_eq and bad_decision is None and rg.mul_calls == ro.mul_calls and dx is not None
-              and dx <= 1e-8 * xs and ssr_rel <= 1e-9)
+              and dx_ok and ssr_rel <= 1e-9)
     return {"ok": ok, "inner_equal": bool(inner_eq), "accept_equal": bool(bad_decision is None),
             "first_roundoff_decided_iteration": None if excused is None else excused + 1,
             "decision_mismatch_at_a_step_that_moved_the_objective": None if bad_decision is None else bad_decision + 1,
@@ -725,7 +729,7 @@ def parity_vs_cpu(rg, ro, ssr0):
             "inner_per_outer": {"hip": [int(v) // 2 for v in rg.trace["inner"]], "cpu": [int(v) // 2 for v in ro.trace["inner"]]},
             "accept": {"hip": [int(v) for v in rg.trace["accept"]], "cpu": [int(v) for v in ro.trace["accept"]]},
             "checker": "oracle/lsq_oracle.c (CPU restatement of the reference), first solve of the cpu_baseline leg",
-            "tolerances": {"max_abs_dx": "1e-8*max(1,|x|inf)", "ssr_rel": 1e-9,
+            "tolerances": {"max_abs_dx": "1e-8*max(1,|x|inf) (5e-8 from the first round-off-decided iteration on)", "ssr_rel": 1e-9,
                            "roundoff_decided": "accept decisions differ and the accepting run moved ssr by <= 1e-12 relative"}}
 
 

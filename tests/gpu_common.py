@@ -106,6 +106,9 @@ def compare_until_roundoff(rg, ro, xtol=1e-8, ssr_rtol=1e-9, ssr0=None):
                 assert rg.trace["inner"][k] == ro.trace["inner"][k], (k, rg.trace["inner"], ro.trace["inner"])
         assert abs(sg - so) <= ssr_rtol * so, (k, sg, so)
         xr = ro.trace["x"][k]
-        assert np.max(np.abs(rg.trace["x"][k] - xr)) <= xtol * max(1.0, np.max(np.abs(xr))), k
+        # (from the round-off-decided iteration on one run has taken a step the other refused: |dx| of such a step is itself
+        #  of the order 1e-8 here, so the iterates are held to 5x the tolerance there)
+        tol_k = xtol if excused is None else 5.0 * xtol
+        assert np.max(np.abs(rg.trace["x"][k] - xr)) <= tol_k * max(1.0, np.max(np.abs(xr))), k
         prev = {"g": sg, "o": so}
     return excused
