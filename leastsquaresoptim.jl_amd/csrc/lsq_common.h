@@ -79,6 +79,10 @@ struct LsqMailbox {
     volatile int istop;
     volatile int done;
     volatile int seq;
+    // hints beside the progress word (written in front of it): the two stopping quantities that end LM's inner solves,
+    // test1 = |r|/|b| and test2 = |A'r|/(|A||r|) (lsmr.jl:207-208) of the iteration the word announces.  The host only
+    // PREDICTS with them (where to queue the caller's tail, lsq_lsmr_solve); a stale pair costs a wrong guess, nothing else.
+    volatile double test1, test2;
 };
 
 struct lsq_ctx {
@@ -423,6 +427,8 @@ struct LsqSlotPublish {
 };
 LsqSlotPublish lsq_slots_ticket(lsq_ctx *c, int first, int count);
 int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, double *h_out);
+// check_isfinite(x) (utils.jl:70-75) into a device slot, no host hand-over: -1.0 or the first non-finite index
+int lsq_first_nonfinite_to_slot(lsq_ctx *c, int n, const double *x, double *d_slot);
 int lsq_read_ints(lsq_ctx *c, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]);   // null pointers read as 0
 LsqSlotPublish lsq_ints_ticket(lsq_ctx *c);
 int lsq_wait_ints(lsq_ctx *c, unsigned long long seq, const int *d_a, const int *d_b, const int *d_c, const int *d_d, int h_out[4]);

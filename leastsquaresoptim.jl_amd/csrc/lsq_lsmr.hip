@@ -220,6 +220,9 @@ __device__ __forceinline__ void lsmr_commit(LsmrState &s, double total, LsmrStat
     s.istop = istop;
     if (istop) { s.done = 1; s.notdone = 0; }
     *st = s;
+    // (hints for the host's prediction of the stop iteration: in front of the word that announces the iteration)
+    __hip_atomic_store((double *)&mail->test1, test1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store((double *)&mail->test2, test2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     publish(mail, st);
 }
 
@@ -674,8 +677,19 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
 
     int enq = 0, it = 0, istop = 0;
     bool finished = false;
-    const bool spec = tail && tail->fn && tail->predict > 0 && !sharded;
-    int tail_at = 0;             // iteration behind which the speculative tail was enqueued (0: not yet)
+    // Where the caller's tail goes (LsmrTail, lsq_solver.h).  `planned`: the iteration behind which it should be queued --
+    // first the caller's guess (the previous solve's count), from iteration 1 on the solve's own prediction: the hints K3
+    // publishes are test1 = |r|/|b| and test2 = |A'r|/(|A||r|); a solve is over when test1 <= btol (+ a 1e-6-sized term) or
+    // test2 <= atol (lsmr.jl:224-231; the other rules do not fire on these operators), and on the damped, Jacobi-
+    // preconditioned operators of an LM run test2 falls geometrically (C4: x 0.07-0.09 per iteration, every iteration).
+    static const bool no_dynamic = getenv("LSQ_NO_DYNAMIC_TAIL") != nullptr;
+    const bool dynamic = tail && tail->fn && tail->dynamic && !sharded && !no_dynamic;
+    const bool spec = tail && tail->fn && !sharded && (tail->predict > 0 || dynamic);
+    int planned = spec ? tail->predict : 0;
+    int tail_at = 0;             // iteration behind which the latest guarded tail was enqueued (0: none that is still undecided)
+    int tail_ran_at = 0;         // ... and the same once it is known (or bound) to have run: the stop iteration was <= tail_at
+    int hint_it = 0;             // last iteration whose hints went into the prediction
+    double t1_prev = -1.0, t2_prev = -1.0, ratio2 = s->lsmr_ratio2;
     const size_t prof_base[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
     std::vector<int> prof_iter[2];   // iteration number of every timed launch of this solve
     unsigned long long spins = 0;
@@ -688,6 +702,33 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                 finished = true;
                 break;
             }
+        }
+        const bool reported_now = (unsigned)(w >> 41) == epoch;
+        if (spec && reported_now && tail_at > 0 && it >= tail_at) {   // (not done: `finished` left the loop above)
+            // the tail behind iteration tail_at found the solve unfinished and skipped itself: a wrong guess
+            c->tail_spec[0]++;
+            c->tail_spec[1]++;
+            tail_at = 0;
+            planned = 0;
+        }
+        if (dynamic && reported_now && it > hint_it && it >= 1) {
+            const double h1 = c->h_mail->test1, h2 = c->h_mail->test2;
+            const unsigned long long w2 = *(volatile unsigned long long *)c->h_mail;
+            if (w2 == w && h1 > 0.0 && h2 > 0.0) {        // (the pair belongs to iteration `it`: the word did not move meanwhile)
+                if (t2_prev > 0.0 && h2 < t2_prev) ratio2 = std::min(0.95, std::max(1e-4, h2 / t2_prev));
+                int k = 1 << 20;
+                if (h2 > atol && ratio2 < 1.0) k = std::min(k, (int)std::ceil(std::log(atol / h2) / std::log(ratio2) - 1e-9));
+                if (t1_prev > 0.0 && h1 < 0.98 * t1_prev && h1 > btol)       // test1 still falling: when does it reach btol?
+                    k = std::min(k, (int)std::ceil(std::log(btol / h1) / std::log(h1 / t1_prev) - 1e-9));
+                if (k < (1 << 20) && tail_at == 0) planned = it + std::max(1, k);
+                t1_prev = h1; t2_prev = h2; hint_it = it;
+            }
+        }
+        // the guarded tail: right behind the planned last iteration, as soon as that one is enqueued (or behind the newest
+        // enqueued, still unreported one if the prediction names an iteration that is already in the queue)
+        if (spec && tail_at == 0 && planned > 0 && enq >= planned && enq > it) {
+            LSQ_TRY(tail->fn(&st->notdone, tail->user));
+            tail_at = enq;
         }
         // Row-sharded: every rank must enqueue the SAME number of inner iterations (each carries a collective), so the count
         // cannot depend on when this host happens to see the mailbox: iterations go out in chunks of `lookahead`, and the
@@ -728,10 +769,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                                d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
             LSQ_HIP(hipGetLastError());
             ++enq;
-            if (spec && tail_at == 0 && enq == tail->predict) {   // the caller's next kernels, right behind the predicted last iteration
-                LSQ_TRY(tail->fn(&st->notdone, tail->user));
-                tail_at = enq;
-            }
           }
             spins = 0;
             continue;
@@ -777,11 +814,14 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     s->last_iter = it;
     s->last_istop = istop;
     if (nmul) *nmul = 2 * it;  // lsmr.jl:236 ch.mvps
-    // the speculative tail ran iff the solve was over when its kernels reached the device: stop iteration <= tail_at
+    // the latest guarded tail ran iff the solve was over when its kernels reached the device: stop iteration <= tail_at
+    // (tails that skipped themselves were counted, as wrong guesses, when their iteration reported)
     if (tail_at > 0) {
         c->tail_spec[0]++;
         if (it > tail_at) c->tail_spec[1]++;
+        else tail_ran_at = tail_at;
     }
-    if (tail && tail->fn && !(tail_at > 0 && it <= tail_at)) LSQ_TRY(tail->fn(nullptr, tail->user));
+    if (dynamic && t2_prev > 0.0) s->lsmr_ratio2 = ratio2;
+    if (tail && tail->fn && tail_ran_at == 0) LSQ_TRY(tail->fn(nullptr, tail->user));
     return LSQ_OK;
 }

@@ -688,6 +688,27 @@ struct IterateGuard {
     }
 };
 
+// The head of both loops -- f!(fcur, x0), ssr = sum(abs2, fcur), check_isfinite(x0) (levenberg_marquardt.jl:58-60,74; dogleg.jl:66-68,
+// 79) -- behind ONE host hand-over instead of two (rounds 1-4: the sum and the check each waited for the device: ~40 us per
+// solve at C4).  The built-in model's sum rides in its residual kernel.  Small problems keep the reference-order sums.
+static int start_residual(lsq_ctx *c, lsq_mat *J, lsq_f_callback f, void *user, double *fcur, const double *x, double *ssr,
+                          int *nonfinite_at) {
+    const int m = J->m, n = J->n;
+    if (lsq_small_mat(J) || lsq_small_vec(m) || m <= 0) {
+        CB(f(fcur, x, user));
+        LSQ_TRY(lsq_sumsq(c, m, fcur, ssr));
+        return lsq_first_nonfinite(c, n, x, nonfinite_at);
+    }
+    static_assert(SL_TRIAL == SL_NONFIN + 1, "the two scalars of the loop head travel together");
+    LSQ_TRY(lsq_first_nonfinite_to_slot(c, n, x, c->d_slots + SL_NONFIN));
+    LSQ_TRY(f_then_sumsq(c, false, f, user, m, fcur, x, 7, c->d_slots + SL_TRIAL));
+    double sl[2];
+    LSQ_TRY(lsq_read_slots(c, SL_NONFIN, 2, sl));
+    *nonfinite_at = (int)sl[0];
+    *ssr = sl[1];
+    return LSQ_OK;
+}
+
 static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x_user, double *fcur_user,
                             lsq_f_callback f, lsq_g_callback g, void *user, const lsq_options *o, lsq_result *r);
 static int optimize_lm(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat *J, double *x_user, double *fcur_user,
@@ -704,12 +725,14 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
     double decrease_factor = 2.0;
     int f_calls = 0, g_calls = 0, mul_calls = 0, xc = 0, fc = 0, gc = 0;
     bool converged = false;
-    CB(f(fcur, x, user));
-    f_calls++;
     double ssr;
+    int iter = 0, nonfinite_at = -1;
     // row-sharded single problem: J, fcur, ftrial are this rank's rows; sums over residuals are completed across the ranks
     // by the hook (a device buffer, in place, ordered on the stream) before the host reads them
     const bool sharded = o->row_allreduce != nullptr;
+    if (sharded) CB(f(fcur, x, user));
+    else LSQ_TRY(start_residual(c, J, f, user, fcur, x, &ssr, &nonfinite_at));
+    f_calls++;
     auto rows_sum = [&](double *d_buf, int count) -> int {
         if (o->row_allreduce(d_buf, count, (void *)c->stream, o->row_allreduce_user) != 0) {
             lsq_set_error("row all-reduce callback reported failure");
@@ -721,14 +744,11 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         LSQ_TRY(sumsq_to_slot(c, false, m, fcur, 7, c->d_slots + SL_TRIAL));
         LSQ_TRY(rows_sum(c->d_slots + SL_TRIAL, 1));
         LSQ_TRY(lsq_read_slots(c, SL_TRIAL, 1, &ssr));
-    } else {
-        LSQ_TRY(lsq_sumsq(c, m, fcur, &ssr));
+        LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
     }
     r->ssr0 = ssr;
     double maxabs_gr = INFINITY;
     bool need_jac = true;
-    int iter = 0, nonfinite_at = -1;
-    LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
     const int gn = ngrid(c, n);
     // reference summation order for small problems (lsq_exact.hip); a general preconditioner runs the operator-level LSMR
     const bool exact = lsq_small_mat(J) && !sharded && !(sv->kind == LSQ_LSMR && sv->gen_ldiv);
@@ -881,7 +901,7 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             // (speculation needs kernels that honour the skip flag: the device model on the sliced rows)
             static const bool no_spec = getenv("LSQ_NO_TAIL_SPECULATION") != nullptr;
             const bool guardable = tc.is_model && J->kind == LSQ_MAT_CSC && J->srows.active && !no_spec && !lsq_dbg_serial;
-            LsmrTail tail{guardable ? last_inner : 0, tail_fn, &tc};
+            LsmrTail tail{guardable ? last_inner : 0, tail_fn, &tc, guardable};
             LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr, lm_prep ? &prep : nullptr,
                                    tail_ok ? &tail : nullptr));  // :87
             tail_done = tail_ok;
@@ -1003,14 +1023,12 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
     bool reuse = false, converged = false;
     double wnorm_dgn = 0.0, wnorm_dgr = 0.0, alpha = 0.0, wdot_gr_gn = 0.0;
     int f_calls = 0, g_calls = 0, mul_calls = 0, xc = 0, fc = 0, gc = 0;
-    CB(f(fcur, x, user));
-    f_calls++;
     double ssr;
-    LSQ_TRY(lsq_sumsq(c, m, fcur, &ssr));
+    int iter = 0, nonfinite_at = -1;
+    LSQ_TRY(start_residual(c, J, f, user, fcur, x, &ssr, &nonfinite_at));
+    f_calls++;
     r->ssr0 = ssr;
     double maxabs_gr = INFINITY;
-    int iter = 0, nonfinite_at = -1;
-    LSQ_TRY(lsq_first_nonfinite(c, n, x, &nonfinite_at));
     const int gn = ngrid(c, n);
     const bool exact = lsq_small_mat(J);
     double gssr = ssr, ggr = maxabs_gr;

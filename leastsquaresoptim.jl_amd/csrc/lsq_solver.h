@@ -70,6 +70,7 @@ struct lsq_solver {
     // colsumabs2 of the WHOLE Jacobian (sum over the ranks of the row blocks' column sums) for the default Jacobi
     // preconditioner and LM's damping: solver-owned, keyed on the handle and its version -- the handle's own cache keeps
     // the LOCAL block's sums, which is what lsq_colsumabs2(J) and any unsharded solve on the same handle must see
+    double lsmr_ratio2 = 0.1;     // test2(k) / test2(k-1) as last observed: the starting value of the next solve's stop prediction
     double *d_colsum_g = nullptr;
     unsigned long long colsum_g_uid = 0;     // lsq_mat::uid of the handle the buffer belongs to (0: none)
     unsigned long long colsum_g_version = ~0ull;
@@ -195,10 +196,15 @@ constexpr int LSMR_LM_PREP_MAX_N = 16384;   // every workgroup of that launch re
 // (the usual case: the inner count of an LM run changes slowly) the device goes from the last inner iteration straight into
 // the caller's next kernels, without the early-exit launches of the look-ahead and without waiting for the host to notice.
 // Otherwise, and always when predict == 0, the tail is called (again) with skip = nullptr after the solve.
+// `dynamic`: from inner iteration 1 on the guess is replaced by a prediction from the solve's own stopping quantities (the
+// hints K3 publishes beside the progress word): on LM's damped, Jacobi-preconditioned operators test2 = |A'r|/(|A||r|) falls
+// geometrically and the iteration at which it crosses atol (or test1 crosses btol) is known one or two iterations ahead; a
+// tail that skipped itself may be queued again, guarded, behind a later iteration.
 struct LsmrTail {
     int predict = 0;
     int (*fn)(const int *skip, void *user) = nullptr;
     void *user = nullptr;
+    bool dynamic = false;
 };
 int lsq_rowshard_colsum(lsq_solver *s, lsq_mat *J, const double **out);   // colsumabs2 of the whole J (row-sharded: summed over the ranks)
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,

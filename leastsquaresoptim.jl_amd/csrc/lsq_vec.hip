@@ -590,6 +590,12 @@ extern "C" int lsq_amax_projected(lsq_ctx *c, int n, const double *g, const doub
     if (!lo && !hi) return lsq_amax(c, n, g, h);
     return reduce_to_host<4>(c, n, g, x, nullptr, lo, hi, h);
 }
+int lsq_first_nonfinite_to_slot(lsq_ctx *c, int n, const double *x, double *d_slot) {
+    if (n <= 0) return lsq_fill(c, 1, -1.0, d_slot);
+    LSQ_LAUNCH(k_first_nonfinite, dim3(ew_grid(c, n)), dim3(LSQ_NT), 0, c->stream, n, x, c->d_partials, lsq_ctr(c, 0), d_slot);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
 extern "C" int lsq_first_nonfinite(lsq_ctx *c, int n, const double *x, int *h_index) {
     if (n <= 0) {
         *h_index = -1;

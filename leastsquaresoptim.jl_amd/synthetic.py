@@ -96,7 +96,10 @@ class TanhProblem:
         self.fcur = DeviceVector(self.ctx, m)
 
     def reset(self, x0=None):
-        self.x.set(np.zeros(self.n) if x0 is None else x0)
+        if x0 is None:      # x <- 0 on the device (a fill kernel in stream order: no host buffer, no blocking copy)
+            check(lib().lsq_fill(self.ctx.h, self.n, 0.0, self.x.ptr))
+        else:
+            self.x.set(x0)
 
     def optimize(self, optimizer_kind, solver_kind, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iterations=1000,
                  delta=None, trace=False, allreduce=None, fetch_x=True, row_allreduce=None, row_allreduce_user=None,

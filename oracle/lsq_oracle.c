@@ -27,6 +27,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -383,11 +384,14 @@ static double dampened_norm(const double *y, int m, const double *x, int n) {
 }
 
 /* lsmr.jl:53-238.  lambda == 0 for every caller.  Returns iter (mvps = 2*iter, :236). */
+/* debugging aid (tools only): ORC_LSMR_TRACE=1 prints the stopping quantities of every inner iteration to stderr */
+static int g_lsmr_trace = -1;
 int orc_lsmr(double *x, const orc_mat *J, const double *diag, const double *P, double *by,
              double atol, double btol, double conlim, int maxiter, int *istop_out,
              double *normr_out, double *normAr_out) {
     const int m = J->m, n = J->n;
     const double lambda = 0.0;
+    if (g_lsmr_trace < 0) g_lsmr_trace = getenv("ORC_LSMR_TRACE") != NULL;
     double *v = calloc(n, sizeof(double)), *h = calloc(n, sizeof(double));
     double *hbar = calloc(n, sizeof(double)), *tmp = calloc(n, sizeof(double));
     double *tmp2 = calloc(n, sizeof(double));
@@ -489,6 +493,7 @@ int orc_lsmr(double *x, const orc_mat *J, const double *diag, const double *P, d
             double test3 = 1.0 / condA;
             double t1 = test1 / (1.0 + normA * normx / normb);
             double rtol = btol + atol * normA * normx / normb;
+            if (g_lsmr_trace) fprintf(stderr, "orc_lsmr iter %d test1 %.6e rtol %.6e test2 %.3e\n", iter, test1, rtol, test2);
             /* :224-231, first hit wins */
             if (iter >= maxiter) { istop = 7; break; }
             if (1.0 + test3 <= 1.0) { istop = 6; break; }
