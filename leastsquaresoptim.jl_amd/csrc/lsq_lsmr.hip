@@ -141,6 +141,8 @@ struct EpiV {
     unsigned *counter;  // unused (deferred)
     double beta, inv_beta;
     int beta_zero, first;
+    double *vout = nullptr;   // where v~ goes (null: in place, over v).  The three-launch iteration (lsq_lsmr3.h) keeps the
+                              // normalised v and the new v~ apart: its next launch reads v~ while it rewrites v
     using has_block_prepare = void;
     __device__ void block_prepare() {
         double b2, bx, unused;
@@ -157,7 +159,7 @@ struct EpiV {
         w *= inv_beta;                              // u = u~/beta
         if (P) w *= P[j];                           // :41
         double vn = first ? w : w - beta * v[j];    // :42-49 (beta == 0 => fill!)
-        v[j] = vn;
+        (vout ? vout : v)[j] = vn;
         racc += vn * vn;
     }
     __device__ void extra(int, double &) const {}
@@ -300,6 +302,8 @@ k_lsmr_update(int n, LsmrState *st, LsqMailbox *mail, const double *pu, const in
 // (Measured and dropped in round 2: K2's two passes + K3 as ONE launch for the sliced columns, one resident workgroup per CU
 //  with two grid barriers -- hierarchical tickets + a polled flag, ~2.2 us each -- and v~ kept in registers.  42.7 us against
 //  25.3 + 5.9 + 9.0 us in three launches: the barriers cost what the two launch ramps cost; 2885 vs 2874-2895 LM it/s on C4.)
+
+#include "lsq_lsmr3.h"
 
 // ---- setup from the caller's J'y in one launch: P, sqrt(damp), state reset and
 // v~ = P.*(J'y)/beta_1 with the block partials of sum(v~^2)  (k_lsmr_prep + k_lsmr_begin +
@@ -534,8 +538,12 @@ static int rowshard_adjoint(lsq_solver *s, lsq_mat *J, const double *src, EpiV e
 
 int lsq_lsmr_alloc(lsq_solver *s) {
     size_t nb = (size_t)(s->n > 0 ? s->n : 1) * sizeof(double);
-    LSQ_HIP(hipMalloc(&s->d_state, sizeof(LsmrState)));
-    LSQ_ZERO(s->d_state, 0, sizeof(LsmrState));
+    LSQ_HIP(hipMalloc(&s->d_state, 2 * sizeof(LsmrState)));    // (two: the three-launch iteration double-buffers it)
+    LSQ_ZERO(s->d_state, 0, 2 * sizeof(LsmrState));
+    // the three-launch iteration (lsq_lsmr3.h): second copies of x, hbar, h; sum(u~^2) partials x 2; the three norms x 2; counts
+    s->f3_elems = 3 * (size_t)(s->n > 0 ? s->n : 1) + 2 * 4096 + 2 * 3 * LSQ_FUSED_UB_MAX + 8;
+    LSQ_HIP(hipMalloc(&s->d_f3, s->f3_elems * sizeof(double)));
+    LSQ_ZERO(s->d_f3, 0, s->f3_elems * sizeof(double));
     LSQ_HIP(hipMalloc(&s->d_u, (size_t)(s->m > 0 ? s->m : 1) * sizeof(double)));
     LSQ_HIP(hipMalloc(&s->d_ux, nb));
     LSQ_HIP(hipMalloc(&s->d_v, nb));
@@ -553,7 +561,7 @@ int lsq_lsmr_alloc(lsq_solver *s) {
 void lsq_lsmr_free(lsq_solver *s) {
     hipFree(s->d_state); hipFree(s->d_u); hipFree(s->d_ux); hipFree(s->d_v); hipFree(s->d_h);
     hipFree(s->d_hbar); hipFree(s->d_t); hipFree(s->d_P); hipFree(s->d_dg); hipFree(s->d_rhs); hipFree(s->d_red);
-    hipFree(s->d_xbuf); hipFree(s->d_one); hipFree(s->d_colsum_g);
+    hipFree(s->d_xbuf); hipFree(s->d_one); hipFree(s->d_colsum_g); hipFree(s->d_f3);
 }
 
 static inline int nvec_grid(const lsq_ctx *c, int n) {
@@ -613,6 +621,17 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     int *npxb[2] = {npu + 2, npu + 3};
 
     if (J->kind == LSQ_MAT_CSC) LSQ_TRY(lsq_ensure_csr(J));
+    // The three-launch iteration (lsq_lsmr3.h): both sliced layouts, x resident in LDS, one rank.  Otherwise K1 | K2 | K3 below.
+    const bool four_env = getenv("LSQ_LSMR_FOUR_LAUNCHES") != nullptr;      // (read per solve: the tests flip it)
+    const bool fused = !four_env && !sharded && J->kind == LSQ_MAT_CSC && J->srows.active && J->srows.ncw == 1 && J->scols.active &&
+                       n >= 1 && m >= 1 && c->num_cus >= 8;
+    double *const f3 = s->d_f3;
+    double *const fx[2] = {xs, f3}, *const fhbar[2] = {s->d_hbar, f3 + n}, *const fh[2] = {s->d_h, f3 + 2 * (size_t)n};
+    double *const fpu[2] = {f3 + 3 * (size_t)n, f3 + 3 * (size_t)n + 4096};
+    double *const fpn[2] = {fpu[1] + 4096, fpu[1] + 4096 + 3 * LSQ_FUSED_UB_MAX};
+    int *const fnpu = (int *)(fpn[1] + 3 * LSQ_FUSED_UB_MAX);     // two counts
+    double *const vset = fused ? s->d_t : s->d_v;                  // where the setup (and every K2) leaves v~
+    if (fused) { pu = fpu[0]; npu = fnpu; }
     // computed once per Jacobian (reference: twice); row-sharded: the sum over the ranks' blocks -- the preconditioner is a
     // replicated n-vector and has to be the same on every rank
     const double *colsum = nullptr;
@@ -642,7 +661,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             return LSQ_EARG;
         }
         LSQ_LAUNCH(k_lm_lsmr_setup, dim3(lsq_div_up(n, 1024)), dim3(1024), 0, c->stream, n, *lm, d_damp, s->d_P, s->d_dg,
-                           s->d_ux, d_Jty, s->d_v, st, pu, npu, y_sumsq, pv, npv, atol, btol, 1.0 / conlim, maxiter, epoch);
+                           s->d_ux, d_Jty, vset, st, pu, npu, y_sumsq, pv, npv, atol, btol, 1.0 / conlim, maxiter, epoch);
+        if (!fused)
         LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
                            s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
@@ -650,8 +670,9 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     } else if (d_Jty) {
         if (!(y_sumsq >= 0.0)) launch_begin();
         LSQ_LAUNCH(k_lsmr_setup, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P, s->d_dg,
-                           s->d_ux, d_Jty, s->d_v, st, pu, npu, y_sumsq >= 0.0 ? y_sumsq : -1.0, pv, npv, atol, btol,
+                           s->d_ux, d_Jty, vset, st, pu, npu, y_sumsq >= 0.0 ? y_sumsq : -1.0, pv, npv, atol, btol,
                            1.0 / conlim, maxiter, epoch, custom_p);
+        if (!fused)
         LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
                            s->d_v, s->d_h, s->d_hbar, xs, d_x, s->d_t, c->d_partials, lsq_ctr(c, 3));
@@ -662,9 +683,11 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         launch_begin();
         LSQ_HIP(hipGetLastError());
         // v~ = A'u (setup), then K3 in "first" mode
+        if (fused) ev.vout = vset;
         if (sharded) LSQ_TRY(rowshard_adjoint(s, J, d_y, ev, pu, npu));
         else LSQ_TRY(launch_product(J, 1, d_y, ev));
         // setup K3: u~x is still zero, so only sum(u~_y^2) enters beta_1; it already forms iteration 1's u~x
+        if (!fused)
         LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail,
                            sharded ? (const double *)(s->d_xbuf + n) : (const double *)pu, sharded ? (const int *)s->d_one : (const int *)npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
@@ -672,11 +695,184 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         LSQ_HIP(hipGetLastError());
     }
 
+    int enq = 0, it = 0, istop = 0;
+    bool finished = false;
+    if (fused) {
+        // ---------------------------------------------------------------------------------------------------------------
+        // three launches per inner iteration: K1' (k_lsmr_fused: decides iteration j-1, updates the n-vectors, J*v of
+        // iteration j) | K2a (k_sell_cols) | K2b (k_combine<EpiV>).  Launch j of K1' reads state / partials / x, hbar, h
+        // number (j-1)&1 and writes number j&1; it reports iteration j-1 in the progress word.
+        // ---------------------------------------------------------------------------------------------------------------
+        static const bool no_dynamic3 = getenv("LSQ_NO_DYNAMIC_TAIL") != nullptr;
+        const bool force_exact = getenv("LSQ_LSMR_EXACT_NORMX") != nullptr;   // (read per solve: the tests flip it)
+        const bool dynamic = tail && tail->fn && tail->dynamic && !no_dynamic3;
+        const bool spec = tail && tail->fn && (tail->predict > 0 || dynamic);
+        int planned = spec ? tail->predict : 0;
+        int tail_at = 0, tail_ran_at = 0, hint_it = 0;
+        double t1_prev = -1.0, t2_prev = -1.0, ratio2 = s->lsmr_ratio2;
+        LsmrState *stb[2] = {s->d_state, s->d_state + 1};
+        const LsqSell &S = J->srows;
+        const int nxpad = (n + 1) & ~1;
+        const size_t lds = (size_t)(nxpad + LSQ_SELL_ROWS_MAX) * sizeof(double);
+        LSQ_TRY(lsq_set_lds(c, (const void *)k_lsmr_fused<0>, (LSQ_LDS_X_MAX + LSQ_SELL_ROWS_MAX) * sizeof(double)));
+        // update workgroups: the CUs the sliced rows leave without a block (C4: 253 blocks on 256 CUs -> 3), at least 2
+        int ub = c->num_cus - S.nblocks;
+        ub = ub < 2 ? 2 : (ub > LSQ_FUSED_UB_MAX ? LSQ_FUSED_UB_MAX : ub);
+        const int pb = std::max(1, std::min(S.nblocks, c->num_cus - ub));
+        int k1 = 0;                  // K1' launches enqueued: enq (whole iterations) or enq + 1
+        const size_t prof_base3[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
+        std::vector<int> prof_it3[2];
+        unsigned long long spins = 0;
+        auto launch_k1 = [&]() -> int {
+            const int j = k1 + 1, in = (j - 1) & 1, out = j & 1;
+            LsmrFused a;
+            a.st_in = stb[in]; a.st_out = stb[out]; a.mail = c->d_mail;
+            a.pu_in = fpu[in]; a.npu_in = fnpu + in; a.pu_out = fpu[out]; a.npu_out = fnpu + out;
+            a.px_in = (damped && j > 1) ? pxb[in] : nullptr; a.npx_in = npxb[in];
+            a.px_out = pxb[out]; a.npx_out = npxb[out];
+            a.pv = pv; a.npv = npv;
+            a.pn_in = fpn[in]; a.pn_out = fpn[out];
+            a.vt = vset; a.P = s->d_P; a.cs = J->d_colscale; a.dg = dgk;
+            a.h_in = fh[in]; a.hbar_in = fhbar[in]; a.x_in = fx[in];
+            a.h_out = fh[out]; a.hbar_out = fhbar[out]; a.x_out = fx[out];
+            a.v = s->d_v; a.xout = d_x; a.ux = s->d_ux;
+            a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
+            a.n = n; a.ub = ub; a.force_exact = force_exact ? 1 : 0;
+            if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 0);
+            hipEvent_t e0, e1;
+            if (lsq_prof_take(c, &e0, &e1)) {
+                LSQ_LAUNCH_TIMED(k_lsmr_fused<0>, dim3(pb + ub), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.wrows, m, nxpad, a);
+                prof_it3[0].push_back(j);
+            } else {
+                LSQ_LAUNCH(k_lsmr_fused<0>, dim3(pb + ub), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.wrows, m, nxpad, a);
+            }
+            if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 1);
+            LSQ_HIP(hipGetLastError());
+            ++k1;
+            return LSQ_OK;
+        };
+        auto launch_k2 = [&]() -> int {      // K2 of iteration enq + 1 (its K1' is launch k1 == enq + 1)
+            const int j = enq + 1, cur = j & 1;
+            EpiV e2{&stb[cur]->done, 0, stb[cur], fpu[cur], fnpu + cur, damped ? pxb[cur] : nullptr, npxb[cur], s->d_P, dgk,
+                    damped ? s->d_ux : nullptr, s->d_v, pv, npv, nullptr, 0.0, 0.0, 0, 0};
+            e2.vout = vset;
+            if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 0);
+            const size_t before = c->prof_ev[1].size();
+            LSQ_TRY(launch_sell_cols<false>(J, s->d_u, &stb[cur]->done));
+            if (c->prof_ev[1].size() > before) prof_it3[1].push_back(j);
+            if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 1);
+            const int nb = lsq_div_up(n, LSQ_CMB_COLS);
+            // (at most 256 workgroups: the next launch's consumer-side sum of their partials is one round of loads)
+            LSQ_LAUNCH((k_combine<EpiV>), dim3(std::min(nb, 256)), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, n, J->scols.ngw, e2, nb,
+                       J->d_colscale);
+            LSQ_HIP(hipGetLastError());
+            ++enq;
+            return LSQ_OK;
+        };
+        while (!finished) {
+            unsigned long long w = *(volatile unsigned long long *)c->h_mail;
+            const bool reported = (unsigned)(w >> 41) == epoch;
+            if (reported) {
+                it = (int)(w & 0xffffffffu);
+                if ((w >> 40) & 1ull) {
+                    istop = (int)((w >> 32) & 0xff);
+                    finished = true;
+                    break;
+                }
+            }
+            if (spec && reported && tail_at > 0 && it >= tail_at) {   // that tail found the solve unfinished and skipped itself
+                c->tail_spec[0]++;
+                c->tail_spec[1]++;
+                tail_at = 0;
+                planned = 0;
+            }
+            if (dynamic && reported && it > hint_it && it >= 1) {
+                const double h1 = c->h_mail->test1, h2 = c->h_mail->test2;
+                const unsigned long long w2 = *(volatile unsigned long long *)c->h_mail;
+                if (w2 == w && h1 > 0.0 && h2 > 0.0) {
+                    if (t2_prev > 0.0 && h2 < t2_prev) ratio2 = std::min(0.95, std::max(1e-4, h2 / t2_prev));
+                    int k = 1 << 20;
+                    if (h2 > atol && ratio2 < 1.0) k = std::min(k, (int)std::ceil(std::log(atol / h2) / std::log(ratio2) - 1e-9));
+                    if (t1_prev > 0.0 && h1 < 0.98 * t1_prev && h1 > btol)
+                        k = std::min(k, (int)std::ceil(std::log(btol / h1) / std::log(h1 / t1_prev) - 1e-9));
+                    if (k < (1 << 20) && tail_at == 0) planned = it + std::max(1, k);
+                    t1_prev = h1; t2_prev = h2; hint_it = it;
+                }
+            }
+            const bool hold = tail_at > 0 && it < tail_at;       // a guarded tail sits behind the commit of iteration tail_at
+            if (!hold) {
+                if (k1 == enq + 1) {                             // the rest of iteration enq + 1
+                    if (spec && tail_at == 0 && planned > 0 && enq >= planned && enq >= 1 && enq > it) {
+                        // (the prediction arrived between the two halves: the launch that commits its iteration is the newest one)
+                        LSQ_TRY(tail->fn(&stb[k1 & 1]->notdone, tail->user));
+                        tail_at = enq;
+                        continue;
+                    }
+                    LSQ_TRY(launch_k2());
+                    spins = 0;
+                    continue;
+                }
+                // K1' number enq + 1 commits iteration enq: it does not count against the look-ahead (nothing is decided without it)
+                if (enq - it < lookahead + 1 && enq < maxiter + 1) {
+                    LSQ_TRY(launch_k1());
+                    // the caller's tail right behind the launch that commits the planned last iteration (or the newest one, if
+                    // the prediction names an iteration whose commit is already in the queue)
+                    if (spec && tail_at == 0 && planned > 0 && enq >= planned && enq >= 1) {
+                        LSQ_TRY(tail->fn(&stb[k1 & 1]->notdone, tail->user));
+                        tail_at = enq;
+                    }
+                    spins = 0;
+                    continue;
+                }
+            }
+            if (c->idle_hook) lsq_run_idle_hook(c);
+            if ((++spins & 0x3ffu) != 0) continue;
+            const hipError_t sq = hipStreamQuery(c->stream);
+            if (sq != hipSuccess && sq != hipErrorNotReady) {
+                lsq_set_error("HIP error inside the LSMR iteration: %s", hipGetErrorString(sq));
+                return LSQ_EHIP;
+            }
+            if (sq == hipSuccess) {
+                w = *(volatile unsigned long long *)c->h_mail;
+                if ((unsigned)(w >> 41) == epoch && ((w >> 40) & 1ull)) continue;
+                if ((unsigned)(w >> 41) == epoch && (int)(w & 0xffffffffu) >= k1 - 1) continue;
+                LsmrState hs;      // mailbox not visible (should not happen with coherent host memory): read the state
+                LSQ_HIP(hipMemcpy(&hs, stb[k1 & 1], sizeof(hs), hipMemcpyDeviceToHost));
+                it = hs.iter;
+                if (hs.done) {
+                    istop = hs.istop;
+                    finished = true;
+                } else if (enq >= maxiter + 1) {
+                    lsq_set_error("lsmr: iteration budget exhausted without a stop rule");
+                    return LSQ_EHIP;
+                }
+            }
+        }
+        for (int k = 0; k < 2; ++k) {     // timed launches queued beyond the stop did no work: drop their samples
+            auto &v = c->prof_ev[k];
+            const int last_working = k == 0 ? it + 1 : it;   // K1' number it + 1 committed the stop but skipped its product
+            while (v.size() > prof_base3[k] && !prof_it3[k].empty() && prof_it3[k].back() > (k == 0 ? last_working - 1 : last_working)) {
+                hipEventDestroy(v.back()); v.pop_back();
+                hipEventDestroy(v.back()); v.pop_back();
+                prof_it3[k].pop_back();
+            }
+        }
+        s->last_iter = it;
+        s->last_istop = istop;
+        if (nmul) *nmul = 2 * it;
+        if (tail_at > 0) {
+            c->tail_spec[0]++;
+            if (it > tail_at) c->tail_spec[1]++;
+            else tail_ran_at = tail_at;
+        }
+        if (dynamic && t2_prev > 0.0) s->lsmr_ratio2 = ratio2;
+        if (tail && tail->fn && tail_ran_at == 0) LSQ_TRY(tail->fn(nullptr, tail->user));
+        return LSQ_OK;
+    }
+
     EpiU eu{done, 0, st, d_y, s->d_u, n, s->d_dg, s->d_t, s->d_ux, pu, npu, nullptr, 0.0};
     ev.ux = damped ? s->d_ux : nullptr;
 
-    int enq = 0, it = 0, istop = 0;
-    bool finished = false;
     // Where the caller's tail goes (LsmrTail, lsq_solver.h).  `planned`: the iteration behind which it should be queued --
     // first the caller's guess (the previous solve's count), from iteration 1 on the solve's own prediction: the hints K3
     // publishes are test1 = |r|/|b| and test2 = |A'r|/(|A||r|); a solve is over when test1 <= btol (+ a 1e-6-sized term) or

@@ -825,3 +825,38 @@ def test_nist_certified_values(key, exact):
         assert got[start] == v["class"] or got[start] in loose.get(start, ()), (key, start, got[start], v["class"])
     if solver == "qr":      # the reference's configuration: what its `println("strd ...")` would show
         assert sum(c == "hit" for c in got.values()) >= 31
+
+
+# --------------------------------------------------------------- three-launch LSMR iteration (round 5)
+@pytest.mark.parametrize("m,n,per_col,opt", [(300000, 2000, 600, "lm"), (300000, 2000, 600, "dogleg"), (1_000_000, 10_000, 1000, "lm")],
+                         ids=["300000x2000-lm", "300000x2000-dogleg", "C4-lm"])
+def test_lsmr_three_launch_iteration(ctx, m, n, per_col, opt, monkeypatch):
+    """Round 5: K3 (k_lsmr_update) folded into the head of the next J*v launch (k_lsmr_fused, lsq_lsmr3.h: every workgroup
+    takes the stop decision of lsmr.jl:205-231 itself, with ||x|| bounded from the previous iterate's norms; the n-vector
+    updates of :152-156 run beside the product) against (a) the four-launch iteration it replaces (LSQ_LSMR_FOUR_LAUNCHES=1)
+    and (b) itself with the exact-norm path forced in every iteration (LSQ_LSMR_EXACT_NORMX=1: every workgroup forms sum(x^2)
+    from the vectors and evaluates the rules as lsmr_commit does).  The stop decisions must be THE SAME in all three: identical
+    iteration counts, LSMR inner counts per outer iteration, accept pattern; (b) runs the same arithmetic on the vectors:
+    identical bits; (a) associates sum(v~^2) / sum(u~x^2) differently: ssr and iterates to 1e-11."""
+    okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
+    runs = []
+    for env in ({}, {"LSQ_LSMR_EXACT_NORMX": "1"}, {"LSQ_LSMR_FOUR_LAUNCHES": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=23, ctx=ctx)
+        pr.reset()
+        r = pr.optimize(okind, lsq._lib.LSMR, trace=True, iterations=10, x_tol=0, f_tol=0, g_tol=0)
+        for k in env:
+            monkeypatch.delenv(k)
+        runs.append((r, pr.fcur.get()))
+        pr.close()
+    (a, fa), (b, fb), (c4, fc) = runs
+    for other in (b, c4):
+        assert a.iterations == other.iterations == 10 and a.mul_calls == other.mul_calls and a.f_calls == other.f_calls
+        assert np.array_equal(a.trace["inner"], other.trace["inner"]), (a.trace["inner"], other.trace["inner"])
+        assert np.array_equal(a.trace["accept"], other.trace["accept"])
+    assert np.sum(a.trace["inner"]) // 2 > 12          # (several multi-iteration solves: the decisions were exercised)
+    assert np.array_equal(np.array(a.trace["x"]), np.array(b.trace["x"])) and np.array_equal(a.trace["ssr"], b.trace["ssr"])
+    assert np.array_equal(fa, fb)
+    np.testing.assert_allclose(a.trace["ssr"], c4.trace["ssr"], rtol=1e-11, atol=0)
+    assert np.max(np.abs(np.array(a.trace["x"]) - np.array(c4.trace["x"]))) <= 1e-11
