@@ -541,7 +541,7 @@ int lsq_lsmr_alloc(lsq_solver *s) {
     LSQ_HIP(hipMalloc(&s->d_state, 2 * sizeof(LsmrState)));    // (two: the three-launch iteration double-buffers it)
     LSQ_ZERO(s->d_state, 0, 2 * sizeof(LsmrState));
     // the three-launch iteration (lsq_lsmr3.h): second copies of x, hbar, h; sum(u~^2) partials x 2; the three norms x 2; counts
-    s->f3_elems = 3 * (size_t)(s->n > 0 ? s->n : 1) + 2 * 4096 + 2 * 3 * LSQ_FUSED_UB_MAX + 8;
+    s->f3_elems = 3 * (size_t)(s->n > 0 ? s->n : 1) + 2 * 4096 + 8 + 8;
     LSQ_HIP(hipMalloc(&s->d_f3, s->f3_elems * sizeof(double)));
     LSQ_ZERO(s->d_f3, 0, s->f3_elems * sizeof(double));
     LSQ_HIP(hipMalloc(&s->d_u, (size_t)(s->m > 0 ? s->m : 1) * sizeof(double)));
@@ -628,8 +628,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     double *const f3 = s->d_f3;
     double *const fx[2] = {xs, f3}, *const fhbar[2] = {s->d_hbar, f3 + n}, *const fh[2] = {s->d_h, f3 + 2 * (size_t)n};
     double *const fpu[2] = {f3 + 3 * (size_t)n, f3 + 3 * (size_t)n + 4096};
-    double *const fpn[2] = {fpu[1] + 4096, fpu[1] + 4096 + 3 * LSQ_FUSED_UB_MAX};
-    int *const fnpu = (int *)(fpn[1] + 3 * LSQ_FUSED_UB_MAX);     // two counts
+    int *const fnpu = (int *)(fpu[1] + 4096);                      // two counts
+    LsmrHandoff *const fho = (LsmrHandoff *)(fpu[1] + 4096 + 8);   // the in-launch record of k_lsmr_fused
     double *const vset = fused ? s->d_t : s->d_v;                  // where the setup (and every K2) leaves v~
     if (fused) { pu = fpu[0]; npu = fnpu; }
     // computed once per Jacobian (reference: twice); row-sharded: the sum over the ranks' blocks -- the preconditioner is a
@@ -704,7 +704,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         // number (j-1)&1 and writes number j&1; it reports iteration j-1 in the progress word.
         // ---------------------------------------------------------------------------------------------------------------
         static const bool no_dynamic3 = getenv("LSQ_NO_DYNAMIC_TAIL") != nullptr;
-        const bool force_exact = getenv("LSQ_LSMR_EXACT_NORMX") != nullptr;   // (read per solve: the tests flip it)
         const bool dynamic = tail && tail->fn && tail->dynamic && !no_dynamic3;
         const bool spec = tail && tail->fn && (tail->predict > 0 || dynamic);
         int planned = spec ? tail->predict : 0;
@@ -731,13 +730,13 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.px_in = (damped && j > 1) ? pxb[in] : nullptr; a.npx_in = npxb[in];
             a.px_out = pxb[out]; a.npx_out = npxb[out];
             a.pv = pv; a.npv = npv;
-            a.pn_in = fpn[in]; a.pn_out = fpn[out];
             a.vt = vset; a.P = s->d_P; a.cs = J->d_colscale; a.dg = dgk;
             a.h_in = fh[in]; a.hbar_in = fhbar[in]; a.x_in = fx[in];
             a.h_out = fh[out]; a.hbar_out = fhbar[out]; a.x_out = fx[out];
             a.v = s->d_v; a.xout = d_x; a.ux = s->d_ux;
             a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
-            a.n = n; a.ub = ub; a.force_exact = force_exact ? 1 : 0;
+            a.n = n; a.ub = ub;
+            a.ho = fho; a.tag = ((unsigned long long)epoch << 32) | (unsigned)j;
             if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 0);
             hipEvent_t e0, e1;
             if (lsq_prof_take(c, &e0, &e1)) {
@@ -856,6 +855,10 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                 hipEventDestroy(v.back()); v.pop_back();
                 prof_it3[k].pop_back();
             }
+        }
+        if (istop == 99) {     // (a product workgroup gave up waiting for workgroup 0's record: lsq_lsmr3.h)
+            lsq_set_error("lsmr: the in-launch hand-off of k_lsmr_fused timed out");
+            return LSQ_EHIP;
         }
         s->last_iter = it;
         s->last_istop = istop;

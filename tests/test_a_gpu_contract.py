@@ -831,16 +831,15 @@ def test_nist_certified_values(key, exact):
 @pytest.mark.parametrize("m,n,per_col,opt", [(300000, 2000, 600, "lm"), (300000, 2000, 600, "dogleg"), (1_000_000, 10_000, 1000, "lm")],
                          ids=["300000x2000-lm", "300000x2000-dogleg", "C4-lm"])
 def test_lsmr_three_launch_iteration(ctx, m, n, per_col, opt, monkeypatch):
-    """Round 5: K3 (k_lsmr_update) folded into the head of the next J*v launch (k_lsmr_fused, lsq_lsmr3.h: every workgroup
-    takes the stop decision of lsmr.jl:205-231 itself, with ||x|| bounded from the previous iterate's norms; the n-vector
-    updates of :152-156 run beside the product) against (a) the four-launch iteration it replaces (LSQ_LSMR_FOUR_LAUNCHES=1)
-    and (b) itself with the exact-norm path forced in every iteration (LSQ_LSMR_EXACT_NORMX=1: every workgroup forms sum(x^2)
-    from the vectors and evaluates the rules as lsmr_commit does).  The stop decisions must be THE SAME in all three: identical
-    iteration counts, LSMR inner counts per outer iteration, accept pattern; (b) runs the same arithmetic on the vectors:
-    identical bits; (a) associates sum(v~^2) / sum(u~x^2) differently: ssr and iterates to 1e-11."""
+    """Round 5: K3 (k_lsmr_update) folded into the next J*v launch (k_lsmr_fused, lsq_lsmr3.h: a few workgroups at the front of
+    the grid take the scalar chain, ||x|| and the stop decision of lsmr.jl:205-231 and the n-vector updates of :152-156 beside
+    the product; the product workgroups gather the UNNORMALISED v~ and apply 1/alpha to the finished dot products) against the
+    four-launch iteration it replaces (LSQ_LSMR_FOUR_LAUNCHES=1).  Same recurrence, other associations (sum(v~^2) over 157
+    instead of 313 partials, (J w)/alpha instead of J (w/alpha), ||x||^2 by one workgroup): identical iteration counts, LSMR
+    inner counts per outer iteration and accept pattern; ssr and iterates to 1e-11; run-to-run identical bits."""
     okind = lsq._lib.LEVENBERG_MARQUARDT if opt == "lm" else lsq._lib.DOGLEG
     runs = []
-    for env in ({}, {"LSQ_LSMR_EXACT_NORMX": "1"}, {"LSQ_LSMR_FOUR_LAUNCHES": "1"}):
+    for env in ({}, {}, {"LSQ_LSMR_FOUR_LAUNCHES": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         pr = lsq.synthetic.TanhProblem(m, n, sparse=True, per_col=per_col, seed=23, ctx=ctx)
