@@ -541,7 +541,7 @@ int lsq_lsmr_alloc(lsq_solver *s) {
     LSQ_HIP(hipMalloc(&s->d_state, 2 * sizeof(LsmrState)));    // (two: the three-launch iteration double-buffers it)
     LSQ_ZERO(s->d_state, 0, 2 * sizeof(LsmrState));
     // the three-launch iteration (lsq_lsmr3.h): second copies of x, hbar, h; sum(u~^2) partials x 2; the three norms x 2; counts
-    s->f3_elems = 3 * (size_t)(s->n > 0 ? s->n : 1) + 2 * 4096 + 8 + 8;
+    s->f3_elems = 3 * (size_t)(s->n > 0 ? s->n : 1) + 2 * 4096 + 8 + 16;
     LSQ_HIP(hipMalloc(&s->d_f3, s->f3_elems * sizeof(double)));
     LSQ_ZERO(s->d_f3, 0, s->f3_elems * sizeof(double));
     LSQ_HIP(hipMalloc(&s->d_u, (size_t)(s->m > 0 ? s->m : 1) * sizeof(double)));
@@ -736,7 +736,9 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.v = s->d_v; a.xout = d_x; a.ux = s->d_ux;
             a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
             a.n = n; a.ub = ub;
-            a.ho = fho; a.tag = ((unsigned long long)epoch << 32) | (unsigned)j;
+            a.ho = fho;
+            if (++s->f3_tag == 0u) s->f3_tag = 1u;     // a counter per solver (= per record buffer): every older record carries
+            a.tag = s->f3_tag;                          // another value; 0 is the zeroed buffer
             if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 0);
             hipEvent_t e0, e1;
             if (lsq_prof_take(c, &e0, &e1)) {

@@ -13,26 +13,50 @@
 //     stop decision taken from a three-word record that workgroup 0 published ~20 us earlier (see "hand-off" below).  If the
 //     finished iteration was the last, the record says so and the epilogue is skipped (the stream of that one launch is wasted:
 //     ~20 us once per solve, where the early-exit launches of the look-ahead used to be).
-// Hand-off inside the launch: workgroup 0 -> every product workgroup, one record {1/alpha, alpha/beta, done} tagged
-// with (solve epoch, launch number); written with agent-scope stores + release, read after the reader's own stream (an acquire
-// load in a bounded spin: workgroup 0 is the FIRST workgroup of the grid, so it is dispatched before any reader; a reader that
-// still gives up -- a second of spinning -- marks the state failed (istop = 99) and the host returns LSQ_EHIP).
+// Hand-off inside the launch: workgroup 0 -> every product workgroup, one record {1/alpha, alpha/beta, done} as
+// tagged words (flag-in-data); requested by a reader before the last slice of its stream and checked after it (bounded re-reads
+// otherwise: workgroup 0 is the FIRST workgroup of the grid, so it is dispatched before any reader; a reader that still gives
+// up -- a second of spinning -- marks the state failed (istop = 99) and the host returns LSQ_EHIP).
 // The state and x, hbar, h are double-buffered (launch k reads set (k-1)&1 and writes set k&1): the update workgroups read ALL of
 // x, hbar, h for ||x|| while their siblings write their own thirds; a late workgroup must not read what its own launch commits.
 #pragma once
 
 constexpr int LSQ_FUSED_UB_MAX = 4;
+// flag-in-data, like the other in-launch exchanges of the library: five 64-bit words, each 32 bits of payload under the 32-bit
+// tag of the launch that wrote it (1/alpha and alpha/beta as two halves each, the decision).  A reader needs no ordering between
+// the words: a word either carries this launch's tag -- then its payload is this launch's -- or it does not, and consecutive
+// launches never share a tag.
 struct LsmrHandoff {
-    double vs, cu;
-    int done, pad;
-    unsigned long long tag;
+    unsigned long long w[8];
 };
+__device__ __forceinline__ void lsmr_handoff_write(LsmrHandoff *ho, unsigned tag, double vs, double cu, int done) {
+    const unsigned long long t = (unsigned long long)tag << 32;
+    const unsigned long long bv = (unsigned long long)__double_as_longlong(vs), bc = (unsigned long long)__double_as_longlong(cu);
+    __hip_atomic_store(&ho->w[0], t | (bv & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ho->w[1], t | (bv >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ho->w[2], t | (bc & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ho->w[3], t | (bc >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ho->w[4], t | (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct LsmrHandoffWords { unsigned long long w[5]; };
+__device__ __forceinline__ LsmrHandoffWords lsmr_handoff_request(const LsmrHandoff *ho) {
+    LsmrHandoffWords r;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r.w[k] = __hip_atomic_load(&ho->w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+__device__ __forceinline__ bool lsmr_handoff_valid(const LsmrHandoffWords &r, unsigned tag) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ok = ok && (unsigned)(r.w[k] >> 32) == tag;
+    return ok;
+}
 struct LsmrFused {
     const LsmrState *st_in;
     LsmrState *st_out;
     LsqMailbox *mail;
     LsmrHandoff *ho;
-    unsigned long long tag;                      // (solve epoch << 32) | launch number
+    unsigned tag;                                // of this launch's record: differs from the previous launch's
     const double *pu_in; const int *npu_in;      // sum(u~_y^2): the previous launch's product workgroups (or the setup)
     double *pu_out; int *npu_out;
     const double *px_in; const int *npx_in;      // sum(u~_x^2): the previous launch's update workgroups (null: u~_x == 0)
@@ -86,16 +110,24 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
     if (upd) {
         // ---- what K3 did (lsmr.jl:119-156, 205-231; iterative_lsmr.jl:92,195-196) ----
         static_assert(sizeof(LsmrState) % 8 == 0 && sizeof(LsmrState) / 8 <= LSQ_BIG_NT, "state copy: one 8-byte word per thread");
+        // These few workgroups run beside 250 streaming ones: a load takes microseconds, so every round of loads is issued as ONE
+        // batch.  Round 1: the state, the partials (inside ordered_sum256x3) and all of x, hbar, h for ||x||.
+        constexpr int NQ = (LSQ_LDS_X_MAX + LSQ_BIG_NT - 1) / LSQ_BIG_NT;
+        double xi[NQ], hbi[NQ], hi[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = min(tid + q * LSQ_BIG_NT, n - 1);
+            xi[q] = a.x_in[j];
+            hbi[q] = a.hbar_in[j];
+            hi[q] = a.h_in[j];
+        }
         if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)&ns)[tid] = ((const unsigned long long *)a.st_in)[tid];
         double beta2, betax2, alpha2;
         ordered_sum256x3(a.pu_in, a.npu_in, a.px_in, a.npx_in, a.pv, a.npv, beta2, betax2, alpha2);   // (its barriers also publish ns)
         if (ns.done) {    // a launch queued behind a finished solve: hand the state on (kernels behind it read st_out), release the readers
             if (blockIdx.x == 0) {
                 if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)a.st_out)[tid] = ((const unsigned long long *)&ns)[tid];
-                if (tid == 0) {
-                    __hip_atomic_store(&a.ho->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&a.ho->tag, a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (tid == 0) lsmr_handoff_write(a.ho, a.tag, 1.0, 0.0, 1);
             }
             return;
         }
@@ -107,10 +139,11 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             // cross-workgroup reduction, the same bits everywhere
             const double c1 = ns.c1, c2 = ns.c2;
             double acc = 0.0;
-            for (int j = tid; j < n; j += LSQ_BIG_NT) {
-                const double hb = a.hbar_in[j] * c1 + a.h_in[j];
-                const double xj = a.x_in[j] + c2 * hb;
-                acc += xj * xj;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const double hb = hbi[q] * c1 + hi[q];
+                const double xj = xi[q] + c2 * hb;
+                acc += (tid + q * LSQ_BIG_NT < n) ? xj * xj : 0.0;
             }
             const double total = block_sum<LSQ_BIG_NT>(acc, sh);
             if (tid == 0) lsmr_decide(ns, total);
@@ -122,12 +155,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
         const bool done_now = ns.done != 0;
         const double vs = ns.vscale, cu = ns.cu, c1 = ns.c1, c2 = ns.c2, c3 = ns.c3;
         if (blockIdx.x == 0) {
-            if (tid == 0) {     // the product workgroups' record first: they are the ones somebody may be waiting with
-                __hip_atomic_store(&a.ho->vs, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.ho->cu, cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.ho->done, done_now ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.ho->tag, a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (tid == 0) lsmr_handoff_write(a.ho, a.tag, vs, cu, done_now ? 1 : 0);   // first: somebody may be waiting for it
             if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)a.st_out)[tid] = ((const unsigned long long *)&ns)[tid];
             if (tid == 0) {
                 if (!was_first) {   // hints for the host's prediction of the stop iteration, in front of the progress word
@@ -137,10 +165,27 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
                 publish(a.mail, &ns);
             }
         }
+        // Round 2: this workgroup's own elements (every ub-th group of 1024), again one batch of loads
+        constexpr int NU = (NQ + 1) / 2;      // ub >= 2
+        double e_vt[NU], e_P[NU], e_dg[NU], e_ux[NU], e_h[NU], e_hb[NU], e_x[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int j = min((int)(blockIdx.x + k * a.ub) * LSQ_BIG_NT + tid, n - 1);
+            e_vt[k] = a.vt[j];
+            e_P[k] = a.P ? a.P[j] : 1.0;
+            e_dg[k] = a.dg ? a.dg[j] : 0.0;
+            e_ux[k] = a.dg ? a.ux[j] : 0.0;
+            e_h[k] = a.h_in[j];
+            e_hb[k] = a.hbar_in[j];
+            e_x[k] = a.x_in[j];
+        }
         double aux = 0.0;
-        for (int j = blockIdx.x * LSQ_BIG_NT + tid; j < n; j += a.ub * LSQ_BIG_NT) {
-            const double Pj = a.P ? a.P[j] : 1.0;
-            const double vj = a.vt[j] * vs;                 // lsmr.jl:78,124 rmul!(v, inv(alpha))
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int j = (int)(blockIdx.x + k * a.ub) * LSQ_BIG_NT + tid;
+            if (j >= n) continue;
+            const double Pj = e_P[k];
+            const double vj = e_vt[k] * vs;                 // lsmr.jl:78,124 rmul!(v, inv(alpha))
             a.v[j] = vj;
             if (was_first) {                                // :89-90, iterative_lsmr.jl:183,242
                 a.h_out[j] = vj;
@@ -148,17 +193,17 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
                 a.x_out[j] = 0.0;
                 a.xout[j] = 0.0;
             } else {
-                const double hj = a.h_in[j];
-                const double hb = a.hbar_in[j] * c1 + hj;   // :152-153
+                const double hj = e_h[k];
+                const double hb = e_hb[k] * c1 + hj;        // :152-153
                 a.hbar_out[j] = hb;
-                const double xj = a.x_in[j] + c2 * hb;      // :154
+                const double xj = e_x[k] + c2 * hb;         // :154
                 a.x_out[j] = xj;
                 a.h_out[j] = hj * c3 + vj;                  // :155-156
                 a.xout[j] = a.P ? xj * Pj : xj;             // the caller's x always holds P.*x of the newest iterate
             }
             if (a.dg && !done_now) {    // damped rows of the NEXT u (iterative_lsmr.jl:92): u~x <- d.*t - cu*u~x
                 const double tj = a.P ? vj * Pj : vj;       // iterative_lsmr.jl:31 ldiv!(tmp, P, a)
-                const double un = tj * a.dg[j] - cu * a.ux[j];
+                const double un = tj * e_dg[k] - cu * e_ux[k];
                 a.ux[j] = un;
                 aux += un * un;
             }
@@ -204,19 +249,39 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
         double pre[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) pre[q] = a.uold[base + min(tid + q * LSQ_BIG_NT, rows - 1)];
-        // (the barrier inside: w staged / the previous window's epilogue is done with yw)
-        sell_wave_slices<false>(S, s0, s1, wv, lane, xl, [&](unsigned pos, double sum, double) { yw[pos] = sum; });
+        // (sell_wave_slices with one addition: wave 0 requests workgroup 0's record BEFORE its last slice, so that the record's
+        //  latency -- microseconds on a saturated memory system -- passes during that slice instead of holding up the epilogue)
+        LsmrHandoffWords rec;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) rec.w[k] = 0ull;
+        {
+            constexpr int NW = LSQ_BIG_NT / 64;
+            int sidx = s0 + wv;
+            SellSliceRef A = sell_slice_ref(S, sidx, s1, lane);
+            __syncthreads();      // w staged / the previous window's epilogue is done with yw
+            for (; sidx < s1; sidx += NW) {
+                const SellSliceRef r = A;
+                A = sell_slice_ref(S, sidx + NW, s1, lane);
+                if (!have_scalars && tid == 0 && sidx + NW >= s1) rec = lsmr_handoff_request(a.ho);
+                const size_t oa = (size_t)r.sm.x + lane * 2;
+                const unsigned pos = r.inf & LSQ_SELL_POS_MASK;
+                double sum = 0.0, sq = 0.0;
+                sell_lane_sum<false>(S.val + oa, S.idx16 + oa, r.sm.y, (int)(r.inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
+                if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
+            }
+        }
         if (!have_scalars && tid == 0) {
-            // the record of workgroup 0: published ~20 us ago in the usual case; bounded wait otherwise
+            // (published ~15 us before the early request in the usual case; otherwise ask again, bounded)
             long long spins = 0;
-            while (__hip_atomic_load(&a.ho->tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.tag) {
+            while (!lsmr_handoff_valid(rec, a.tag)) {
                 if (++spins > LSQ_FUSED_SPIN_LIMIT) break;
                 __builtin_amdgcn_s_sleep(8);
+                rec = lsmr_handoff_request(a.ho);
             }
             const bool ok = spins <= LSQ_FUSED_SPIN_LIMIT;
-            s_vs = __hip_atomic_load(&a.ho->vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_cu = __hip_atomic_load(&a.ho->cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_done = ok ? __hip_atomic_load(&a.ho->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2;
+            s_vs = __longlong_as_double((long long)((rec.w[0] & 0xffffffffull) | (rec.w[1] << 32)));
+            s_cu = __longlong_as_double((long long)((rec.w[2] & 0xffffffffull) | (rec.w[3] << 32)));
+            s_done = ok ? (int)(rec.w[4] & 0xffffffffull) : 2;
             if (!ok) {      // never silent: the solve ends with istop = 99 and the host returns an error
                 __hip_atomic_store(&a.st_out->istop, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&a.st_out->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -61,6 +61,7 @@ struct lsq_solver {
     double *d_red = nullptr;   // deferred-reduction partials: pu[4096] | pv[4096] | int counts[2]
     double *d_f3 = nullptr;    // three-launch iteration (lsq_lsmr3.h): x2 | hbar2 | h2 (n each) | pu[2][4096] | pn[2][3][UB_MAX] | int counts
     size_t f3_elems = 0;
+    unsigned f3_tag = 0;       // tag of the newest in-launch record of k_lsmr_fused
     unsigned epoch = 0;
     int last_iter = 0, last_istop = 0;
     // row-sharded single problem (lsq_options.row_allreduce): J is this rank's row block; J'u and sum(u^2) are summed over
