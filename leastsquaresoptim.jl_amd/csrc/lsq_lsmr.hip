@@ -143,6 +143,8 @@ struct EpiV {
     int beta_zero, first;
     double *vout = nullptr;   // where v~ goes (null: in place, over v).  The three-launch iteration (lsq_lsmr3.h) keeps the
                               // normalised v and the new v~ apart: its next launch reads v~ while it rewrites v
+    const double *cs = nullptr;   // ... and takes the gather vector of its next J*v straight from here: wout = (v~ .* P) .* s
+    double *wout = nullptr;       // (s: the column scale of J = V diag(s), or null)
     using has_block_prepare = void;
     __device__ void block_prepare() {
         double b2, bx, unused;
@@ -160,6 +162,10 @@ struct EpiV {
         if (P) w *= P[j];                           // :41
         double vn = first ? w : w - beta * v[j];    // :42-49 (beta == 0 => fill!)
         (vout ? vout : v)[j] = vn;
+        if (wout) {
+            const double t = P ? vn * P[j] : vn;
+            wout[j] = cs ? t * cs[j] : t;
+        }
         racc += vn * vn;
     }
     __device__ void extra(int, double &) const {}
@@ -314,7 +320,8 @@ __global__ void __launch_bounds__(LSQ_NT)
 k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp, double *__restrict__ P,
              double *__restrict__ dg, double *__restrict__ ux, const double *__restrict__ Jty,
              double *__restrict__ v, LsmrState *st, double *pu, int *npu, double ysumsq, double *pv, int *npv,
-             double atol, double btol, double ctol, int maxiter, unsigned epoch, int custom_p) {
+             double atol, double btol, double ctol, int maxiter, unsigned epoch, int custom_p,
+             const double *__restrict__ cs = nullptr, double *__restrict__ wout = nullptr) {
     __shared__ double sh[LSQ_NT / 64];
     const double beta2 = ysumsq >= 0.0 ? ysumsq : ordered_sum256(pu, *npu);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -345,6 +352,7 @@ k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp
         if (!beta_zero) {            // lsmr.jl:76 (beta == 0: v is left untouched, :120)
             const double w = Jty[j] * inv_beta * Pj;
             v[j] = w;
+            if (wout) wout[j] = cs ? (w * Pj) * cs[j] : w * Pj;     // the gather vector of the first J*v (lsq_lsmr3.h)
             acc += w * w;
         }
     }
@@ -364,7 +372,8 @@ k_lsmr_setup(int n, const double *__restrict__ colsum, double *__restrict__ damp
 __global__ void __launch_bounds__(1024)
 k_lm_lsmr_setup(int n, LsmrLmPrep lm, double *__restrict__ damp, double *__restrict__ P, double *__restrict__ dg,
                 double *__restrict__ ux, const double *__restrict__ g, double *__restrict__ v, LsmrState *st, double *pu, int *npu,
-                double ysumsq, double *pv, int *npv, double atol, double btol, double ctol, int maxiter, unsigned epoch) {
+                double ysumsq, double *pv, int *npv, double atol, double btol, double ctol, int maxiter, unsigned epoch,
+                const double *__restrict__ colscale = nullptr, double *__restrict__ wout = nullptr) {
     constexpr int R = LSMR_LM_PREP_MAX_N / 1024;
     __shared__ double sh[16], shm[16];
     __shared__ double s_mean;
@@ -438,6 +447,7 @@ k_lm_lsmr_setup(int n, LsmrLmPrep lm, double *__restrict__ damp, double *__restr
         if (!beta_zero) {                      // lsmr.jl:76 (beta == 0: v is left untouched, :120)
             const double w = g0 * inv_beta * Pj;
             v[j] = w;
+            if (wout) wout[j] = colscale ? (w * Pj) * colscale[j] : w * Pj;     // the gather vector of the first J*v (lsq_lsmr3.h)
             a2 = w * w;
         }
     }
@@ -541,7 +551,7 @@ int lsq_lsmr_alloc(lsq_solver *s) {
     LSQ_HIP(hipMalloc(&s->d_state, 2 * sizeof(LsmrState)));    // (two: the three-launch iteration double-buffers it)
     LSQ_ZERO(s->d_state, 0, 2 * sizeof(LsmrState));
     // the three-launch iteration (lsq_lsmr3.h): second copies of x, hbar, h; sum(u~^2) partials x 2; the three norms x 2; counts
-    s->f3_elems = 3 * (size_t)(s->n > 0 ? s->n : 1) + 2 * 4096 + 8 + 16;
+    s->f3_elems = 4 * (size_t)(s->n > 0 ? s->n : 1) + 2 * 4096 + 8 + 16;
     LSQ_HIP(hipMalloc(&s->d_f3, s->f3_elems * sizeof(double)));
     LSQ_ZERO(s->d_f3, 0, s->f3_elems * sizeof(double));
     LSQ_HIP(hipMalloc(&s->d_u, (size_t)(s->m > 0 ? s->m : 1) * sizeof(double)));
@@ -627,7 +637,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                        n >= 1 && m >= 1 && c->num_cus >= 8;
     double *const f3 = s->d_f3;
     double *const fx[2] = {xs, f3}, *const fhbar[2] = {s->d_hbar, f3 + n}, *const fh[2] = {s->d_h, f3 + 2 * (size_t)n};
-    double *const fpu[2] = {f3 + 3 * (size_t)n, f3 + 3 * (size_t)n + 4096};
+    double *const fw = f3 + 3 * (size_t)n;                          // gather vector of the next J*v: (v~ .* P) .* s
+    double *const fpu[2] = {f3 + 4 * (size_t)n, f3 + 4 * (size_t)n + 4096};
     int *const fnpu = (int *)(fpu[1] + 4096);                      // two counts
     LsmrHandoff *const fho = (LsmrHandoff *)(fpu[1] + 4096 + 8);   // the in-launch record of k_lsmr_fused
     double *const vset = fused ? s->d_t : s->d_v;                  // where the setup (and every K2) leaves v~
@@ -661,7 +672,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             return LSQ_EARG;
         }
         LSQ_LAUNCH(k_lm_lsmr_setup, dim3(lsq_div_up(n, 1024)), dim3(1024), 0, c->stream, n, *lm, d_damp, s->d_P, s->d_dg,
-                           s->d_ux, d_Jty, vset, st, pu, npu, y_sumsq, pv, npv, atol, btol, 1.0 / conlim, maxiter, epoch);
+                           s->d_ux, d_Jty, vset, st, pu, npu, y_sumsq, pv, npv, atol, btol, 1.0 / conlim, maxiter, epoch,
+                           (const double *)(fused ? J->d_colscale : nullptr), (double *)(fused ? fw : nullptr));
         if (!fused)
         LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
@@ -671,7 +683,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         if (!(y_sumsq >= 0.0)) launch_begin();
         LSQ_LAUNCH(k_lsmr_setup, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, colsum, d_damp, s->d_P, s->d_dg,
                            s->d_ux, d_Jty, vset, st, pu, npu, y_sumsq >= 0.0 ? y_sumsq : -1.0, pv, npv, atol, btol,
-                           1.0 / conlim, maxiter, epoch, custom_p);
+                           1.0 / conlim, maxiter, epoch, custom_p, (const double *)(fused ? J->d_colscale : nullptr),
+                           (double *)(fused ? fw : nullptr));
         if (!fused)
         LSQ_LAUNCH(k_lsmr_update, dim3(gn), dim3(LSQ_NT), 0, c->stream, n, st, c->d_mail, pu, npu, pv, npv,
                            (const double *)nullptr, (const int *)nullptr, pxb[0], npxb[0], dgk, s->d_ux, s->d_P,
@@ -683,7 +696,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         launch_begin();
         LSQ_HIP(hipGetLastError());
         // v~ = A'u (setup), then K3 in "first" mode
-        if (fused) ev.vout = vset;
+        if (fused) { ev.vout = vset; ev.cs = J->d_colscale; ev.wout = fw; }
         if (sharded) LSQ_TRY(rowshard_adjoint(s, J, d_y, ev, pu, npu));
         else LSQ_TRY(launch_product(J, 1, d_y, ev));
         // setup K3: u~x is still zero, so only sum(u~_y^2) enters beta_1; it already forms iteration 1's u~x
@@ -730,7 +743,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.px_in = (damped && j > 1) ? pxb[in] : nullptr; a.npx_in = npxb[in];
             a.px_out = pxb[out]; a.npx_out = npxb[out];
             a.pv = pv; a.npv = npv;
-            a.vt = vset; a.P = s->d_P; a.cs = J->d_colscale; a.dg = dgk;
+            a.vt = vset; a.w = fw; a.P = s->d_P; a.dg = dgk;
             a.h_in = fh[in]; a.hbar_in = fhbar[in]; a.x_in = fx[in];
             a.h_out = fh[out]; a.hbar_out = fhbar[out]; a.x_out = fx[out];
             a.v = s->d_v; a.xout = d_x; a.ux = s->d_ux;
@@ -756,15 +769,14 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             const int j = enq + 1, cur = j & 1;
             EpiV e2{&stb[cur]->done, 0, stb[cur], fpu[cur], fnpu + cur, damped ? pxb[cur] : nullptr, npxb[cur], s->d_P, dgk,
                     damped ? s->d_ux : nullptr, s->d_v, pv, npv, nullptr, 0.0, 0.0, 0, 0};
-            e2.vout = vset;
+            e2.vout = vset; e2.cs = J->d_colscale; e2.wout = fw;
             if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 0);
             const size_t before = c->prof_ev[1].size();
             LSQ_TRY(launch_sell_cols<false>(J, s->d_u, &stb[cur]->done));
             if (c->prof_ev[1].size() > before) prof_it3[1].push_back(j);
             if (c->prof_kernels & 2) lsq_prof_mark(c, 1, 1);
             const int nb = lsq_div_up(n, LSQ_CMB_COLS);
-            // (at most 256 workgroups: the next launch's consumer-side sum of their partials is one round of loads)
-            LSQ_LAUNCH((k_combine<EpiV>), dim3(std::min(nb, 256)), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, n, J->scols.ngw, e2, nb,
+            LSQ_LAUNCH((k_combine<EpiV>), dim3(std::min(nb, 2048)), dim3(LSQ_NT), 0, c->stream, J->scols.d_part, n, J->scols.ngw, e2, nb,
                        J->d_colscale);
             LSQ_HIP(hipGetLastError());
             ++enq;

@@ -7,8 +7,8 @@
 //     ||x|| and the seven stopping rules (lsmr.jl:205-231) -- each of them over ALL of x, redundantly and identically, so no
 //     reduction across workgroups is needed --, the n-vector updates of lsmr.jl:152-156 (v, hbar, x, h; the caller's P.*x; the
 //     damped rows u~x of iterative_lsmr.jl:92); workgroup 0 commits the state and publishes the progress word;
-//   * the J*v workgroups stage the gather vector themselves and UNNORMALISED, w = (P.*s).*v~ (consumer-side: they read v~ and P
-//     instead of t), so their stream starts at once, exactly like k_sell_rows'; J (P.*v) = (J w)/alpha is finished in the
+//   * the J*v workgroups gather the UNNORMALISED w = (v~.*P).*s, which the producer of v~ (K2's epilogue, or the setup) leaves beside
+//     it, so their stream starts at once, exactly like k_sell_rows'; J (P.*v) = (J w)/alpha is finished in the
 //     epilogue -- like u, v is never normalised on the way into a product (lsmr.jl:118,124) -- with 1/alpha, alpha/beta and the
 //     stop decision taken from a three-word record that workgroup 0 published ~20 us earlier (see "hand-off" below).  If the
 //     finished iteration was the last, the record says so and the epilogue is skipped (the stream of that one launch is wasted:
@@ -63,7 +63,8 @@ struct LsmrFused {
     double *px_out; int *npx_out;
     const double *pv; const int *npv;            // sum(v~^2): the previous K2 (or the setup)
     const double *vt;                            // v~ (n)
-    const double *P, *cs, *dg;                   // preconditioner (or null), column scale of J (or null), sqrt(damp) (or null)
+    const double *w;                             // (v~ .* P) .* s: the gather vector, left by the producer of v~
+    const double *P, *dg;                        // preconditioner (or null), sqrt(damp) (or null)
     const double *h_in, *hbar_in, *x_in;
     double *h_out, *hbar_out, *x_out;
     double *v, *xout, *ux;
@@ -216,27 +217,16 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
         return;
     }
 
-    // ---- product workgroups: u~ <- (J w)/alpha - cu u~ with w = (P .* s) .* v~  (lsmr.jl:118) ----
+    // ---- product workgroups: u~ <- (J w)/alpha - cu u~ with w = (v~ .* P) .* s  (lsmr.jl:118) ----
     constexpr int XR = (LSQ_LDS_X_MAX + LSQ_BIG_NT - 1) / LSQ_BIG_NT;
     {
-        double xr[XR], pr[XR];
+        double xr[XR];
 #pragma unroll
-        for (int q = 0; q < XR; ++q) xr[q] = a.vt[min(tid + q * LSQ_BIG_NT, n - 1)];
-        if (a.P) {
-#pragma unroll
-            for (int q = 0; q < XR; ++q) pr[q] = a.P[min(tid + q * LSQ_BIG_NT, n - 1)];
-        }
-        if (a.cs) {     // column-scaled J = V diag(s): one factor array stays live
-            double sr[XR];
-#pragma unroll
-            for (int q = 0; q < XR; ++q) sr[q] = a.cs[min(tid + q * LSQ_BIG_NT, n - 1)];
-#pragma unroll
-            for (int q = 0; q < XR; ++q) pr[q] = a.P ? pr[q] * sr[q] : sr[q];
-        }
+        for (int q = 0; q < XR; ++q) xr[q] = a.w[min(tid + q * LSQ_BIG_NT, n - 1)];
         const int dflag = a.st_in->done;
 #pragma unroll
         for (int q = 0; q < XR; ++q)
-            if (tid + q * LSQ_BIG_NT < n) xl[tid + q * LSQ_BIG_NT] = (a.P || a.cs) ? xr[q] * pr[q] : xr[q];
+            if (tid + q * LSQ_BIG_NT < n) xl[tid + q * LSQ_BIG_NT] = xr[q];
         if (dflag) return;      // launches queued behind a finished solve stop here
     }
     constexpr int Q = LSQ_SELL_ROWS_MAX / LSQ_BIG_NT;
@@ -259,7 +249,12 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             int sidx = s0 + wv;
             SellSliceRef A = sell_slice_ref(S, sidx, s1, lane);
             __syncthreads();      // w staged / the previous window's epilogue is done with yw
+            unsigned long long poll = 0ull;     // the decision word as it was when this wave's previous slice began
             for (; sidx < s1; sidx += NW) {
+                // the finished iteration was the last: stop streaming (the launch that commits the stop costs ~12 us instead of a
+                // whole product; the word was requested a slice ago, so looking at it waits for nothing)
+                if (!have_scalars && (unsigned)(poll >> 32) == a.tag && (poll & 1ull)) break;
+                if (!have_scalars) poll = __hip_atomic_load(&a.ho->w[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const SellSliceRef r = A;
                 A = sell_slice_ref(S, sidx + NW, s1, lane);
                 if (!have_scalars && tid == 0 && sidx + NW >= s1) rec = lsmr_handoff_request(a.ho);

@@ -6,7 +6,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 # a solve starts with the residual at x0 (k_sell_rows<EpiResidual...> or k_tanh in front of it)
-starts = [i for i, e in enumerate(ev) if "EpiResidual" in e[2] and "Sq" not in e[2].split("EpiResidual")[1][:2]]
+starts = [i for i, e in enumerate(ev) if "k_first_nonfinite" in e[2]]
 a, b = starts[which], starts[which + 1]
 t0 = ev[a][0]
 prev_end = ev[a][0]
