@@ -732,11 +732,14 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         ub = ub < 2 ? 2 : (ub > LSQ_FUSED_UB_MAX ? LSQ_FUSED_UB_MAX : ub);
         const int pb = std::max(1, std::min(S.nblocks, c->num_cus - ub));
         int k1 = 0;                  // K1' launches enqueued: enq (whole iterations) or enq + 1
+        bool need_product = false;   // launch k1 went out commit-only: its product half is still owed (if the solve goes on)
+        static const bool no_halves = getenv("LSQ_LSMR_NO_HALVES") != nullptr;
         const size_t prof_base3[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
         std::vector<int> prof_it3[2];
         unsigned long long spins = 0;
-        auto launch_k1 = [&]() -> int {
-            const int j = k1 + 1, in = (j - 1) & 1, out = j & 1;
+        // mode 0: the whole launch; 1: commit-only (update workgroups); 2: product-only, the half that a commit-only launch left out
+        auto launch_k1 = [&](int mode) -> int {
+            const int j = mode == 2 ? k1 : k1 + 1, in = (j - 1) & 1, out = j & 1;
             LsmrFused a;
             a.st_in = stb[in]; a.st_out = stb[out]; a.mail = c->d_mail;
             a.pu_in = fpu[in]; a.npu_in = fnpu + in; a.pu_out = fpu[out]; a.npu_out = fnpu + out;
@@ -748,21 +751,24 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.h_out = fh[out]; a.hbar_out = fhbar[out]; a.x_out = fx[out];
             a.v = s->d_v; a.xout = d_x; a.ux = s->d_ux;
             a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
-            a.n = n; a.ub = ub;
+            a.n = n; a.ub = mode == 2 ? 0 : ub;
             a.ho = fho;
-            if (++s->f3_tag == 0u) s->f3_tag = 1u;     // a counter per solver (= per record buffer): every older record carries
-            a.tag = s->f3_tag;                          // another value; 0 is the zeroed buffer
-            if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 0);
+            if (mode != 2 && ++s->f3_tag == 0u) s->f3_tag = 1u;    // a counter per solver (= per record buffer): every older record
+            a.tag = s->f3_tag;                                      // carries another value; 0 is the zeroed buffer
+            if (mode == 2) a.st_in = stb[out];                      // (the state its commit-only half has committed)
+            const int grid = mode == 1 ? ub : (mode == 2 ? pb : pb + ub);
+            if (mode != 1 && (c->prof_kernels & 1)) lsq_prof_mark(c, 0, 0);
             hipEvent_t e0, e1;
-            if (lsq_prof_take(c, &e0, &e1)) {
-                LSQ_LAUNCH_TIMED(k_lsmr_fused<0>, dim3(pb + ub), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.wrows, m, nxpad, a);
+            if (mode != 1 && lsq_prof_take(c, &e0, &e1)) {
+                LSQ_LAUNCH_TIMED(k_lsmr_fused<0>, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.wrows, m, nxpad, a);
                 prof_it3[0].push_back(j);
             } else {
-                LSQ_LAUNCH(k_lsmr_fused<0>, dim3(pb + ub), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.wrows, m, nxpad, a);
+                LSQ_LAUNCH(k_lsmr_fused<0>, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.wrows, m, nxpad, a);
             }
-            if (c->prof_kernels & 1) lsq_prof_mark(c, 0, 1);
+            if (mode != 1 && (c->prof_kernels & 1)) lsq_prof_mark(c, 0, 1);
             LSQ_HIP(hipGetLastError());
-            ++k1;
+            if (mode != 2) ++k1;
+            need_product = mode == 1;
             return LSQ_OK;
         };
         auto launch_k2 = [&]() -> int {      // K2 of iteration enq + 1 (its K1' is launch k1 == enq + 1)
@@ -814,6 +820,11 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             }
             const bool hold = tail_at > 0 && it < tail_at;       // a guarded tail sits behind the commit of iteration tail_at
             if (!hold) {
+                if (k1 == enq + 1 && need_product) {             // the tail behind a commit-only launch skipped itself: the solve goes on
+                    LSQ_TRY(launch_k1(2));
+                    spins = 0;
+                    continue;
+                }
                 if (k1 == enq + 1) {                             // the rest of iteration enq + 1
                     if (spec && tail_at == 0 && planned > 0 && enq >= planned && enq >= 1 && enq > it) {
                         // (the prediction arrived between the two halves: the launch that commits its iteration is the newest one)
@@ -827,10 +838,12 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                 }
                 // K1' number enq + 1 commits iteration enq: it does not count against the look-ahead (nothing is decided without it)
                 if (enq - it < lookahead + 1 && enq < maxiter + 1) {
-                    LSQ_TRY(launch_k1());
                     // the caller's tail right behind the launch that commits the planned last iteration (or the newest one, if
-                    // the prediction names an iteration whose commit is already in the queue)
-                    if (spec && tail_at == 0 && planned > 0 && enq >= planned && enq >= 1) {
+                    // the prediction names an iteration whose commit is already in the queue) -- and that launch commit-only: if
+                    // the plan holds there is no next product
+                    const bool place = spec && tail_at == 0 && planned > 0 && enq >= planned && enq >= 1;
+                    LSQ_TRY(launch_k1(place && !no_halves ? 1 : 0));
+                    if (place) {
                         LSQ_TRY(tail->fn(&stb[k1 & 1]->notdone, tail->user));
                         tail_at = enq;
                     }

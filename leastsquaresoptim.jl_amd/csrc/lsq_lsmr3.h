@@ -19,6 +19,9 @@
 // up -- a second of spinning -- marks the state failed (istop = 99) and the host returns LSQ_EHIP).
 // The state and x, hbar, h are double-buffered (launch k reads set (k-1)&1 and writes set k&1): the update workgroups read ALL of
 // x, hbar, h for ||x|| while their siblings write their own thirds; a late workgroup must not read what its own launch commits.
+// The launch also comes in halves (the host's choice, lsq_lsmr_solve): COMMIT-ONLY (grid = the update workgroups: the launch that
+// is expected to find the solve finished -- nothing streams, ~7 us) and, should that expectation fail, PRODUCT-ONLY (grid = the
+// product workgroups, ub = 0; the record of the commit-only launch, same tag, is already there).
 #pragma once
 
 constexpr int LSQ_FUSED_UB_MAX = 4;
@@ -95,6 +98,43 @@ __device__ inline void lsmr_decide(LsmrState &s, double total) {
 
 constexpr long long LSQ_FUSED_SPIN_LIMIT = 1LL << 24;      // x ~64 cycles of s_sleep: about a second
 
+// ordered_sum256x3 (lsq_spmv.h: same association, same bits) with the first 512 entries of every array requested up front: K2's
+// 313 partials of sum(v~^2) then cost ONE round of loads -- beside 250 streaming workgroups a round is microseconds.  The arrays
+// hold 4096 entries.
+__device__ __forceinline__ void ordered_sum512x3(const double *pa, const int *na, const double *pb, const int *nb,
+                                                 const double *pc, const int *nc, double &ra, double &rb, double &rc) {
+    __shared__ double s_w5[3][4];
+    __shared__ double s_tot5[3];
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        const double a0 = pa ? pa[tid] : 0.0, b0 = pb ? pb[tid] : 0.0, c0 = pc ? pc[tid] : 0.0;
+        const double a1 = pa ? pa[tid + 256] : 0.0, b1 = pb ? pb[tid + 256] : 0.0, c1 = pc ? pc[tid + 256] : 0.0;
+        const int ca = pa ? *na : 0, cb = pb ? *nb : 0, cc = pc ? *nc : 0;
+        double a = tid < ca ? a0 : 0.0, b = tid < cb ? b0 : 0.0, c = tid < cc ? c0 : 0.0;
+        if (tid + 256 < ca) a += a1;
+        if (tid + 256 < cb) b += b1;
+        if (tid + 256 < cc) c += c1;
+        for (int i = tid + 512; i < ca; i += 256) a += pa[i];
+        for (int i = tid + 512; i < cb; i += 256) b += pb[i];
+        for (int i = tid + 512; i < cc; i += 256) c += pc[i];
+        a = wave_sum(a);
+        b = wave_sum(b);
+        c = wave_sum(c);
+        if ((tid & 63) == 0) {
+            s_w5[0][tid >> 6] = a;
+            s_w5[1][tid >> 6] = b;
+            s_w5[2][tid >> 6] = c;
+        }
+    }
+    __syncthreads();
+    if (tid < 3) s_tot5[tid] = ((s_w5[tid][0] + s_w5[tid][1]) + s_w5[tid][2]) + s_w5[tid][3];
+    __syncthreads();
+    ra = s_tot5[0];
+    rb = s_tot5[1];
+    rc = s_tot5[2];
+    __syncthreads();
+}
+
 template <int = 0>
 __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows, int m, int nxpad, LsmrFused a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -124,7 +164,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
         }
         if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)&ns)[tid] = ((const unsigned long long *)a.st_in)[tid];
         double beta2, betax2, alpha2;
-        ordered_sum256x3(a.pu_in, a.npu_in, a.px_in, a.npx_in, a.pv, a.npv, beta2, betax2, alpha2);   // (its barriers also publish ns)
+        ordered_sum512x3(a.pu_in, a.npu_in, a.px_in, a.npx_in, a.pv, a.npv, beta2, betax2, alpha2);   // (its barriers also publish ns)
         if (ns.done) {    // a launch queued behind a finished solve: hand the state on (kernels behind it read st_out), release the readers
             if (blockIdx.x == 0) {
                 if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)a.st_out)[tid] = ((const unsigned long long *)&ns)[tid];
