@@ -752,6 +752,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.v = s->d_v; a.xout = d_x; a.ux = s->d_ux;
             a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
             a.n = n; a.ub = mode == 2 ? 0 : ub;
+            static const bool late_pub = getenv("LSQ_F3_LATE_PUBLISH") != nullptr;
+            a.late_publish = late_pub ? 1 : 0;
             a.ho = fho;
             if (mode != 2 && ++s->f3_tag == 0u) s->f3_tag = 1u;    // a counter per solver (= per record buffer): every older record
             a.tag = s->f3_tag;                                      // carries another value; 0 is the zeroed buffer

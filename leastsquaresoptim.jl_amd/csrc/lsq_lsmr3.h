@@ -73,6 +73,7 @@ struct LsmrFused {
     double *v, *xout, *ux;
     const double *uold; double *unew;            // m
     int n, ub;
+    int late_publish;                            // (experiment) progress word at the end of workgroup 0's work instead of its head
 };
 
 // ||x||^2 = total: lsmr_commit's evaluation of the rules (lsmr.jl:205-231), without the store
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
         if (blockIdx.x == 0) {
             if (tid == 0) lsmr_handoff_write(a.ho, a.tag, vs, cu, done_now ? 1 : 0);   // first: somebody may be waiting for it
             if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)a.st_out)[tid] = ((const unsigned long long *)&ns)[tid];
-            if (tid == 0) {
+            if (tid == 0 && !a.late_publish) {
                 if (!was_first) {   // hints for the host's prediction of the stop iteration, in front of the progress word
                     __hip_atomic_store((double *)&a.mail->test1, ns.normr / ns.normb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store((double *)&a.mail->test2, ns.normAr / (ns.normA * ns.normr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -253,6 +254,13 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
         if (tid == 0) {
             a.px_out[blockIdx.x] = bux;
             if (blockIdx.x == 0) *a.npx_out = a.ub;
+            if (blockIdx.x == 0 && a.late_publish) {
+                if (!was_first) {
+                    __hip_atomic_store((double *)&a.mail->test1, ns.normr / ns.normb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store((double *)&a.mail->test2, ns.normAr / (ns.normA * ns.normr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                publish(a.mail, &ns);
+            }
         }
         return;
     }

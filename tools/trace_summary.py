@@ -10,7 +10,10 @@ import csv, sys, collections
 rows = collections.defaultdict(list)
 with open(sys.argv[1]) as fh:
     for r in csv.DictReader(fh):
-        rows[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        name = r["Kernel_Name"]
+        if "k_lsmr_fused" in name:      # the launch comes whole, commit-only (a few workgroups) or product-only: keep them apart
+            name += " grid=%s" % r.get("Grid_Size", r.get("Grid_Size_X", "?"))
+        rows[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in rows.values())
 print("| kernel | launches | avg us (all) | working launches | avg us (working) | min us | max us | % of GPU time |")
 print("|---|---|---|---|---|---|---|---|")
