@@ -731,7 +731,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         int ub = c->num_cus - S.nblocks;
         ub = ub < 3 ? 3 : (ub > LSQ_FUSED_UB_MAX ? LSQ_FUSED_UB_MAX : ub);
         const int pb = std::max(1, std::min(S.nblocks, c->num_cus - ub));
-        if (tail && tail->step) { tail->step_taken = true; tail->step_parts = ub; }    // (every commit of a stop takes the step)
         int k1 = 0;                  // K1' launches enqueued: enq (whole iterations) or enq + 1
         bool need_product = false;   // launch k1 went out commit-only: its product half is still owed (if the solve goes on)
         static const bool no_halves = getenv("LSQ_LSMR_NO_HALVES") != nullptr;
@@ -753,13 +752,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.v = s->d_v; a.xout = d_x; a.ux = s->d_ux;
             a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
             a.n = n; a.ub = mode == 2 ? 0 : ub;
-            const LsmrStepFuse *sf = tail ? tail->step : nullptr;
-            a.sx = sf ? sf->x : nullptr; a.sxt = sf ? sf->xt : nullptr; a.st_out_ = sf ? sf->t_out : nullptr;
-            a.ss_out = sf ? sf->s_out : nullptr; a.spart_dx = sf ? sf->part_dx : nullptr; a.spart_nf = sf ? sf->part_nf : nullptr;
-            static const bool late_pub = getenv("LSQ_F3_LATE_PUBLISH") != nullptr;
-            a.late_publish = late_pub ? 1 : 0;
-            static const bool stamps = getenv("LSQ_F3_STAMPS") != nullptr;
-            a.stamps = stamps ? 1 : 0;
             a.ho = fho;
             if (mode != 2 && ++s->f3_tag == 0u) s->f3_tag = 1u;    // a counter per solver (= per record buffer): every older record
             a.tag = s->f3_tag;                                      // carries another value; 0 is the zeroed buffer
@@ -890,14 +882,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                 hipEventDestroy(v.back()); v.pop_back();
                 prof_it3[k].pop_back();
             }
-        }
-        if (getenv("LSQ_F3_STAMPS")) {      // diagnostics: phases of workgroup 0 in the LAST launch of this solve (10 ns ticks)
-            LsmrHandoff hh;
-            hipStreamSynchronize(c->stream);
-            if (hipMemcpy(&hh, fho, sizeof(hh), hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "f3 stamps (us from start): sums %.2f chain %.2f decide %.2f publish+loads %.2f update %.2f blocksum %.2f\n",
-                        (hh.stamp[1] - hh.stamp[0]) * 0.01, (hh.stamp[2] - hh.stamp[0]) * 0.01, (hh.stamp[3] - hh.stamp[0]) * 0.01,
-                        (hh.stamp[4] - hh.stamp[0]) * 0.01, (hh.stamp[5] - hh.stamp[0]) * 0.01, (hh.stamp[6] - hh.stamp[0]) * 0.01);
         }
         if (istop == 99) {     // (a product workgroup gave up waiting for workgroup 0's record: lsq_lsmr3.h)
             lsq_set_error("lsmr: the in-launch hand-off of k_lsmr_fused timed out");

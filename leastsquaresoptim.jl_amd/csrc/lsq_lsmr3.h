@@ -31,7 +31,6 @@ constexpr int LSQ_FUSED_UB_MAX = 4;
 // launches never share a tag.
 struct LsmrHandoff {
     unsigned long long w[8];
-    unsigned long long stamp[8];     // (LSQ_F3_STAMPS=1: wall-clock stamps of workgroup 0's phases, 10 ns units; diagnostics)
 };
 __device__ __forceinline__ void lsmr_handoff_write(LsmrHandoff *ho, unsigned tag, double vs, double cu, int done) {
     const unsigned long long t = (unsigned long long)tag << 32;
@@ -74,10 +73,6 @@ struct LsmrFused {
     double *v, *xout, *ux;
     const double *uold; double *unew;            // m
     int n, ub;
-    // the caller's trust-region step, taken by the launch that finds the solve finished (LsmrStepFuse, lsq_solver.h); sx null: not
-    const double *sx; double *sxt, *st_out_, *ss_out, *spart_dx, *spart_nf;
-    int late_publish;                            // (experiment) progress word at the end of workgroup 0's work instead of its head
-    int stamps;                                  // (diagnostics) workgroup 0 leaves wall-clock stamps of its phases in ho->stamp
 };
 
 // ||x||^2 = total: lsmr_commit's evaluation of the rules (lsmr.jl:205-231), without the store
@@ -151,6 +146,26 @@ __device__ __forceinline__ void ordered_sum512x3(const double *pa, const int *na
     __syncthreads();
 }
 
+// Block reductions for the tail of the update workgroups, where global STORES are in flight: __syncthreads() makes a wave wait for
+// its outstanding stores (vmcnt(0)) before it joins the barrier -- microseconds here (measured: 4.4 us at the last barrier of the
+// commit-only launch) for an exchange that only goes through LDS.  These wait for the LDS counter alone.
+__device__ __forceinline__ void lsq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool IS_MAX>
+__device__ __forceinline__ double lsq_block_reduce_lds(double v, double *sh /* 16 doubles */) {
+    v = IS_MAX ? wave_max(v) : wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    lsq_lds_barrier();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        r = sh[0];
+#pragma unroll
+        for (int i = 1; i < LSQ_BIG_NT / 64; ++i) r = IS_MAX ? fmax(r, sh[i]) : r + sh[i];
+    }
+    lsq_lds_barrier();
+    return r;
+}
+
 template <int = 0>
 __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows, int m, int nxpad, LsmrFused a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -166,8 +181,6 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
 
     if (upd) {
         // ---- what K3 did (lsmr.jl:119-156, 205-231; iterative_lsmr.jl:92,195-196) ----
-        const bool stamping = a.stamps && blockIdx.x == 0 && tid == 0;
-        if (stamping) a.ho->stamp[0] = wall_clock64();
         static_assert(sizeof(LsmrState) % 8 == 0 && sizeof(LsmrState) / 8 <= LSQ_BIG_NT, "state copy: one 8-byte word per thread");
         // These few workgroups run beside 250 streaming ones: a load takes microseconds, so every round of loads is issued as ONE
         // batch.  Round 1: the state, the partials (inside ordered_sum256x3) and all of x, hbar, h for ||x||.
@@ -191,10 +204,8 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             return;
         }
         const bool was_first = ns.first != 0;
-        if (stamping) a.ho->stamp[1] = wall_clock64();
         if (tid == 0) lsmr_scalars(ns, beta2, betax2, alpha2, a.dg != nullptr, a.px_in != nullptr);
         __syncthreads();
-        if (stamping) a.ho->stamp[2] = wall_clock64();
         if (!was_first) {
             // ||x_k||^2 over ALL of x in every update workgroup alike (thread-strided, wave tree, 16 waves in order): no
             // cross-workgroup reduction, the same bits everywhere
@@ -214,12 +225,11 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
         }
         __syncthreads();
         const bool done_now = ns.done != 0;
-        if (stamping) a.ho->stamp[3] = wall_clock64();
         const double vs = ns.vscale, cu = ns.cu, c1 = ns.c1, c2 = ns.c2, c3 = ns.c3;
         if (blockIdx.x == 0) {
             if (tid == 0) lsmr_handoff_write(a.ho, a.tag, vs, cu, done_now ? 1 : 0);   // first: somebody may be waiting for it
             if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)a.st_out)[tid] = ((const unsigned long long *)&ns)[tid];
-            if (tid == 0 && !a.late_publish) {
+            if (tid == 0) {
                 if (!was_first) {   // hints for the host's prediction of the stop iteration, in front of the progress word
                     __hip_atomic_store((double *)&a.mail->test1, ns.normr / ns.normb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store((double *)&a.mail->test2, ns.normAr / (ns.normA * ns.normr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -229,12 +239,10 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
         }
         // Round 2: this workgroup's own elements (every ub-th group of 1024), again one batch of loads
         constexpr int NU = (NQ + 2) / 3;      // ub >= 3
-        double e_vt[NU], e_P[NU], e_dg[NU], e_ux[NU], e_h[NU], e_hb[NU], e_x[NU], e_sx[NU];
-        const bool stepping = done_now && a.sx != nullptr;
+        double e_vt[NU], e_P[NU], e_dg[NU], e_ux[NU], e_h[NU], e_hb[NU], e_x[NU];
 #pragma unroll
         for (int k = 0; k < NU; ++k) {
             const int j = min((int)(blockIdx.x + k * a.ub) * LSQ_BIG_NT + tid, n - 1);
-            e_sx[k] = stepping ? a.sx[j] : 0.0;
             e_vt[k] = a.vt[j];
             e_P[k] = a.P ? a.P[j] : 1.0;
             e_dg[k] = a.dg ? a.dg[j] : 0.0;
@@ -243,8 +251,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             e_hb[k] = a.hbar_in[j];
             e_x[k] = a.x_in[j];
         }
-        if (stamping) a.ho->stamp[4] = wall_clock64();
-        double aux = 0.0, smx = 0.0, scode = 0.0;
+        double aux = 0.0;
 #pragma unroll
         for (int k = 0; k < NU; ++k) {
             const int j = (int)(blockIdx.x + k * a.ub) * LSQ_BIG_NT + tid;
@@ -252,7 +259,6 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             const double Pj = e_P[k];
             const double vj = e_vt[k] * vs;                 // lsmr.jl:78,124 rmul!(v, inv(alpha))
             a.v[j] = vj;
-            double dxj = 0.0;                               // the caller's x (= P.*x) at this element
             if (was_first) {                                // :89-90, iterative_lsmr.jl:183,242
                 a.h_out[j] = vj;
                 a.hbar_out[j] = 0.0;
@@ -265,10 +271,8 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
                 const double xj = e_x[k] + c2 * hb;         // :154
                 a.x_out[j] = xj;
                 a.h_out[j] = hj * c3 + vj;                  // :155-156
-                dxj = a.P ? xj * Pj : xj;
-                a.xout[j] = dxj;                            // the caller's x always holds P.*x of the newest iterate
+                a.xout[j] = a.P ? xj * Pj : xj;             // the caller's x always holds P.*x of the newest iterate
             }
-            e_x[k] = dxj;       // (kept for the step below)
             if (a.dg && !done_now) {    // damped rows of the NEXT u (iterative_lsmr.jl:92): u~x <- d.*t - cu*u~x
                 const double tj = a.P ? vj * Pj : vj;       // iterative_lsmr.jl:31 ldiv!(tmp, P, a)
                 const double un = tj * e_dg[k] - cu * e_ux[k];
@@ -276,47 +280,11 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
                 aux += un * un;
             }
         }
-        if (stamping) a.ho->stamp[5] = wall_clock64();
-        if (stepping) {     // the solve is over and dx is final: the caller's step (k_step's arithmetic, levenberg_marquardt.jl:106)
-#pragma unroll
-            for (int k = 0; k < NU; ++k) {
-                const int j = (int)(blockIdx.x + k * a.ub) * LSQ_BIG_NT + tid;
-                if (j < n) {
-                    const double dxj = e_x[k];
-                    const double vstep = e_sx[k] + -1.0 * dxj;  // axpy!(-1, dx, x)
-                    a.sxt[j] = vstep;
-                    if (a.st_out_) {
-                        const double th = tanh(vstep);
-                        a.st_out_[j] = th;
-                        a.ss_out[j] = 1.0 - th * th;
-                    }
-                    double ad = fabs(dxj);
-                    if (isnan(ad)) ad = INFINITY;
-                    smx = fmax(smx, ad);
-                    if (!isfinite(vstep) && scode == 0.0) scode = 1e15 - (double)(j + 1);
-                }
-                asm volatile("" ::: "memory");      // (one tanh expansion at a time: four in flight spill)
-            }
-            const double bm = block_max<LSQ_BIG_NT>(smx, sh);
-            const double bc = block_max<LSQ_BIG_NT>(scode, sh);
-            if (tid == 0) {
-                a.spart_dx[blockIdx.x] = bm;
-                a.spart_nf[blockIdx.x] = bc;
-            }
-        }
-        if (done_now && !a.late_publish) return;        // (no next iteration: nobody reads sum(u~x^2); the barrier below would wait for the stores)
-        const double bux = block_sum<LSQ_BIG_NT>(aux, sh);
-        if (stamping) a.ho->stamp[6] = wall_clock64();
+        if (done_now) return;        // (no next iteration: nobody reads sum(u~x^2))
+        const double bux = lsq_block_reduce_lds<false>(aux, sh);     // (block_sum's association: wave tree, 16 waves in order)
         if (tid == 0) {
             a.px_out[blockIdx.x] = bux;
             if (blockIdx.x == 0) *a.npx_out = a.ub;
-            if (blockIdx.x == 0 && a.late_publish) {
-                if (!was_first) {
-                    __hip_atomic_store((double *)&a.mail->test1, ns.normr / ns.normb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store((double *)&a.mail->test2, ns.normAr / (ns.normA * ns.normr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                publish(a.mail, &ns);
-            }
         }
         return;
     }

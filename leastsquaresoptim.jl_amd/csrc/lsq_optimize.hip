@@ -15,9 +15,7 @@ static constexpr double DECREASE_THRESHOLD = 0.25, INCREASE_THRESHOLD = 0.75;
 
 // scalar slots used by the loops (ctx->d_slots)
 enum { SL_GRAD = 8, SL_DX = 9, SL_NONFIN = 10, SL_TRIAL = 11, SL_PRED = 12, SL_SSR = 13, SL_W0 = 14, SL_W1 = 15,
-       SL_W2 = 16, SL_SUM = 17,
-       // the trust-region step taken inside the LSMR solve (LsmrStepFuse): per-workgroup max|dx| and non-finite codes, reduced by the host
-       SL_DXP0 = 18, SL_NFP0 = 22, SL_STEP_END = 26 };
+       SL_W2 = 16, SL_SUM = 17 };
 
 // ---------------------------------------------------------------------------------------------
 // solver objects
@@ -864,23 +862,18 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             const double *x, *fcur; double *xt, *ftrial;
             int m, n, gn; bool is_model; LsqSlotPublish pub; int launched;
             bool want_spec; double ssr; bool spec_launched; bool *spec_pending;
-            const bool *step_taken;     // the solve takes x_trial = x - dx itself (LsmrStepFuse): no k_step launch, 18 scalars travel
-            int step_parts;
         } tc{c, J, &b, f, user, x, fcur, xt, ftrial, m, n, gn, !exact && f == model_f, LsqSlotPublish(), 0, spec_ok, ssr, false,
-             &spec_pending, nullptr, 0};
+             &spec_pending};
         auto tail_fn = [](const int *skip, void *u) -> int {
             TailCtx &t = *(TailCtx *)u;
             lsq_ctx *c = t.c;
             double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)
             if (t.is_model) model_trial_buffers(t.user, t.xt, &t_out, &s_out);
-            const bool stepped = t.step_taken && *t.step_taken;     // (the solve's last launch wrote x_trial and its maxima)
-            if (!stepped)
-                LSQ_LAUNCH(k_step, dim3(t.gn), dim3(LSQ_NT), 0, c->stream, t.n, t.x, t.b->dx, t.xt, c->d_partials,
-                                   lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out, skip);   // :106
+            LSQ_LAUNCH(k_step, dim3(t.gn), dim3(LSQ_NT), 0, c->stream, t.n, t.x, t.b->dx, t.xt, c->d_partials,
+                               lsq_ctr(c, 5), c->d_slots + SL_DX, c->d_slots + SL_NONFIN, t_out, s_out, skip);   // :106
             LSQ_HIP(hipGetLastError());
             // the last kernel of the iteration hands the scalars to the host
-            // (the sixth: the device's own acceptance decision, k_sell_rows_pair; behind it the step's per-workgroup maxima)
-            t.pub = lsq_slots_ticket(c, SL_GRAD, stepped ? SL_STEP_END - SL_GRAD : 6);
+            t.pub = lsq_slots_ticket(c, SL_GRAD, 6);      // (the sixth: the device's own acceptance decision, k_sell_rows_pair)
             bool pair = false;
             SpecGrad sg{t.want_spec ? next_gate(c, *t.b) : nullptr, t.ssr, t.b->grad, false};
             if (t.is_model && model_pair_tail(t.user, t.J, t.b->dx, t.fcur, t.ftrial, t.xt, c->d_slots + SL_PRED, c->d_slots + SL_TRIAL,
@@ -909,18 +902,9 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             static const bool no_spec = getenv("LSQ_NO_TAIL_SPECULATION") != nullptr;
             const bool guardable = tc.is_model && J->kind == LSQ_MAT_CSC && J->srows.active && !no_spec && !lsq_dbg_serial;
             LsmrTail tail{guardable ? last_inner : 0, tail_fn, &tc, guardable};
-            // the step x_trial = x - dx goes with the solve where the solve can take it (three-launch iteration; tail_ok: no bounds)
-            LsmrStepFuse sfuse{x, xt, nullptr, nullptr, c->d_slots + SL_DXP0, c->d_slots + SL_NFP0};
-            static const bool no_step_fuse = getenv("LSQ_NO_STEP_FUSE") != nullptr;
-            if (tail_ok && !no_step_fuse) {
-                if (tc.is_model) model_trial_buffers(user, xt, &sfuse.t_out, &sfuse.s_out);
-                tail.step = &sfuse;
-                tc.step_taken = &tail.step_taken;
-            }
             LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr, lm_prep ? &prep : nullptr,
                                    tail_ok ? &tail : nullptr));  // :87
             tail_done = tail_ok;
-            tc.step_parts = tail.step_parts;
             last_inner = lmiter / 2;
         }
         else LSQ_TRY(lsq_ldiv_damped(sv, J, fcur, b.dtd, b.dx, &lmiter));
@@ -928,20 +912,11 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
         if (o->allreduce && c->idle_status != LSQ_OK) return c->idle_status;
         mul_calls += lmiter;
         inner_total += lmiter / 2;
-        double sl[SL_STEP_END - SL_GRAD] = {0, 0, 0, 0, 0, 0};
+        double sl[6] = {0, 0, 0, 0, 0, 0};
         if (tail_done) {
             f_calls++;
             spec_launched = tc.spec_launched;
-            LSQ_TRY(lsq_wait_slots(c, SL_GRAD, tc.pub.count, tc.pub.seq, sl));
-            if (tc.pub.count > 6) {     // the step was taken inside the solve: its maxima come per workgroup
-                double mx = 0.0, code = 0.0;
-                for (int k = 0; k < tc.step_parts; ++k) {
-                    mx = std::fmax(mx, sl[SL_DXP0 - SL_GRAD + k]);
-                    code = std::fmax(code, sl[SL_NFP0 - SL_GRAD + k]);
-                }
-                sl[1] = mx;
-                sl[2] = code == 0.0 ? -1.0 : (1e15 - code) - 1.0;
-            }
+            LSQ_TRY(lsq_wait_slots(c, SL_GRAD, 6, tc.pub.seq, sl));
         } else {
         LSQ_TRY(lsq_box_clip(c, n, b.dx, x, b.lo, b.hi));                // :89-98
         double *t_out = nullptr, *s_out = nullptr;   // (the built-in model takes tanh(x_trial) from this launch)

@@ -203,26 +203,11 @@ constexpr int LSMR_LM_PREP_MAX_N = 16384;   // every workgroup of that launch re
 // hints K3 publishes beside the progress word): on LM's damped, Jacobi-preconditioned operators test2 = |A'r|/(|A||r|) falls
 // geometrically and the iteration at which it crosses atol (or test1 crosses btol) is known one or two iterations ahead; a
 // tail that skipped itself may be queued again, guarded, behind a later iteration.
-// `step` (optional): the first thing every caller's tail does is the trust-region step x_trial = x - dx with max|dx| and the
-// non-finite check (levenberg_marquardt.jl:106, utils.jl:70-75; for the built-in model also tanh(x_trial) and its derivative
-// factor).  The three-launch iteration (lsq_lsmr3.h) takes it over: the launch that finds the solve finished holds the final dx
-// in registers and writes x_trial in passing -- one n-length launch less per outer iteration.  The solver says whether it did
-// (`step_taken`, set before the first call of fn) and how many per-workgroup maxima it left (`step_parts` entries of part_dx /
-// part_nf; the caller reduces them: a max is a max in any order).
-struct LsmrStepFuse {
-    const double *x;            // the current iterate
-    double *xt;                 // x - dx
-    double *t_out, *s_out;      // tanh(xt), 1 - tanh(xt)^2, or nulls
-    double *part_dx, *part_nf;  // per-workgroup max|dx| and non-finite codes (1e15 - (index + 1), 0 = none: k_step's coding)
-};
 struct LsmrTail {
     int predict = 0;
     int (*fn)(const int *skip, void *user) = nullptr;
     void *user = nullptr;
     bool dynamic = false;
-    const LsmrStepFuse *step = nullptr;
-    mutable bool step_taken = false;
-    mutable int step_parts = 0;
 };
 int lsq_rowshard_colsum(lsq_solver *s, lsq_mat *J, const double **out);   // colsumabs2 of the whole J (row-sharded: summed over the ranks)
 int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp, double *d_x, int *nmul,
