@@ -733,11 +733,13 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         const int pb = std::max(1, std::min(S.nblocks, c->num_cus - ub));
         int k1 = 0;                  // K1' launches enqueued: enq (whole iterations) or enq + 1
         bool need_product = false;   // launch k1 went out commit-only: its product half is still owed (if the solve goes on)
-        static const bool no_halves = getenv("LSQ_LSMR_NO_HALVES") != nullptr;
+        static const bool use_halves = getenv("LSQ_LSMR_HALVES") != nullptr;          // (A/B: commit-only + product-only launches)
+        static const bool no_cautious = getenv("LSQ_LSMR_NO_CAUTIOUS") != nullptr;    // (A/B: always the plain fused launch)
         const size_t prof_base3[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
         std::vector<int> prof_it3[2];
         unsigned long long spins = 0;
-        // mode 0: the whole launch; 1: commit-only (update workgroups); 2: product-only, the half that a commit-only launch left out
+        // mode 0: the whole launch; 1: commit-only (update workgroups); 2: product-only, the half that a commit-only launch left out;
+        // 3: the whole launch, cautious (the product workgroups wait for the decision before they stream)
         auto launch_k1 = [&](int mode) -> int {
             const int j = mode == 2 ? k1 : k1 + 1, in = (j - 1) & 1, out = j & 1;
             LsmrFused a;
@@ -752,6 +754,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.v = s->d_v; a.xout = d_x; a.ux = s->d_ux;
             a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
             a.n = n; a.ub = mode == 2 ? 0 : ub;
+            a.cautious = mode == 3 ? 1 : 0;
             a.ho = fho;
             if (mode != 2 && ++s->f3_tag == 0u) s->f3_tag = 1u;    // a counter per solver (= per record buffer): every older record
             a.tag = s->f3_tag;                                      // carries another value; 0 is the zeroed buffer
@@ -842,7 +845,11 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                     // the prediction names an iteration whose commit is already in the queue) -- and that launch commit-only: if
                     // the plan holds there is no next product
                     const bool place = spec && tail_at == 0 && planned > 0 && enq >= planned && enq >= 1;
-                    LSQ_TRY(launch_k1(place && !no_halves ? 1 : 0));
+                    // ... and cautious also where nothing is known yet: the launch that decides iteration 1, unless the previous
+                    // solve was a long one
+                    const bool unknown = spec && enq == 1 && hint_it == 0 && tail->predict <= 3;
+                    const int mode = no_cautious ? 0 : (place ? (use_halves ? 1 : 3) : (unknown && !use_halves ? 3 : 0));
+                    LSQ_TRY(launch_k1(mode));
                     if (place) {
                         LSQ_TRY(tail->fn(&stb[k1 & 1]->notdone, tail->user));
                         tail_at = enq;

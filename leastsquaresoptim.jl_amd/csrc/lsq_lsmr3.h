@@ -19,9 +19,10 @@
 // up -- a second of spinning -- marks the state failed (istop = 99) and the host returns LSQ_EHIP).
 // The state and x, hbar, h are double-buffered (launch k reads set (k-1)&1 and writes set k&1): the update workgroups read ALL of
 // x, hbar, h for ||x|| while their siblings write their own thirds; a late workgroup must not read what its own launch commits.
-// The launch also comes in halves (the host's choice, lsq_lsmr_solve): COMMIT-ONLY (grid = the update workgroups: the launch that
-// is expected to find the solve finished -- nothing streams, ~7 us) and, should that expectation fail, PRODUCT-ONLY (grid = the
-// product workgroups, ub = 0; the record of the commit-only launch, same tag, is already there).
+// Where the host expects the launch to find the solve finished (lsq_lsmr_solve: the predicted last iteration; the first iteration
+// when nothing is known yet) it asks for a CAUTIOUS launch: the product workgroups wait for the record before they stream.  (The
+// launch also comes in halves -- COMMIT-ONLY, grid = the update workgroups, and PRODUCT-ONLY, ub = 0, the record of the commit-only
+// launch already there -- LSQ_LSMR_HALVES=1: the first form of the same idea, kept for A/B.)
 #pragma once
 
 constexpr int LSQ_FUSED_UB_MAX = 4;
@@ -73,6 +74,7 @@ struct LsmrFused {
     double *v, *xout, *ux;
     const double *uold; double *unew;            // m
     int n, ub;
+    int cautious;      // the product workgroups wait for the record BEFORE they stream (this launch may well find the solve finished)
 };
 
 // ||x||^2 = total: lsmr_commit's evaluation of the rules (lsmr.jl:205-231), without the store
@@ -305,6 +307,33 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
     const int pb = (int)blockIdx.x - a.ub, npb = (int)gridDim.x - a.ub;
     double racc = 0.0;
     bool have_scalars = false;
+    if (a.cautious) {
+        // CAUTIOUS launch: the host expects (or cannot exclude) that the finished iteration was the last.  The product workgroups
+        // look at workgroup 0's record first -- ~8 us into the launch -- and stream only if the solve goes on: a launch that commits
+        // the stop then costs what the update workgroups cost, and one that does not starts its product 8 us late instead of paying a
+        // wasted product, a skipped tail and a host round trip.  (Same bounded wait, same failure path as below.)
+        if (tid == 0) {
+            LsmrHandoffWords rec = lsmr_handoff_request(a.ho);
+            long long spins = 0;
+            while (!lsmr_handoff_valid(rec, a.tag)) {
+                if (++spins > LSQ_FUSED_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(8);
+                rec = lsmr_handoff_request(a.ho);
+            }
+            const bool ok = spins <= LSQ_FUSED_SPIN_LIMIT;
+            s_vs = __longlong_as_double((long long)((rec.w[0] & 0xffffffffull) | (rec.w[1] << 32)));
+            s_cu = __longlong_as_double((long long)((rec.w[2] & 0xffffffffull) | (rec.w[3] << 32)));
+            s_done = ok ? (int)(rec.w[4] & 0xffffffffull) : 2;
+            if (!ok) {
+                __hip_atomic_store(&a.st_out->istop, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.st_out->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.st_out->notdone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (s_done) return;
+        have_scalars = true;
+    }
     for (int w = pb; w < S.nblocks; w += npb) {
         const int base = w * wrows, rows = min(wrows, m - base);
         const int s0 = w * S.spw, s1 = s0 + S.spw;
