@@ -279,7 +279,10 @@ def main():
     k1_raw_ms = avg[0] if cnt[0] > 0 else float("nan")
     k1_ms = k1_raw_ms
     achieved = bytes_k1 / (k1_ms * 1e-3) / 1e9 if cnt[0] > 0 else None
-    roof = {"bound": "hbm", "kernel": "k_sell_rows<EpiU> (LSMR J*v: u <- J t - cu*u, + sum u^2)",
+    three = not os.environ.get("LSQ_LSMR_FOUR_LAUNCHES") and n <= 12160
+    roof = {"bound": "hbm", "kernel": ("k_lsmr_fused (LSMR J*v: u <- (J w)/alpha - cu*u, + sum u^2; the n-vector updates and the stop test of "
+                                        "the previous iteration ride in 3 extra workgroups)" if three else
+                                        "k_sell_rows<EpiU> (LSMR J*v: u <- J t - cu*u, + sum u^2)"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
             "algorithmic_bytes_per_launch": bytes_k1, "avg_launch_ms": k1_ms, "launches_timed": int(cnt[0]),
@@ -377,6 +380,8 @@ def main():
                                   "no Jacobian copy is multiplied out (lsq_mat_set_colscale; LSQ_NO_COLSCALE=1 restores the "
                                   "multiplied-out copies of rounds 1-2)" if not os.environ.get("LSQ_NO_COLSCALE") else
                                   "multiplied out into both sliced copies by g!",
+                      "lsmr_iteration": ("three launches: k_lsmr_fused | k_sell_cols | k_combine<EpiV> (LSQ_LSMR_FOUR_LAUNCHES=1 restores "
+                                         "k_sell_rows<EpiU> | k_sell_cols | k_combine<EpiV> | k_lsmr_update)" if three else "four launches"),
                       "lm_tail": ("predicted residual and trial residual in ONE pass over A (k_sell_rows_pair, n <= 10200; LSQ_NO_PAIR_TAIL=1 "
                                   "restores the two launches)" if n <= 10200 and not os.environ.get("LSQ_NO_PAIR_TAIL")
                                   and not os.environ.get("LSQ_NO_COLSCALE") else "two passes over A (predicted residual, trial residual)"),
