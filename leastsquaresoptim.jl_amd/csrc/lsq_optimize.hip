@@ -1500,7 +1500,8 @@ static int model_pair_tail(void *user, lsq_mat *J, const double *dx, const doubl
         return 0;
     const LsqSell &S = J->srows;
     const int nxpad = (J->n + 1) & ~1;
-    const size_t lds = (size_t)2 * nxpad * sizeof(double);
+    // (two gather vectors; after a block's stream their LDS is the output window of its LSQ_SELL_ROWS_MAX rows)
+    const size_t lds = (size_t)std::max(2 * nxpad, LSQ_SELL_ROWS_MAX) * sizeof(double);
     if (lsq_set_lds(c, (const void *)k_sell_rows_pair<0>, (size_t)2 * LSQ_PAIR_X_MAX * sizeof(double)) != LSQ_OK) return 0;
     // slice-order mirrors: b once; f from the slot that mirrors fcur (filled by an earlier launch of this kernel if the step that
     // produced fcur was accepted, else permuted now); the other slot takes this launch's trial residual
