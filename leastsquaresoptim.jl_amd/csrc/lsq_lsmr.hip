@@ -755,6 +755,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
             a.n = n; a.ub = mode == 2 ? 0 : ub;
             a.cautious = mode == 3 ? 1 : 0;
+            a.test_no_record = getenv("LSQ_TEST_EXCHANGE_TIMEOUT") ? 1 : 0;    // (test hook: the in-launch hand-off fails)
             a.ho = fho;
             if (mode != 2 && ++s->f3_tag == 0u) s->f3_tag = 1u;    // a counter per solver (= per record buffer): every older record
             a.tag = s->f3_tag;                                      // carries another value; 0 is the zeroed buffer

@@ -58,6 +58,13 @@ def csc_matvec(m, colptr, rowval, nzval, t):
     return np.bincount(rowval, weights=nzval * t[cols], minlength=m)
 
 
+class _Handle:      # minimal handle wrapper for _run_native
+    __slots__ = ("h",)
+
+    def __init__(self, h):
+        self.h = h
+
+
 class TanhProblem:
     """Device-resident problem: Jacobian handle + model (A, b) + x / fcur vectors."""
 
@@ -94,6 +101,8 @@ class TanhProblem:
         self.model = md
         self.x = DeviceVector(self.ctx, n)
         self.fcur = DeviceVector(self.ctx, m)
+        self._Jd = None
+        self._fg = None
 
     def reset(self, x0=None):
         if x0 is None:      # x <- 0 on the device (a fill kernel in stream order: no host buffer, no blocking copy)
@@ -104,15 +113,15 @@ class TanhProblem:
     def optimize(self, optimizer_kind, solver_kind, x_tol=1e-8, f_tol=1e-8, g_tol=1e-8, iterations=1000,
                  delta=None, trace=False, allreduce=None, fetch_x=True, row_allreduce=None, row_allreduce_user=None,
                  global_rows=0):
-        L = lib()
-
-        class _H:  # minimal handle wrappers for _run_native
-            pass
-
-        Jd = _H()
-        Jd.h = self.J
+        # (the handle wrapper and the two callback pointers are made once per problem: a solve of the bench schedule takes 2 ms,
+        #  and tens of microseconds of interpreter work per call showed in its timeline)
+        if self._Jd is None:
+            L = lib()
+            self._Jd = _Handle(self.J)
+            self._fg = (L.lsq_model_f(), L.lsq_model_g())
+        Jd = self._Jd
         st, res, tr = _run_native(self.ctx, optimizer_kind, solver_kind, Jd, self.x, self.fcur,
-                                  L.lsq_model_f(), L.lsq_model_g(), self.model, x_tol, f_tol, g_tol,
+                                  self._fg[0], self._fg[1], self.model, x_tol, f_tol, g_tol,
                                   iterations, delta, None, None, trace, self.n, allreduce=allreduce,
                                   row_allreduce=row_allreduce, row_allreduce_user=row_allreduce_user, global_rows=global_rows)
         check(st)

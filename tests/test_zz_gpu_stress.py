@@ -232,3 +232,27 @@ def test_dense_solves_next_to_a_busy_neighbour(ctx):
     fired = {k: after[k] - before[k] for k in after}
     print("fallbacks fired next to a busy neighbour:", fired, svc.stats(), svq.stats())
     assert all(v <= 2 for v in fired.values()), fired          # a path that gave up is paused, not retried every solve
+
+
+def test_lsmr_in_launch_handoff_failure_is_never_silent(ctx, monkeypatch):
+    """Round 5: the three-launch LSMR iteration hands {1/alpha, alpha/beta, done} from workgroup 0 to the product workgroups of the
+    same launch (lsq_lsmr3.h) with a bounded wait.  LSQ_TEST_EXCHANGE_TIMEOUT makes workgroup 0 keep its record
+    to itself: every reader gives up, the state is marked failed and the solve comes back as an error (LSQ_EHIP) -- no hang, no
+    silently wrong iterate; the same solver then solves normally again, with the oracle's result."""
+    m, n = 300000, 2000
+    S = rand_csc(m, n, 0.002, 41)
+    y = np.random.default_rng(42).standard_normal(m)
+    J = lsq.DeviceMatrix(ctx, S)
+    sv = lsq.AllocatedSolver(J, lsq.LSMR(), for_lm=True)
+    damp = np.full(n, 0.3)
+    x = lsq.DeviceVector(ctx, n)
+    monkeypatch.setenv("LSQ_TEST_EXCHANGE_TIMEOUT", "1")
+    with pytest.raises(Exception) as ei:
+        sv.ldiv_(x, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+    assert "hand-off" in str(ei.value) or "HIP" in str(ei.value)
+    monkeypatch.delenv("LSQ_TEST_EXCHANGE_TIMEOUT")
+    _, nmul = sv.ldiv_(x, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+    st, xo, nmul_o, _ = O.ldiv(O.LSMR, O.Mat.from_scipy(S), y, damp)
+    assert nmul == nmul_o and np.max(np.abs(x.get() - xo)) <= 1e-8 * max(1.0, np.max(np.abs(xo)))
+    sv.free()
+    J.free()
