@@ -643,7 +643,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
     LsmrHandoff *const fho = (LsmrHandoff *)(fpu[1] + 4096 + 8);   // the in-launch record of k_lsmr_fused
     double *const vset = fused ? s->d_t : s->d_v;                  // where the setup (and every K2) leaves v~
     if (fused) { pu = fpu[0]; npu = fnpu; }
-    bool first_lm = false;
     // computed once per Jacobian (reference: twice); row-sharded: the sum over the ranks' blocks -- the preconditioner is a
     // replicated n-vector and has to be the same on every rank
     const double *colsum = nullptr;
@@ -672,9 +671,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             lsq_set_error("lsmr: LM preparation requested where it does not apply");
             return LSQ_EARG;
         }
-        // (three-launch iteration, no bounds: the setup rides in launch 1 of k_lsmr_fused -- LsmrFirstLm, lsq_lsmr3.h)
-        first_lm = fused && !lm->lo && !lm->hi && !getenv("LSQ_LSMR_SEPARATE_SETUP3");
-        if (!first_lm)
         LSQ_LAUNCH(k_lm_lsmr_setup, dim3(lsq_div_up(n, 1024)), dim3(1024), 0, c->stream, n, *lm, d_damp, s->d_P, s->d_dg,
                            s->d_ux, d_Jty, vset, st, pu, npu, y_sumsq, pv, npv, atol, btol, 1.0 / conlim, maxiter, epoch,
                            (const double *)(fused ? J->d_colscale : nullptr), (double *)(fused ? fw : nullptr));
@@ -731,7 +727,6 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         const int nxpad = (n + 1) & ~1;
         const size_t lds = (size_t)(nxpad + LSQ_SELL_ROWS_MAX) * sizeof(double);
         LSQ_TRY(lsq_set_lds(c, (const void *)k_lsmr_fused<0>, (LSQ_LDS_X_MAX + LSQ_SELL_ROWS_MAX) * sizeof(double)));
-        LSQ_TRY(lsq_set_lds(c, (const void *)k_lsmr_first<0>, (LSQ_LDS_X_MAX + LSQ_SELL_ROWS_MAX) * sizeof(double)));
         // update workgroups: the CUs the sliced rows leave without a block (C4: 253 blocks on 256 CUs -> 3), at least 3
         int ub = c->num_cus - S.nblocks;
         ub = ub < 3 ? 3 : (ub > LSQ_FUSED_UB_MAX ? LSQ_FUSED_UB_MAX : ub);
@@ -765,20 +760,10 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             if (mode != 2 && ++s->f3_tag == 0u) s->f3_tag = 1u;    // a counter per solver (= per record buffer): every older record
             a.tag = s->f3_tag;                                      // carries another value; 0 is the zeroed buffer
             if (mode == 2) a.st_in = stb[out];                      // (the state its commit-only half has committed)
-            LsmrFirstLm fl{};
-            const bool with_setup = first_lm && j == 1 && mode != 2;
-            if (with_setup) {
-                fl.colsum = lm->colsum; fl.g = d_Jty; fl.cs = J->d_colscale;
-                fl.inv_delta = lm->inv_delta; fl.min_diag = lm->min_diag; fl.max_diag = lm->max_diag; fl.ysumsq = y_sumsq;
-                fl.damp = d_damp; fl.P = s->d_P; fl.dg = s->d_dg; fl.out_grad = lm->out_grad;
-                fl.atol = atol; fl.btol = btol; fl.ctol = 1.0 / conlim; fl.maxiter = maxiter; fl.epoch = epoch;
-            }
             const int grid = mode == 1 ? ub : (mode == 2 ? pb : pb + ub);
             if (mode != 1 && (c->prof_kernels & 1)) lsq_prof_mark(c, 0, 0);
             hipEvent_t e0, e1;
-            if (with_setup) {
-                LSQ_LAUNCH(k_lsmr_first<0>, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, sell_dev(S), S.wrows, m, nxpad, a, fl);
-            } else if (mode != 1 && lsq_prof_take(c, &e0, &e1)) {
+            if (mode != 1 && lsq_prof_take(c, &e0, &e1)) {
                 LSQ_LAUNCH_TIMED(k_lsmr_fused<0>, dim3(grid), dim3(LSQ_BIG_NT), lds, c->stream, e0, e1, 0, sell_dev(S), S.wrows, m, nxpad, a);
                 prof_it3[0].push_back(j);
             } else {

@@ -78,64 +78,6 @@ struct LsmrFused {
     int cautious;      // the product workgroups wait for the record BEFORE they stream (this launch may well find the solve finished)
 };
 
-// Launch 1 of an LM solve can take the solve's SETUP along (k_lm_lsmr_setup, lsq_lsmr.hip: levenberg_marquardt.jl:82-86 damping from
-// colsumabs2, iterative_lsmr.jl:129-141 Jacobi preconditioner, :246-252 sqrt(damp) rows, lsmr.jl:73-78 v~ = P.*(J'y)/beta_1): every
-// workgroup forms mean(colsum) itself, over all n, in the order of the kernel it replaces (same bits), the product workgroups build
-// their gather vector from the gradient, the update workgroups write P, sqrt(damp), the vectors and the first state.  One
-// n-length launch (7.5 us) less per outer iteration.  colsum == null: not this launch.
-struct LsmrFirstLm {
-    const double *colsum, *g, *cs;       // colsumabs2(J), J'f (= LM's gradient), the column scale of J or null
-    double inv_delta, min_diag, max_diag, ysumsq;
-    double *damp, *P, *dg, *out_grad;
-    double atol, btol, ctol;
-    int maxiter;
-    unsigned epoch;
-};
-// mean(colsum) exactly as k_lm_lsmr_setup takes it (thread-sequential with stride 1024, wave tree, 16 waves in order), and max|g|
-template <int NQ>
-__device__ __forceinline__ void lsmr_first_mean(const double (&cs)[NQ], const double (&gv)[NQ], int n, double *sh, double *shm,
-                                                double &mean, double &gmax) {
-    const int tid = threadIdx.x;
-    double acc = 0.0, mg = 0.0;
-#pragma unroll
-    for (int k = 0; k < NQ; ++k)
-        if (tid + k * LSQ_BIG_NT < n) {
-            acc += cs[k];
-            double a = fabs(gv[k]);
-            if (isnan(a)) a = INFINITY;
-            mg = fmax(mg, a);
-        }
-    acc = wave_sum(acc);
-    mg = wave_max(mg);
-    if ((tid & 63) == 0) {
-        sh[tid >> 6] = acc;
-        shm[tid >> 6] = mg;
-    }
-    __syncthreads();
-    double tt = 0.0, tm = shm[0];
-#pragma unroll
-    for (int w = 0; w < LSQ_BIG_NT / 64; ++w) tt += sh[w];
-#pragma unroll
-    for (int w = 1; w < LSQ_BIG_NT / 64; ++w) tm = fmax(tm, shm[w]);
-    __syncthreads();
-    mean = tt / n;
-    gmax = tm;
-}
-// one element of the setup: damping, preconditioner, v~ (the arithmetic of k_lm_lsmr_setup, statement by statement)
-struct LsmrFirstElem { double r, P, vt; };
-__device__ __forceinline__ LsmrFirstElem lsmr_first_elem(double c0, double g0, double lo_d, double hi_d, double inv_delta, double inv_beta,
-                                                         bool beta_zero) {
-    double c = c0;
-    c = c > hi_d ? hi_d : (c < lo_d ? lo_d : c);
-    const double d = c * inv_delta;        // rmul!(dtd, 1/Delta)
-    const double s = c0 + d;               // iterative_lsmr.jl:251
-    LsmrFirstElem e;
-    e.r = sqrt(d);                         // :252
-    e.P = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
-    e.vt = beta_zero ? 0.0 : g0 * inv_beta * e.P;      // lsmr.jl:76
-    return e;
-}
-
 // ||x||^2 = total: lsmr_commit's evaluation of the rules (lsmr.jl:205-231), without the store
 __device__ inline void lsmr_decide(LsmrState &s, double total) {
     s.iter += 1;
@@ -225,112 +167,6 @@ __device__ __forceinline__ double lsq_block_reduce_lds(double v, double *sh /* 1
     }
     lsq_lds_barrier();
     return r;
-}
-
-// the product half of a launch, from the staged gather vector on: (cautious: wait for the record) | stream | record | epilogue
-__device__ __forceinline__ void lsmr3_product(const SellDev &S, int wrows, int m, const LsmrFused &a, const double *xl, double *yw,
-                                              double *sh, double *s_vs, double *s_cu, int *s_done) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int Q = LSQ_SELL_ROWS_MAX / LSQ_BIG_NT;
-    const int pb = (int)blockIdx.x - a.ub, npb = (int)gridDim.x - a.ub;
-    double racc = 0.0;
-    bool have_scalars = false;
-    if (a.cautious) {
-        // CAUTIOUS launch: the host expects (or cannot exclude) that the finished iteration was the last.  The product workgroups
-        // look at workgroup 0's record first -- ~8 us into the launch -- and stream only if the solve goes on: a launch that commits
-        // the stop then costs what the update workgroups cost, and one that does not starts its product 8 us late instead of paying a
-        // wasted product, a skipped tail and a host round trip.  (Same bounded wait, same failure path as below.)
-        if (tid == 0) {
-            LsmrHandoffWords rec = lsmr_handoff_request(a.ho);
-            long long spins = 0;
-            while (!lsmr_handoff_valid(rec, a.tag)) {
-                if (++spins > (a.test_no_record ? 4096 : LSQ_FUSED_SPIN_LIMIT)) break;
-                __builtin_amdgcn_s_sleep(8);
-                rec = lsmr_handoff_request(a.ho);
-            }
-            const bool ok = spins <= (a.test_no_record ? 4096 : LSQ_FUSED_SPIN_LIMIT);
-            *s_vs = __longlong_as_double((long long)((rec.w[0] & 0xffffffffull) | (rec.w[1] << 32)));
-            *s_cu = __longlong_as_double((long long)((rec.w[2] & 0xffffffffull) | (rec.w[3] << 32)));
-            *s_done = ok ? (int)(rec.w[4] & 0xffffffffull) : 2;
-            if (!ok) {
-                __hip_atomic_store(&a.st_out->istop, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.st_out->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.st_out->notdone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        if (*s_done) return;
-        have_scalars = true;
-    }
-    for (int w = pb; w < S.nblocks; w += npb) {
-        const int base = w * wrows, rows = min(wrows, m - base);
-        const int s0 = w * S.spw, s1 = s0 + S.spw;
-        double pre[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) pre[q] = a.uold[base + min(tid + q * LSQ_BIG_NT, rows - 1)];
-        // (sell_wave_slices with one addition: wave 0 requests workgroup 0's record BEFORE its last slice, so that the record's
-        //  latency -- microseconds on a saturated memory system -- passes during that slice instead of holding up the epilogue)
-        LsmrHandoffWords rec;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) rec.w[k] = 0ull;
-        {
-            constexpr int NW = LSQ_BIG_NT / 64;
-            int sidx = s0 + wv;
-            SellSliceRef A = sell_slice_ref(S, sidx, s1, lane);
-            __syncthreads();      // w staged / the previous window's epilogue is done with yw
-            unsigned long long poll = 0ull;     // the decision word as it was when this wave's previous slice began
-            for (; sidx < s1; sidx += NW) {
-                // the finished iteration was the last: stop streaming (the launch that commits the stop costs ~12 us instead of a
-                // whole product; the word was requested a slice ago, so looking at it waits for nothing)
-                if (!have_scalars && (unsigned)(poll >> 32) == a.tag && (poll & 1ull)) break;
-                if (!have_scalars) poll = __hip_atomic_load(&a.ho->w[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const SellSliceRef r = A;
-                A = sell_slice_ref(S, sidx + NW, s1, lane);
-                if (!have_scalars && tid == 0 && sidx + NW >= s1) rec = lsmr_handoff_request(a.ho);
-                const size_t oa = (size_t)r.sm.x + lane * 2;
-                const unsigned pos = r.inf & LSQ_SELL_POS_MASK;
-                double sum = 0.0, sq = 0.0;
-                sell_lane_sum<false>(S.val + oa, S.idx16 + oa, r.sm.y, (int)(r.inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
-                if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
-            }
-        }
-        if (!have_scalars && tid == 0) {
-            // (published ~15 us before the early request in the usual case; otherwise ask again, bounded)
-            long long spins = 0;
-            while (!lsmr_handoff_valid(rec, a.tag)) {
-                if (++spins > (a.test_no_record ? 4096 : LSQ_FUSED_SPIN_LIMIT)) break;
-                __builtin_amdgcn_s_sleep(8);
-                rec = lsmr_handoff_request(a.ho);
-            }
-            const bool ok = spins <= (a.test_no_record ? 4096 : LSQ_FUSED_SPIN_LIMIT);
-            *s_vs = __longlong_as_double((long long)((rec.w[0] & 0xffffffffull) | (rec.w[1] << 32)));
-            *s_cu = __longlong_as_double((long long)((rec.w[2] & 0xffffffffull) | (rec.w[3] << 32)));
-            *s_done = ok ? (int)(rec.w[4] & 0xffffffffull) : 2;
-            if (!ok) {      // never silent: the solve ends with istop = 99 and the host returns an error
-                __hip_atomic_store(&a.st_out->istop, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.st_out->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.st_out->notdone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        have_scalars = true;
-        __syncthreads();
-        if (*s_done) return;                 // the finished iteration was the last (the update workgroups finish x), or the hand-off failed
-        const double vs = *s_vs, cu = *s_cu;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int i = tid + q * LSQ_BIG_NT;
-            if (i < rows) {
-                const double un = vs * yw[i] - cu * pre[q];
-                a.unew[base + i] = un;
-                racc += un * un;
-            }
-        }
-    }
-    const double bv = block_sum<LSQ_BIG_NT>(racc, sh);
-    if (tid == 0) {
-        a.pu_out[pb] = bv;
-        if (pb == 0) *a.npu_out = npb;
-    }
 }
 
 template <int = 0>
@@ -471,121 +307,104 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             if (tid + q * LSQ_BIG_NT < n) xl[tid + q * LSQ_BIG_NT] = xr[q];
         if (dflag) return;      // launches queued behind a finished solve stop here
     }
-    lsmr3_product(S, wrows, m, a, xl, yw, sh, &s_vs, &s_cu, &s_done);
-}
-
-// Launch 1 of an LM solve with the setup riding along (LsmrFirstLm): a kernel of its own, so that the square roots and divisions
-// of the setup (a dozen per thread, twice) do not weigh on the registers of the launch that runs 2-6 times per solve.
-template <int = 0>
-__global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_first(SellDev S, int wrows, int m, int nxpad, LsmrFused a, LsmrFirstLm fl) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double sh[LSQ_BIG_NT / 64];
-    __shared__ double shm[LSQ_BIG_NT / 64];
-    __shared__ LsmrState ns;
-    __shared__ double s_vs, s_cu;
-    __shared__ int s_done;
-    double *xl = smem;            // nxpad doubles
-    double *yw = smem + nxpad;    // LSQ_SELL_ROWS_MAX doubles
-    const int tid = threadIdx.x;
-    const int n = a.n;
-    const bool upd = (int)blockIdx.x < a.ub;
-    if (upd) {
-        // ---- launch 1 of an LM solve with the setup riding along (LsmrFirstLm) ----
-        constexpr int NQ1 = (LSQ_LDS_X_MAX + LSQ_BIG_NT - 1) / LSQ_BIG_NT;
-        double cs[NQ1], gv[NQ1];
-#pragma unroll
-        for (int q = 0; q < NQ1; ++q) {
-            const int j = min(tid + q * LSQ_BIG_NT, n - 1);
-            cs[q] = fl.colsum[j];
-            gv[q] = fl.g[j];
-        }
-        double mean, gmax;
-        lsmr_first_mean<NQ1>(cs, gv, n, sh, shm, mean, gmax);
-        const double lo_d = fl.min_diag * mean, hi_d = fl.max_diag * mean;
-        const double beta = dampened_norm(fl.ysumsq, 0.0);   // u_x = 0 (zerosvector, il:246)
-        const bool beta_zero = !(beta > 0.0);
-        const double inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
-        double a2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < NQ1; ++q)
-            if (tid + q * LSQ_BIG_NT < n) {
-                const LsmrFirstElem e = lsmr_first_elem(cs[q], gv[q], lo_d, hi_d, fl.inv_delta, inv_beta, beta_zero);
-                a2 += e.vt * e.vt;
-            }
-        const double alpha2 = block_sum<LSQ_BIG_NT>(a2, sh);     // (valid in thread 0)
-        if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)&ns)[tid] = 0ull;
-        __syncthreads();
+    constexpr int Q = LSQ_SELL_ROWS_MAX / LSQ_BIG_NT;
+    const int pb = (int)blockIdx.x - a.ub, npb = (int)gridDim.x - a.ub;
+    double racc = 0.0;
+    bool have_scalars = false;
+    if (a.cautious) {
+        // CAUTIOUS launch: the host expects (or cannot exclude) that the finished iteration was the last.  The product workgroups
+        // look at workgroup 0's record first -- ~8 us into the launch -- and stream only if the solve goes on: a launch that commits
+        // the stop then costs what the update workgroups cost, and one that does not starts its product 8 us late instead of paying a
+        // wasted product, a skipped tail and a host round trip.  (Same bounded wait, same failure path as below.)
         if (tid == 0) {
-            ns.notdone = 1; ns.first = 1;
-            ns.atol = fl.atol; ns.btol = fl.btol; ns.ctol = fl.ctol;
-            ns.maxiter = fl.maxiter; ns.epoch = fl.epoch;
-            lsmr_scalars(ns, fl.ysumsq, 0.0, alpha2, true, false);
-            ns.first = 0;
-            if (!(ns.normAr != 0.0)) { ns.done = 1; ns.notdone = 0; }      // lsmr.jl:115: exit if b = 0 or A'b = 0
+            LsmrHandoffWords rec = lsmr_handoff_request(a.ho);
+            long long spins = 0;
+            while (!lsmr_handoff_valid(rec, a.tag)) {
+                if (++spins > (a.test_no_record ? 4096 : LSQ_FUSED_SPIN_LIMIT)) break;
+                __builtin_amdgcn_s_sleep(8);
+                rec = lsmr_handoff_request(a.ho);
+            }
+            const bool ok = spins <= (a.test_no_record ? 4096 : LSQ_FUSED_SPIN_LIMIT);
+            s_vs = __longlong_as_double((long long)((rec.w[0] & 0xffffffffull) | (rec.w[1] << 32)));
+            s_cu = __longlong_as_double((long long)((rec.w[2] & 0xffffffffull) | (rec.w[3] << 32)));
+            s_done = ok ? (int)(rec.w[4] & 0xffffffffull) : 2;
+            if (!ok) {
+                __hip_atomic_store(&a.st_out->istop, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.st_out->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.st_out->notdone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
-        const bool done_now = ns.done != 0;
-        const double vs = ns.vscale, cu = ns.cu;
-        if (blockIdx.x == 0) {
-            if (tid == 0 && !a.test_no_record) lsmr_handoff_write(a.ho, a.tag, vs, cu, done_now ? 1 : 0);
-            if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)a.st_out)[tid] = ((const unsigned long long *)&ns)[tid];
-            if (tid == 0) {
-                *fl.out_grad = gmax;
-                publish_relaxed(a.mail, &ns);
-            }
-        }
-        double aux = 0.0;
-#pragma unroll
-        for (int q = 0; q < NQ1; ++q) {
-            const int j = tid + q * LSQ_BIG_NT;
-            if (j < n && (q % a.ub) == (int)blockIdx.x) {       // this workgroup's share: every ub-th group of 1024
-                const LsmrFirstElem e = lsmr_first_elem(cs[q], gv[q], lo_d, hi_d, fl.inv_delta, inv_beta, beta_zero);
-                fl.dg[j] = e.r;
-                fl.damp[j] = e.r;                             // the reference clobbers the caller's damp (:252)
-                fl.P[j] = e.P;
-                const double vj = e.vt * vs;                    // lsmr.jl:78 rmul!(v, inv(alpha))
-                a.v[j] = vj;
-                a.h_out[j] = vj;                                // :89-90, iterative_lsmr.jl:183,242
-                a.hbar_out[j] = 0.0;
-                a.x_out[j] = 0.0;
-                a.xout[j] = 0.0;
-                const double un = (vj * e.P) * e.r;            // damped rows of u_1: d.*t - cu*0 (zerosvector, :246)
-                a.ux[j] = un;
-                aux += un * un;
-            }
-        }
-        if (done_now) return;
-        const double bux = lsq_block_reduce_lds<false>(aux, sh);
-        if (tid == 0) {
-            a.px_out[blockIdx.x] = bux;
-            if (blockIdx.x == 0) *a.npx_out = a.ub;
-        }
-        return;
+        if (s_done) return;
+        have_scalars = true;
     }
-    constexpr int XR = (LSQ_LDS_X_MAX + LSQ_BIG_NT - 1) / LSQ_BIG_NT;
-    {
-        // launch 1 with the setup riding along: w = ((g/beta_1 .* P) .* P) .* s, every factor formed here (LsmrFirstLm)
-        double cs[XR], gv[XR], sr[XR];
+    for (int w = pb; w < S.nblocks; w += npb) {
+        const int base = w * wrows, rows = min(wrows, m - base);
+        const int s0 = w * S.spw, s1 = s0 + S.spw;
+        double pre[Q];
 #pragma unroll
-        for (int q = 0; q < XR; ++q) {
-            const int j = min(tid + q * LSQ_BIG_NT, n - 1);
-            cs[q] = fl.colsum[j];
-            gv[q] = fl.g[j];
-            sr[q] = fl.cs ? fl.cs[j] : 1.0;
-        }
-        double mean, gmax;
-        lsmr_first_mean<XR>(cs, gv, n, sh, shm, mean, gmax);
-        const double lo_d = fl.min_diag * mean, hi_d = fl.max_diag * mean;
-        const double beta = dampened_norm(fl.ysumsq, 0.0);
-        const bool beta_zero = !(beta > 0.0);
-        const double inv_beta = beta > 0.0 ? 1.0 / beta : 1.0;
+        for (int q = 0; q < Q; ++q) pre[q] = a.uold[base + min(tid + q * LSQ_BIG_NT, rows - 1)];
+        // (sell_wave_slices with one addition: wave 0 requests workgroup 0's record BEFORE its last slice, so that the record's
+        //  latency -- microseconds on a saturated memory system -- passes during that slice instead of holding up the epilogue)
+        LsmrHandoffWords rec;
 #pragma unroll
-        for (int q = 0; q < XR; ++q)
-            if (tid + q * LSQ_BIG_NT < n) {
-                const LsmrFirstElem e = lsmr_first_elem(cs[q], gv[q], lo_d, hi_d, fl.inv_delta, inv_beta, beta_zero);
-                const double t = e.vt * e.P;
-                xl[tid + q * LSQ_BIG_NT] = fl.cs ? t * sr[q] : t;
+        for (int k = 0; k < 5; ++k) rec.w[k] = 0ull;
+        {
+            constexpr int NW = LSQ_BIG_NT / 64;
+            int sidx = s0 + wv;
+            SellSliceRef A = sell_slice_ref(S, sidx, s1, lane);
+            __syncthreads();      // w staged / the previous window's epilogue is done with yw
+            unsigned long long poll = 0ull;     // the decision word as it was when this wave's previous slice began
+            for (; sidx < s1; sidx += NW) {
+                // the finished iteration was the last: stop streaming (the launch that commits the stop costs ~12 us instead of a
+                // whole product; the word was requested a slice ago, so looking at it waits for nothing)
+                if (!have_scalars && (unsigned)(poll >> 32) == a.tag && (poll & 1ull)) break;
+                if (!have_scalars) poll = __hip_atomic_load(&a.ho->w[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const SellSliceRef r = A;
+                A = sell_slice_ref(S, sidx + NW, s1, lane);
+                if (!have_scalars && tid == 0 && sidx + NW >= s1) rec = lsmr_handoff_request(a.ho);
+                const size_t oa = (size_t)r.sm.x + lane * 2;
+                const unsigned pos = r.inf & LSQ_SELL_POS_MASK;
+                double sum = 0.0, sq = 0.0;
+                sell_lane_sum<false>(S.val + oa, S.idx16 + oa, r.sm.y, (int)(r.inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
+                if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
             }
+        }
+        if (!have_scalars && tid == 0) {
+            // (published ~15 us before the early request in the usual case; otherwise ask again, bounded)
+            long long spins = 0;
+            while (!lsmr_handoff_valid(rec, a.tag)) {
+                if (++spins > (a.test_no_record ? 4096 : LSQ_FUSED_SPIN_LIMIT)) break;
+                __builtin_amdgcn_s_sleep(8);
+                rec = lsmr_handoff_request(a.ho);
+            }
+            const bool ok = spins <= (a.test_no_record ? 4096 : LSQ_FUSED_SPIN_LIMIT);
+            s_vs = __longlong_as_double((long long)((rec.w[0] & 0xffffffffull) | (rec.w[1] << 32)));
+            s_cu = __longlong_as_double((long long)((rec.w[2] & 0xffffffffull) | (rec.w[3] << 32)));
+            s_done = ok ? (int)(rec.w[4] & 0xffffffffull) : 2;
+            if (!ok) {      // never silent: the solve ends with istop = 99 and the host returns an error
+                __hip_atomic_store(&a.st_out->istop, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.st_out->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.st_out->notdone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        have_scalars = true;
+        __syncthreads();
+        if (s_done) return;                 // the finished iteration was the last (the update workgroups finish x), or the hand-off failed
+        const double vs = s_vs, cu = s_cu;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int i = tid + q * LSQ_BIG_NT;
+            if (i < rows) {
+                const double un = vs * yw[i] - cu * pre[q];
+                a.unew[base + i] = un;
+                racc += un * un;
+            }
+        }
     }
-    lsmr3_product(S, wrows, m, a, xl, yw, sh, &s_vs, &s_cu, &s_done);
+    const double bv = block_sum<LSQ_BIG_NT>(racc, sh);
+    if (tid == 0) {
+        a.pu_out[pb] = bv;
+        if (pb == 0) *a.npu_out = npb;
+    }
 }
