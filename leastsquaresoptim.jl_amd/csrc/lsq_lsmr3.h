@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
                 const size_t oa = (size_t)r.sm.x + lane * 2;
                 const unsigned pos = r.inf & LSQ_SELL_POS_MASK;
                 double sum = 0.0, sq = 0.0;
-                sell_lane_sum<false>(S.val + oa, S.idx16 + oa, r.sm.y, (int)(r.inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
+                sell_lane_sum<false>(S.val + oa, S.idx16 + oa, r.sm.y, (int)(r.inf >> LSQ_SELL_POS_BITS), xl, sum, sq, lane);
                 if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
             }
         }

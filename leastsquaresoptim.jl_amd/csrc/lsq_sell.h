@@ -15,9 +15,11 @@
 //       J'*y: <= 2560 consecutive columns of one <= 16384-row gather window (y[window] in LDS); blocks are placed XCD-aware
 //             (lsq_xcd_block: the column blocks of a window behind one L2)
 //   * inside a block the outputs are sorted by entry count and grouped 64 at a time (a slice,
-//     lane = output); a slice stores max-count (rounded up to even) entries per lane, interleaved
+//     lane = output); a slice stores max-count L entries per lane, interleaved
 //     in pairs:  slot(j, lane) = off + ((j/2)*64 + lane)*2 + (j%2)   -> a lane reads one 16-byte
-//     value pair and one 4-byte index pair per step, a wave reads 1 KiB + 256 B contiguous.
+//     value pair and one 4-byte index pair per step, a wave reads 1 KiB + 256 B contiguous;
+//     an ODD slice (round 5: L is no longer rounded up to even) ends with one unpaired entry per lane in a
+//     compact group of its own:  slot(L-1, lane) = off + (L/2)*128 + lane  (512 B + 128 B per wave).
 //     Sorting makes the padding small (~7 % on the Poisson(10) rows of the C4 workload).
 //   * every block is padded to the same number of slices (empty ones at the end), so block b owns slices
 //     [b * spw, (b + 1) * spw) and no per-block table has to be read at the head of a launch;
@@ -80,7 +82,9 @@ __device__ __forceinline__ void sell_batch_sum(SellBatch<U> &B, int p0, int np, 
         double p0v = B.a[u].x * x0, p1v = B.a[u].y * x1;
         asm volatile("" : "+v"(p0v), "+v"(p1v));   // (the products exist here, whatever the selections below)
         const int j = 2 * (p0 + u);
-        const bool in0 = j < len, in1 = j + 1 < len;   // (len <= 2 np: clamped surplus pairs are never selected)
+        // (clamped surplus pairs are never selected: an odd slice has len up to 2 np + 1, so the pair index decides, not len alone)
+        const bool pin = !CLAMP || p0 + u < np;
+        const bool in0 = pin && j < len, in1 = pin && j + 1 < len;
         const double t0 = sum + p0v;
         sum = in0 ? t0 : sum;
         const double t1 = sum + p1v;
@@ -97,10 +101,39 @@ __device__ __forceinline__ void sell_batch_sum(SellBatch<U> &B, int p0, int np, 
 // all products of one lane's output inside one slice (L entries per lane, even and wave-uniform; `len` of them real), added in
 // index order.  A slice of the C4 workload holds 4-10 pairs per lane: one batch, one memory round trip (the round-1 loop paid one
 // per 4 pairs plus one per leftover pair, in sequence).
+// The unpaired last entry of an odd slice (compact group behind the pairs).  vp / ip point at the lane's first pair (off + 2 lane):
+// the group's element for this lane sits at off + (L/2)*128 + lane.  Requested with the batches, added last (index order).
+struct SellTail {
+    double a;
+    unsigned short c;
+};
+__device__ __forceinline__ SellTail sell_tail_load(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L, int lane) {
+    SellTail t;
+    const long long o = (long long)(L >> 1) * 128 - lane;
+    t.a = vp[o];
+    t.c = ip[o];
+    return t;
+}
+template <bool SQ>
+__device__ __forceinline__ void sell_tail_sum(const SellTail &t, int L, int len, const double *xl, double &sum, double &sq) {
+    double p = t.a * xl[t.c];
+    asm volatile("" : "+v"(p));
+    const bool in = L - 1 < len;
+    const double s1 = sum + p;
+    sum = in ? s1 : sum;
+    if constexpr (SQ) {
+        const double q1 = sq + t.a * t.a;
+        sq = in ? q1 : sq;
+    }
+}
 template <bool SQ>
 __device__ __forceinline__ void sell_lane_sum_from(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int p0, int L,
-                                                   int len, const double *xl, double &sum, double &sq) {
+                                                   int len, const double *xl, double &sum, double &sq, int lane) {
     const int np = L >> 1;
+    SellTail tail;
+    tail.a = 0.0;
+    tail.c = 0;
+    if (L & 1) tail = sell_tail_load(vp, ip, L, lane);      // (wave-uniform; in flight with the batches)
     for (; p0 + 8 <= np; p0 += 8) {
         SellBatch<8> B;
         sell_batch_load<8, false>(B, vp, ip, p0, np);
@@ -120,12 +153,13 @@ __device__ __forceinline__ void sell_lane_sum_from(const double *__restrict__ vp
         sell_batch_load<2, true>(B, vp, ip, p0, np);
         sell_batch_sum<2, true, SQ>(B, p0, np, len, xl, sum, sq);
     }
+    if (L & 1) sell_tail_sum<SQ>(tail, L, len, xl, sum, sq);
 }
 
 template <bool SQ>
 __device__ __forceinline__ void sell_lane_sum(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L, int len,
-                                              const double *xl, double &sum, double &sq) {
-    sell_lane_sum_from<SQ>(vp, ip, 0, L, len, xl, sum, sq);
+                                              const double *xl, double &sum, double &sq, int lane) {
+    sell_lane_sum_from<SQ>(vp, ip, 0, L, len, xl, sum, sq, lane);
 }
 
 // The slices of one wave (s0 + wave, + 16, ...), with the next slice's descriptor requested before the current slice's stream.
@@ -159,7 +193,7 @@ __device__ __forceinline__ void sell_wave_slices(const SellDev &S, int s0, int s
         const size_t oa = (size_t)a.sm.x + lane * 2;
         const unsigned pos = a.inf & LSQ_SELL_POS_MASK;
         double sum = 0.0, sq = 0.0;
-        sell_lane_sum<SQ>(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
+        sell_lane_sum<SQ>(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), xl, sum, sq, lane);
         if (pos != LSQ_SELL_POS_MASK) out(pos, sum, sq);
     }
 }
@@ -244,7 +278,8 @@ __device__ __forceinline__ void sell_batch_sum2(SellBatch<U> &B, int p0, int np,
         double a0 = B.a[u].x * xa[i0], a1 = B.a[u].y * xa[i1], b0 = B.a[u].x * xb[i0], b1 = B.a[u].y * xb[i1];
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));   // (the products exist here: see sell_batch_sum)
         const int j = 2 * (p0 + u);
-        const bool in0 = j < len, in1 = j + 1 < len;
+        const bool pin = !CLAMP || p0 + u < np;
+        const bool in0 = pin && j < len, in1 = pin && j + 1 < len;
         const double ta0 = sa + a0;
         sa = in0 ? ta0 : sa;
         const double ta1 = sa + a1;
@@ -256,9 +291,13 @@ __device__ __forceinline__ void sell_batch_sum2(SellBatch<U> &B, int p0, int np,
     }
 }
 __device__ __forceinline__ void sell_lane_sum2(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int L, int len,
-                                               const double *xa, const double *xb, double &sa, double &sb) {
+                                               const double *xa, const double *xb, double &sa, double &sb, int lane) {
     const int np = L >> 1;
     int p0 = 0;
+    SellTail tail;
+    tail.a = 0.0;
+    tail.c = 0;
+    if (L & 1) tail = sell_tail_load(vp, ip, L, lane);      // (the unpaired last entry of an odd slice)
     for (; p0 + 8 <= np; p0 += 8) {
         SellBatch<8> B;
         sell_batch_load<8, false>(B, vp, ip, p0, np);
@@ -277,6 +316,14 @@ __device__ __forceinline__ void sell_lane_sum2(const double *__restrict__ vp, co
         SellBatch<2> B;
         sell_batch_load<2, true>(B, vp, ip, p0, np);
         sell_batch_sum2<2, true>(B, p0, np, len, xa, xb, sa, sb);
+    }
+    if (L & 1) {
+        double pa = tail.a * xa[tail.c], pb = tail.a * xb[tail.c];
+        asm volatile("" : "+v"(pa), "+v"(pb));
+        const bool in = L - 1 < len;
+        const double ta = sa + pa, tb = sb + pb;
+        sa = in ? ta : sa;
+        sb = in ? tb : sb;
     }
 }
 constexpr int LSQ_PAIR_X_MAX = 10200;      // doubles per gather vector: 2 x 10200 x 8 B + the kernel's static LDS (~140 B) <= 160 KB
@@ -377,7 +424,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows_pair(SellDev S, int wr
                 const double fa = e.fa[pidx], fb = e.fb[pidx];        // (coalesced; in flight during the stream)
                 const size_t oa = (size_t)a.sm.x + lane * 2;
                 double sum_a = 0.0, sum_b = 0.0;
-                sell_lane_sum2(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), la, lb, sum_a, sum_b);
+                sell_lane_sum2(S.val + oa, S.idx16 + oa, a.sm.y, (int)(a.inf >> LSQ_SELL_POS_BITS), la, lb, sum_a, sum_b, lane);
                 if (valid) {
                     const double r_a = sum_a - fa, r_b = sum_b - fb;
                     e.out_b_perm[pidx] = r_b;
@@ -480,11 +527,15 @@ __global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int w
             fetch_x(cw);
             SellSliceRef a[G];
             SellBatch<2> B[G];
+            SellTail T[G];       // the unpaired last entry of an odd slice of <= 4 entries (longer ones: with the rest, below)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 a[g] = A[g];
                 const size_t oa = (size_t)a[g].sm.x + lane * 2;   // (an empty slice: a valid address, nothing selected)
                 sell_batch_load<2, true>(B[g], S.val + oa, S.idx16 + oa, 0, max(a[g].sm.y >> 1, 1));
+                T[g].a = 0.0;
+                T[g].c = 0;
+                if ((a[g].sm.y & 1) && a[g].sm.y <= 4) T[g] = sell_tail_load(S.val + oa, S.idx16 + oa, a[g].sm.y, lane);   // (wave-uniform)
             }
             const bool more = cw + 1 < ncw, next_block = w + (int)gridDim.x < nrb;
             if (more) refs_at(w, cw + 1);
@@ -500,11 +551,12 @@ __global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int w
             __syncthreads();
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int np = a[g].sm.y >> 1, len = (int)(a[g].inf >> LSQ_SELL_POS_BITS);
+                const int L = a[g].sm.y, np = L >> 1, len = (int)(a[g].inf >> LSQ_SELL_POS_BITS);
                 const unsigned pos = a[g].inf & LSQ_SELL_POS_MASK;
-                if (np == 0) continue;   // (wave-uniform)
+                if (L == 0) continue;   // (wave-uniform)
                 double sum = pos != LSQ_SELL_POS_MASK ? yw[pos] : 0.0, sq = 0.0;
-                sell_batch_sum<2, true, false>(B[g], 0, np, len, xl, sum, sq);
+                if (np > 0) sell_batch_sum<2, true, false>(B[g], 0, np, len, xl, sum, sq);
+                if ((L & 1) && L <= 4) sell_tail_sum<false>(T[g], L, len, xl, sum, sq);     // (index order: behind the pairs)
                 if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
             }
             // rows with more than four entries inside the window: the rest of their slices, one slice after the other
@@ -514,7 +566,7 @@ __global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int w
                 const unsigned pos = a[g].inf & LSQ_SELL_POS_MASK;
                 const size_t oa = (size_t)a[g].sm.x + lane * 2;
                 double sum = pos != LSQ_SELL_POS_MASK ? yw[pos] : 0.0, sq = 0.0;
-                sell_lane_sum_from<false>(S.val + oa, S.idx16 + oa, 2, a[g].sm.y, (int)(a[g].inf >> LSQ_SELL_POS_BITS), xl, sum, sq);
+                sell_lane_sum_from<false>(S.val + oa, S.idx16 + oa, 2, a[g].sm.y, (int)(a[g].inf >> LSQ_SELL_POS_BITS), xl, sum, sq, lane);
                 if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
             }
         }

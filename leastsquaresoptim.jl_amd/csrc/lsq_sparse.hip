@@ -182,7 +182,9 @@ static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, cons
                 const int sg = first + ord[g * 64 + l];
                 L = std::max(L, ptr[sg + 1] - ptr[sg]);
             }
-            L = (L + 1) & ~1;
+            // (round 5: L is NOT rounded up to even any more.  An odd slice ends with one UNPAIRED entry per lane, stored as a
+            //  compact group of 64 values behind the pairs -- at 3.3 entries per sub-row (wide n) the rounding was 13 % of the
+            //  stream, on C4's rows 4.7 %.  lsq_sell.h: sell_tail_*)
             if (nstore + (long long)L * 64 > 2147480000LL) return LSQ_EDIM;
             const long long off = nstore;
             nstore += (long long)L * 64;
@@ -201,7 +203,8 @@ static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, cons
                 info.push_back((unsigned)pos | ((unsigned)len << LSQ_SELL_POS_BITS));
                 for (int j = 0; j < len; ++j) {
                     const int e = ptr[sg] + j;
-                    const size_t slot_e = (size_t)off + ((size_t)(j / 2) * 64 + l) * 2 + (j & 1);
+                    const size_t slot_e = (L & 1) && j == L - 1 ? (size_t)off + (size_t)(L >> 1) * 128 + l
+                                                                : (size_t)off + ((size_t)(j / 2) * 64 + l) * 2 + (j & 1);
                     map[slot_e] = srcmap[e];
                     idx16[slot_e] = idx16_of(e);
                     if (want_col16) col16[slot_e] = col_of(e);
@@ -1063,8 +1066,10 @@ k_sell_rowsq(SellDev S, int wrows, int m, int ncw, int cwidth, double *__restric
                 const unsigned short *ip = S.idx16 + (size_t)sm.x + lane * 2;
                 double acc = (ncw > 1 && valid) ? out[base + pos] : 0.0;
                 for (int j = 0; j < len; ++j) {
-                    double a = vp[(size_t)(j / 2) * 128 + (j & 1)];
-                    if (cscale) a *= cscale[cw * cwidth + ip[(size_t)(j / 2) * 128 + (j & 1)]];   // (column-scaled: the entry of J)
+                    // (pairs, then -- odd slice -- the unpaired last entry in its compact group: lsq_sell.h)
+                    const long long o = (sm.y & 1) && j == sm.y - 1 ? (long long)(sm.y >> 1) * 128 - lane : (long long)(j / 2) * 128 + (j & 1);
+                    double a = vp[o];
+                    if (cscale) a *= cscale[cw * cwidth + ip[o]];   // (column-scaled: the entry of J)
                     acc += a * a;
                 }
                 if (valid) out[base + pos] = acc;
