@@ -126,14 +126,14 @@ __device__ __forceinline__ void sell_tail_sum(const SellTail &t, int L, int len,
         sq = in ? q1 : sq;
     }
 }
-template <bool SQ>
+template <bool SQ, bool TAIL = true>
 __device__ __forceinline__ void sell_lane_sum_from(const double *__restrict__ vp, const unsigned short *__restrict__ ip, int p0, int L,
                                                    int len, const double *xl, double &sum, double &sq, int lane) {
     const int np = L >> 1;
     SellTail tail;
     tail.a = 0.0;
     tail.c = 0;
-    if (L & 1) tail = sell_tail_load(vp, ip, L, lane);      // (wave-uniform; in flight with the batches)
+    if (TAIL && (L & 1)) tail = sell_tail_load(vp, ip, L, lane);      // (wave-uniform; in flight with the batches)
     for (; p0 + 8 <= np; p0 += 8) {
         SellBatch<8> B;
         sell_batch_load<8, false>(B, vp, ip, p0, np);
@@ -153,7 +153,7 @@ __device__ __forceinline__ void sell_lane_sum_from(const double *__restrict__ vp
         sell_batch_load<2, true>(B, vp, ip, p0, np);
         sell_batch_sum<2, true, SQ>(B, p0, np, len, xl, sum, sq);
     }
-    if (L & 1) sell_tail_sum<SQ>(tail, L, len, xl, sum, sq);
+    if (TAIL && (L & 1)) sell_tail_sum<SQ>(tail, L, len, xl, sum, sq);
 }
 
 template <bool SQ>
@@ -527,15 +527,11 @@ __global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int w
             fetch_x(cw);
             SellSliceRef a[G];
             SellBatch<2> B[G];
-            SellTail T[G];       // the unpaired last entry of an odd slice of <= 4 entries (longer ones: with the rest, below)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 a[g] = A[g];
                 const size_t oa = (size_t)a[g].sm.x + lane * 2;   // (an empty slice: a valid address, nothing selected)
                 sell_batch_load<2, true>(B[g], S.val + oa, S.idx16 + oa, 0, max(a[g].sm.y >> 1, 1));
-                T[g].a = 0.0;
-                T[g].c = 0;
-                if ((a[g].sm.y & 1) && a[g].sm.y <= 4) T[g] = sell_tail_load(S.val + oa, S.idx16 + oa, a[g].sm.y, lane);   // (wave-uniform)
             }
             const bool more = cw + 1 < ncw, next_block = w + (int)gridDim.x < nrb;
             if (more) refs_at(w, cw + 1);
@@ -551,12 +547,13 @@ __global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int w
             __syncthreads();
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int L = a[g].sm.y, np = L >> 1, len = (int)(a[g].inf >> LSQ_SELL_POS_BITS);
+                // (the column-windowed layout keeps EVEN slices -- build_sell's allow_odd = false: this kernel holds the heads of eight
+                //  slices, a window of x and the next descriptors in 256 registers, and every form of the unpaired-entry path spilled)
+                const int np = a[g].sm.y >> 1, len = (int)(a[g].inf >> LSQ_SELL_POS_BITS);
                 const unsigned pos = a[g].inf & LSQ_SELL_POS_MASK;
-                if (L == 0) continue;   // (wave-uniform)
+                if (np == 0) continue;   // (wave-uniform)
                 double sum = pos != LSQ_SELL_POS_MASK ? yw[pos] : 0.0, sq = 0.0;
-                if (np > 0) sell_batch_sum<2, true, false>(B[g], 0, np, len, xl, sum, sq);
-                if ((L & 1) && L <= 4) sell_tail_sum<false>(T[g], L, len, xl, sum, sq);     // (index order: behind the pairs)
+                sell_batch_sum<2, true, false>(B[g], 0, np, len, xl, sum, sq);
                 if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
             }
             // rows with more than four entries inside the window: the rest of their slices, one slice after the other
@@ -566,7 +563,7 @@ __global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int w
                 const unsigned pos = a[g].inf & LSQ_SELL_POS_MASK;
                 const size_t oa = (size_t)a[g].sm.x + lane * 2;
                 double sum = pos != LSQ_SELL_POS_MASK ? yw[pos] : 0.0, sq = 0.0;
-                sell_lane_sum_from<false>(S.val + oa, S.idx16 + oa, 2, a[g].sm.y, (int)(a[g].inf >> LSQ_SELL_POS_BITS), xl, sum, sq, lane);
+                sell_lane_sum_from<false, false>(S.val + oa, S.idx16 + oa, 2, a[g].sm.y, (int)(a[g].inf >> LSQ_SELL_POS_BITS), xl, sum, sq, lane);
                 if (pos != LSQ_SELL_POS_MASK) yw[pos] = sum;
             }
         }

@@ -142,7 +142,7 @@ static void free_segs(LsqSegs &S) {
 // skip_empty: segments without entries get no lane (the kernel must not rely on every output of a block being written).
 template <class SegRange, class Idx16, class ColOf>
 static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, const std::vector<int> &srcmap,
-                      SegRange seg_range, Idx16 idx16_of, ColOf col_of, bool want_col16, bool skip_empty = false) {
+                      SegRange seg_range, Idx16 idx16_of, ColOf col_of, bool want_col16, bool skip_empty = false, bool allow_odd = true) {
     std::vector<int> map;
     std::vector<int2> smeta;
     std::vector<unsigned> info;
@@ -185,6 +185,7 @@ static int build_sell(LsqSell &S, int nblocks, const std::vector<int> &ptr, cons
             // (round 5: L is NOT rounded up to even any more.  An odd slice ends with one UNPAIRED entry per lane, stored as a
             //  compact group of 64 values behind the pairs -- at 3.3 entries per sub-row (wide n) the rounding was 13 % of the
             //  stream, on C4's rows 4.7 %.  lsq_sell.h: sell_tail_*)
+            if (!allow_odd) L = (L + 1) & ~1;        // (the column-windowed J*v kernel: lsq_sell.h, k_sell_rows_wide)
             if (nstore + (long long)L * 64 > 2147480000LL) return LSQ_EDIM;
             const long long off = nstore;
             nstore += (long long)L * 64;
@@ -366,7 +367,8 @@ static int csc_create_impl(lsq_ctx *c, int m, int n, const int *colptr, const in
                     first = cw * m + rb * wrows;
                     count = std::min(wrows, m - rb * wrows);
                 },
-                [&](int e) { return (unsigned short)widx[e]; }, [&](int e) { return (unsigned short)widx[e]; }, false, true);
+                [&](int e) { return (unsigned short)widx[e]; }, [&](int e) { return (unsigned short)widx[e]; }, false, true,
+                /*allow_odd=*/false);
             J->srows.ncw = ncw;
             J->srows.cwidth = cwidth;
             if (st == LSQ_OK) LSQ_HIP(hipMalloc(&J->srows.d_sx, (size_t)n * sizeof(double)));
