@@ -340,7 +340,8 @@ static int csc_create_impl(lsq_ctx *c, int m, int n, const int *colptr, const in
             st = build_sell(
                 J->srows, nrb, rptr, map,
                 [&](int b, int &first, int &count) { first = b * wrows; count = std::min(wrows, m - first); },
-                [&](int e) { return (unsigned short)ridx[e]; }, [&](int e) { return (unsigned short)ridx[e]; }, false);
+                [&](int e) { return (unsigned short)ridx[e]; }, [&](int e) { return (unsigned short)ridx[e]; }, false, false,
+                /*allow_odd=*/!getenv("LSQ_SELL_EVEN_ROWS"));
         } else {
             // sub-rows (window, row): entries of a row keep their column order inside every window
             const int cwidth = (((n + ncw - 1) / ncw) + 1) & ~1;
@@ -418,7 +419,8 @@ static int csc_create_impl(lsq_ctx *c, int m, int n, const int *colptr, const in
                     first = gw * n + cb * ccols;
                     count = std::max(0, std::min(ccols, n - cb * ccols));
                 },
-                [&](int e) { return (unsigned short)(gidx[e] % grows); }, [&](int e) { return gcol[e]; }, n <= 65535);
+                [&](int e) { return (unsigned short)(gidx[e] % grows); }, [&](int e) { return gcol[e]; }, n <= 65535, false,
+                /*allow_odd=*/!getenv("LSQ_SELL_EVEN_COLS"));
             if (st == LSQ_OK) {
                 J->scols.ncb = ncb; J->scols.ccols = ccols; J->scols.ngw = ngw; J->scols.grows = grows;
                 LSQ_HIP(hipMalloc(&J->scols.d_part, (size_t)ngw * n * 2 * sizeof(double)));
