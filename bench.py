@@ -306,6 +306,24 @@ def main():
             pass
 
     # (the headline measurement is complete at this point: a failure in the reported-alongside legs must not lose it)
+    # Order: the device-only secondary legs FIRST.  The OpenMP legs after them (oracle/lsq_oracle_omp.c under
+    # OMP_PROC_BIND=close, then tools/hostg's producer threads) leave bound threads behind in this process, and the
+    # host-synchronous Dogleg loop of dense_secondary measured 20.3 instead of 8.0 ms per outer iteration when it ran after both
+    # (either one alone: 8.0; putting this thread's affinity mask back did not cure it).
+    skip = set(filter(None, os.environ.get("LSQ_BENCH_SKIP", "").split(",")))     # diagnostics: legs to leave out (generic, dense, wide)
+    dense = None
+    if not a.no_cpu and world == 1 and not a.no_dense and "dense" not in skip:
+        try:
+            dense = dense_secondary(ctx, lsq)
+        except Exception as e:   # noqa: BLE001
+            dense = {"error": repr(e)}
+
+    wide = None
+    if not a.no_cpu and world == 1 and "wide" not in skip:
+        try:
+            wide = sparse_secondary(ctx, lsq)
+        except Exception as e:   # noqa: BLE001
+            wide = {"error": repr(e)}
     cpu = parity = None
     if not a.no_cpu and a.cpu_steps > 0 and world == 1:   # reported at N = 1 only
         try:
@@ -340,24 +358,11 @@ def main():
         except Exception as e:   # noqa: BLE001
             ref_sched = {"error": repr(e)}
     generic = None
-    if not a.no_cpu and world == 1:
+    if not a.no_cpu and world == 1 and "generic" not in skip:
         try:
             generic = generic_g(a, ctx, lsq, inputs, pr.b)
         except Exception as e:   # noqa: BLE001
             generic = {"error": repr(e)}
-    dense = None
-    if not a.no_cpu and world == 1 and not a.no_dense:
-        try:
-            dense = dense_secondary(ctx, lsq)
-        except Exception as e:   # noqa: BLE001
-            dense = {"error": repr(e)}
-
-    wide = None
-    if not a.no_cpu and world == 1:
-        try:
-            wide = sparse_secondary(ctx, lsq)
-        except Exception as e:   # noqa: BLE001
-            wide = {"error": repr(e)}
 
     value = a.steps * world / dt
     out = {"metric": "lm_lsmr_outer_iterations_per_sec", "value": value, "unit": "LM outer iterations/s",
@@ -545,11 +550,15 @@ def generic_g(a, ctx, lsq, inputs, b):
         return {"value": a.steps / dt, "unit": "LM outer iterations/s", "ms_per_step": dt / a.steps * 1e3,
                 "final_ssr": r.ssr, "g_calls_per_solve": r.g_calls}
 
-    leg = timed(lambda k: pr2.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, fetch_x=False))
-    leg["g"] = "device kernel, every stored value of both sliced copies rewritten (LSQ_NO_COLSCALE=1, two-pass tail)"
-    out["device_g_all_nnz"] = leg
+    legs = os.environ.get("LSQ_BENCH_GENERIC_LEGS", "device,host").split(",")      # (diagnostics)
+    if "device" in legs:
+        leg = timed(lambda k: pr2.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, fetch_x=False))
+        leg["g"] = "device kernel, every stored value of both sliced copies rewritten (LSQ_NO_COLSCALE=1, two-pass tail)"
+        out["device_g_all_nnz"] = leg
 
     try:
+        if "host" not in legs:
+            raise RuntimeError("leg switched off (LSQ_BENCH_GENERIC_LEGS)")
         here = os.path.join(ROOT, "tools", "hostg")
         so = os.path.join(here, "libhostg.so")
         if not os.path.exists(so):

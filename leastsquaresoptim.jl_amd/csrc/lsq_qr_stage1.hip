@@ -489,7 +489,15 @@ k_qr1_wreduce(const double *__restrict__ Wp, int ncolsB, int kslices, double *__
     const long long tot = (long long)ntile * Q2_NB * Q2_NB;
     for (long long e = (long long)tile0 * Q2_NB * Q2_NB + blockIdx.x * 256LL + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
         double s = 0.0;
-        for (int sl = 0; sl < kslices; ++sl) s += Wp[(size_t)sl * tot + e];
+        int sl = 0;
+        for (; sl + 8 <= kslices; sl += 8) {           // eight loads in flight, added in slice order
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = Wp[(size_t)(sl + u) * tot + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; sl < kslices; ++sl) s += Wp[(size_t)sl * tot + e];
         W[e] = s;   // layout [tile][col][row] == [cb][row]
     }
 }
@@ -722,6 +730,144 @@ k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int
     }
 }
 
+// The same update with WAVE-PRIVATE tiles (round 5): no LDS, no barriers.  At NB = 64 the block update is 8 flops per byte of
+// A2 -- the fp64 MFMA issue ceiling (48 TFLOP/s) and the streaming rate (6 TB/s) meet.  Measured on this kernel (C3, average
+// over the 32 panels): A2 traffic alone 39.4 us (6.2 TB/s), MFMAs alone 44.5 us, k_qr1_update (LDS-staged, 4 barriers per
+// 64-column tile) 68.6 us.  Forms tried: one tile of prefetch 67 us (one tile's MFMAs, 2 us, do not cover a loaded memory
+// round trip); V in LDS 80 us (a ds_read in front of every MFMA: MFMAs alone 68 us); this one 58 us:
+//  * a wavefront owns 32 rows x 16 columns per tile and computes the TRANSPOSED product (V W2)' = W2' V': the MFMA result
+//    layout then has a lane's 16 neighbours on 16 consecutive rows of one column, and the read-modify-write of A2 goes
+//    straight from / to registers in 128-byte pieces -- no product image in LDS;
+//  * its V fragment (32 x 64) stays in registers for all its tiles; the A2 tiles of the next U3_DA tiles are in flight
+//    (register ring), W2 fragments (L2-resident, 32-byte pieces per lane, k index permuted alike in both operands) one
+//    tile ahead; 242 VGPRs, two waves per SIMD (held to three the ring spills);
+//  * panels 0-5 of C3 stay at 4 TB/s: their trailing matrix (> 230 MB) does not fit the 256 MB MALL between k_qr1_vtb's
+//    read and this kernel's; from there on 5 TB/s.
+//   lane (ij = lane & 15, kq = lane >> 4), step s: k = 16 (s >> 2) + 4 kq + (s & 3)
+//   a operand  W2[col jj + ij][k]      b operand  V[row r0 + 16 b + ij][k]      D'[col jj + kq + 4 r][row r0 + 16 b + ij]
+constexpr int U3_DA = 4;                    // depth of the A2 ring
+template <int DBG>     // 0: the product; 1: no MFMAs (memory side alone); 2: no A2 traffic (MFMA side alone) -- timing experiments only
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int M, int c0, int cend, int n,
+               double *__restrict__ rhs, int ncols /* n - cend + 1 */, const double *__restrict__ W2, int jbeg, int jend, int tpw) {
+    const int rows = M - c0;
+    const int nrg = (rows + Q2_NB - 1) / Q2_NB;         // row groups of 64 rows: waves 0,1 the upper half, 2,3 the lower
+    const int rg = blockIdx.x % nrg, cg = blockIdx.x / nrg;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ij = lane & 15, kq = lane >> 4;
+    const int rbase = rg * Q2_NB;
+    const int r0 = rbase + 32 * (w >> 1);
+    const int ncolsA = n - cend;                        // columns of A proper; column ncolsA is the right-hand side
+    const bool rfull = r0 + 32 <= rows;
+    const int row0 = r0 + ij, row1 = r0 + 16 + ij;
+    const bool in0 = row0 < rows, in1 = row1 < rows;
+    // tiles of this wave: jfirst + 32 t, t = 0 .. nt - 1 (the two waves of a row half take alternate 16-column tiles)
+    const int jfirst = jbeg + cg * 32 * tpw + 16 * (w & 1);
+    const int jstop = min(jend, jbeg + (cg + 1) * 32 * tpw);
+    if (r0 >= rows || jfirst >= jstop) return;
+    const int nt = (jstop - jfirst + 31) >> 5;
+    double v0[16], v1[16];                              // the wave's V fragment: 32 rows x 64, for all its tiles
+    {
+        const double *p0 = Vb + (in0 ? row0 : 0), *p1 = Vb + (in1 ? row1 : 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const size_t k = 16 * (s >> 2) + 4 * kq + (s & 3);
+            const double x0 = p0[k * ldv], x1 = p1[k * ldv];
+            v0[s] = in0 ? x0 : 0.0;
+            v1[s] = in1 ? x1 : 0.0;
+        }
+    }
+    auto colptr = [&](int col) -> double * { return (col < ncolsA ? A + (size_t)(cend + col) * M : rhs) + c0; };
+    auto fetch_w = [&](int t, double *wf) {
+        const int col = min(jfirst + 32 * t + ij, ncols - 1);
+        const double *pw = W2 + (size_t)col * Q2_NB + 4 * kq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wf[4 * g + u] = pw[16 * g + u];
+    };
+    auto fetch_a = [&](int t, double *at) {
+        const int jj = jfirst + 32 * t;
+        if (DBG == 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) at[r] = 0.0;
+        } else if (rfull && jj + 16 <= ncolsA) {
+            const double *pa = A + (size_t)(cend + jj + kq) * M + c0 + row0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                at[r] = pa[(size_t)4 * r * M];
+                at[4 + r] = pa[(size_t)4 * r * M + 16];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = jj + kq + 4 * r;
+                const double *pc = colptr(min(col, ncols - 1));
+                const double x0 = pc[in0 ? row0 : 0], x1 = pc[in1 ? row1 : 0];
+                at[r] = x0;
+                at[4 + r] = x1;
+            }
+        }
+    };
+    auto tile = [&](int t, const double *wf, const double *at) {
+        const int jj = jfirst + 32 * t;
+        v4d_qr c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;       // [row tile][k half]: four independent chains
+        if (DBG == 1) { c00[0] = wf[0] * v0[0]; c10[0] = wf[1] * v1[1]; }
+        else
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[s], v0[s], c00, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[s], v1[s], c10, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[s + 1], v0[s + 1], c01, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[s + 1], v1[s + 1], c11, 0, 0, 0);
+        }
+        if (DBG == 2) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc += (c00[r] + c01[r]) + (c10[r] + c11[r]);
+            if (sacc == 1.2345e300) rhs[0] = sacc;      // (keeps the products alive)
+        } else if (rfull && jj + 16 <= ncolsA) {
+            double *pa = A + (size_t)(cend + jj + kq) * M + c0 + row0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pa[(size_t)4 * r * M] = at[r] - (c00[r] + c01[r]);
+                pa[(size_t)4 * r * M + 16] = at[4 + r] - (c10[r] + c11[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = jj + kq + 4 * r;
+                if (col < ncols) {
+                    double *pc = colptr(col);
+                    if (in0) pc[row0] = at[r] - (c00[r] + c01[r]);
+                    if (in1) pc[row1] = at[4 + r] - (c10[r] + c11[r]);
+                }
+            }
+        }
+    };
+    double wa[16], wb[16], a0[8], a1[8], a2[8], a3[8];
+    static_assert(U3_DA == 4, "the ring below is written out for four stages");
+    fetch_w(0, wa);
+    fetch_a(0, a0);
+    if (1 < nt) fetch_a(1, a1);
+    if (2 < nt) fetch_a(2, a2);
+    if (3 < nt) fetch_a(3, a3);
+    // one step: W2 of tile t + 1 requested, tile t multiplied and written back, its ring slot refilled with tile t + U3_DA
+#define U3_STEP(T, WCUR, WNXT, ACUR)                          \
+    {                                                         \
+        if ((T) >= nt) break;                                 \
+        if ((T) + 1 < nt) fetch_w((T) + 1, WNXT);             \
+        tile((T), WCUR, ACUR);                                \
+        if ((T) + U3_DA < nt) fetch_a((T) + U3_DA, ACUR);     \
+    }
+    for (int t = 0; t < nt; t += 4) {
+        U3_STEP(t, wa, wb, a0)
+        U3_STEP(t + 1, wb, wa, a1)
+        U3_STEP(t + 2, wa, wb, a2)
+        U3_STEP(t + 3, wb, wa, a3)
+    }
+#undef U3_STEP
+}
+
 // R (upper triangle of the factored A, zeros below) and the first n entries of Q1'b -> stage-2 operands
 __global__ void __launch_bounds__(256)
 k_qr1_extract(const double *__restrict__ A, int M, int n, const double *__restrict__ rhs, double *__restrict__ R,
@@ -734,6 +880,30 @@ k_qr1_extract(const double *__restrict__ A, int M, int n, const double *__restri
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) rhs2[i] = rhs[i];
 }
 
+// launches the wave-private update (default since round 5; LSQ_QR_UPDATE_W=0: false, the caller launches k_qr1_update; 2 / 3: the
+// timing experiments DBG 1 / 2 -- wrong results).  All read per call.
+static bool qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int M, int c0, int cend, int n, double *rhs,
+                            int ncols, const double *W2) {
+    const char *e = getenv("LSQ_QR_UPDATE_W");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0) return false;
+    const int rows = M - c0, nrg = (rows + Q2_NB - 1) / Q2_NB;
+    // 32-column tile pairs per workgroup: as many as leave one workgroup per CU, at most 32 -- a wave's V fragment then serves
+    // many tiles (measured at C3, all panels: 32 pairs 57.8 us, 16 58.9, 8 61.0, 4 62.3; a rule that keeps two workgroups per
+    // CU 60.1)
+    const char *t = getenv("LSQ_QR_UPDATE_TPW");
+    const int npair = (ncols + 31) / 32, want = std::max(1, c->num_cus / nrg);
+    const int tpw = t ? std::max(1, atoi(t)) : std::max(2, std::min(32, (npair + want - 1) / want));
+    const int ncg = (npair + tpw - 1) / tpw;
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nrg * ncg), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncols, W2, 0, ncols, tpw);
+    };
+    if (mode == 2) go(k_qr1_update_w<1>);
+    else if (mode == 3) go(k_qr1_update_w<2>);
+    else go(k_qr1_update_w<0>);
+    return true;
+}
+
 static void qr2_free(void *p) {
     Qr2Work *q = (Qr2Work *)p;
     if (!q) return;
@@ -743,6 +913,20 @@ static void qr2_free(void *p) {
     if (q->h_fro) hipHostFree(q->h_fro);
     lsq_cqr_free(&q->cq);
     delete q;
+}
+
+// k slices of k_qr1_vtb for a panel with `nt` tiles to form out of `ntile` (the partials are indexed slice * ntile + tile):
+// about four workgroups per CU whatever the width of the trailing matrix.  (Until round 5 the count was fixed by the WIDEST
+// panel -- 31 at C3 -- so that the last panels ran 62 workgroups of 15 dependent slabs each: 33 us for 1 % of the flops.)
+static int qr1_vtb_slices(const lsq_ctx *c, const Qr2Work *q, int rows, int nt, int ntile) {
+    const char *e = getenv("LSQ_QR_VTB_KSMAX");
+    const int ksmax = e ? atoi(e) : 64;
+    // (rounded DOWN, and four slots kept free: k_cqr_top holds a CU's LDS on the side stream while this grid runs -- a
+    //  workgroup over the resident 4 per CU waits for a whole second round: 127 against 102 us at 30 tiles x 35 slices)
+    int ks = ksmax > 0 ? std::min(ksmax, (4 * c->num_cus - 4) / std::max(1, nt)) : q->kslices;
+    ks = std::min(ks, q->wp_slots / std::max(1, ntile));
+    ks = std::min(ks, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC));
+    return std::max(1, ks);
 }
 
 static bool qr2_applies(int M, int n) {
@@ -816,7 +1000,10 @@ static int qr2_workspace(lsq_solver *s, int M, int n) {
         const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
         q->kslices = std::max(1, std::min(64, (4 * c->num_cus + ntile - 1) / ntile));   // (4 workgroups per CU: their barriers and LDS phases interleave)
         LSQ_HIP(hipMalloc(&q->Vb, ((size_t)M * Q2_NB + 64) * sizeof(double)));
-        LSQ_HIP(hipMalloc(&q->Wp, (size_t)q->kslices * ntile * Q2_NB * Q2_NB * sizeof(double)));
+        // split-K partials of V'[A2 | b]: room for the widest panel at q->kslices slices AND for the narrow last panels at many
+        // more slices each (qr1_vtb_slices)
+        q->wp_slots = std::max(q->kslices * ntile, 4 * c->num_cus + 2 * ntile + 256);
+        LSQ_HIP(hipMalloc(&q->Wp, (size_t)q->wp_slots * Q2_NB * Q2_NB * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->W, (size_t)ntile * Q2_NB * Q2_NB * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->W2, (size_t)ntile * Q2_NB * Q2_NB * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->R, ((size_t)n * n + 8) * sizeof(double)));
@@ -858,7 +1045,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, q->Vb, ldv, q->d_err));
             const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
             const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
-            int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
+            const int ks = qr1_vtb_slices(c, q, rows, ntile - 1, ntile);
             // (V'V, tile 0, is not formed: the basis-kernel form needs V'[A2 | b] only.  Measured and dropped in round 4: the sum
             //  over the k slices taken by k_cqr_tw itself instead of the k_qr1_wreduce launch -- 32 workgroups reading 1 MB of
             //  partials each take longer than the 10 us launch over 256: C3 7.83 against 7.60 ms, profiles/r04/ab_c3_tw.txt)
@@ -872,6 +1059,8 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
             {
                 const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
+                if (qr1_update_wave(c, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols, q->W2)) { }
+                else
                 LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M,
                                    c0, cend, n, rhs, ncols, q->W2);
             }
@@ -934,7 +1123,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
                                lazy ? (const double *)(q->lazy + n) : (const double *)nullptr,
                                side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
         }
-        int ks = std::max(1, std::min(q->kslices, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC)));
+        const int ks = qr1_vtb_slices(c, q, rows, ntile, ntile);
         LSQ_LAUNCH(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
                            q->Wp, 0);
         {
@@ -946,6 +1135,8 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
                                q->tau1, c0, nb, q->W2);
         {
             const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
+            if (qr1_update_wave(c, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols, q->W2)) { }
+            else
             LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols,
                                q->W2);
         }

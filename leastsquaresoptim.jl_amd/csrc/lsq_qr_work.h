@@ -36,7 +36,7 @@ struct Qr2Work {
     double *Pn = nullptr;                  // stage 1: side panel (M x 64) for the later pivot columns of a launch
     double *tsS[2] = {nullptr, nullptr}, *tsr[2] = {nullptr, nullptr};   // TSQR levels (ping-pong): stacked slab triangles ((slabs*n) x n) and Q'b entries
     int *colat = nullptr;     // stage 2: position map, double-buffered (2n)
-    int kslices = 0, M = 0, n = 0;
+    int kslices = 0, wp_slots = 0, M = 0, n = 0;
     CqrWork cq;               // stage 1: CholeskyQR2 panel (lsq_qr_cholqr.hip)
     bool no_cholqr = false;   //   ... off for this solver after a breakdown (ill-conditioned / rank-deficient panels)
     bool cholqr_used = false; //   the current factorisation took it at least once

@@ -2,7 +2,7 @@
 # Kernel-time breakdown of one dense solve (run through gpurun): tools/qr_profile.sh qr:16384:2048:0
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/qrprof
+OUT=${QRPROF_OUT:-gpurun_out/qrprof}
 rm -rf $OUT && mkdir -p $OUT
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o qr --output-format csv -- python tools/dense_bench.py "$@" > $OUT/run.log 2>&1
 python - <<PY
