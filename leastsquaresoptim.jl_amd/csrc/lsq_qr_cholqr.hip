@@ -183,7 +183,9 @@ __device__ __forceinline__ void cq_rows_times_inv(const double *__restrict__ P, 
 
 // PASS 0: Gram partials of the raw panel.   PASS 1: R1 = chol(G), Q1 = P inv(R1) in place, Gram partials of Q1.
 // PASS 2: R2 from G2 = Q1'Q1, Q = Q1 inv(R2) -> Vb.      P = A(c0 + [0, rows), c0 + [0, 64)), column-major, ld lda.
-template <int PASS>
+// PRE: inv(R) was computed once by k_cqr_factor (G points at it) instead of by every workgroup -- the look-ahead panel, whose
+// passes share the CUs with the trailing update: 256 redundant 64 x 64 factorisations are 18 us of every CU's ALU and LDS time.
+template <int PASS, bool PRE = false>
 __global__ void __launch_bounds__(256)
 k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__restrict__ G, double *__restrict__ Gp,
            double *__restrict__ R1g, double *__restrict__ Vb, int ldv, int *__restrict__ err) {
@@ -211,12 +213,16 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
         CQ_T(2);
         return;
     }
-    int bad;
-    cq_factor<PASS>(G, M1, M2, T, &s_fail, s_red, &bad, tid);     // every workgroup, identically
-    if (bad && slab == 0 && tid == 0) atomicOr(err, CQ_FAIL);
-    CQ_T(PASS * 16 + 2);
-    if (PASS == 1 && slab == 0)
-        for (int e = tid; e < 4096; e += 256) R1g[e] = M1[(e >> 6) * S64_LS + (e & 63)];
+    if (PRE) {
+        cq_load64(M2, G, tid);                                    // inv(R), row-major 64 x 64
+    } else {
+        int bad;
+        cq_factor<PASS>(G, M1, M2, T, &s_fail, s_red, &bad, tid);     // every workgroup, identically
+        if (bad && slab == 0 && tid == 0) atomicOr(err, CQ_FAIL);
+        CQ_T(PASS * 16 + 2);
+        if (PASS == 1 && slab == 0)
+            for (int e = tid; e < 4096; e += 256) R1g[e] = M1[(e >> 6) * S64_LS + (e & 63)];
+    }
     __syncthreads();                                              // R is dead from here on: its LDS becomes the slab image
     // ---- slab product  Qslab = Pslab * inv(R) ------------------------------------------------------------------
     CQ_T(PASS * 16 + 3);
@@ -243,6 +249,25 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
     CQ_T(PASS * 16 + 5);
     if (PASS == 1) cq_slab_gram(Qs, Gp + (size_t)slab * 4096, tid);
     CQ_T(PASS * 16 + 6);
+}
+
+// ONE workgroup: the factor of a pass from its reduced Gram matrix, inv(R) -> Minv (row-major), R1 -> R1g (pass 1)
+template <int PASS>
+__global__ void __launch_bounds__(256)
+k_cqr_factor(const double *__restrict__ G, double *__restrict__ Minv, double *__restrict__ R1g, int *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *M2 = sm, *M1 = sm + S64_MAT, *T = sm + 2 * S64_MAT;
+    __shared__ int s_fail;
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    int bad;
+    cq_factor<PASS>(G, M1, M2, T, &s_fail, s_red, &bad, tid);
+    if (bad && tid == 0) atomicOr(err, CQ_FAIL);
+    __syncthreads();
+    for (int e = tid; e < 4096; e += 256) {
+        Minv[e] = M2[(e >> 6) * S64_LS + (e & 63)];
+        if (PASS == 1) R1g[e] = M1[(e >> 6) * S64_LS + (e & 63)];
+    }
 }
 
 // G = sum of the slab partials (fixed order): 16 outputs per workgroup, 16 partial sums per output (one batch of loads
@@ -412,18 +437,26 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
     LSQ_HIP(hipMalloc(&w->R1, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->G2, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->Binv, 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->Minv, 2 * 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->S, 64 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->SR, 4096 * sizeof(double)));
     {   // highest priority: its single workgroup (141 KB of LDS) must get a CU before the caller's V'[A2 | b] grid fills them
         int lo = 0, hi = 0;
         LSQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         LSQ_HIP(hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, hi));
+        LSQ_HIP(hipStreamCreateWithPriority(&w->ahead, hipStreamNonBlocking, hi));
     }
+    LSQ_HIP(hipEventCreateWithFlags(&w->ev_first, hipEventDisableTiming));
+    LSQ_HIP(hipEventCreateWithFlags(&w->ev_panel, hipEventDisableTiming));
     LSQ_HIP(hipEventCreateWithFlags(&w->ev_q, hipEventDisableTiming));
     LSQ_HIP(hipEventCreateWithFlags(&w->ev_lu, hipEventDisableTiming));
     LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_pass<0>, CQ_LDS));
     LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_pass<1>, CQ_LDS));
     LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_pass<2>, CQ_LDS));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_pass<1, true>, CQ_LDS));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_pass<2, true>, CQ_LDS));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_factor<1>, CQ_LDS));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_factor<2>, CQ_LDS));
     LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_top, CQ_LDS_LU));
     LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_tw, CQ_LDS_TW));
     w->ready = true;
@@ -432,20 +465,26 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
 
 void lsq_cqr_free(CqrWork *w) {
     if (!w || !w->ready) return;
-    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->S); hipFree(w->SR);
-    hipEventDestroy(w->ev_q); hipEventDestroy(w->ev_lu);
-    hipStreamDestroy(w->side);
+    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->Minv); hipFree(w->S); hipFree(w->SR);
+    hipEventDestroy(w->ev_q); hipEventDestroy(w->ev_lu); hipEventDestroy(w->ev_first); hipEventDestroy(w->ev_panel);
+    hipStreamDestroy(w->side); hipStreamDestroy(w->ahead);
     w->ready = false;
 }
 
-int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err) {
+int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps) {
     const int rows = M - c0, nslab = (rows + CQ_RS - 1) / CQ_RS;
-    hipStream_t ps = c->stream;
+    (void)c;
+    const bool pre = ps == w->ahead && !getenv("LSQ_QR_AHEAD_REDUNDANT");     // one factor kernel instead of one factor per workgroup
     LSQ_LAUNCH(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
                        w->R1, Vb, ldv, d_err);
     LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G);
-    LSQ_LAUNCH(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G, w->Gp,
-                       w->R1, Vb, ldv, d_err);
+    if (pre) {
+        LSQ_LAUNCH(k_cqr_factor<1>, dim3(1), dim3(256), CQ_LDS, ps, (const double *)w->G, w->Minv, w->R1, d_err);
+        LSQ_LAUNCH((k_cqr_pass<1, true>), dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->Minv, w->Gp,
+                           w->R1, Vb, ldv, d_err);
+    } else
+        LSQ_LAUNCH(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G, w->Gp,
+                           w->R1, Vb, ldv, d_err);
     LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G2);
     LSQ_HIP(hipGetLastError());
     // everything that hangs on the top 64 rows (the 64-step LU among it) runs on the side stream from here on, beside
@@ -455,8 +494,13 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
     LSQ_LAUNCH(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1,
                        (const double *)A, M, c0, w->Binv, w->S, w->SR, d_err);
     LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
-    LSQ_LAUNCH(k_cqr_pass<2>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G2, w->Gp,
-                       w->R1, Vb, ldv, d_err);
+    if (pre) {
+        LSQ_LAUNCH(k_cqr_factor<2>, dim3(1), dim3(256), CQ_LDS, ps, (const double *)w->G2, w->Minv + 4096, w->R1, d_err);
+        LSQ_LAUNCH((k_cqr_pass<2, true>), dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)(w->Minv + 4096), w->Gp,
+                           w->R1, Vb, ldv, d_err);
+    } else
+        LSQ_LAUNCH(k_cqr_pass<2>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G2, w->Gp,
+                           w->R1, Vb, ldv, d_err);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

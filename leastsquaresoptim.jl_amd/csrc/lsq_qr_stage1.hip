@@ -482,6 +482,107 @@ k_qr1_vtb(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, 
             }
 }
 
+// The same partial products with WAVE-PRIVATE tiles (round 5): no LDS, no barriers.  k_qr1_vtb parks its four waves at two
+// barriers per 32-row slab (32 MFMAs per wave between them); here a wavefront owns 32 columns of B and all 64 of V over its
+// k slice and feeds the MFMAs straight from global memory:
+//   D'[B col j][V col i] = sum_rows B[row][j] V[row][i]:   a operand B[row][16 jt + ij], b operand V[row][16 it + ij],
+//   lane (ij = lane & 15, kq = lane >> 4), step s of a 16-row chunk: row = chunk + 4 kq + s  (32 contiguous bytes per lane and
+//   column: whole 128-byte lines per 4 lanes), result lane layout: B col 16 jt + kq + 4 r, V col 16 it + ij -- the partials
+//   leave in 128-byte pieces.  Chunks of the next V3_D steps are in flight (register ring).  The four waves of a workgroup
+//   take neighbouring 32-column groups over the SAME rows, so that three of their four reads of V hit the CU's L1; workgroups
+//   of one k slice sit behind one L2 (slice = blockIdx % kslices).
+constexpr int V3_D = 3;
+template <int DBG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_qr1_vtb_w(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, int M, int c0, int cend, int n,
+            const double *__restrict__ rhs, int ncolsB, int kslices, double *__restrict__ Wp, int tile0) {
+    const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
+    const int rows = M - c0;
+    const int slice = blockIdx.x % kslices, cgrp = blockIdx.x / kslices;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, ij = lane & 15, kq = lane >> 4;
+    const int cb0 = tile0 * Q2_NB + cgrp * 128 + w * 32;          // first B column of this wave
+    if (cb0 >= ncolsB) return;
+    const int kper = ((rows + kslices - 1) / kslices + 15) / 16 * 16;
+    const int kb = slice * kper, ke = min(rows, kb + kper);
+    // column pointers of the lane: two of B, four of V (rows from c0)
+    const int cbA = min(cb0 + ij, ncolsB - 1), cbB = min(cb0 + 16 + ij, ncolsB - 1);
+    const double *pa0 = q2_bcol(Vb, ldv, A, M, c0, cend, n, rhs, cbA) + 4 * kq;
+    const double *pa1 = q2_bcol(Vb, ldv, A, M, c0, cend, n, rhs, cbB) + 4 * kq;
+    const double *pv = Vb + (size_t)ij * ldv + 4 * kq;
+    const size_t vstep = (size_t)16 * ldv;
+    v4d_qr acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d_qr){0.0, 0.0, 0.0, 0.0};
+    auto fetch = [&](int R, double (*af)[4], double (*bf)[4]) {           // a full chunk
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            af[0][s] = pa0[R + s];
+            af[1][s] = pa1[R + s];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bf[it][s] = pv[it * vstep + R + s];
+    };
+    auto chunk = [&](double (*af)[4], double (*bf)[4]) {
+        if (DBG == 1) { acc[0][0][0] += af[0][0] * bf[0][0] + af[1][3] * bf[3][3]; return; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[jt][s], bf[it][s], acc[jt][it], 0, 0, 0);
+    };
+    double a0[2][4], b0[4][4], a1[2][4], b1[4][4], a2[2][4], b2[4][4];
+    static_assert(V3_D == 3, "the ring below is written out for three stages");
+    const int kfull = kb + ((max(ke - kb, 0)) & ~15);           // end of the full 16-row chunks
+    if (kb < kfull) fetch(kb, a0, b0);
+    if (kb + 16 < kfull) fetch(kb + 16, a1, b1);
+    if (kb + 32 < kfull) fetch(kb + 32, a2, b2);
+#define V3_STEP(R, AF, BF)                                     \
+    {                                                          \
+        if ((R) >= kfull) break;                               \
+        chunk(AF, BF);                                         \
+        if ((R) + 16 * V3_D < kfull) fetch((R) + 16 * V3_D, AF, BF); \
+    }
+    for (int R = kb; R < kfull; R += 16 * V3_D) {
+        V3_STEP(R, a0, b0)
+        V3_STEP(R + 16, a1, b1)
+        V3_STEP(R + 32, a2, b2)
+    }
+#undef V3_STEP
+    if (kfull < ke) {                              // the ragged last chunk: clamped addresses, zeroed by selection
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = kfull + 4 * kq + s, rc = min(r, ke - 1) - 4 * kq;
+            const double x0 = pa0[rc], x1 = pa1[rc];
+            a0[0][s] = r < ke ? x0 : 0.0;
+            a0[1][s] = r < ke ? x1 : 0.0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const double y = pv[it * vstep + rc];
+                b0[it][s] = r < ke ? y : 0.0;
+            }
+        }
+        chunk(a0, b0);
+    }
+    // partials: Wp[slice][tile][B col in tile][V col]
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cb = cb0 + 16 * jt + kq + 4 * r;
+            if (cb < ntile * Q2_NB) {
+                double *out = Wp + ((size_t)slice * ntile + cb / Q2_NB) * (Q2_NB * Q2_NB) + (size_t)(cb % Q2_NB) * Q2_NB + ij;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) out[16 * it] = cb < ncolsB ? acc[jt][it][r] : 0.0;
+            }
+        }
+}
+
 // W[cb][0:64] = sum over slices (fixed order)
 __global__ void __launch_bounds__(256)
 k_qr1_wreduce(const double *__restrict__ Wp, int ncolsB, int kslices, double *__restrict__ W, int tile0 /* first tile formed by k_qr1_vtb */) {
@@ -883,20 +984,27 @@ k_qr1_extract(const double *__restrict__ A, int M, int n, const double *__restri
 // launches the wave-private update (default since round 5; LSQ_QR_UPDATE_W=0: false, the caller launches k_qr1_update; 2 / 3: the
 // timing experiments DBG 1 / 2 -- wrong results).  All read per call.
 static bool qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int M, int c0, int cend, int n, double *rhs,
-                            int ncols, const double *W2) {
+                            int ncols, const double *W2, int jbeg = 0, int jend = -1, bool beside_passes = false) {
     const char *e = getenv("LSQ_QR_UPDATE_W");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
+    if (jend < 0) jend = ncols;
+    if (jbeg >= jend) return true;
     const int rows = M - c0, nrg = (rows + Q2_NB - 1) / Q2_NB;
     // 32-column tile pairs per workgroup: as many as leave one workgroup per CU, at most 32 -- a wave's V fragment then serves
     // many tiles (measured at C3, all panels: 32 pairs 57.8 us, 16 58.9, 8 61.0, 4 62.3; a rule that keeps two workgroups per
     // CU 60.1)
     const char *t = getenv("LSQ_QR_UPDATE_TPW");
-    const int npair = (ncols + 31) / 32, want = std::max(1, c->num_cus / nrg);
-    const int tpw = t ? std::max(1, atoi(t)) : std::max(2, std::min(32, (npair + want - 1) / want));
+    const int npair = (jend - jbeg + 31) / 32, want = std::max(1, c->num_cus / nrg);
+    const int tpw = t ? std::max(1, atoi(t)) : std::max(2, std::min(beside_passes ? 64 : 32, (npair + want - 1) / want));
     const int ncg = (npair + tpw - 1) / tpw;
+    // beside the next panel's passes (look-ahead): ONE workgroup per CU, by an LDS reservation it does not use -- two of them
+    // fill a CU's registers (242 VGPRs per wave) and the pass workgroups (75 KB of LDS, 4 waves) would wait for them to end
+    const char *le = getenv("LSQ_QR_UPDATE_LDS");
+    const size_t lds = beside_passes ? (le ? (size_t)atoi(le) : (size_t)84 * 1024) : 0;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(nrg * ncg), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncols, W2, 0, ncols, tpw);
+        if (lds > 0 && lsq_set_lds(c, (const void *)kern, lds) != LSQ_OK) return;
+        hipLaunchKernelGGL(kern, dim3(nrg * ncg), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncols, W2, jbeg, jend, tpw);
     };
     if (mode == 2) go(k_qr1_update_w<1>);
     else if (mode == 3) go(k_qr1_update_w<2>);
@@ -907,7 +1015,7 @@ static bool qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, in
 static void qr2_free(void *p) {
     Qr2Work *q = (Qr2Work *)p;
     if (!q) return;
-    hipFree(q->Vb); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
+    hipFree(q->Vb); hipFree(q->Vb2); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
     hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
     hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn); hipFree(q->tsS[0]); hipFree(q->tsS[1]); hipFree(q->tsr[0]); hipFree(q->tsr[1]);
     if (q->h_fro) hipHostFree(q->h_fro);
@@ -927,6 +1035,33 @@ static int qr1_vtb_slices(const lsq_ctx *c, const Qr2Work *q, int rows, int nt, 
     ks = std::min(ks, q->wp_slots / std::max(1, ntile));
     ks = std::min(ks, (rows + 4 * Q2_KC - 1) / (4 * Q2_KC));
     return std::max(1, ks);
+}
+
+// V'[A2 | b] partials by the wave-private kernel (default; LSQ_QR_VTB_W=0: k_qr1_vtb; 2: timing experiment without MFMAs).
+// Returns the number of k slices written (for k_qr1_wreduce).
+static int qr1_vtb_launch(lsq_ctx *c, Qr2Work *q, const double *Vb, int ldv, const double *A, int M, int c0, int cend, int n,
+                          const double *rhs, int ncolsB, int tile0) {
+    const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB, rows = M - c0;
+    const char *e = getenv("LSQ_QR_VTB_W");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0) {
+        const int ks = qr1_vtb_slices(c, q, rows, ntile - tile0, ntile);
+        hipLaunchKernelGGL(k_qr1_vtb, dim3((ntile - tile0) * ks), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
+                           q->Wp, tile0);
+        return ks;
+    }
+    // workgroups of 4 waves x 32 columns; ONE per CU (measured at C3, average over the panels: 56.2 us; two per CU -- what
+    // the registers allow -- 59.0; four queued 71.1; k_qr1_vtb 64.0)
+    const int ncgrp = (ncolsB - tile0 * Q2_NB + 127) / 128;
+    const char *k = getenv("LSQ_QR_VTB_WGS");
+    const int per_cu = k ? std::max(1, atoi(k)) : 1;
+    int ks = std::max(1, (per_cu * c->num_cus - 2) / std::max(1, ncgrp));
+    ks = std::min(ks, 128);
+    ks = std::min(ks, q->wp_slots / std::max(1, ntile));
+    ks = std::max(1, std::min(ks, (rows + 63) / 64));
+    if (mode == 2) hipLaunchKernelGGL(k_qr1_vtb_w<1>, dim3(ncgrp * ks), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp, tile0);
+    else hipLaunchKernelGGL(k_qr1_vtb_w<0>, dim3(ncgrp * ks), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp, tile0);
+    return ks;
 }
 
 static bool qr2_applies(int M, int n) {
@@ -1035,6 +1170,19 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     // CholeskyQR2 panels (lsq_qr_cholqr.hip) need the error word to travel back with the certificate's copy
     const bool cq_ok = !q->no_cholqr && !getenv("LSQ_QR1_NO_CHOLQR") && !getenv("LSQ_QR_ALWAYS_PIVOT");
     q->cholqr_used = false;
+    // LOOK-AHEAD (round 5): once panel k's W2 is known, the NEXT panel's 64 columns are updated first and its passes run on
+    // their own stream beside the update of the other trailing columns; its Q goes to the second V buffer.  (Round 3 built
+    // this on LDS-staged update kernels: pass and update workgroups fought for the CUs' LDS, both stretched, 8.0 against
+    // 7.55 ms.  The wave-private update holds no LDS.)  Only with the wave-private update (it takes a column range).
+    const char *lae = getenv("LSQ_QR_LOOKAHEAD");
+    const char *uwe = getenv("LSQ_QR_UPDATE_W");
+    const bool la_on = cq_ok && (lae ? atoi(lae) != 0 : true) && (uwe ? atoi(uwe) == 1 : true);
+    // worth it while the update of the other columns outlasts most of the passes (which run 1.5-2x slower beside it):
+    // measured at C3 7.20 -> 7.06 ms, 18432 x 2048 8.94 -> 8.22; 4096 x 512 and 3000 x 700 lose 3-5 % with it
+    const char *lmc = getenv("LSQ_QR_LOOKAHEAD_MINCOLS");
+    const int la_min_cols = lmc ? atoi(lmc) : 1024;
+    bool pre = false;                        // this panel was factored ahead (its Q is in vcur, ev_panel says when)
+    double *vcur = q->Vb;
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
         if (cq_ok && nb == Q2_NB && M - c0 >= 256) {
@@ -1042,26 +1190,43 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             if (!q->cq.ready) LSQ_TRY(lsq_cqr_alloc(c, &q->cq, q->M));
             q->cholqr_used = true;
             const int rows = M - c0, ldv = rows;
-            LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, q->Vb, ldv, q->d_err));
+            if (pre) LSQ_HIP(hipStreamWaitEvent(c->stream, q->cq.ev_panel, 0));
+            else {
+                vcur = q->Vb;
+                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, vcur, ldv, q->d_err, c->stream));
+            }
+            pre = false;
             const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
             const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
-            const int ks = qr1_vtb_slices(c, q, rows, ntile - 1, ntile);
             // (V'V, tile 0, is not formed: the basis-kernel form needs V'[A2 | b] only.  Measured and dropped in round 4: the sum
             //  over the k slices taken by k_cqr_tw itself instead of the k_qr1_wreduce launch -- 32 workgroups reading 1 MB of
             //  partials each take longer than the 10 us launch over 256: C3 7.83 against 7.60 ms, profiles/r04/ab_c3_tw.txt)
-            LSQ_LAUNCH(k_qr1_vtb, dim3((ntile - 1) * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
-                               q->Wp, 1);
+            const int ks = qr1_vtb_launch(c, q, vcur, ldv, A, M, c0, cend, n, rhs, ncolsB, 1);
             {
                 long long tot = (long long)(ntile - 1) * Q2_NB * Q2_NB;
                 int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
                 LSQ_LAUNCH(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W, 1);
             }
-            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, q->Vb, ldv, q->W2));
-            {
+            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, vcur, ldv, q->W2));
+            // is the next panel a CholeskyQR2 panel too, with enough other columns beside it?
+            const int c1 = cend;
+            const bool ahead = la_on && n - c1 >= Q2_NB && M - c1 >= 256 && ncols - 1 >= Q2_NB + la_min_cols;
+            if (ahead) {
+                if (!q->Vb2) LSQ_HIP(hipMalloc(&q->Vb2, ((size_t)q->M * Q2_NB + 64) * sizeof(double)));
+                double *vnext = vcur == q->Vb ? q->Vb2 : q->Vb;
+                qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, 0, Q2_NB);
+                LSQ_HIP(hipEventRecord(q->cq.ev_first, c->stream));
+                LSQ_HIP(hipStreamWaitEvent(q->cq.ahead, q->cq.ev_first, 0));
+                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c1, vnext, M - c1, q->d_err, q->cq.ahead));
+                LSQ_HIP(hipEventRecord(q->cq.ev_panel, q->cq.ahead));
+                qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, Q2_NB, ncols, true);
+                vcur = vnext;
+                pre = true;
+            } else {
                 const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
-                if (qr1_update_wave(c, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols, q->W2)) { }
+                if (qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2)) { }
                 else
-                LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M,
+                LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, vcur, ldv, A, M,
                                    c0, cend, n, rhs, ncols, q->W2);
             }
             continue;
@@ -1123,9 +1288,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
                                lazy ? (const double *)(q->lazy + n) : (const double *)nullptr,
                                side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
         }
-        const int ks = qr1_vtb_slices(c, q, rows, ntile, ntile);
-        LSQ_LAUNCH(k_qr1_vtb, dim3(ntile * ks), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
-                           q->Wp, 0);
+        const int ks = qr1_vtb_launch(c, q, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, 0);
         {
             long long tot = (long long)ntile * Q2_NB * Q2_NB;
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
