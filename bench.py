@@ -134,6 +134,20 @@ def main():
     import lsq_amd as lsq
     L = lsq.lib()
     ctx = lsq.Context(local_rank)
+
+    def probe(stage):      # diagnostics (LSQ_BENCH_PROBE=1): the dense Dogleg+QR outer iteration measured at this point of the run
+        if not os.environ.get("LSQ_BENCH_PROBE"):
+            return
+        p3 = lsq.synthetic.TanhProblem(16384, 2048, sparse=False, seed=lsq.synthetic.BASE_SEED, ctx=ctx)
+        p3.reset()
+        p3.optimize(lsq._lib.DOGLEG, lsq._lib.QR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=2, fetch_x=False)
+        p3.reset()
+        t_ = time.perf_counter()
+        r_ = p3.optimize(lsq._lib.DOGLEG, lsq._lib.QR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=6, fetch_x=False)
+        ctx.sync()
+        print("probe[%s]: %.2f ms per Dogleg+QR outer iteration" % (stage, (time.perf_counter() - t_) / r_.iterations * 1e3), file=sys.stderr)
+        p3.close()
+    probe("context created")
     m, n, pc = a.m, a.n, a.per_col
     nnz = n * pc
     seed = lsq.synthetic.BASE_SEED + rank  # the 8 problems of C5 differ
@@ -191,12 +205,14 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
+    probe("problem created")
     if a.warmup > 0:
         run(a.warmup)
     # The timed region is EXACTLY K steps between barrier + synchronize; it is repeated --repeats times (each
     # repeat bracketed the same way) and `value` comes from the MEDIAN region, so the headline is not one sample
     # of a few milliseconds.  Every twelfth J*v launch of every region carries its own start/stop events (250 samples
     # per run; a timed launch costs ~9 us of pipeline gaps, so every third -- rounds 1-3 -- cost 1.5 % of the rate it measured).
+    probe("warm-up done")
     stride = int(os.environ.get("LSQ_BENCH_PROF_STRIDE", "12"))
     L.lsq_prof_select(ctx.h, 1 | (stride << 8))     # bits 0-7: kernel mask; bits 8+: time every k-th launch
     L.lsq_prof_begin(ctx.h, 1 << 16)
@@ -210,9 +226,11 @@ def main():
         region_s.append(time.perf_counter() - t0)
         inner_local += inner_rep
         assert steps_done == a.steps, (steps_done, a.steps)
+    probe("timed regions done")
     avg = (C.c_double * 2)()
     cnt = (C.c_int * 2)()
     L.lsq_prof_end(ctx.h, avg, cnt)
+    probe("lsq_prof_end")
     # the J'u kernel is timed in a separate (untimed) pass of one solve: every instrumented launch
     # costs a few microseconds of pipeline gaps, which the timed region should not pay twice
     L.lsq_prof_select(ctx.h, 2)
@@ -225,6 +243,7 @@ def main():
     L.lsq_prof_select(ctx.h, 3)
     ev_ovh = C.c_double(0.0)   # what an EMPTY event pair measures on this stream (marker overhead)
     L.lsq_prof_overhead(ctx.h, 50, C.byref(ev_ovh))
+    probe("J'u pass + overhead")
     region_s_local = list(region_s)
     own_srt = sorted(region_s_local)
     own_rate = a.steps / own_srt[len(own_srt) // 2]
@@ -257,6 +276,8 @@ def main():
     lsq._lib.check(L.lsq_bench_mul(pr.J, 0, 50, xv.ptr, yv.ptr, 1.0, C.byref(ms)))
     ms_t = C.c_float(0)
     lsq._lib.check(L.lsq_bench_mul(pr.J, 1, 50, yv.ptr, xv.ptr, 1.0, C.byref(ms_t)))
+
+    probe("lsq_bench_mul")
 
     def leave_group():
         if dist is not None:
@@ -314,7 +335,7 @@ def main():
     dense = None
     if not a.no_cpu and world == 1 and not a.no_dense and "dense" not in skip:
         try:
-            dense = dense_secondary(ctx, lsq)
+            dense = dense_secondary(ctx, lsq, probe)
         except Exception as e:   # noqa: BLE001
             dense = {"error": repr(e)}
 
@@ -609,13 +630,16 @@ def generic_g(a, ctx, lsq, inputs, b):
     return out
 
 
-def dense_secondary(ctx, lsq):
+def dense_secondary(ctx, lsq, probe=lambda stage: None):
     """BASELINE.json's secondary figures: time per ldiv! of the dense solvers at the C2 / C3 sizes,
     measured after the timed region on fresh N(0,1)/sqrt(m) matrices, next to the host's LAPACK (numpy/scipy, all threads,
     warmed, median of 3) on the same operands, with the useful flops of SURVEY 8d against the fp64 MFMA peak.  Not part of
     `value`."""
     import numpy as np
     out = {}
+    if os.environ.get("LSQ_BENCH_DENSE_SLEEP"):       # (diagnostics)
+        time.sleep(float(os.environ["LSQ_BENCH_DENSE_SLEEP"]))
+    probe("dense_secondary: start")
     rng = np.random.default_rng(lsq.synthetic.BASE_SEED)
     for name, m, n, solver, for_lm in (("c2_cholesky_damped_4096x512", 4096, 512, lsq.Cholesky(), True),
                                        ("c3_qr_16384x2048", 16384, 2048, lsq.QR(), False)):
@@ -679,6 +703,7 @@ def dense_secondary(ctx, lsq):
                                           "split and MFMA counters: profiles/r04/dense_kernel_summary.md"},
                      "path": {k: info.get(k) for k in ("qr_path", "qr_panel", "chol_path")}}
         J.free()
+        probe("dense_secondary: after the ldiv! leg of " + name)
     # time per OUTER iteration of the dense tanh problems (f!, g! and the trust-region bookkeeping included)
     for name, m, n, opt, sol in (("c2_lm_cholesky_4096x512", 4096, 512, lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.CHOLESKY),
                                  ("c3_dogleg_qr_16384x2048", 16384, 2048, lsq._lib.DOGLEG, lsq._lib.QR)):
@@ -696,6 +721,7 @@ def dense_secondary(ctx, lsq):
             best = ms if best is None else min(best, ms)
         out[name] = {"outer_iteration_ms": best, "iterations": r.iterations, "ssr": r.ssr}
         pr.close()
+        probe("dense_secondary: after the outer loop of " + name)
     return out
 
 

@@ -93,6 +93,11 @@ struct lsq_ctx {
     double *h_slots;      // pinned + mapped host mirror: [0..NSLOTS) values, [NSLOTS] = sequence word
     double *d_hslots;     // device address of h_slots
     unsigned long long slot_seq = 0;
+    // two high-priority helper streams shared by every solver of the context (lsq_ctx_helper_stream; the dense QR's k_cqr_top
+    // and its look-ahead passes).  Per-SOLVER streams were a trap: HIP multiplexes streams onto four hardware queues, so with
+    // a second QR solver alive the fifth stream shared a queue with the main one and every stage-1 kernel waited behind
+    // k_cqr_top (Dogleg+QR 7.7 -> 17 ms per outer iteration, measured in round 5).
+    hipStream_t helper_stream[2] = {nullptr, nullptr};
     double *d_partials;   // LSQ_MAX_PARTIALS block partials
     unsigned *d_counters; // LSQ_NSLOTS arrival counters (zero between kernels)
     LsqMailbox *h_mail;   // pinned + mapped

@@ -440,11 +440,14 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
     LSQ_HIP(hipMalloc(&w->Minv, 2 * 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->S, 64 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->SR, 4096 * sizeof(double)));
-    {   // highest priority: its single workgroup (141 KB of LDS) must get a CU before the caller's V'[A2 | b] grid fills them
+    {   // highest priority: k_cqr_top's single workgroup (141 KB of LDS) must get a CU before the caller's V'[A2 | b] grid fills
+        // them.  The two streams belong to the CONTEXT (lsq_ctx::helper_stream): solvers of one context run one after the other
         int lo = 0, hi = 0;
         LSQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        LSQ_HIP(hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, hi));
-        LSQ_HIP(hipStreamCreateWithPriority(&w->ahead, hipStreamNonBlocking, hi));
+        for (int k = 0; k < 2; ++k)
+            if (!c->helper_stream[k]) LSQ_HIP(hipStreamCreateWithPriority(&c->helper_stream[k], hipStreamNonBlocking, hi));
+        w->side = c->helper_stream[0];
+        w->ahead = c->helper_stream[1];
     }
     LSQ_HIP(hipEventCreateWithFlags(&w->ev_first, hipEventDisableTiming));
     LSQ_HIP(hipEventCreateWithFlags(&w->ev_panel, hipEventDisableTiming));
@@ -467,7 +470,7 @@ void lsq_cqr_free(CqrWork *w) {
     if (!w || !w->ready) return;
     hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->Minv); hipFree(w->S); hipFree(w->SR);
     hipEventDestroy(w->ev_q); hipEventDestroy(w->ev_lu); hipEventDestroy(w->ev_first); hipEventDestroy(w->ev_panel);
-    hipStreamDestroy(w->side); hipStreamDestroy(w->ahead);
+    w->side = w->ahead = nullptr;          // (the context's)
     w->ready = false;
 }
 

@@ -150,6 +150,8 @@ extern "C" int lsq_ctx_destroy(lsq_ctx *c) {
     for (hipEvent_t e : c->prof_pool) hipEventDestroy(e);
     if (c->copy_done) hipEventDestroy(c->copy_done);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    for (hipStream_t hs : c->helper_stream)
+        if (hs) hipStreamDestroy(hs);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return LSQ_OK;
@@ -323,6 +325,7 @@ int lsq_wait_slots(lsq_ctx *c, int first, int count, unsigned long long seq, dou
     unsigned long long spins = 0;
     while (*hw != seq) {
         if ((++spins & 0xfffffu) != 0) continue;
+        if (getenv("LSQ_DEBUG_WAITS")) fprintf(stderr, "lsq_wait_slots: 2^20 spins waiting for seq %llu, word %llu (first %d count %d)\n", seq, (unsigned long long)*hw, first, count);
         const hipError_t q = hipStreamQuery(c->stream);
         if (q == hipErrorNotReady) continue;
         if (q != hipSuccess) {   // launch failure / device fault: the word will never arrive
@@ -371,6 +374,7 @@ int lsq_wait_ints(lsq_ctx *c, unsigned long long seq, const int *d_a, const int 
     unsigned long long spins = 0;
     while (*hw != p.seq) {
         if ((++spins & 0xfffffu) != 0) continue;
+        if (getenv("LSQ_DEBUG_WAITS")) fprintf(stderr, "lsq_wait_ints: 2^20 spins waiting for seq %llu, word %llu\n", p.seq, (unsigned long long)*hw);
         const hipError_t q = hipStreamQuery(c->stream);
         if (q == hipErrorNotReady) continue;
         if (q != hipSuccess) {
