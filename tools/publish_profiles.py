@@ -14,12 +14,13 @@ bench = json.loads(open(os.path.join(dst, "bench.json")).read())
 prof = json.loads(open(os.path.join(dst, "bench_under_rocprof.json")).read())
 table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_summary.py"),
                         os.path.join(src, "kt", "bench_kernel_trace.csv")], capture_output=True, text=True).stdout
-k1 = [l for l in table.splitlines() if "k_sell_rows<EpiU>" in l]
+k1 = [l for l in table.splitlines() if "k_lsmr_fused" in l and "grid=262144" in l] or [l for l in table.splitlines() if "k_sell_rows<EpiU>" in l]
+K1NAME = "k_lsmr_fused" if any("k_lsmr_fused" in l for l in k1) else "k_sell_rows<EpiU>"
 k1_work = float(k1[0].split("|")[5]) if k1 else float("nan")
 with open(os.path.join(dst, "kernel_summary.md"), "w") as fh:
     fh.write("# rocprofv3 --kernel-trace of `python bench.py --no-cpu`, per kernel\n\n"
              "`--stats` (bench_kernel_stats.csv) averages the early-exit launches of finished LSMR solves together\n"
-             "with the working launches; this table separates them.  The LSMR J*v kernel is `k_sell_rows<EpiU>`:\n"
+             "with the working launches; this table separates them.  The LSMR J*v kernel is `" + K1NAME + "`:\n"
              "its working-launch average here (%.2f us) is what `roofline.avg_launch_ms` measures with the launch's\n"
              "own start/stop events (%.2f us in the same profiled run, %.2f us in the un-profiled bench.json).\n\n"
              % (k1_work, prof["roofline"]["avg_launch_ms"] * 1e3, bench["roofline"]["avg_launch_ms"] * 1e3))
@@ -33,7 +34,7 @@ def find(sub):
         if sub in k:
             return float(v[3]), float(v[4])
     return None
-k1f = find("k_sell_rows<EpiU>")
+k1f = find(K1NAME)
 cal = find("k_scale_lds<true>")
 if cal is None and os.path.exists(os.path.join(src, "pmc_fetch_cal", "f_counter_collection.csv")):
     # since round 3 the default run multiplies nothing out: the calibration kernel comes from the LSQ_NO_COLSCALE=1 passes
@@ -54,10 +55,10 @@ with open(os.path.join(dst, "pmc_traffic.md"), "w") as fh:
         fh.write("`k_scale_lds<true>` reads (8+2) B and writes 8 B per stored entry -> raw FETCH %.1f MB (x2 = %.1f MB), raw WRITE %.1f MB.\n"
                  % (cal[0] * 1024 / 1e6, 2 * cal[0] * 1024 / 1e6, cal[1] * 1024 / 1e6))
     if k1f:
-        fh.write("LSMR J*v kernel (`k_sell_rows<EpiU>`): %.1f MB per launch against %.2f MB of algorithmic bytes.\n"
+        fh.write("LSMR J*v kernel (`" + K1NAME + "`): %.1f MB per launch against %.2f MB of algorithmic bytes.\n"
                  % ((2 * k1f[0] + k1f[1]) * 1024 / 1e6, bench["roofline"]["algorithmic_bytes_per_launch"] / 1e6))
 if k1f:
-    json.dump({"kernel": "k_sell_rows<EpiU>", "config": {"m": cfg["m"], "n": cfg["n"], "nnz": cfg["nnz"]},
+    json.dump({"kernel": K1NAME, "config": {"m": cfg["m"], "n": cfg["n"], "nnz": cfg["nnz"]},
                "fetch_size_kib_raw": k1f[0], "write_size_kib_raw": k1f[1],
                "hbm_bytes_per_launch": int((2 * k1f[0] + k1f[1]) * 1024),
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2*FETCH+WRITE)*1024 (gfx950 FETCH_SIZE halving, calibrated in-run)",

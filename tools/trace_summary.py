@@ -19,9 +19,9 @@ print("| kernel | launches | avg us (all) | working launches | avg us (working) 
 print("|---|---|---|---|---|---|---|---|")
 for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
     mn = min(v)
-    early = any(t in name for t in ("k_seg_", "k_sell_", "k_combine", "k_lsmr_update"))
+    early = any(t in name for t in ("k_seg_", "k_sell_", "k_combine", "k_lsmr_update", "k_lsmr_fused"))
     p90 = sorted(v)[min(len(v) - 1, int(0.9 * len(v)))]
-    work = [d for d in v if d > 0.6 * p90] if early and mn < 0.5 * p90 else v
+    work = [d for d in v if d > (0.8 if "k_lsmr_fused" in name else 0.6) * p90] if early and mn < 0.5 * p90 else v
     work = work or v
     print("| `%s` | %d | %.2f | %d | %.2f | %.2f | %.2f | %.1f |" % (
         name[:100], len(v), sum(v) / len(v), len(work), sum(work) / len(work), mn, max(v), 100 * sum(v) / tot))
