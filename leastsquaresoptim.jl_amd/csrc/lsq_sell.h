@@ -486,6 +486,9 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_sell_rows_pair(SellDev S, int wr
 // 512 threads (8 waves, one workgroup per CU: 256 VGPRs per lane) so that the heads of a wave's 8 slices, the window of x and
 // the next window's descriptors are all live in registers at once; with 1024 threads (128 VGPRs) the same code spilled.
 constexpr int LSQ_WIDE_NT = 512;
+// Width cap of a column window: 12544 doubles (98 KB) beside the 32 KB output window.  A little more than LSQ_LDS_X_MAX so
+// that n <= 25088 needs TWO windows: measured at 10^6 x 25000 (nnz 10^7) 39.9 / 35.8 / 32.8 us with 5 / 4 / 3 windows.
+constexpr int LSQ_SELL_WIDE_X_MAX = 12544;
 constexpr int LSQ_SELL_WIDE_G = LSQ_SELL_ROWS_MAX / 64 / (LSQ_WIDE_NT / 64);   // slices per wave and (row block, window)
 
 template <class Epi>
@@ -498,7 +501,7 @@ __global__ void __launch_bounds__(LSQ_WIDE_NT) k_sell_rows_wide(SellDev S, int w
     double *yw = smem + cwidth;     // LSQ_SELL_ROWS_MAX doubles
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nrb = S.nblocks / ncw;
-    constexpr int XR = (LSQ_LDS_X_MAX + LSQ_WIDE_NT - 1) / LSQ_WIDE_NT;
+    constexpr int XR = (LSQ_SELL_WIDE_X_MAX + LSQ_WIDE_NT - 1) / LSQ_WIDE_NT;
     constexpr int Q = LSQ_SELL_ROWS_MAX / LSQ_WIDE_NT;
     SellSliceRef A[G];
     double xr[XR];

@@ -320,6 +320,7 @@ static int csc_create_impl(lsq_ctx *c, int m, int n, const int *colptr, const in
     // order and keeps the rows' running sums in the output window, so a row is still summed left to right)
     int xmax = LSQ_LDS_X_MAX;
     if (const char *e = getenv("LSQ_SELL_XMAX")) xmax = std::min(LSQ_LDS_X_MAX, std::max(64, atoi(e)));   // tests: narrow windows
+    else if (n > LSQ_LDS_X_MAX) xmax = LSQ_SELL_WIDE_X_MAX;      // windows may be a little wider than what the one-window kernels hold
     const int ncw = n >= 1 ? (n + xmax - 1) / xmax : 1;
     // a window pass costs a row block ~4 us whatever it holds (two barriers, one exposed round trip), so the windows pay while
     // every pass still moves >= 60 KB per CU.  MI355X, nnz = 1e7, m = 1e6: n = 25000 (3 windows) 32.7 us against 49.6 us with

@@ -854,7 +854,7 @@ static inline int launch_sell_rows(lsq_mat *J, const double *xscale, const doubl
     if (S.ncw > 1) {   // n > LSQ_LDS_X_MAX: one column window of x in LDS at a time
         const size_t lds = (size_t)(S.cwidth + LSQ_SELL_ROWS_MAX) * sizeof(double);
         auto kern = k_sell_rows_wide<Epi>;
-        LSQ_TRY(lsq_set_lds(c, (const void *)kern, (LSQ_LDS_X_MAX + 2 + LSQ_SELL_ROWS_MAX) * sizeof(double)));
+        LSQ_TRY(lsq_set_lds(c, (const void *)kern, (LSQ_SELL_WIDE_X_MAX + 2 + LSQ_SELL_ROWS_MAX) * sizeof(double)));
         if (xscale) {   // column-scaled handle: the gather vector s .* x once, not once per row block and window
             LSQ_LAUNCH(k_sell_vmul<0>, dim3(std::min(lsq_div_up(J->n, LSQ_NT), c->num_cus * 4)), dim3(LSQ_NT), 0, c->stream,
                                J->n, x, xscale, S.d_sx);
