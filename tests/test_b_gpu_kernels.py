@@ -521,6 +521,54 @@ def test_ldiv_qr_two_stage(ctx, m, n, rank, monkeypatch):
         assert np.allclose(v, ref, rtol=1e-8, atol=1e-10), k
 
 
+@pytest.mark.parametrize("m,n", [(2049, 321), (1500, 700), (777, 513), (4099, 200), (1030, 1030)])
+def test_qr_wave_private_kernels_and_lookahead(ctx, m, n, monkeypatch):
+    """Round 5's trailing kernels of the blocked QR (k_qr1_vtb_w, k_qr1_update_w: wave-private tiles, no LDS) and the
+    look-ahead of the next panel against the LDS-staged kernels of rounds 2-4 and against the oracle (dense_qr.jl:30-88), on
+    shapes that exercise every ragged edge: rows not a multiple of 32 / 64, trailing columns not a multiple of 16, odd leading
+    dimensions (8-byte aligned fragments), the right-hand side as the last column of the last tile, the stacked damped
+    operand.  The wave-private kernels sum the 64-term dot products in a different order (k permuted, two halves): agreement
+    to 1e-11 relative, not bit for bit; look-ahead on / off must agree bit for bit (same kernels, same order)."""
+    rng = np.random.default_rng(9000 + m + n)
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    y = rng.standard_normal(m)
+    damp = rng.random(n) + 0.01
+    J = lsq.DeviceMatrix(ctx, A)
+    dxo = lsq.DeviceVector(ctx, n)
+    xr, rk, *_ = O.qr_solve(A, y)
+    st, xd, _, _ = O.ldiv(O.QR, O.Mat(dense=A), y, damp)
+    monkeypatch.setenv("LSQ_QR_TWO_STAGE", "1")
+    combos = {"default": {},
+              "lookahead_everywhere": {"LSQ_QR_LOOKAHEAD_MINCOLS": "0"},
+              "no_lookahead": {"LSQ_QR_LOOKAHEAD": "0"},
+              "lds_update": {"LSQ_QR_UPDATE_W": "0"},
+              "lds_vtb": {"LSQ_QR_VTB_W": "0"},
+              "lds_both": {"LSQ_QR_UPDATE_W": "0", "LSQ_QR_VTB_W": "0"},
+              "redundant_factor_ahead": {"LSQ_QR_LOOKAHEAD_MINCOLS": "0", "LSQ_QR_AHEAD_REDUNDANT": "1"}}
+    got, gotd = {}, {}
+    for name, env in combos.items():
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sv = lsq.AllocatedSolver(J, lsq.QR(), for_lm=False)
+        sv.ldiv_(dxo, lsq.DeviceVector(ctx, m, y))
+        info = sv.info()
+        assert info["qr_path"] == "two-stage-certified" and info["qr_panel"] == "cholqr2" and info["qr_rank"] == rk == n, (name, info)
+        got[name] = dxo.get()
+        svd = lsq.AllocatedSolver(J, lsq.QR(), for_lm=True)
+        svd.ldiv_(dxo, lsq.DeviceVector(ctx, m, y), lsq.DeviceVector(ctx, n, damp))
+        gotd[name] = dxo.get()
+        for k in env:
+            monkeypatch.delenv(k)
+    scale, scaled = np.max(np.abs(xr)), np.max(np.abs(xd))
+    for name in combos:
+        assert np.max(np.abs(got[name] - xr)) <= 1e-9 * scale, name
+        assert np.max(np.abs(gotd[name] - xd)) <= 1e-9 * scaled, name
+        assert np.max(np.abs(got[name] - got["lds_both"])) <= 1e-11 * scale, name
+        assert np.max(np.abs(gotd[name] - gotd["lds_both"])) <= 1e-11 * scaled, name
+    for a, b in (("default", "no_lookahead"), ("lookahead_everywhere", "no_lookahead"), ("redundant_factor_ahead", "no_lookahead")):
+        assert np.array_equal(got[a], got[b]) and np.array_equal(gotd[a], gotd[b]), (a, b)
+
+
 @pytest.mark.parametrize("m", [3000, 6000, 12000, 18000, 22000])
 @pytest.mark.parametrize("coop", ["1", "0"])
 def test_ldiv_qr_panel_variants(ctx, m, coop, monkeypatch):
