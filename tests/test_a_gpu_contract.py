@@ -103,11 +103,12 @@ def test_c4_sparse_full_size_properties(ctx, n, pc):
     pr.close()
 
 
-@pytest.mark.parametrize("n,pc", [(10_000, 1000), (30_000, 333)], ids=["C4", "n30000_wide"])
+@pytest.mark.parametrize("n,pc", [(10_000, 1000), (30_000, 333), (25_000, 400)], ids=["C4", "n30000_wide", "n25000_two_windows"])
 def test_c4_full_size_matches_oracle(ctx, n, pc):
     """C4 AT FULL SIZE against the oracle: LevenbergMarquardt(LSMR()) on the bench's own problem (10^6 x 10^4,
     nnz 10^7, BASE_SEED) -- the kernels the headline times (k_sell_rows<EpiU>, k_sell_cols + k_combine, k_sell_rows_pair, the
-    speculative gradient pass) -- and the same entry count over n = 30000 columns (k_sell_rows_wide, two-launch tail) vs
+    speculative gradient pass) -- and the same entry count over n = 30000 columns (k_sell_rows_wide: three column windows of 10000; two-launch tail) and over
+    n = 25000 (two windows of 12500: the widest the kernel's LDS holds, the sparse_secondary shape of the bench) vs
     O.optimize on the same inputs: levenberg_marquardt.jl:72-140, iterative_lsmr.jl:238-259.
     (1) The reference's own run (default tolerances): identical iteration / f / g / mul counts, convergence flags, LSMR inner
         counts per outer iteration and accept pattern; every iterate to 1e-8 max(1, |x|_inf), ssr to 1e-9, Delta exactly equal
