@@ -276,6 +276,12 @@ __global__ void __launch_bounds__(256) k_cqr_reduce(const double *__restrict__ G
     __shared__ double part[16][17];
     const int tid = threadIdx.x, o = tid & 15, p = tid >> 4;
     const int e = blockIdx.x * 16 + o;
+    // (a workgroup's 16 outputs are one row of one 16 x 16 tile; the strictly LOWER tiles are never formed by cq_slab_gram nor read
+    //  by cq_factor: 6 of 16 -- 3 MB of the 8 MB of partials at 256 slabs -- are not fetched)
+    if (((blockIdx.x * 16) >> 10) > ((blockIdx.x * 16 & 63) >> 4)) {
+        if (p == 0) G[e] = 0.0;
+        return;
+    }
     const int per = (nslab + 15) / 16, s0 = p * per, s1 = min(nslab, s0 + per);
     double acc = 0.0;
     int s = s0;
