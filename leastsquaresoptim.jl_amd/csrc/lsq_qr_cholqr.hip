@@ -33,8 +33,10 @@ constexpr int CQ_RS = 64;                  // rows of the panel per workgroup (2
 constexpr int CQ_QST = CQ_RS + 2;          // slab image [col][row], row stride (doubles)
 // pass kernels: inv(R) | R | scratch; the slab image (64 * CQ_QST doubles) lives over R + scratch once the factor is done:
 // 75 KB instead of 109, i.e. two slab workgroups per CU (LM's stacked 18432-row operand has 288 slabs: 9.3 -> 8.5 ms).
-// (Look-ahead -- panel k+1's passes on a high-priority stream beside the update of panel k -- was built on top of this and
-//  measured: the passes do start beside the update, but both stretch; 8.0 ms against 7.55 at C3.  Dropped.)
+// (Look-ahead -- panel k+1's passes on a high-priority stream beside the update of panel k -- was built on top of this in
+//  round 3 and measured: the passes do start beside the LDS-staged update, but both stretch; 8.0 ms against 7.55 at C3.
+//  Round 5 built it again on the LDS-free update, lsq_qr_stage1.hip: qr2_factor_core, and with ONE factor workgroup per pass,
+//  k_cqr_factor below: 7.20 -> 7.06 ms at C3, taken while >= 1024 other columns remain.)
 constexpr int CQ_LDS_DOUBLES = 2 * S64_MAT + S64_TMP;
 static_assert(S64_MAT + S64_TMP >= 64 * CQ_QST, "slab image over R + scratch");
 constexpr size_t CQ_LDS = (size_t)CQ_LDS_DOUBLES * sizeof(double);
