@@ -5,12 +5,14 @@
 A "step" is ONE Levenberg-Marquardt outer iteration of the hot path (levenberg_marquardt.jl:72-140)
 on the synthetic tanh model: g! (when the previous step was accepted), colsumabs2, the damped
 preconditioned LSMR solve (k inner iterations of J*v / J'*u), J'f, f!, J*dx and the accept/reject
-logic -- everything resident in HBM, f!/g! on the device.  The timed region is EXACTLY K steps:
-solves of --iters-per-solve (default 8) iterations from x0 = 0, repeated until K steps are done
-(tolerances are 0 so a solve cannot stop early).  Eight is the length of this problem's useful
-trajectory: with the reference's default tolerances it converges in 6 iterations and after the
-8th every further step is rejected (no g!, one inner iteration) -- timing those would inflate
-the rate.
+logic -- everything resident in HBM, f!/g! on the device.  The timed region is EXACTLY K steps of
+the REFERENCE'S OWN SCHEDULE (round 6): solves from x0 = 0 with the reference's default tolerances
+(x_tol = f_tol = g_tol = 1e-8, levenberg_marquardt.jl:41), each of which stops by itself at
+convergence (6 iterations on this problem, levenberg_marquardt.jl:123-124), repeated until K steps
+are done (the last solve is cut at K).  Every timed step is one the reference would run, and one at
+which the HIP path and the oracle take the same decisions (`parity_ok`).  The zero-tolerance
+8-iteration schedule of rounds 1-5 (two cheap steps past convergence per solve) is reported beside
+it as `value_fixed8_schedule`, never as `value`.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]         (N > 1: spawns N ranks under torch.distributed.run itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -20,7 +22,10 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, the J*v pro
 = 140.08 MB, plus 24*n for the fused damping rows) / average launch duration measured with HIP
 events on the library's stream inside the timed region.  `cpu_baseline` is the oracle (scalar C
 port, 1 thread) timed on this box's host on a bounded sample of the same workload, with an OpenMP
-all-cores variant of the same path beside it (`cpu_baseline.all_cores`).
+all-cores variant of the same path beside it (`cpu_baseline.cpu_all_cores_value`).  The driver's
+record keeps scalars of `config`, `roofline` and `cpu_baseline` only, so every companion figure
+(generic g!, fixed-8 schedule, C2 / C3 / wide-n legs, J'u, parity, tail speculation) is ALSO a
+scalar inside one of those three objects (and at top level).
 """
 import argparse
 import ctypes as C
@@ -183,19 +188,30 @@ def main():
 
     LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
 
-    def run(iters):
-        """`iters` outer iterations as solves of --iters-per-solve from x0 = 0; returns
-        (iterations done, inner iterations, last result)."""
-        done = inner = 0
+    SOLVE_CAP = 50      # (a solve of the reference schedule that did not converge would end here; C4 converges in 6)
+
+    def run(iters, fixed=0):
+        """`iters` LM outer iterations.  fixed == 0: the reference's schedule -- solves from x0 = 0 with the DEFAULT tolerances, each
+        stopping by itself at convergence, the last one cut at `iters`.  fixed == k > 0: the schedule of rounds 1-5 (solves of k
+        iterations, zero tolerances).  Returns (iterations counted by the loops, iterations that did device work on this rank --
+        a rank of a sharded run that has converged takes part in the exchange without working --, inner iterations, last result)."""
+        done = real = inner = 0
         r = None
         while done < iters:
-            k = min(a.iters_per_solve, iters - done)
-            pr.reset()
-            r = pr.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, allreduce=allreduce, fetch_x=False)
-            assert r.iterations == k, (r.iterations, k)
-            done += k
+            if fixed:
+                k = min(fixed, iters - done)
+                pr.reset()
+                r = pr.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, allreduce=allreduce, fetch_x=False)
+                assert r.iterations == k, (r.iterations, k)
+            else:
+                k = min(SOLVE_CAP, iters - done)
+                pr.reset()
+                r = pr.optimize(LM, LSMR, iterations=k, allreduce=allreduce, fetch_x=False)     # x_tol = f_tol = g_tol = 1e-8
+                assert 0 < r.iterations <= k, (r.iterations, k)
+            done += r.iterations
+            real += r.f_calls - 1                 # (one f! per working iteration + the one at x0)
             inner += r.lsmr_iterations
-        return done, inner, r
+        return done, real, inner, r
 
     def barrier():
         if dist is not None:
@@ -216,16 +232,24 @@ def main():
     stride = int(os.environ.get("LSQ_BENCH_PROF_STRIDE", "12"))
     L.lsq_prof_select(ctx.h, 1 | (stride << 8))     # bits 0-7: kernel mask; bits 8+: time every k-th launch
     L.lsq_prof_begin(ctx.h, 1 << 16)
-    region_s, inner_local, r = [], 0, None
+    region_s, inner_local, real_local, r = [], 0, 0, None
+    tail_before = ctx.tail_stats()
     reps = max(1, a.repeats)
     for _ in range(reps):
         barrier()
         t0 = time.perf_counter()
-        steps_done, inner_rep, r = run(a.steps)
+        steps_done, real_rep, inner_rep, r = run(a.steps)
         barrier()
         region_s.append(time.perf_counter() - t0)
         inner_local += inner_rep
+        real_local += real_rep
         assert steps_done == a.steps, (steps_done, a.steps)
+        assert world > 1 or real_rep == a.steps, (real_rep, a.steps)
+    tail_timed = tuple(int(x - y) for x, y in zip(ctx.tail_stats(), tail_before))
+    iters_per_ref_solve = None
+    if r is not None:
+        pr.reset()
+        iters_per_ref_solve = pr.optimize(LM, LSMR, iterations=SOLVE_CAP, allreduce=allreduce, fetch_x=False).iterations
     probe("timed regions done")
     avg = (C.c_double * 2)()
     cnt = (C.c_int * 2)()
@@ -235,7 +259,7 @@ def main():
     # costs a few microseconds of pipeline gaps, which the timed region should not pay twice
     L.lsq_prof_select(ctx.h, 2)
     L.lsq_prof_begin(ctx.h, 8192)
-    run(a.iters_per_solve)
+    run(a.iters_per_solve, fixed=a.iters_per_solve)
     avg2 = (C.c_double * 2)()
     cnt2 = (C.c_int * 2)()
     L.lsq_prof_end(ctx.h, avg2, cnt2)
@@ -256,11 +280,11 @@ def main():
         rr[rank] = own_rate
         dist.all_reduce(rr)                             # every rank's own median rate, for the line (a straggler shows)
         rank_rates = [float(v) for v in rr.tolist()]
-        it = torch.tensor([float(inner_local)], dtype=torch.float64, device="cuda")
+        it = torch.tensor([float(inner_local), float(real_local)], dtype=torch.float64, device="cuda")
         dist.all_reduce(it)
-        inner_total = float(it.item())
+        inner_total, real_total = float(it[0].item()), float(it[1].item())
     else:
-        inner_total = float(inner_local)
+        inner_total, real_total = float(inner_local), float(real_local)
     # every rank's own rate on stderr: a straggler among N ranks is visible next to the max-over-ranks headline
     own = sorted(region_s_local)
     print("bench: rank %d/%d own median region %.3f ms = %.1f LM it/s (inner %d)"
@@ -268,6 +292,7 @@ def main():
     srt = sorted(region_s)
     dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     inner_total /= reps                                  # per region
+    real_total /= reps                                   # working LM iterations of all ranks per region (N = 1: exactly K)
 
     # generic J*v (y <- J x + y) timed back-to-back with HIP events, for reference
     xv = lsq.DeviceVector(ctx, n, np.random.default_rng(0).standard_normal(n))
@@ -349,35 +374,34 @@ def main():
     if not a.no_cpu and a.cpu_steps > 0 and world == 1:   # reported at N = 1 only
         try:
             # the solve the timed region repeats, once more with its trace kept: the CPU leg's first solve is the same
-            # problem on the same schedule, so the two trajectories are compared instead of thrown away
+            # problem on the same schedule, so the two trajectories are compared instead of thrown away; and the
+            # zero-tolerance 8-iteration solve of rounds 1-5 (two iterations past convergence) beside it
+            pr.reset()
+            rgd = pr.optimize(LM, LSMR, iterations=SOLVE_CAP, trace=True)
             pr.reset()
             rgt = pr.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=a.iters_per_solve, trace=True)
-            cpu, parity = cpu_baseline(a, pr, inputs, rgt)
+            cpu, parity = cpu_baseline(a, pr, inputs, rgd, rgt)
         except Exception as e:   # noqa: BLE001
             cpu = {"value": None, "unit": "LM outer iterations/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
-    # the reference's OWN schedule, beside the headline: solves from x0 = 0 with the default tolerances (1e-8), which stop by
-    # themselves at convergence (6 iterations here; the headline's 8-iteration zero-tolerance solves run two cheap
-    # one-inner-iteration steps past it)
-    ref_sched = None
+    # the schedule of rounds 1-5 beside the headline: solves of --iters-per-solve (8) iterations with zero tolerances, i.e. two
+    # cheap one-inner-iteration steps past convergence per solve (they flatter the rate: never `value`)
+    fixed_sched = None
     if world == 1:
         try:
-            pr.reset()
-            pr.optimize(LM, LSMR, iterations=50, fetch_x=False)
-            ctx.sync()
-            t0 = time.perf_counter()
-            its = inn = 0
-            for _ in range(12):
-                pr.reset()
-                rr = pr.optimize(LM, LSMR, iterations=50, fetch_x=False)
-                its += rr.iterations
-                inn += rr.lsmr_iterations
-            ctx.sync()
-            dtm = time.perf_counter() - t0
-            ref_sched = {"value": its / dtm, "unit": "LM outer iterations/s", "ms_per_step": dtm / its * 1e3,
-                         "iterations_per_solve": rr.iterations, "converged": bool(rr.converged), "solves": 12,
-                         "lsmr_inner_per_outer": inn / its, "tolerances": "x_tol = f_tol = g_tol = 1e-8 (reference defaults)"}
+            run(a.iters_per_solve, fixed=a.iters_per_solve)
+            ts = []
+            for _ in range(5):
+                ctx.sync()
+                t0 = time.perf_counter()
+                _, _, inn, _ = run(a.steps, fixed=a.iters_per_solve)
+                ctx.sync()
+                ts.append(time.perf_counter() - t0)
+            dtm = sorted(ts)[len(ts) // 2]
+            fixed_sched = {"value": a.steps / dtm, "unit": "LM outer iterations/s", "ms_per_step": dtm / a.steps * 1e3,
+                           "iterations_per_solve": a.iters_per_solve, "lsmr_inner_per_outer": inn / a.steps,
+                           "tolerances": "x_tol = f_tol = g_tol = 0 (rounds 1-5: runs two iterations past convergence)"}
         except Exception as e:   # noqa: BLE001
-            ref_sched = {"error": repr(e)}
+            fixed_sched = {"error": repr(e)}
     generic = None
     if not a.no_cpu and world == 1 and "generic" not in skip:
         try:
@@ -385,42 +409,93 @@ def main():
         except Exception as e:   # noqa: BLE001
             generic = {"error": repr(e)}
 
-    value = a.steps * world / dt
+    def g(d, *path):        # nested lookup that tolerates failed legs
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    value = real_total / dt         # N = 1: exactly K / dt; N > 1: the working iterations of all ranks / the slowest rank's time
+    # ---- companions of the headline as SCALARS inside the three objects the driver's record keeps (and at top level) ----
+    parity_ok = None if parity is None else bool(parity["ok"])
+    flat = {"parity_ok": parity_ok,
+            "schedule_iterations_per_solve": iters_per_ref_solve,
+            "value_fixed8_schedule": g(fixed_sched, "value"),
+            "value_generic_g_device": g(generic, "device_g_all_nnz", "value"),
+            "value_generic_g_host_pinned_async": g(generic, "host_g_pinned_async", "value"),
+            "c2_ldiv_ms": g(dense, "c2_cholesky_damped_4096x512", "ldiv_ms"),
+            "c2_frac": g(dense, "c2_cholesky_damped_4096x512", "roofline", "frac"),
+            "c2_lm_cholesky_outer_ms": g(dense, "c2_lm_cholesky_4096x512", "outer_iteration_ms"),
+            "c3_ldiv_ms": g(dense, "c3_qr_16384x2048", "ldiv_ms"),
+            "c3_frac": g(dense, "c3_qr_16384x2048", "roofline", "frac"),
+            "c3_dogleg_qr_outer_ms": g(dense, "c3_dogleg_qr_16384x2048", "outer_iteration_ms"),
+            "wide_jv_frac": g(wide, "jv", "roofline", "frac"), "wide_jtu_frac": g(wide, "jtu", "roofline", "frac"),
+            "wide_lm_lsmr_outer_ms": g(wide, "lm_lsmr_outer_iteration_ms"),
+            "tail_guesses": tail_timed[0], "tail_wrong": tail_timed[1],
+            "tail_wrong_frac": (tail_timed[1] / tail_timed[0]) if tail_timed[0] else None}
+    roof["jtu_frac"] = (roof["jtu_GBps"] / HBM_PEAK_GBS) if roof.get("jtu_GBps") else None
+    # the PHYSICAL rate of the dominant kernel beside the algorithmic one: PMC bytes per launch / the launch's duration
+    roof["physical_GBps"] = (roof["traffic"] / (k1_ms * 1e-3) / 1e9) if (roof.get("traffic") and cnt[0] > 0) else None
+    roof["physical_frac"] = (roof["physical_GBps"] / HBM_PEAK_GBS) if roof["physical_GBps"] else None
+    for k in ("c2_ldiv_ms", "c2_frac", "c3_ldiv_ms", "c3_frac", "wide_jv_frac", "wide_jtu_frac"):
+        roof[k] = flat[k]
+    config = {"workload": "C4: sparse CSC %dx%d, nnz=%d (%.3g%%), LevenbergMarquardt(LSMR()), tanh model, "
+                          "1 problem per GPU" % (m, n, nnz, 100.0 * nnz / (m * n)),
+              "schedule": "reference: solves from x0 = 0 with the default tolerances (1e-8), each stopping at convergence "
+                          "(levenberg_marquardt.jl:41,123-124); K steps = consecutive solves, the last one cut at K",
+              "m": m, "n": n, "nnz": nnz, "seed": lsq.synthetic.BASE_SEED, "problems": world,
+              "exchange_backend": exchange_backend, "rccl_ranks": rccl_ranks,
+              "exchange": (dict(xchg_c.stats(), served_by="liblsqrccl.so lsq_rccl_xchg_* (C, direct ncclAllReduce)")
+                           if xchg_c is not None else None),
+              "per_rank_it_per_s": rank_rates,
+              "per_rank_it_per_s_min": min(rank_rates), "per_rank_it_per_s_max": max(rank_rates),
+              "working_iterations_all_ranks_per_region": real_total,
+              "lsmr_inner_iterations_total": inner_total,
+              "lsmr_inner_per_outer": inner_total / max(real_total, 1e-9),
+              "lsmr_inner_iterations_per_sec": inner_total / dt, "iters_per_solve_fixed8_leg": a.iters_per_solve,
+              "jacobian": "column-scaled handle J = A diag(1 - tanh(x)^2) on the sliced layouts: g! writes n factors, "
+                          "no Jacobian copy is multiplied out (lsq_mat_set_colscale; LSQ_NO_COLSCALE=1 restores the "
+                          "multiplied-out copies of rounds 1-2)" if not os.environ.get("LSQ_NO_COLSCALE") else
+                          "multiplied out into both sliced copies by g!",
+              "lsmr_iteration": lsmr_iteration_text(three),
+              "lm_tail": ("predicted residual and trial residual in ONE pass over A (k_sell_rows_pair, n <= 10200; LSQ_NO_PAIR_TAIL=1 "
+                          "restores the two launches)" if n <= 10200 and not os.environ.get("LSQ_NO_PAIR_TAIL")
+                          and not os.environ.get("LSQ_NO_COLSCALE") else "two passes over A (predicted residual, trial residual)"),
+              "final_ssr": r.ssr, "setup_seconds": t_setup,
+              # what the launch heuristics saw: 256 CUs / 8 XCDs = an unpartitioned MI355X (SPX); a partitioned device
+              # (CPX: 32 CUs) takes other kernels in the dense solvers (no slab exchange) and fewer workgroups everywhere
+              "device": ctx.device_info(), "debug_modes": dict(zip(("launch_jitter_us", "serial", "stalls"), lsq.debug_get()))}
+    if xchg_c is not None:      # the exchange's counters as scalars too (a future SCALE line is checkable from the record)
+        for k, v in xchg_c.stats().items():
+            if isinstance(v, (int, float)):
+                config["exchange_" + k] = v
+    config.update(flat)
+    if cpu is not None and cpu.get("value") is not None:
+        ac = cpu.get("all_cores") or {}
+        cpu["cpu_all_cores_value"] = ac.get("value")
+        cpu["cpu_all_cores_threads"] = ac.get("cores")
+        cpu["gpu_over_cpu_1_thread"] = value / cpu["value"] if cpu["value"] else None
+        cpu["gpu_generic_g_over_cpu_1_thread"] = (flat["value_generic_g_device"] / cpu["value"]
+                                                   if flat["value_generic_g_device"] and cpu["value"] else None)
+        cpu["gpu_over_cpu_all_cores"] = value / ac["value"] if ac.get("value") else None
+        cpu["parity_ok"] = parity_ok
     out = {"metric": "lm_lsmr_outer_iterations_per_sec", "value": value, "unit": "LM outer iterations/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "repeats": reps, "region_ms": {"median": dt * 1e3, "min": srt[0] * 1e3, "max": srt[-1] * 1e3},
-           "value_min": a.steps * world / srt[-1], "value_max": a.steps * world / srt[0],
-           "config": {"workload": "C4: sparse CSC %dx%d, nnz=%d (%.3g%%), LevenbergMarquardt(LSMR()), tanh model, "
-                                  "1 problem per GPU" % (m, n, nnz, 100.0 * nnz / (m * n)),
-                      "m": m, "n": n, "nnz": nnz, "seed": lsq.synthetic.BASE_SEED, "problems": world,
-                      "exchange_backend": exchange_backend, "rccl_ranks": rccl_ranks,
-                      "exchange": (dict(xchg_c.stats(), served_by="liblsqrccl.so lsq_rccl_xchg_* (C, direct ncclAllReduce)")
-                                   if xchg_c is not None else None),
-                      "per_rank_it_per_s": rank_rates,
-                      "lsmr_inner_iterations_total": inner_total,
-                      "lsmr_inner_per_outer": inner_total / (a.steps * world),
-                      "lsmr_inner_iterations_per_sec": inner_total / dt, "iters_per_solve": a.iters_per_solve,
-                      "jacobian": "column-scaled handle J = A diag(1 - tanh(x)^2) on the sliced layouts: g! writes n factors, "
-                                  "no Jacobian copy is multiplied out (lsq_mat_set_colscale; LSQ_NO_COLSCALE=1 restores the "
-                                  "multiplied-out copies of rounds 1-2)" if not os.environ.get("LSQ_NO_COLSCALE") else
-                                  "multiplied out into both sliced copies by g!",
-                      "lsmr_iteration": ("three launches: k_lsmr_fused | k_sell_cols | k_combine<EpiV> (LSQ_LSMR_FOUR_LAUNCHES=1 restores "
-                                         "k_sell_rows<EpiU> | k_sell_cols | k_combine<EpiV> | k_lsmr_update)" if three else "four launches"),
-                      "lm_tail": ("predicted residual and trial residual in ONE pass over A (k_sell_rows_pair, n <= 10200; LSQ_NO_PAIR_TAIL=1 "
-                                  "restores the two launches)" if n <= 10200 and not os.environ.get("LSQ_NO_PAIR_TAIL")
-                                  and not os.environ.get("LSQ_NO_COLSCALE") else "two passes over A (predicted residual, trial residual)"),
-                      "final_ssr": r.ssr, "setup_seconds": t_setup,
-                      # what the launch heuristics saw: 256 CUs / 8 XCDs = an unpartitioned MI355X (SPX); a partitioned device
-                      # (CPX: 32 CUs) takes other kernels in the dense solvers (no slab exchange) and fewer workgroups everywhere
-                      "device": ctx.device_info(), "debug_modes": dict(zip(("launch_jitter_us", "serial", "stalls"), lsq.debug_get()))},
-           "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu": parity, "reference_schedule": ref_sched, "generic_g": generic,
+           "value_min": real_total / srt[-1], "value_max": real_total / srt[0],
+           "config": config,
+           "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu": parity, "fixed8_schedule": fixed_sched, "generic_g": generic,
            "dense_secondary": dense, "sparse_secondary": wide,
            # bounded-wait give-ups of the fast paths that assume co-resident workgroups (include/lsqhip.h: lsq_solver_stats)
            "fallback_giveups": ctx.fallback_stats(),
-           # LM+LSMR: solves whose follow-up kernels were queued behind a guessed last inner iteration, and wrong guesses
-           "tail_speculation": dict(zip(("guesses", "wrong"), ctx.tail_stats()))}
+           # LM+LSMR: solves whose follow-up kernels were queued behind a guessed last inner iteration, and wrong guesses --
+           # inside the timed regions (`timed_regions`) and over the whole process (`whole_run`)
+           "tail_speculation": {"timed_regions": dict(zip(("guesses", "wrong"), tail_timed)),
+                                "whole_run": dict(zip(("guesses", "wrong"), ctx.tail_stats()))}}
+    out.update(flat)
     leave_group()
     if parity is not None and not parity["ok"]:
         # a rate measured on a trajectory that is not the reference's is not a measurement of this path: the line fails
@@ -430,6 +505,13 @@ def main():
     os.write(real_stdout, (json.dumps(out) + "\n").encode())   # fd 1 stays on stderr: RCCL prints its banner at exit
     if out.get("invalid"):
         raise SystemExit(3)
+
+
+def lsmr_iteration_text(three):
+    if not three:
+        return "four launches: k_sell_rows<EpiU> | k_sell_cols | k_combine<EpiV> | k_lsmr_update"
+    return ("three launches: k_lsmr_fused | k_sell_cols | k_combine<EpiV> (LSQ_LSMR_FOUR_LAUNCHES=1 restores "
+            "k_sell_rows<EpiU> | k_sell_cols | k_combine<EpiV> | k_lsmr_update)")
 
 
 def dry_run(a, rank, world, real_stdout):
@@ -473,6 +555,15 @@ def dry_run(a, rank, world, real_stdout):
 
 
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense fp64 matrix peak
+
+
+def newest_profile(name):
+    """profiles/rNN/<name> of the newest round that holds it (the committed rocprofv3 summaries the line's figures refer to)."""
+    base = os.path.join(ROOT, "profiles")
+    for rnd in sorted((d for d in os.listdir(base) if d.startswith("r")), reverse=True):
+        if os.path.exists(os.path.join(base, rnd, name)):
+            return "profiles/%s/%s" % (rnd, name)
+    return "profiles/ (none committed)"
 
 
 def sparse_secondary(ctx, lsq):
@@ -533,8 +624,8 @@ def generic_g(a, ctx, lsq, inputs, b):
     m, n, pc = a.m, a.n, a.per_col
     LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
     colptr, rowval, nzval = inputs
-    out = {"workload": "same C4 problem and schedule as the headline (solves of %d iterations from x0 = 0, zero tolerances)"
-                       % a.iters_per_solve,
+    out = {"workload": "same C4 problem and schedule as the headline (solves from x0 = 0 with the reference's default tolerances, "
+                       "each stopping at convergence)",
            "headline_g": "column-scaled handle: g! writes n factors (model-specific)"}
     saved = {k: os.environ.get(k) for k in ("LSQ_NO_COLSCALE", "LSQ_NO_PAIR_TAIL")}
     os.environ["LSQ_NO_COLSCALE"] = "1"     # (read when the model is created: it keeps A aside and J gets multiplied out)
@@ -553,11 +644,11 @@ def generic_g(a, ctx, lsq, inputs, b):
             done = 0
             r = None
             while done < iters:
-                k = min(a.iters_per_solve, iters - done)
+                k = min(50, iters - done)
                 pr2.reset()
                 r = optimize(k)
-                assert r.iterations == k, (r.iterations, k)
-                done += k
+                assert 0 < r.iterations <= k, (r.iterations, k)
+                done += r.iterations
             return r
         run(a.iters_per_solve)
         ts = []
@@ -573,7 +664,7 @@ def generic_g(a, ctx, lsq, inputs, b):
 
     legs = os.environ.get("LSQ_BENCH_GENERIC_LEGS", "device,host").split(",")      # (diagnostics)
     if "device" in legs:
-        leg = timed(lambda k: pr2.optimize(LM, LSMR, x_tol=0.0, f_tol=0.0, g_tol=0.0, iterations=k, fetch_x=False))
+        leg = timed(lambda k: pr2.optimize(LM, LSMR, iterations=k, fetch_x=False))
         leg["g"] = "device kernel, every stored value of both sliced copies rewritten (LSQ_NO_COLSCALE=1, two-pass tail)"
         out["device_g_all_nnz"] = leg
 
@@ -610,7 +701,7 @@ def generic_g(a, ctx, lsq, inputs, b):
         def opt_host(k):
             from lsq_amd.api import LeastSquaresResult, _run_native
             st, res, _ = _run_native(ctx, LM, LSMR, _H, pr2.x, pr2.fcur, fcb, gcb, C.cast(C.pointer(hg), C.c_void_p),
-                                     0.0, 0.0, 0.0, k, None, None, None, False, n)
+                                     1e-8, 1e-8, 1e-8, k, None, None, None, False, n)
             lsq._lib.check(st)
             r = LeastSquaresResult()
             r.iterations, r.ssr, r.g_calls = res.iterations, float(res.ssr), res.g_calls
@@ -700,7 +791,7 @@ def dense_secondary(ctx, lsq, probe=lambda stage: None):
                      "roofline": {"bound": "mfma", "useful_flops": flops, "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS, "dominant_kernels": dom,
                                   "note": "whole ldiv! (factorisation + solve) over the useful flops of SURVEY 8d; per-kernel "
-                                          "split and MFMA counters: profiles/r04/dense_kernel_summary.md"},
+                                          "split and MFMA counters: " + newest_profile("dense_kernel_summary.md")},
                      "path": {k: info.get(k) for k in ("qr_path", "qr_panel", "chol_path")}}
         J.free()
         probe("dense_secondary: after the ldiv! leg of " + name)
@@ -725,10 +816,10 @@ def dense_secondary(ctx, lsq, probe=lambda stage: None):
     return out
 
 
-def parity_vs_cpu(rg, ro, ssr0):
-    """The HIP run of the timed region's solve against the oracle's run of the same solve (same inputs, same schedule):
-    levenberg_marquardt.jl:72-140 / iterative_lsmr.jl:238-259.  The schedule runs on past convergence (zero tolerances; the
-    reference's own run stops at `useful_iterations`, see reference_schedule), where a step changes the objective by ~1e-15
+def parity_past_convergence(rg, ro, ssr0):
+    """The HIP run of rounds 1-5's fixed schedule (8 iterations, zero tolerances) against the oracle's run of the same solve:
+    levenberg_marquardt.jl:72-140 / iterative_lsmr.jl:238-259.  That schedule runs on past convergence (the
+    reference's own run stops at `useful_iterations`: the timed schedule), where a step changes the objective by ~1e-15
     relative and the gain ratio rho is a quotient of rounding errors of two sums over m squares: an iteration at which the two
     runs disagree about acceptance AND the accepting run changed ssr by less than 1e-12 relative is ROUND-OFF-DECIDED
     (tests/gpu_common.py::compare_until_roundoff, the same rule).  `ok` = up to the first such iteration identical accept
@@ -773,19 +864,19 @@ def parity_vs_cpu(rg, ro, ssr0):
                            "roundoff_decided": "accept decisions differ and the accepting run moved ssr by <= 1e-12 relative"}}
 
 
-def cpu_baseline(a, pr, inputs, gpu_run=None):
+def cpu_baseline(a, pr, inputs, gpu_ref_run, gpu_fixed_run):
     """The oracle (scalar C port of the reference, 1 thread -- the reference's sparse products and vector loops ARE serial,
-    SURVEY 8d) on the SAME inputs and schedule, bounded sample, one warm-up solve first -- whose trajectory is compared
-    with the HIP run of the same solve (`parity_vs_cpu`).  NB the CPU leg's g! multiplies J = A diag(1 - tanh(x)^2) out
-    entry by entry (orc_tanh_g: what a generic g! of the reference does, test/nonlinearleastsquares.jl:47-86); the headline
-    GPU leg keeps a column-scaled handle (n factors) -- `generic_g` in the same line is the GPU doing what the CPU leg does.
-    Next to it, labelled, the
-    "generous CPU" figure BASELINE.md promises: the same algorithm restructured for all host cores with OpenMP
-    (oracle/lsq_oracle_omp.c: CSR mirror for J*v, both copies written by g!, parallel reductions)."""
+    SURVEY 8d) on the SAME inputs and the SAME schedule as the timed region (solves from x0 = 0 with the default tolerances,
+    each stopping at convergence), bounded sample, one warm-up solve first -- whose trajectory is compared with the HIP run
+    of the same solve (`parity_vs_cpu`: every count, flag, inner count and accept decision identical, iterates to 1e-8, ssr to
+    1e-9).  The zero-tolerance 8-iteration solve of rounds 1-5 is compared as well (`past_convergence`, the round-off-decided
+    rule of parity_past_convergence).  NB the CPU leg's g! multiplies J = A diag(1 - tanh(x)^2) out entry by entry (orc_tanh_g:
+    what a generic g! of the reference does, test/nonlinearleastsquares.jl:47-86); the headline GPU leg keeps a column-scaled
+    handle (n factors) -- `value_generic_g_device` in the same line is the GPU doing what the CPU leg does.  Julia itself is
+    not in the image: both CPU figures are `"kind": "port"` (the C restatement; the OpenMP variant restructured for all host
+    cores: oracle/lsq_oracle_omp.c, CSR mirror for J*v, both copies written by g!, parallel reductions)."""
     import numpy as np
-    import lsq_amd as lsq
     from oracle import oracle as O
-    pr_LM, pr_LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
     m, n = a.m, a.n
     colptr, rowval, nzval = inputs
     A = O.Mat(csc=(m, n, colptr, rowval, nzval))
@@ -794,36 +885,42 @@ def cpu_baseline(a, pr, inputs, gpu_run=None):
 
     def solves(total):
         done = inner = 0
-        while done < total:  # same schedule as the GPU: solves of --iters-per-solve from x0 = 0
-            k = min(a.iters_per_solve, total - done)
-            ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=k, x_tol=0.0, f_tol=0.0,
-                            g_tol=0.0, trace=True, trace_x=False)
-            done += k
+        while done < total:  # same schedule as the GPU: solves from x0 = 0 with the default tolerances, the last one cut
+            k = min(50, total - done)
+            ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=k, trace=True, trace_x=False)
+            done += int(ro.iterations)
             inner += int(ro.trace["inner"].sum()) // 2
         return inner
     # warm-up (page faults, caches) = the solve whose trajectory is checked against the GPU's
-    ro = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=a.iters_per_solve, x_tol=0.0, f_tol=0.0,
-                    g_tol=0.0, trace=True, trace_x=True)
-    parity = parity_vs_cpu(gpu_run, ro, float(np.sum(np.asarray(pr.b) ** 2))) if gpu_run is not None else None
-    if parity is not None:
-        # the reference's OWN run of this problem (default tolerances 1e-8: it stops by itself) on both sides
-        pr.reset()
-        rgd = pr.optimize(pr_LM, pr_LSMR, iterations=50, trace=True)
-        rod = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=50, trace=True, trace_x=False)
-        parity["reference_run_default_tolerances"] = {
-            "iterations": [int(rgd.iterations), int(rod.iterations)], "converged": [bool(rgd.converged), bool(rod.converged)],
-            "flags_xfg": [[bool(rgd.x_converged), bool(rgd.f_converged), bool(rgd.g_converged)],
-                          [bool(rod.x_converged), bool(rod.f_converged), bool(rod.g_converged)]],
-            "counts_f_g_mul": [[int(rgd.f_calls), int(rgd.g_calls), int(rgd.mul_calls)], [int(rod.f_calls), int(rod.g_calls), int(rod.mul_calls)]],
-            "inner_equal": bool(rgd.iterations == rod.iterations and np.array_equal(rgd.trace["inner"], rod.trace["inner"])),
-            "accept_equal": bool(rgd.iterations == rod.iterations and np.array_equal(rgd.trace["accept"], rod.trace["accept"])),
-            "ssr_rel": float(abs(rgd.ssr - rod.ssr) / rod.ssr)}
-        d = parity["reference_run_default_tolerances"]
-        d["ok"] = bool(d["iterations"][0] == d["iterations"][1] and d["converged"][0] == d["converged"][1]
-                       and d["flags_xfg"][0] == d["flags_xfg"][1] and d["counts_f_g_mul"][0] == d["counts_f_g_mul"][1]
-                       and d["inner_equal"] and d["accept_equal"] and d["ssr_rel"] <= 1e-9)
-        parity["useful_iterations"] = int(rod.iterations)
-        parity["ok"] = bool(parity["ok"] and d["ok"])
+    rod = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=50, trace=True, trace_x=True)
+    rgd = gpu_ref_run
+    k_all = min(int(rgd.iterations), int(rod.iterations))
+    xs = max(1.0, float(np.max(np.abs(rod.trace["x"][:k_all])))) if k_all else 1.0
+    dxs = [float(np.max(np.abs(np.asarray(rgd.trace["x"][i]) - rod.trace["x"][i]))) for i in range(k_all)]
+    ssr_rel = (float(np.max(np.abs(np.asarray(rgd.trace["ssr"][:k_all]) - rod.trace["ssr"][:k_all]) / rod.trace["ssr"][:k_all]))
+               if k_all else None)
+    same = int(rgd.iterations) == int(rod.iterations)
+    parity = {
+        "schedule": "the timed schedule: one solve from x0 = 0 with the default tolerances (1e-8)",
+        "iterations": [int(rgd.iterations), int(rod.iterations)], "converged": [bool(rgd.converged), bool(rod.converged)],
+        "flags_xfg": [[bool(rgd.x_converged), bool(rgd.f_converged), bool(rgd.g_converged)],
+                      [bool(rod.x_converged), bool(rod.f_converged), bool(rod.g_converged)]],
+        "counts_f_g_mul": [[int(rgd.f_calls), int(rgd.g_calls), int(rgd.mul_calls)], [int(rod.f_calls), int(rod.g_calls), int(rod.mul_calls)]],
+        "inner_equal": bool(same and np.array_equal(rgd.trace["inner"], rod.trace["inner"])),
+        "accept_equal": bool(same and np.array_equal(rgd.trace["accept"], rod.trace["accept"])),
+        "inner_per_outer": {"hip": [int(v) // 2 for v in rgd.trace["inner"]], "cpu": [int(v) // 2 for v in rod.trace["inner"]]},
+        "max_abs_dx": max(dxs) if dxs else None, "ssr_rel": ssr_rel,
+        "checker": "oracle/lsq_oracle.c (CPU restatement of the reference), warm-up solve of the cpu_baseline leg",
+        "tolerances": {"max_abs_dx": "1e-8*max(1,|x|inf)", "ssr_rel": 1e-9, "counts, flags, inner counts, accept pattern": "identical"}}
+    parity["ok"] = bool(same and parity["converged"][0] == parity["converged"][1] and parity["flags_xfg"][0] == parity["flags_xfg"][1]
+                        and parity["counts_f_g_mul"][0] == parity["counts_f_g_mul"][1] and parity["inner_equal"]
+                        and parity["accept_equal"] and dxs and max(dxs) <= 1e-8 * xs and ssr_rel <= 1e-9)
+    parity["useful_iterations"] = int(rod.iterations)
+    if gpu_fixed_run is not None:     # rounds 1-5's schedule, two iterations past convergence: reported, and still has to hold
+        ro8 = O.optimize(O.LM, O.LSMR, J, np.zeros(n), f, g, ud=ud, iterations=a.iters_per_solve, x_tol=0.0, f_tol=0.0,
+                         g_tol=0.0, trace=True, trace_x=True)
+        parity["past_convergence"] = parity_past_convergence(gpu_fixed_run, ro8, float(np.sum(np.asarray(pr.b) ** 2)))
+        parity["ok"] = bool(parity["ok"] and parity["past_convergence"]["ok"])
     t0 = time.perf_counter()
     inner = solves(a.cpu_steps)
     dt = time.perf_counter() - t0
@@ -836,22 +933,23 @@ def cpu_baseline(a, pr, inputs, gpu_run=None):
     t_mv = (time.perf_counter() - t1) / reps
     nnz = len(nzval)
     out = {"value": a.cpu_steps / dt, "unit": "LM outer iterations/s", "cores": 1, "kind": "port",
-           "sample": "%d LM outer iterations (%d LSMR inner; solves of %d iterations from x0=0) of the same C4 "
-                     "problem with oracle/lsq_oracle.c, 1 thread, after one warm-up solve, %.1f s; its g! multiplies "
-                     "J = A diag(1 - tanh(x)^2) out entry by entry (compare with generic_g.device_g_all_nnz, not only with "
-                     "the column-scaled headline)" % (a.cpu_steps, inner, a.iters_per_solve, dt),
+           "sample": "%d LM outer iterations (%d LSMR inner; solves from x0=0 with the default tolerances, %d iterations each: "
+                     "the timed schedule) of the same C4 problem with oracle/lsq_oracle.c (C restatement of the reference; no "
+                     "Julia in the image), 1 thread, after one warm-up solve, %.1f s; its g! multiplies J = A diag(1 - tanh(x)^2) "
+                     "out entry by entry (like for like: value_generic_g_device)"
+                     % (a.cpu_steps, inner, int(rod.iterations), dt),
            "lsmr_inner_iterations_per_sec": inner / dt, "host_cores_available": os.cpu_count(),
            "jv_GBps": (12 * nnz + 4 * (m + 1) + 8 * n + 16 * m) / t_mv / 1e9}
     try:   # the all-cores figure (a restructured, OpenMP-parallel port: labelled, not the reference's serial path)
         b = np.ascontiguousarray(pr.b, dtype=np.float64)
-        k = a.iters_per_solve
+        k = int(rod.iterations)       # (the OpenMP port runs a fixed count with zero tolerances: the reference run's length)
         best = None
         ncpu = os.cpu_count() or 1
         for thr in sorted({t for t in (16, 32, 64, ncpu // 2, ncpu) if 1 < t <= ncpu}):
             op = O.OmpProblem(m, n, colptr, rowval, nzval, b, threads=thr)     # (layout build: not timed, as on the GPU)
             try:
                 op.run(np.zeros(n), k)                                          # warm-up
-                nsolve = 3
+                nsolve = 4
                 t0 = time.perf_counter()
                 inner_o = sum(op.run(np.zeros(n), k)[2] for _ in range(nsolve))
                 dto = time.perf_counter() - t0

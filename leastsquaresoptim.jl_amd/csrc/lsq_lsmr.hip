@@ -155,7 +155,21 @@ struct EpiV {
         first = st->first;
     }
     __device__ void seg(int j, double dot, double &racc) const {
-        if (beta_zero) return;                      // lsmr.jl:120
+        if (beta_zero) {                            // lsmr.jl:120: v (and alpha) stay as they are
+            // The three-launch iteration reads v~ and the gather vector from buffers of their own and rescales them by 1/alpha:
+            // with beta == 0 they must hold the NORMALISED v (the consumer's scale is 1 then, lsmr_scalars), not the previous
+            // iteration's unnormalised v~.  Setup pass (first): v is still zero (lsmr.jl:76 never ran).
+            if (vout) {
+                const double vj = first ? 0.0 : v[j];
+                vout[j] = vj;
+                if (wout) {
+                    const double t = P ? vj * P[j] : vj;
+                    wout[j] = cs ? t * cs[j] : t;
+                }
+                racc += vj * vj;
+            }
+            return;
+        }
         double w = dot;
         if (dg && ux) w += ux[j] * dg[j];           // iterative_lsmr.jl:107
         w *= inv_beta;                              // u = u~/beta
@@ -735,6 +749,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         bool need_product = false;   // launch k1 went out commit-only: its product half is still owed (if the solve goes on)
         static const bool use_halves = getenv("LSQ_LSMR_HALVES") != nullptr;          // (A/B: commit-only + product-only launches)
         static const bool no_cautious = getenv("LSQ_LSMR_NO_CAUTIOUS") != nullptr;    // (A/B: always the plain fused launch)
+        const int test_no_record = getenv("LSQ_TEST_EXCHANGE_TIMEOUT") ? 1 : 0;       // (read once per solve, not per launch)
         const size_t prof_base3[2] = {c->prof_ev[0].size(), c->prof_ev[1].size()};
         std::vector<int> prof_it3[2];
         unsigned long long spins = 0;
@@ -755,8 +770,9 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             a.uold = j == 1 ? d_y : s->d_u; a.unew = s->d_u;
             a.n = n; a.ub = mode == 2 ? 0 : ub;
             a.cautious = mode == 3 ? 1 : 0;
-            a.test_no_record = getenv("LSQ_TEST_EXCHANGE_TIMEOUT") ? 1 : 0;    // (test hook: the in-launch hand-off fails)
+            a.test_no_record = test_no_record;                      // (test hook: the in-launch hand-off fails)
             a.ho = fho;
+            a.tag_prev = j > 1 ? s->f3_tag : 0u;                    // (mode 2 has no update workgroups: unused there)
             if (mode != 2 && ++s->f3_tag == 0u) s->f3_tag = 1u;    // a counter per solver (= per record buffer): every older record
             a.tag = s->f3_tag;                                      // carries another value; 0 is the zeroed buffer
             if (mode == 2) a.st_in = stb[out];                      // (the state its commit-only half has committed)

@@ -16,7 +16,8 @@
 // Hand-off inside the launch: workgroup 0 -> every product workgroup, one record {1/alpha, alpha/beta, done} as
 // tagged words (flag-in-data); requested by a reader before the last slice of its stream and checked after it (bounded re-reads
 // otherwise: workgroup 0 is the FIRST workgroup of the grid, so it is dispatched before any reader; a reader that still gives
-// up -- a second of spinning -- marks the state failed (istop = 99) and the host returns LSQ_EHIP).
+// up -- a second of spinning -- leaves its launch's tag in a word of its own; the next launch's update workgroups end the solve
+// with istop = 99 and the host returns LSQ_EHIP).
 // The state and x, hbar, h are double-buffered (launch k reads set (k-1)&1 and writes set k&1): the update workgroups read ALL of
 // x, hbar, h for ||x|| while their siblings write their own thirds; a late workgroup must not read what its own launch commits.
 // Where the host expects the launch to find the solve finished (lsq_lsmr_solve: the predicted last iteration; the first iteration
@@ -42,6 +43,12 @@ __device__ __forceinline__ void lsmr_handoff_write(LsmrHandoff *ho, unsigned tag
     __hip_atomic_store(&ho->w[3], t | (bc >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&ho->w[4], t | (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A reader that gives up waiting for the record leaves its launch's tag in w[6] -- a word nobody else writes (marking
+// the committed state itself was unsafe, workgroup 0 of the same launch copies its whole state over it when it finally runs).  The
+// update workgroups of the NEXT launch find the tag there and end the solve with istop = 99; the host returns LSQ_EHIP.
+__device__ __forceinline__ void lsmr_handoff_fail(LsmrHandoff *ho, unsigned tag) {
+    __hip_atomic_store(&ho->w[6], (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 struct LsmrHandoffWords { unsigned long long w[5]; };
 __device__ __forceinline__ LsmrHandoffWords lsmr_handoff_request(const LsmrHandoff *ho) {
     LsmrHandoffWords r;
@@ -61,6 +68,8 @@ struct LsmrFused {
     LsqMailbox *mail;
     LsmrHandoff *ho;
     unsigned tag;                                // of this launch's record: differs from the previous launch's
+    unsigned tag_prev;                           // the previous launch's tag: a reader of THAT launch that gave up left it in ho->w[6]
+                                                 // (0: launch 1 of a solve -- the launch in front of it is the setup, nothing to check)
     const double *pu_in; const int *npu_in;      // sum(u~_y^2): the previous launch's product workgroups (or the setup)
     double *pu_out; int *npu_out;
     const double *px_in; const int *npx_in;      // sum(u~_x^2): the previous launch's update workgroups (null: u~_x == 0)
@@ -197,6 +206,9 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             hi[q] = a.h_in[j];
         }
         if (tid < (int)(sizeof(LsmrState) / 8)) ((unsigned long long *)&ns)[tid] = ((const unsigned long long *)a.st_in)[tid];
+        // (did a product workgroup of the previous launch give up on its record?  every update workgroup looks, all decide alike)
+        const bool prev_failed = a.tag_prev != 0u &&
+                                 (unsigned)__hip_atomic_load(&a.ho->w[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag_prev;
         double beta2, betax2, alpha2;
         ordered_sum512x3(a.pu_in, a.npu_in, a.px_in, a.npx_in, a.pv, a.npv, beta2, betax2, alpha2);   // (its barriers also publish ns)
         if (ns.done) {    // a launch queued behind a finished solve: hand the state on (kernels behind it read st_out), release the readers
@@ -229,6 +241,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             ns.first = 0;
             if (!(ns.normAr != 0.0)) { ns.done = 1; ns.notdone = 0; }      // lsmr.jl:115: exit if b = 0 or A'b = 0
         }
+        if (tid == 0 && prev_failed) { ns.istop = 99; ns.done = 1; ns.notdone = 0; }   // u~ of the previous launch is incomplete
         __syncthreads();
         const bool done_now = ns.done != 0;
         const double vs = ns.vscale, cu = ns.cu, c1 = ns.c1, c2 = ns.c2, c3 = ns.c3;
@@ -328,11 +341,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             s_vs = __longlong_as_double((long long)((rec.w[0] & 0xffffffffull) | (rec.w[1] << 32)));
             s_cu = __longlong_as_double((long long)((rec.w[2] & 0xffffffffull) | (rec.w[3] << 32)));
             s_done = ok ? (int)(rec.w[4] & 0xffffffffull) : 2;
-            if (!ok) {
-                __hip_atomic_store(&a.st_out->istop, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.st_out->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.st_out->notdone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (!ok) lsmr_handoff_fail(a.ho, a.tag);
         }
         __syncthreads();
         if (s_done) return;
@@ -382,11 +391,7 @@ __global__ void __launch_bounds__(LSQ_BIG_NT) k_lsmr_fused(SellDev S, int wrows,
             s_vs = __longlong_as_double((long long)((rec.w[0] & 0xffffffffull) | (rec.w[1] << 32)));
             s_cu = __longlong_as_double((long long)((rec.w[2] & 0xffffffffull) | (rec.w[3] << 32)));
             s_done = ok ? (int)(rec.w[4] & 0xffffffffull) : 2;
-            if (!ok) {      // never silent: the solve ends with istop = 99 and the host returns an error
-                __hip_atomic_store(&a.st_out->istop, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.st_out->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.st_out->notdone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (!ok) lsmr_handoff_fail(a.ho, a.tag);      // never silent: the next launch ends the solve with istop = 99
         }
         have_scalars = true;
         __syncthreads();

@@ -57,6 +57,23 @@ extern "C" int lsq_solver_destroy(lsq_solver *s) {
     return LSQ_OK;
 }
 
+// include/lsqhip.h: "calls that return host scalars synchronise the stream".  The LSMR driver learns about the stop from a
+// progress word that the committing workgroup publishes BEFORE its sibling workgroups have finished writing x (lsq_lsmr3.h:
+// relaxed publish), and launches of the look-ahead may still be queued: the public entry points drain the stream
+// before they hand nmul back, so that x may be read from another stream or with a blocking copy.  (Polled, not
+// hipStreamSynchronize: what is left in the queue is microseconds of work, a sleeping wait wakes up after ~50 us.)  The LM /
+// Dogleg loops call lsq_lsmr_solve directly and stay stream-ordered.
+static int lsmr_drain(lsq_solver *s) {
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s->ctx->stream);
+        if (q == hipSuccess) return LSQ_OK;
+        if (q != hipErrorNotReady) {
+            lsq_set_error("HIP error behind an LSMR solve: %s", hipGetErrorString(q));
+            return LSQ_EHIP;
+        }
+    }
+}
+
 extern "C" int lsq_ldiv(lsq_solver *s, lsq_mat *J, const double *y, double *x, int *nmul) {
     LSQ_RANGE("lsq_ldiv");
     if (!s || !J || !y || !x) return LSQ_EARG;
@@ -65,7 +82,7 @@ extern "C" int lsq_ldiv(lsq_solver *s, lsq_mat *J, const double *y, double *x, i
         return LSQ_EDIM;
     }
     switch (s->kind) {
-    case LSQ_LSMR: return lsq_lsmr_solve(s, J, y, nullptr, x, nmul);
+    case LSQ_LSMR: LSQ_TRY(lsq_lsmr_solve(s, J, y, nullptr, x, nmul)); return lsmr_drain(s);
     case LSQ_CHOLESKY: return lsq_cholesky_solve(s, J, y, nullptr, x, nmul);
     default: return lsq_qr_solve(s, J, y, nullptr, x, nmul);
     }
@@ -75,7 +92,7 @@ extern "C" int lsq_ldiv_damped(lsq_solver *s, lsq_mat *J, const double *y, doubl
     LSQ_RANGE("lsq_ldiv_damped");
     if (!s || !J || !y || !x || !damp) return LSQ_EARG;
     switch (s->kind) {
-    case LSQ_LSMR: return lsq_lsmr_solve(s, J, y, damp, x, nmul);
+    case LSQ_LSMR: LSQ_TRY(lsq_lsmr_solve(s, J, y, damp, x, nmul)); return lsmr_drain(s);
     case LSQ_CHOLESKY: return lsq_cholesky_solve(s, J, y, damp, x, nmul);
     default: return lsq_qr_solve(s, J, y, damp, x, nmul);
     }
@@ -1084,7 +1101,9 @@ static int optimize_dogleg_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_
                 LSQ_TRY(global_exchange(o, &gssr, &ggr, &all));
                 exchanged = true;
             }
-            LSQ_TRY(lsq_ldiv(sv, J, fcur, b.dgn, &ls_iter));              // :115
+            // :115 (LSMR: the driver itself -- what follows is ordered on the stream, the public entry's drain is not needed)
+            if (sv->kind == LSQ_LSMR) LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, nullptr, b.dgn, &ls_iter));
+            else LSQ_TRY(lsq_ldiv(sv, J, fcur, b.dgn, &ls_iter));
             mul_calls += ls_iter;
             inner_total += ls_iter / 2;
             LSQ_TRY(wdot_to_slot(c, exact, n, b.dgn, b.dgn, b.dtd, 5, c->d_slots + SL_W1));     // :117

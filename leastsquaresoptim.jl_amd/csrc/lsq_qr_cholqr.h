@@ -1,6 +1,36 @@
 // CholeskyQR2 panel + basis-kernel block reflector for the blocked QR (lsq_qr_cholqr.hip); used by lsq_dense.hip
 #pragma once
 #include "lsq_common.h"
+#include "lsq_small64.h"
+
+constexpr int CQ_RS = 64;                  // rows of the panel per workgroup (256 workgroups at 16384 rows: every CU)
+constexpr int CQ_QST = CQ_RS + 2;          // slab image [col][row], row stride (doubles)
+
+// Gram of the slab image, UPPER 16 x 16 tiles only (10 of 16; the consumers read the upper triangle), 3 / 3 / 2 / 2 tiles
+// per wavefront, K = CQ_RS; partial -> Gp (row-major 64 x 64; the strictly lower tiles stay as allocated: zero)
+__device__ __forceinline__ void cq_slab_gram(const double *__restrict__ Qs, double *__restrict__ Gp, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    const int ij = lane & 15, kq = lane >> 4;
+    const int first = w < 2 ? 3 * w : 6 + 2 * (w - 2), count = w < 2 ? 3 : 2;
+    for (int t = 0; t < count; ++t) {
+        const int id = first + t;                       // 0..9 -> (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+        const int ti = id < 4 ? 0 : id < 7 ? 1 : id < 9 ? 2 : 3;
+        const int tj = id < 4 ? id : id < 7 ? id - 3 : id < 9 ? id - 5 : 3;
+        const double *pa = Qs + (16 * ti + ij) * CQ_QST + kq, *pb = Qs + (16 * tj + ij) * CQ_QST + kq;
+        s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k0 = 0; k0 < CQ_RS; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = pa[k0 + 4 * u]; b[u] = pb[k0 + 4 * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gp[(16 * ti + kq + 4 * r) * 64 + 16 * tj + ij] = acc[r];
+    }
+}
+
 
 struct CqrWork {
     double *Gp = nullptr;    // [max_slabs][64 x 64] Gram partials of the 128-row slabs
@@ -8,6 +38,8 @@ struct CqrWork {
     double *R1 = nullptr;    // R1 (row-major 64 x 64)
     double *Binv = nullptr;  // inv(Q_top - S)
     double *Minv = nullptr;  // look-ahead panel: inv(R1) | inv(R2) from k_cqr_factor (2 x 64 x 64, row-major)
+    double *R2inv = nullptr; // Q1 form (round 6): inv(R2) from k_cqr_top, applied to the 64 x N matrices by k_cqr_tw_q1
+    bool q1form = false;     //   ... the form the panel in flight was launched in (lsq_cqr_panel sets it, lsq_cqr_tw reads it)
     double *S = nullptr;     // 64 signs
     double *SR = nullptr;    // S R2 R1, the panel's part of the factor ([col][row]); k_cqr_tw moves it into A
     int max_slabs = 0;
@@ -20,10 +52,17 @@ struct CqrWork {
 int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M);
 void lsq_cqr_free(CqrWork *w);
 // Panel c0..c0+63 of A (column-major, leading dimension M, rows c0..M-1).  In stream order afterwards: Vb (ldv = M - c0)
-// holds Q, and the panel's part of R (w->SR) and the kernel of the block reflector are on their way on the side stream;
-// lsq_cqr_tw puts the former into A's 64 x 64 triangle.  A breakdown (cond(panel) beyond ~1e7) sets bit 1 of *d_err.
+// holds Q1 (Q1 form, round 6: the panel has had ONE orthogonalisation pass; inv(R2) is applied to the small matrices by
+// lsq_cqr_tw) or Q (LSQ_QR_CQR_PASS2=1: both passes), and the panel's part of R (w->SR) and the kernel of the block reflector
+// are on their way on the side stream; lsq_cqr_tw puts the former into A's 64 x 64 triangle.  A breakdown (cond(panel) beyond
+// ~1e7) sets bit 1 of *d_err.
 // ps: the stream the passes run on (the context's, or w->ahead for a look-ahead panel).
-int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps);
-// after W = Vb'[Vb | A2 | b] (k_qr1_vtb + k_qr1_wreduce):  W2 = T'W for the trailing columns and b; turns Vb into V = Q - [S; 0]
+// gram_ready: w->Gp already holds the Gram partials of this panel's 64-row slabs (left by the previous panel's update).
+int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps,
+                  bool gram_ready = false);
+bool lsq_cqr_q1form();
+// after W = Vb'[Vb | A2 | b] (k_qr1_vtb + k_qr1_wreduce):  the update kernel's 64 x N operand for the trailing columns and b.
+// Q1 form: A2 -= Vb W2 over ALL rows finishes the block step (the [S W2; 0] part has been added to A2's top rows here);
+// three-pass form: Vb becomes V = Q - [S; 0] here.
 int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, int M, int c0, int cend, int n,
-               const double *rhs, double *Vb, int ldv, double *W2);
+               double *rhs, double *Vb, int ldv, double *W2);

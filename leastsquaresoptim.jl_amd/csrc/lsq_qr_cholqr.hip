@@ -29,8 +29,7 @@
 #include "lsq_qr_cholqr.h"
 #include "lsq_small64.h"
 
-constexpr int CQ_RS = 64;                  // rows of the panel per workgroup (256 workgroups at 16384 rows: every CU)
-constexpr int CQ_QST = CQ_RS + 2;          // slab image [col][row], row stride (doubles)
+// (CQ_RS, CQ_QST and cq_slab_gram live in lsq_qr_cholqr.h: the trailing update of the previous panel forms the Gram partials too)
 // pass kernels: inv(R) | R | scratch; the slab image (64 * CQ_QST doubles) lives over R + scratch once the factor is done:
 // 75 KB instead of 109, i.e. two slab workgroups per CU (LM's stacked 18432-row operand has 288 slabs: 9.3 -> 8.5 ms).
 // (Look-ahead -- panel k+1's passes on a high-priority stream beside the update of panel k -- was built on top of this in
@@ -42,6 +41,7 @@ static_assert(S64_MAT + S64_TMP >= 64 * CQ_QST, "slab image over R + scratch");
 constexpr size_t CQ_LDS = (size_t)CQ_LDS_DOUBLES * sizeof(double);
 constexpr size_t CQ_LDS_LU = (size_t)(4 * S64_MAT + S64_TMP) * sizeof(double);
 constexpr size_t CQ_LDS_TW = (size_t)(2 * S64_MAT) * sizeof(double);
+constexpr size_t CQ_LDS_TW_Q1 = (size_t)(4 * S64_MAT) * sizeof(double);
 #ifdef CQ_TIMING   // phase time stamps of workgroup 0 (tools/micro/cqr_bench.hip only)
 __device__ unsigned long long cq_tbuf[64];
 #define CQ_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) cq_tbuf[k] = wall_clock64(); } while (0)
@@ -60,31 +60,6 @@ __device__ __forceinline__ void cq_load64(double *__restrict__ dst, const double
     for (int q = 0; q < 16; ++q) {
         const int e = tid + 256 * q;
         dst[(e >> 6) * S64_LS + (e & 63)] = t[q];
-    }
-}
-
-// Gram of the slab image, UPPER 16 x 16 tiles only (10 of 16; the consumers read the upper triangle), 3 / 3 / 2 / 2 tiles
-// per wavefront, K = CQ_RS; partial -> Gp (row-major 64 x 64; the strictly lower tiles stay as allocated: zero)
-__device__ __forceinline__ void cq_slab_gram(const double *__restrict__ Qs, double *__restrict__ Gp, int tid) {
-    const int lane = tid & 63, w = tid >> 6;
-    const int ij = lane & 15, kq = lane >> 4;
-    const int first = w < 2 ? 3 * w : 6 + 2 * (w - 2), count = w < 2 ? 3 : 2;
-    for (int t = 0; t < count; ++t) {
-        const int id = first + t;                       // 0..9 -> (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
-        const int ti = id < 4 ? 0 : id < 7 ? 1 : id < 9 ? 2 : 3;
-        const int tj = id < 4 ? id : id < 7 ? id - 3 : id < 9 ? id - 5 : 3;
-        const double *pa = Qs + (16 * ti + ij) * CQ_QST + kq, *pb = Qs + (16 * tj + ij) * CQ_QST + kq;
-        s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k0 = 0; k0 < CQ_RS; k0 += 16) {
-            double a[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = pa[k0 + 4 * u]; b[u] = pb[k0 + 4 * u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Gp[(16 * ti + kq + 4 * r) * 64 + 16 * tj + ij] = acc[r];
     }
 }
 
@@ -190,7 +165,8 @@ __device__ __forceinline__ void cq_rows_times_inv(const double *__restrict__ P, 
 template <int PASS, bool PRE = false>
 __global__ void __launch_bounds__(256)
 k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__restrict__ G, double *__restrict__ Gp,
-           double *__restrict__ R1g, double *__restrict__ Vb, int ldv, int *__restrict__ err) {
+           double *__restrict__ R1g, double *__restrict__ Vb, int ldv, int *__restrict__ err, int q1vb = 0 /* PASS 1: Q1 -> Vb
+           instead of in place (the Q1 form of the block reflector, round 6: no pass 2) */) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *M2 = sm, *M1 = sm + S64_MAT, *T = sm + 2 * S64_MAT, *Qs = M1;   // (Qs aliases R and the scratch: used after them)
     __shared__ int s_fail;
@@ -239,8 +215,9 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
     }
     __syncthreads();
     CQ_T(PASS * 16 + 4);
-    double *dst = PASS == 1 ? P : Vb + r0;
-    const size_t ldd = PASS == 1 ? (size_t)lda : (size_t)ldv;
+    const bool inplace = PASS == 1 && !q1vb;
+    double *dst = inplace ? P : Vb + r0;
+    const size_t ldd = inplace ? (size_t)lda : (size_t)ldv;
     {
         const int row = tid & (CQ_RS - 1), cq = tid >> 6;
         if (row < nr) {
@@ -312,9 +289,13 @@ __global__ void __launch_bounds__(256) k_cqr_reduce(const double *__restrict__ G
 // beside it on the main stream and its slab 0 reads Q1's top rows from exactly the elements S R belongs in (a write
 // after read with nothing ordering it -- the round-3 defect: a host stall between the two launches let the store win and
 // slab 0 built V's top rows from S R).  k_cqr_tw, behind both kernels, moves SRg into A's triangle.
+// Q1 form (round 6, R2inv != null): there is no pass 2 at all -- the block reflector is applied with Q1 and the small factor
+// inv(R2) is folded into the 64 x N matrices (k_cqr_tw_q1), so this kernel also hands out inv(R2), reads Q1's top rows from
+// where pass 1 left them (Vb: Q1top / ldq) and raises the breakdown flag that pass 2 used to raise.
 __global__ void __launch_bounds__(256)
-k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, const double *__restrict__ A, int lda, int c0,
-          double *__restrict__ Binv, double *__restrict__ Sg, double *__restrict__ SRg, int *__restrict__ err) {
+k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, const double *__restrict__ Q1top, int ldq,
+          double *__restrict__ Binv, double *__restrict__ Sg, double *__restrict__ SRg, int *__restrict__ err,
+          double *__restrict__ R2inv) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *B0 = sm, *B1 = sm + S64_MAT, *B2 = sm + 2 * S64_MAT, *B3 = sm + 3 * S64_MAT, *T = sm + 4 * S64_MAT;
     __shared__ double sS[64], sR[64], s_red[4];
@@ -322,15 +303,19 @@ k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, const d
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     CQ_T(48);
     int bad;
-    cq_factor<2>(G2, B0, B1, T, &s_fail, s_red, &bad, tid);       // B0 = R2, B1 = inv(R2)  (the flag is raised by pass 2)
-    (void)bad; (void)err;
+    cq_factor<2>(G2, B0, B1, T, &s_fail, s_red, &bad, tid);       // B0 = R2, B1 = inv(R2)  (old form: the flag is raised by pass 2)
+    if (R2inv) {
+        if (bad && tid == 0) atomicOr(err, CQ_FAIL);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q; R2inv[e] = B1[(e >> 6) * S64_LS + (e & 63)]; }
+    }
     cq_load64(B2, R1g, tid);
     __syncthreads();
     s64_gemm<false, false, S64_UU>(B3, B0, B2, 1.0, tid);          // B3 = R = R2 R1
     {   // Q_top (row-major) -> B2
-        const double *P = A + (size_t)c0 * lda + c0;               // Q1's top rows (pass 1 wrote them in place)
+        const double *P = Q1top;                                   // Q1's top rows (pass 1: in place in A, or in Vb)
         s64_v4d acc[4];
-        cq_rows_times_inv(P, (size_t)lda, 64, B1, acc, lane, wv);
+        cq_rows_times_inv(P, (size_t)ldq, 64, B1, acc, lane, wv);
         __syncthreads();                                           // (the product above has read B2 = R1)
         const int ij = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -435,6 +420,78 @@ k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Bi
     }
 }
 
+// Q1 FORM of the block reflector (round 6).  With Q = Q1 inv(R2), V = Q - [S; 0]:
+//      V'[A2 | b] = inv(R2)' (Q1'[A2 | b]) - S A2_top          A2 - V W2 = A2 - Q1 (inv(R2) W2) + [S W2; 0]
+// so pass 2 over the panel (Q = Q1 inv(R2) -> Vb: a launch of 13 us on the critical path of every panel, plus the Gram reduce
+// in front of it) is not needed: the trailing kernels take Q1 as it leaves pass 1, and the 64 x 64 factor inv(R2) = I + O(eps
+// cond(P)^2) is applied to the 64 x N matrices here.  W comes in as Q1'[A2 | b] (k_qr1_vtb on Q1 + k_qr1_wreduce);
+//      WQ = inv(R2)' W;   W2 = inv(B)(A2_top - S WQ);   A2_top += S W2  (written back: every workgroup owns its 64 columns);
+//      W3 = inv(R2) W2 -> the update kernel's operand (it then subtracts Q1 W3 from ALL rows of A2, the top ones included).
+// R2inv, Binv, S, SR: k_cqr_top on the side stream (ev_lu).  The extra workgroup puts the panel's part of R into A.
+__global__ void __launch_bounds__(256)
+k_cqr_tw_q1(const double *__restrict__ W, int ncolsB, const double *__restrict__ Binv, const double *__restrict__ Sg,
+            const double *__restrict__ SRg, const double *__restrict__ R2inv, double *A, int lda, int c0, int cend, int n,
+            double *rhs, double *__restrict__ W2) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *sBi = sm, *sRi = sm + S64_MAT, *X = sm + 2 * S64_MAT, *Y = sm + 3 * S64_MAT;
+    const int tid = threadIdx.x;
+    const int ncols = ncolsB - 64, j0 = blockIdx.x * 64;
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+        double t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = SRg[tid + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, col = e >> 6, row = e & 63;
+            if (row <= col) A[(size_t)(c0 + col) * lda + c0 + row] = t[q];
+        }
+        return;
+    }
+    cq_load64(sBi, Binv, tid);
+    cq_load64(sRi, R2inv, tid);
+    double top[16];
+    const int k = tid & 63;                       // (e = tid + 256 q: row k = e & 63 is the thread's own, column j = e >> 6)
+    const double sk = Sg[k];
+    {
+        double wq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int j = (tid >> 6) + 4 * q, col = min(j0 + j, ncols - 1), a = cend + col;
+            top[q] = a < n ? A[(size_t)a * lda + c0 + k] : rhs[c0 + k];
+            wq[q] = W[(size_t)(64 + col) * 64 + k];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int j = (tid >> 6) + 4 * q;
+            X[k * S64_LS + j] = j0 + j < ncols ? wq[q] : 0.0;
+        }
+    }
+    __syncthreads();
+    s64_gemm<true, false, S64_LF>(Y, sRi, X, 1.0, tid);            // Y = WQ = inv(R2)' (Q1'[A2 | b])
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = (tid >> 6) + 4 * q;
+        Y[k * S64_LS + j] = j0 + j < ncols ? top[q] - sk * Y[k * S64_LS + j] : 0.0;
+    }
+    __syncthreads();
+    s64_gemm<false, false, S64_FULL>(X, sBi, Y, 1.0, tid);         // X = W2 = inv(B)(A2_top - S WQ)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                                 // A2_top += S W2: the [S W2; 0] part of V W2
+        const int j = (tid >> 6) + 4 * q, col = j0 + j, a = cend + col;
+        if (col < ncols) {
+            const double v = top[q] + sk * X[k * S64_LS + j];
+            if (a < n) A[(size_t)a * lda + c0 + k] = v;
+            else rhs[c0 + k] = v;
+        }
+    }
+    s64_gemm<false, false, S64_UF>(Y, sRi, X, 1.0, tid);           // Y = W3 = inv(R2) W2
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = (tid >> 6) + 4 * q;
+        if (j0 + j < ncols) W2[(size_t)(j0 + j) * 64 + k] = Y[k * S64_LS + j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
     w->max_slabs = (M + CQ_RS - 1) / CQ_RS;
@@ -446,6 +503,7 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
     LSQ_HIP(hipMalloc(&w->G2, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->Binv, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->Minv, 2 * 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->R2inv, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->S, 64 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->SR, 4096 * sizeof(double)));
     {   // highest priority: k_cqr_top's single workgroup (141 KB of LDS) must get a CU before the caller's V'[A2 | b] grid fills
@@ -470,32 +528,55 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
     LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_factor<2>, CQ_LDS));
     LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_top, CQ_LDS_LU));
     LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_tw, CQ_LDS_TW));
+    LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_tw_q1, CQ_LDS_TW_Q1));
     w->ready = true;
     return LSQ_OK;
 }
 
 void lsq_cqr_free(CqrWork *w) {
     if (!w || !w->ready) return;
-    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->Minv); hipFree(w->S); hipFree(w->SR);
+    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->Minv); hipFree(w->R2inv); hipFree(w->S); hipFree(w->SR);
     hipEventDestroy(w->ev_q); hipEventDestroy(w->ev_lu); hipEventDestroy(w->ev_first); hipEventDestroy(w->ev_panel);
     w->side = w->ahead = nullptr;          // (the context's)
     w->ready = false;
 }
 
-int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps) {
+// The Q1 form (default since round 6; LSQ_QR_CQR_PASS2=1 restores the three-pass panel of rounds 2-5 for A/B): read per call.
+bool lsq_cqr_q1form() { return getenv("LSQ_QR_CQR_PASS2") == nullptr; }
+
+int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps,
+                  bool gram_ready) {
     const int rows = M - c0, nslab = (rows + CQ_RS - 1) / CQ_RS;
     (void)c;
     const bool pre = ps == w->ahead && !getenv("LSQ_QR_AHEAD_REDUNDANT");     // one factor kernel instead of one factor per workgroup
-    LSQ_LAUNCH(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
-                       w->R1, Vb, ldv, d_err);
+    const bool q1 = lsq_cqr_q1form();
+    w->q1form = q1;
+    // (gram_ready: the update of the previous panel left the Gram partials of this panel's slabs in w->Gp itself)
+    if (!gram_ready)
+        LSQ_LAUNCH(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
+                           w->R1, Vb, ldv, d_err, 0);
     LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G);
     if (pre) {
         LSQ_LAUNCH(k_cqr_factor<1>, dim3(1), dim3(256), CQ_LDS, ps, (const double *)w->G, w->Minv, w->R1, d_err);
         LSQ_LAUNCH((k_cqr_pass<1, true>), dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->Minv, w->Gp,
-                           w->R1, Vb, ldv, d_err);
+                           w->R1, Vb, ldv, d_err, q1 ? 1 : 0);
     } else
         LSQ_LAUNCH(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G, w->Gp,
-                           w->R1, Vb, ldv, d_err);
+                           w->R1, Vb, ldv, d_err, q1 ? 1 : 0);
+    if (q1) {
+        // Q1 form: the panel is DONE on this stream -- Q1 is in Vb, the caller's V'[A2 | b] product may start.  The Gram reduce of
+        // pass 1's partials and everything that hangs on G2 (R2, the 64-step LU of Q_top, inv(B), S R) run on the side stream
+        // beside that product; k_cqr_tw_q1 waits for them (ev_lu).
+        LSQ_HIP(hipGetLastError());
+        LSQ_HIP(hipEventRecord(w->ev_q, ps));
+        LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
+        LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, w->side, (const double *)w->Gp, nslab, w->G2);
+        LSQ_LAUNCH(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1,
+                           (const double *)Vb, ldv, w->Binv, w->S, w->SR, d_err, w->R2inv);
+        LSQ_HIP(hipGetLastError());
+        LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
+        return LSQ_OK;
+    }
     LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G2);
     LSQ_HIP(hipGetLastError());
     // everything that hangs on the top 64 rows (the 64-step LU among it) runs on the side stream from here on, beside
@@ -503,23 +584,30 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
     LSQ_HIP(hipEventRecord(w->ev_q, ps));
     LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
     LSQ_LAUNCH(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1,
-                       (const double *)A, M, c0, w->Binv, w->S, w->SR, d_err);
+                       (const double *)(A + (size_t)c0 * M + c0), M, w->Binv, w->S, w->SR, d_err, (double *)nullptr);
     LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
     if (pre) {
         LSQ_LAUNCH(k_cqr_factor<2>, dim3(1), dim3(256), CQ_LDS, ps, (const double *)w->G2, w->Minv + 4096, w->R1, d_err);
         LSQ_LAUNCH((k_cqr_pass<2, true>), dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)(w->Minv + 4096), w->Gp,
-                           w->R1, Vb, ldv, d_err);
+                           w->R1, Vb, ldv, d_err, 0);
     } else
         LSQ_LAUNCH(k_cqr_pass<2>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G2, w->Gp,
-                           w->R1, Vb, ldv, d_err);
+                           w->R1, Vb, ldv, d_err, 0);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 
 int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, int M, int c0, int cend, int n,
-               const double *rhs, double *Vb, int ldv, double *W2) {
+               double *rhs, double *Vb, int ldv, double *W2) {
     LSQ_HIP(hipStreamWaitEvent(c->stream, w->ev_lu, 0));
     const int ncols = ncolsB - 64;
+    if (w->q1form) {
+        LSQ_LAUNCH(k_cqr_tw_q1, dim3(std::max(1, (ncols + 63) / 64) + 1), dim3(256), CQ_LDS_TW_Q1, c->stream, W, ncolsB,
+                           (const double *)w->Binv, (const double *)w->S, (const double *)w->SR, (const double *)w->R2inv, A, M, c0, cend,
+                           n, rhs, W2);
+        LSQ_HIP(hipGetLastError());
+        return LSQ_OK;
+    }
     LSQ_LAUNCH(k_cqr_tw, dim3(std::max(1, (ncols + 63) / 64) + 1), dim3(256), CQ_LDS_TW, c->stream, W, ncolsB,
                        (const double *)w->Binv, (const double *)w->S, (const double *)w->SR, A, M, c0, cend, n, rhs, Vb, ldv, W2);
     LSQ_HIP(hipGetLastError());

@@ -847,13 +847,27 @@ k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int
 //   lane (ij = lane & 15, kq = lane >> 4), step s: k = 16 (s >> 2) + 4 kq + (s & 3)
 //   a operand  W2[col jj + ij][k]      b operand  V[row r0 + 16 b + ij][k]      D'[col jj + kq + 4 r][row r0 + 16 b + ij]
 constexpr int U3_DA = 4;                    // depth of the A2 ring
-template <int DBG>     // 0: the product; 1: no MFMAs (memory side alone); 2: no A2 traffic (MFMA side alone) -- timing experiments only
+// GRAM (round 6): the launch carries nrg extra workgroups AT ITS FRONT that update the NEXT panel's 64 columns (trailing columns
+// 0..63, whatever jbeg says) and, with the updated 64 x 64 block still at hand, form the Gram partial of that slab for the next
+// panel's CholeskyQR pass (what k_cqr_pass<0> would read back from memory one launch later: same values, same cq_slab_gram,
+// same bits) -- row group rg of this panel is slab rg - 1 of the next (its first 64 rows become rows of R).  The other
+// workgroups take columns jbeg..jend as before (the caller passes jbeg >= 64).
+template <int DBG, bool GRAM = false>     // DBG 0: the product; 1: no MFMAs (memory side alone); 2: no A2 traffic (MFMA side alone) -- timing experiments only
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int M, int c0, int cend, int n,
-               double *__restrict__ rhs, int ncols /* n - cend + 1 */, const double *__restrict__ W2, int jbeg, int jend, int tpw) {
+               double *__restrict__ rhs, int ncols /* n - cend + 1 */, const double *__restrict__ W2, int jbeg, int jend, int tpw,
+               double *__restrict__ gram_out = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) double u3_qs[];      // GRAM: the slab image [col][row], CQ_QST apart
     const int rows = M - c0;
     const int nrg = (rows + Q2_NB - 1) / Q2_NB;         // row groups of 64 rows: waves 0,1 the upper half, 2,3 the lower
-    const int rg = blockIdx.x % nrg, cg = blockIdx.x / nrg;
+    int bid = blockIdx.x;
+    bool narrow = false;
+    if (GRAM) {
+        narrow = bid < nrg;
+        if (!narrow) bid -= nrg;
+        else { jbeg = 0; jend = Q2_NB; tpw = 2; }
+    }
+    const int rg = bid % nrg, cg = bid / nrg;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ij = lane & 15, kq = lane >> 4;
     const int rbase = rg * Q2_NB;
     const int r0 = rbase + 32 * (w >> 1);
@@ -864,10 +878,16 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
     // tiles of this wave: jfirst + 32 t, t = 0 .. nt - 1 (the two waves of a row half take alternate 16-column tiles)
     const int jfirst = jbeg + cg * 32 * tpw + 16 * (w & 1);
     const int jstop = min(jend, jbeg + (cg + 1) * 32 * tpw);
-    if (r0 >= rows || jfirst >= jstop) return;
-    const int nt = (jstop - jfirst + 31) >> 5;
+    if (GRAM && narrow) {
+        // rows past the end of the matrix (the ragged last slab) count as zeros; every wavefront stays for the Gram
+        for (int e = tid; e < Q2_NB * CQ_QST; e += 256) u3_qs[e] = 0.0;
+        __syncthreads();
+    }
+    const bool idle = r0 >= rows || jfirst >= jstop;
+    if (idle && !(GRAM && narrow)) return;
+    const int nt = idle ? 0 : (jstop - jfirst + 31) >> 5;
     double v0[16], v1[16];                              // the wave's V fragment: 32 rows x 64, for all its tiles
-    {
+    if (!idle) {
         const double *p0 = Vb + (in0 ? row0 : 0), *p1 = Vb + (in1 ? row1 : 0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -930,8 +950,14 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
             double *pa = A + (size_t)(cend + jj + kq) * M + c0 + row0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pa[(size_t)4 * r * M] = at[r] - (c00[r] + c01[r]);
-                pa[(size_t)4 * r * M + 16] = at[4 + r] - (c10[r] + c11[r]);
+                const double n0 = at[r] - (c00[r] + c01[r]), n1 = at[4 + r] - (c10[r] + c11[r]);
+                pa[(size_t)4 * r * M] = n0;
+                pa[(size_t)4 * r * M + 16] = n1;
+                if (GRAM && narrow) {       // (column jj + kq + 4 r of the next panel, rows of this slab)
+                    double *qs = u3_qs + (jj + kq + 4 * r) * CQ_QST + 32 * (w >> 1) + ij;
+                    qs[0] = n0;
+                    qs[16] = n1;
+                }
             }
         } else {
 #pragma unroll
@@ -939,16 +965,24 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
                 const int col = jj + kq + 4 * r;
                 if (col < ncols) {
                     double *pc = colptr(col);
-                    if (in0) pc[row0] = at[r] - (c00[r] + c01[r]);
-                    if (in1) pc[row1] = at[4 + r] - (c10[r] + c11[r]);
+                    const double n0 = at[r] - (c00[r] + c01[r]), n1 = at[4 + r] - (c10[r] + c11[r]);
+                    if (in0) pc[row0] = n0;
+                    if (in1) pc[row1] = n1;
+                    if (GRAM && narrow && col < Q2_NB) {
+                        double *qs = u3_qs + col * CQ_QST + 32 * (w >> 1) + ij;
+                        if (in0) qs[0] = n0;
+                        if (in1) qs[16] = n1;
+                    }
                 }
             }
         }
     };
     double wa[16], wb[16], a0[8], a1[8], a2[8], a3[8];
     static_assert(U3_DA == 4, "the ring below is written out for four stages");
-    fetch_w(0, wa);
-    fetch_a(0, a0);
+    if (0 < nt) {
+        fetch_w(0, wa);
+        fetch_a(0, a0);
+    }
     if (1 < nt) fetch_a(1, a1);
     if (2 < nt) fetch_a(2, a2);
     if (3 < nt) fetch_a(3, a3);
@@ -967,6 +1001,10 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
         U3_STEP(t + 3, wb, wa, a3)
     }
 #undef U3_STEP
+    if (GRAM && narrow) {
+        __syncthreads();                               // the slab's 64 x 64 block of the next panel is in the image
+        if (rg >= 1 && gram_out) cq_slab_gram(u3_qs, gram_out + (size_t)(rg - 1) * 4096, tid);
+    }
 }
 
 // R (upper triangle of the factored A, zeros below) and the first n entries of Q1'b -> stage-2 operands
@@ -983,33 +1021,42 @@ k_qr1_extract(const double *__restrict__ A, int M, int n, const double *__restri
 
 // launches the wave-private update (default since round 5; LSQ_QR_UPDATE_W=0: false, the caller launches k_qr1_update; 2 / 3: the
 // timing experiments DBG 1 / 2 -- wrong results).  All read per call.
-static bool qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int M, int c0, int cend, int n, double *rhs,
-                            int ncols, const double *W2, int jbeg = 0, int jend = -1, bool beside_passes = false) {
+// gram_out (or null): the launch also updates trailing columns 0..63 -- the next panel -- in nrg workgroups of their own and leaves
+// the Gram partials of the next panel's slabs there (k_qr1_update_w<0, true>); the caller then passes jbeg >= 64 (jbeg == jend:
+// those workgroups alone).
+static int qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int M, int c0, int cend, int n, double *rhs,
+                           int ncols, const double *W2, bool *taken, int jbeg = 0, int jend = -1, bool beside_passes = false,
+                           double *gram_out = nullptr) {
     const char *e = getenv("LSQ_QR_UPDATE_W");
     const int mode = e ? atoi(e) : 1;
-    if (mode == 0) return false;
+    *taken = mode != 0;
+    if (mode == 0) return LSQ_OK;
     if (jend < 0) jend = ncols;
-    if (jbeg >= jend) return true;
+    if (jbeg >= jend && !gram_out) return LSQ_OK;
     const int rows = M - c0, nrg = (rows + Q2_NB - 1) / Q2_NB;
     // 32-column tile pairs per workgroup: as many as leave one workgroup per CU, at most 32 -- a wave's V fragment then serves
     // many tiles (measured at C3, all panels: 32 pairs 57.8 us, 16 58.9, 8 61.0, 4 62.3; a rule that keeps two workgroups per
     // CU 60.1)
     const char *t = getenv("LSQ_QR_UPDATE_TPW");
-    const int npair = (jend - jbeg + 31) / 32, want = std::max(1, c->num_cus / nrg);
+    const int npair = (std::max(jend - jbeg, 0) + 31) / 32, want = std::max(1, c->num_cus / nrg);
     const int tpw = t ? std::max(1, atoi(t)) : std::max(2, std::min(beside_passes ? 64 : 32, (npair + want - 1) / want));
     const int ncg = (npair + tpw - 1) / tpw;
     // beside the next panel's passes (look-ahead): ONE workgroup per CU, by an LDS reservation it does not use -- two of them
     // fill a CU's registers (242 VGPRs per wave) and the pass workgroups (75 KB of LDS, 4 waves) would wait for them to end
     const char *le = getenv("LSQ_QR_UPDATE_LDS");
-    const size_t lds = beside_passes ? (le ? (size_t)atoi(le) : (size_t)84 * 1024) : 0;
-    auto go = [&](auto kern) {
-        if (lds > 0 && lsq_set_lds(c, (const void *)kern, lds) != LSQ_OK) return;
-        hipLaunchKernelGGL(kern, dim3(nrg * ncg), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncols, W2, jbeg, jend, tpw);
+    size_t lds = beside_passes ? (le ? (size_t)atoi(le) : (size_t)84 * 1024) : 0;
+    if (gram_out) lds = std::max(lds, (size_t)Q2_NB * CQ_QST * sizeof(double));
+    const int grid = nrg * ncg + (gram_out ? nrg : 0);
+    auto go = [&](auto kern) -> int {
+        if (lds > 48 * 1024) LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
+        LSQ_LAUNCH(kern, dim3(grid), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncols, W2, jbeg, jend, tpw, gram_out);
+        LSQ_HIP(hipGetLastError());
+        return LSQ_OK;
     };
-    if (mode == 2) go(k_qr1_update_w<1>);
-    else if (mode == 3) go(k_qr1_update_w<2>);
-    else go(k_qr1_update_w<0>);
-    return true;
+    if (gram_out) return go(k_qr1_update_w<0, true>);
+    if (mode == 2) return go(k_qr1_update_w<1>);
+    if (mode == 3) return go(k_qr1_update_w<2>);
+    return go(k_qr1_update_w<0>);
 }
 
 static void qr2_free(void *p) {
@@ -1038,7 +1085,7 @@ static int qr1_vtb_slices(const lsq_ctx *c, const Qr2Work *q, int rows, int nt, 
 }
 
 // V'[A2 | b] partials by the wave-private kernel (default; LSQ_QR_VTB_W=0: k_qr1_vtb; 2: timing experiment without MFMAs).
-// Returns the number of k slices written (for k_qr1_wreduce).
+// Returns the number of k slices written (for k_qr1_wreduce), or -1 if the launch failed.
 static int qr1_vtb_launch(lsq_ctx *c, Qr2Work *q, const double *Vb, int ldv, const double *A, int M, int c0, int cend, int n,
                           const double *rhs, int ncolsB, int tile0) {
     const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB, rows = M - c0;
@@ -1046,9 +1093,9 @@ static int qr1_vtb_launch(lsq_ctx *c, Qr2Work *q, const double *Vb, int ldv, con
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) {
         const int ks = qr1_vtb_slices(c, q, rows, ntile - tile0, ntile);
-        hipLaunchKernelGGL(k_qr1_vtb, dim3((ntile - tile0) * ks), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
+        LSQ_LAUNCH(k_qr1_vtb, dim3((ntile - tile0) * ks), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks,
                            q->Wp, tile0);
-        return ks;
+        return hipGetLastError() == hipSuccess ? ks : -1;
     }
     // workgroups of 4 waves x 32 columns; ONE per CU (measured at C3, average over the panels: 56.2 us; two per CU -- what
     // the registers allow -- 59.0; four queued 71.1; k_qr1_vtb 64.0)
@@ -1059,9 +1106,20 @@ static int qr1_vtb_launch(lsq_ctx *c, Qr2Work *q, const double *Vb, int ldv, con
     ks = std::min(ks, 128);
     ks = std::min(ks, q->wp_slots / std::max(1, ntile));
     ks = std::max(1, std::min(ks, (rows + 63) / 64));
-    if (mode == 2) hipLaunchKernelGGL(k_qr1_vtb_w<1>, dim3(ncgrp * ks), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp, tile0);
-    else hipLaunchKernelGGL(k_qr1_vtb_w<0>, dim3(ncgrp * ks), dim3(256), 0, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp, tile0);
-    return ks;
+    // An LDS reservation the kernel does not use (round 6): with more than half a CU's LDS per workgroup there is at most ONE of
+    // these workgroups on a CU, so the grid (<= CUs - 2 workgroups) leaves whole CUs free -- and k_cqr_top (141 KB of LDS, on
+    // the high-priority side stream beside this product) can only be placed on one of THOSE: it runs alone on its CU instead of
+    // sharing issue slots with a product workgroup (measured: 47 us alone, 78 us beside one).
+    const char *le = getenv("LSQ_QR_VTB_LDS");
+    const size_t lds = per_cu == 1 ? (le ? (size_t)atoi(le) : (size_t)84 * 1024) : 0;
+    if (mode == 2) {
+        if (lds > 48 * 1024 && lsq_set_lds(c, (const void *)k_qr1_vtb_w<1>, lds) != LSQ_OK) return -1;
+        LSQ_LAUNCH(k_qr1_vtb_w<1>, dim3(ncgrp * ks), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp, tile0);
+    } else {
+        if (lds > 48 * 1024 && lsq_set_lds(c, (const void *)k_qr1_vtb_w<0>, lds) != LSQ_OK) return -1;
+        LSQ_LAUNCH(k_qr1_vtb_w<0>, dim3(ncgrp * ks), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp, tile0);
+    }
+    return hipGetLastError() == hipSuccess ? ks : -1;
 }
 
 static bool qr2_applies(int M, int n) {
@@ -1182,6 +1240,10 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     const char *lmc = getenv("LSQ_QR_LOOKAHEAD_MINCOLS");
     const int la_min_cols = lmc ? atoi(lmc) : 1024;
     bool pre = false;                        // this panel was factored ahead (its Q is in vcur, ev_panel says when)
+    // FUSED GRAM (round 6): the update of panel k forms the Gram partials of panel k + 1 (its first pass, k_cqr_pass<0>, is one
+    // launch less on every panel's chain); only the wave-private update does it (mode 1, no timing experiment)
+    const bool gram_on = cq_ok && !getenv("LSQ_QR_NO_FUSED_GRAM") && (uwe ? atoi(uwe) == 1 : true);
+    bool gram_ready = false;                 // ... and did so for the panel at hand
     double *vcur = q->Vb;
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
@@ -1193,15 +1255,17 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             if (pre) LSQ_HIP(hipStreamWaitEvent(c->stream, q->cq.ev_panel, 0));
             else {
                 vcur = q->Vb;
-                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, vcur, ldv, q->d_err, c->stream));
+                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, vcur, ldv, q->d_err, c->stream, gram_ready));
             }
             pre = false;
+            gram_ready = false;
             const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
             const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
             // (V'V, tile 0, is not formed: the basis-kernel form needs V'[A2 | b] only.  Measured and dropped in round 4: the sum
             //  over the k slices taken by k_cqr_tw itself instead of the k_qr1_wreduce launch -- 32 workgroups reading 1 MB of
             //  partials each take longer than the 10 us launch over 256: C3 7.83 against 7.60 ms, profiles/r04/ab_c3_tw.txt)
             const int ks = qr1_vtb_launch(c, q, vcur, ldv, A, M, c0, cend, n, rhs, ncolsB, 1);
+            if (ks < 0) { lsq_set_error("qr: the V'[A2 | b] launch failed"); return LSQ_EHIP; }
             {
                 long long tot = (long long)(ntile - 1) * Q2_NB * Q2_NB;
                 int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
@@ -1210,22 +1274,31 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, vcur, ldv, q->W2));
             // is the next panel a CholeskyQR2 panel too, with enough other columns beside it?
             const int c1 = cend;
-            const bool ahead = la_on && n - c1 >= Q2_NB && M - c1 >= 256 && ncols - 1 >= Q2_NB + la_min_cols;
+            const bool next_cq = n - c1 >= Q2_NB && M - c1 >= 256;       // the next panel is a CholeskyQR panel too
+            const bool ahead = la_on && next_cq && ncols - 1 >= Q2_NB + la_min_cols;
+            double *const gram_out = gram_on && next_cq ? q->cq.Gp : nullptr;
             if (ahead) {
                 if (!q->Vb2) LSQ_HIP(hipMalloc(&q->Vb2, ((size_t)q->M * Q2_NB + 64) * sizeof(double)));
                 double *vnext = vcur == q->Vb ? q->Vb2 : q->Vb;
-                qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, 0, Q2_NB);
+                bool tk = false;
+                if (gram_out) LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, Q2_NB, false, gram_out));
+                else LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, 0, Q2_NB));
                 LSQ_HIP(hipEventRecord(q->cq.ev_first, c->stream));
                 LSQ_HIP(hipStreamWaitEvent(q->cq.ahead, q->cq.ev_first, 0));
-                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c1, vnext, M - c1, q->d_err, q->cq.ahead));
+                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c1, vnext, M - c1, q->d_err, q->cq.ahead, gram_out != nullptr));
                 LSQ_HIP(hipEventRecord(q->cq.ev_panel, q->cq.ahead));
-                qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, Q2_NB, ncols, true);
+                LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, ncols, true));
                 vcur = vnext;
                 pre = true;
             } else {
                 const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
-                if (qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2)) { }
-                else
+                bool tk = false;
+                if (gram_out) {
+                    LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, ncols, false, gram_out));
+                    gram_ready = true;
+                } else
+                LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk));
+                if (!tk)
                 LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, vcur, ldv, A, M,
                                    c0, cend, n, rhs, ncols, q->W2);
             }
@@ -1289,6 +1362,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
                                side_k ? (const double *)q->Pn : (const double *)nullptr, std::max(1, side_k));
         }
         const int ks = qr1_vtb_launch(c, q, q->Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, 0);
+        if (ks < 0) { lsq_set_error("qr: the V'[A2 | b] launch failed"); return LSQ_EHIP; }
         {
             long long tot = (long long)ntile * Q2_NB * Q2_NB;
             int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
@@ -1298,8 +1372,9 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
                                q->tau1, c0, nb, q->W2);
         {
             const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
-            if (qr1_update_wave(c, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols, q->W2)) { }
-            else
+            bool tk = false;
+            LSQ_TRY(qr1_update_wave(c, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk));
+            if (!tk)
             LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, q->Vb, ldv, A, M, c0, cend, n, rhs, ncols,
                                q->W2);
         }

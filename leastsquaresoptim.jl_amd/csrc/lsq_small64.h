@@ -351,8 +351,9 @@ __device__ __forceinline__ void s64_lu_modified(double *__restrict__ M, double *
 //              else is written (the caller reads the upper triangle); k-tiles 0..ti                               (20 of 64)
 //   S64_UL     op(A) upper, op(B) lower: full result, k-tiles max(ti, tj)..3                                       (30 of 64)
 //   S64_LF     op(A) lower, op(B) full: k-tiles 0..ti                                                                (40 of 64)
+//   S64_UF     op(A) upper, op(B) full: k-tiles ti..3                                                                (40 of 64)
 // ldc: row stride of C (S64_LS for an LDS matrix, 64 for a row-major matrix in global memory).
-enum { S64_FULL = 0, S64_UU = 1, S64_LtU = 2, S64_UL = 3, S64_LF = 4 };
+enum { S64_FULL = 0, S64_UU = 1, S64_LtU = 2, S64_UL = 3, S64_LF = 4, S64_UF = 5 };
 template <bool TA, bool TB, int SHAPE = S64_FULL>
 __device__ __forceinline__ void s64_gemm(double *__restrict__ C, const double *__restrict__ A, const double *__restrict__ B,
                                          double sgn, int tid, int ldc = S64_LS) {
@@ -361,13 +362,14 @@ __device__ __forceinline__ void s64_gemm(double *__restrict__ C, const double *_
     for (int q = wv; q < 16; q += 4) {
         // tiles are dealt so that the four wavefronts get equal work for the triangular shapes (ti + tj pairs)
         const int ti = (SHAPE == S64_LF) ? ((q >> 2) + (q & 3)) & 3 : q >> 2;      // (S64_LF: rows dealt round-robin: equal work)
-        const int tj = (SHAPE == S64_FULL || SHAPE == S64_UL || SHAPE == S64_LF) ? (q & 3) : ((q & 3) + ti) & 3;
+        const int tj = (SHAPE == S64_FULL || SHAPE == S64_UL || SHAPE == S64_LF || SHAPE == S64_UF) ? (q & 3) : ((q & 3) + ti) & 3;
         int k0 = 0, k1 = 4;
         bool live = true;
         if (SHAPE == S64_UU) { live = ti <= tj; k0 = ti; k1 = tj + 1; }
         if (SHAPE == S64_LtU) { live = ti <= tj; k1 = ti + 1; }
         if (SHAPE == S64_UL) { k0 = ti > tj ? ti : tj; }
         if (SHAPE == S64_LF) { k1 = ti + 1; }
+        if (SHAPE == S64_UF) { k0 = ti; }       // (ti = q >> 2: every wavefront gets one tile row of each length)
         s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
         if (live) {
             for (int kt = k0; kt < k1; ++kt) {

@@ -631,8 +631,24 @@ def test_operator_level_loops(opt, sol, sparse):
     lsq.set_exact(None)
 
 
-def test_kat_trajectories():
-    """SURVEY 8c KAT-DL / KAT-LM through the HIP path."""
+# Round 6: every assertion the REFERENCE'S OWN tests hold -- the known-answer trajectories, the factor model's
+# outcome pins (test/nonlinearleastsquares.jl:107-108), the bound problems (test/bounds.jl:12-14,23-26,33-36), the README examples
+# (test/runtests.jl:19-46) -- through BOTH code paths: kernels = "reference-order" is what these small problems take by default
+# (lsq_exact.hip: the reference's summation order, identical counts against the oracle); kernels = "fast" forces the kernels the
+# headline runs (tree reductions, fused epilogues, device-resident LSMR, blocked dense solvers: lsq.set_exact(False)), which are
+# held to the reference-held assertions themselves -- counts against the oracle only where the problem is count-stable.
+KERNELS = ["reference-order", "fast"]
+
+
+@pytest.fixture(params=KERNELS)
+def kernels(request):
+    lsq.set_exact(None if request.param == "reference-order" else False)
+    yield request.param
+    lsq.set_exact(None)
+
+
+def test_kat_trajectories(kernels):
+    """SURVEY 8c KAT-DL / KAT-LM through the HIP path (hand-derived from the reference's formulas: exact in any summation order)."""
     r = gpu_run(P.readme_rosenbrock(), lsq.Dogleg, lsq.QR(), iterations=2)
     assert r.trace["rho"][0] == pytest.approx(-9999.0, rel=1e-12)
     assert r.trace["rho"][1] == pytest.approx(-624.25 / 0.75, rel=1e-12)
@@ -642,26 +658,32 @@ def test_kat_trajectories():
 
 
 @pytest.mark.parametrize("opt", ["dogleg", "lm"])
-def test_factor_model(opt):
+def test_factor_model(opt, kernels):
     """test/nonlinearleastsquares.jl:96-110 (rank-deficient J'J: pins the min-norm QR solve)."""
     name, f, g, x0 = P.factor_dense()
     nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.ones(9), f_=f, g_=g, J=np.ones((9, 6)))
     r = lsq.optimize_(nls, OPT[opt][0](lsq.QR()), full_trace=True)
     ff, gg = P.wrap_dense(f, g, 9, 6)
     ro = O.optimize(OPT[opt][1], O.QR, O.Mat(dense=np.zeros((9, 6))), x0, ff, gg)
-    assert r.converged and r.ssr <= 12
-    assert r.iterations == ro.iterations and np.allclose(r.minimizer, ro.minimizer, rtol=1e-6, atol=1e-8)
+    assert r.converged and r.ssr <= 12                                  # the reference's own pin (:107)
+    if kernels == "reference-order":
+        assert r.iterations == ro.iterations and np.allclose(r.minimizer, ro.minimizer, rtol=1e-6, atol=1e-8)
+    else:   # (a rank-deficient problem: the minimiser is not unique, the objective is)
+        assert abs(r.ssr - ro.ssr) <= 1e-8 * max(1.0, ro.ssr)
     name, f, gs, x0, (m, n, colptr, rowval) = P.factor_sparse()
     J = sp.csc_matrix((np.ones(18), rowval, colptr), shape=(9, 6))
     nls = lsq.LeastSquaresProblem(x=x0.copy(), y=np.ones(9), f_=f, g_=lambda Jm, x: gs(Jm.data, x), J=J)
     r = lsq.optimize_(nls, OPT[opt][0](lsq.LSMR()), full_trace=True)
     ro = O.optimize(OPT[opt][1], O.LSMR, O.Mat(csc=(m, n, colptr, rowval, np.zeros(18))), x0, f, gs)
-    assert r.converged and r.ssr <= 12
-    assert r.iterations == ro.iterations and r.mul_calls == ro.mul_calls
+    assert r.converged and r.ssr <= 12                                  # (:108)
+    if kernels == "reference-order":
+        assert r.iterations == ro.iterations and r.mul_calls == ro.mul_calls
+    else:
+        assert abs(r.ssr - ro.ssr) <= 1e-8 * max(1.0, ro.ssr)
 
 
 @pytest.mark.parametrize("opt", ["dogleg", "lm"])
-def test_bounds(opt):
+def test_bounds(opt, kernels):
     """test/bounds.jl:7-38"""
     mk = OPT[opt][0]
 
@@ -680,7 +702,7 @@ def test_bounds(opt):
         go(P.readme_rosenbrock(), lower=[1.0, 1.0])
 
 
-def test_finite_difference_and_defaults():
+def test_finite_difference_and_defaults(kernels):
     """test/runtests.jl:19-70 + test/nonlinearsolvers.jl:619-628"""
     rosen = lambda x: np.array([1 - x[0], 100 * (x[1] - x[0] ** 2)])
     for o in (lsq.Dogleg(), lsq.LevenbergMarquardt()):

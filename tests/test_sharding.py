@@ -157,6 +157,79 @@ def test_c_exchange_equals_python_hook_gloo_world2():
     assert res[0][3][2]["collectives"] == res[1][3][2]["collectives"] == 1
 
 
+def _scripts_world8(rank, world):
+    """Round 6: made-up inputs for EIGHT ranks.  a: staggered convergence -- rank r freezes at call 2 + r, so
+    for most of the run some ranks are active (previous-result semantics, exchange in flight) while others are frozen
+    (synchronous calls), and the run ends at the call in which the slowest rank reports convergence.  b: one rank (5) leaves
+    with an error at its 4th call while ranks 0..2 are already frozen and the others active: every rank must stop with the
+    same number of collectives.  c: the LAST rank leaves at the very first call."""
+    a = [(1.0 / (it + 1) + rank, 10.0 - 0.5 * it + rank, 1.0 if it >= 2 + rank else 0.0) for it in range(world + 4)]
+    b = [(2.0 + rank, 1.0 + it, -1.0 if (rank == 5 and it == 3) else (1.0 if it >= 1 + rank and rank < 3 else 0.0)) for it in range(8)]
+    c = [(1.0, 0.5, -1.0 if (rank == world - 1 and it == 0) else 0.0) for it in range(3)]
+    return [a, b, c]
+
+
+def _worker_c_vs_python_world8(rank, world, port, q):
+    _init(rank, world, port)
+    out = []
+    for script in _scripts_world8(rank, world):
+        py = _drive(lsq.sharding.make_allreduce_callback(dist, rank, world, "cpu"), script)
+        lsq.sharding.drain_all()
+        dist.barrier()
+        x = lsq.sharding.TorchTransportExchange(dist, rank, world)
+        cc = _drive(x, script)
+        x.drain()
+        st = x.stats()
+        x.close()
+        dist.barrier()
+        out.append((py, cc, st))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_c_exchange_gloo_world8_staggered_and_abort():
+    """C5 readiness without an 8-GPU node: the exchange protocol served in C (liblsqrccl.so through
+    lsq_rccl_xchg_create_custom, gloo transport) at the world size of BASELINE's C5 -- eight ranks, staggered convergence, one
+    aborting rank -- against its Python twin call by call, with equal collective counts on every rank."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_c_vs_python_world8, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        for k, (py, cc, st) in enumerate(res[r]):
+            assert py == cc, (r, k, py, cc)
+    # script a: everybody leaves at the call in which the slowest rank (7: call index 9) reports convergence, with "all
+    # converged" and the global sum / max of THAT call; nobody aborted; the collective counts agree
+    na = 2 + (world - 1) + 1
+    for r in range(world):
+        cc, st = res[r][0][1], res[r][0][2]
+        assert len(cc) >= na and all(v[0] == 0 for v in cc[:na])
+        assert cc[na - 1][3] == 1.0 and all(v[3] == 0.0 for v in cc[:na - 1])
+        assert cc[na - 1][1] == pytest.approx(sum(1.0 / na + k for k in range(world)), rel=1e-15)
+        assert not st["aborted"]
+    assert len({res[r][0][2]["collectives"] for r in range(world)}) == 1
+    # script b: rank 5 leaves at its 4th call (rc 0 for itself); every other rank is told (rc 2) at its 4th or 5th call, and ALL
+    # ranks have issued the same number of collectives
+    assert [v[0] for v in res[5][1][1]] == [0, 0, 0, 0]
+    for r in range(world):
+        if r != 5:
+            rcs = [v[0] for v in res[r][1][1]]
+            assert rcs[-1] == 2 and all(v == 0 for v in rcs[:-1]) and len(rcs) in (4, 5), (r, rcs)
+        assert res[r][1][2]["aborted"]
+    assert len({res[r][1][2]["collectives"] for r in range(world)}) == 1
+    # script c: the last rank leaves at once; everybody else's synchronous first call sees it; one collective each
+    for r in range(world):
+        rcs = [v[0] for v in res[r][2][1]]
+        assert rcs == ([0] if r == world - 1 else [2]), (r, rcs)
+        assert res[r][2][2]["collectives"] == 1
+
+
 def test_c_exchange_symbols_and_one_rank_protocol():
     """include/lsqrccl.h's exchange entry points are exported, and the protocol at world 1 over the built-in transport double
     (no process group): first call and frozen calls synchronous, active calls return the previous exchange."""
@@ -430,6 +503,70 @@ def test_two_ranks_lm_with_c_exchange_over_gloo():
     assert d0 == 0.0 and d1 == 0.0
     assert ssr0 == pytest.approx(s0 + s1, rel=1e-12) and ssr1 == pytest.approx(ssr0, rel=1e-15)
     assert st0["collectives"] == st1["collectives"] and st0["collectives"] in (it0, it0 + 1)
+
+
+def _worker_c5_shared(rank, world, port, q):
+    """One rank of an 8-rank C5 run squeezed onto the ONE device of the box: a reduced C4 problem (125 000 x 10 000, nnz 1.25e6:
+    both sliced layouts, the three-launch LSMR iteration, the speculative tail -- the kernels of the headline), seed 20260928 +
+    rank as in bench.py, the exchange served in C over a gloo transport."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = lsq.Context(0)
+    pr = lsq.synthetic.TanhProblem(125_000, 10_000, sparse=True, per_col=125, seed=lsq.synthetic.BASE_SEED + rank, ctx=ctx)
+    x = lsq.sharding.TorchTransportExchange(dist, rank, world)
+    LM, LSMR = lsq._lib.LEVENBERG_MARQUARDT, lsq._lib.LSMR
+    dist.barrier()
+    pr.reset()
+    r = pr.optimize(LM, LSMR, iterations=40, allreduce=x, trace=True)      # default tolerances: the ranks converge on their own
+    x.drain()
+    st = x.stats()
+    dist.barrier()                                                          # the neighbours are done
+    pr.reset()
+    r1 = pr.optimize(LM, LSMR, iterations=40, trace=True)                   # the same problem, alone on the device
+    k = r1.iterations
+    same = (np.array_equal(np.array(r.trace["x"])[:k], np.array(r1.trace["x"])[:k]) and
+            np.array_equal(np.asarray(r.trace["ssr"])[:k], np.asarray(r1.trace["ssr"])[:k]) and
+            np.array_equal(np.asarray(r.trace["inner"])[:k], np.asarray(r1.trace["inner"])[:k]) and
+            np.array_equal(np.asarray(r.trace["accept"])[:k], np.asarray(r1.trace["accept"])[:k]))
+    q.put((rank, r.iterations, bool(r.converged), float(r.ssr), r1.iterations, bool(r1.converged), float(r1.ssr), bool(same),
+           float(np.max(np.abs(r.minimizer - r1.minimizer))), st, ctx.fallback_stats()))
+    x.close()
+    pr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_eight_ranks_share_one_device_c5_protocol():
+    """C5 readiness without an 8-GPU node: EIGHT processes drive the one device at once, each with its own
+    reduced C4 problem and the C exchange over gloo -- eight launch threads contending for the host and the queue, which world 2
+    cannot show.  Every rank's trajectory (iterates, ssr, inner counts, accept pattern) is bit-identical to the same problem run
+    alone, all ranks leave in the same outer iteration with the global ssr, and all issued the same number of collectives."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_c5_shared, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rec = q.get(timeout=900)
+        res[rec[0]] = rec[1:]
+    for p in ps:
+        p.join(180)
+        assert p.exitcode == 0
+    its = {res[r][0] for r in range(world)}
+    alone = [res[r][3] for r in range(world)]
+    assert len(its) == 1 and its.pop() in (max(alone), max(alone) + 1)
+    total = sum(res[r][5] for r in range(world))
+    for r in range(world):
+        it, conv, ssr, it1, conv1, ssr1, same, dx, st, fb = res[r]
+        assert conv and conv1, r
+        assert same and dx == 0.0, ("rank %d: trajectory beside 7 neighbours differs from the run alone" % r, dx)
+        assert ssr == pytest.approx(total, rel=1e-12)
+        assert not st["aborted"]
+    assert len({res[r][8]["collectives"] for r in range(world)}) == 1
 
 
 @pytest.mark.gpu
