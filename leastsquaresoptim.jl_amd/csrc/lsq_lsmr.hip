@@ -145,6 +145,19 @@ struct EpiV {
                               // normalised v and the new v~ apart: its next launch reads v~ while it rewrites v
     const double *cs = nullptr;   // ... and takes the gather vector of its next J*v straight from here: wout = (v~ .* P) .* s
     double *wout = nullptr;       // (s: the column scale of J = V diag(s), or null)
+    // k_combine requests the column's own operands with its first round of partials (has_col_prefetch): seg() finds them in
+    // registers when it is called for THAT column (the workgroup's first and, on the LSMR path, only column block)
+    using has_col_prefetch = void;
+    int pf_j = -1;
+    double pf_P = 1.0, pf_dg = 0.0, pf_ux = 0.0, pf_v = 0.0, pf_cs = 1.0;
+    __device__ void col_prefetch(int j) {
+        pf_j = j;
+        pf_P = P ? P[j] : 1.0;
+        pf_dg = dg ? dg[j] : 0.0;
+        pf_ux = (dg && ux) ? ux[j] : 0.0;
+        pf_v = v[j];
+        pf_cs = (wout && cs) ? cs[j] : 1.0;
+    }
     using has_block_prepare = void;
     __device__ void block_prepare() {
         double b2, bx, unused;
@@ -170,15 +183,17 @@ struct EpiV {
             }
             return;
         }
+        const bool pf = j == pf_j;                  // (the same operands, fetched a round trip earlier)
         double w = dot;
-        if (dg && ux) w += ux[j] * dg[j];           // iterative_lsmr.jl:107
+        if (dg && ux) w += (pf ? pf_ux : ux[j]) * (pf ? pf_dg : dg[j]);           // iterative_lsmr.jl:107
         w *= inv_beta;                              // u = u~/beta
-        if (P) w *= P[j];                           // :41
-        double vn = first ? w : w - beta * v[j];    // :42-49 (beta == 0 => fill!)
+        const double Pj = P ? (pf ? pf_P : P[j]) : 1.0;
+        if (P) w *= Pj;                             // :41
+        double vn = first ? w : w - beta * (pf ? pf_v : v[j]);    // :42-49 (beta == 0 => fill!)
         (vout ? vout : v)[j] = vn;
         if (wout) {
-            const double t = P ? vn * P[j] : vn;
-            wout[j] = cs ? t * cs[j] : t;
+            const double t = P ? vn * Pj : vn;
+            wout[j] = cs ? t * (pf ? pf_cs : cs[j]) : t;
         }
         racc += vn * vn;
     }

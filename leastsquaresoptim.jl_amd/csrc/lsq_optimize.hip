@@ -918,7 +918,20 @@ static int optimize_lm_loop(lsq_ctx *c, lsq_solver *sv, LoopBuffers &b, lsq_mat 
             // (speculation needs kernels that honour the skip flag: the device model on the sliced rows)
             static const bool no_spec = getenv("LSQ_NO_TAIL_SPECULATION") != nullptr;
             const bool guardable = tc.is_model && J->kind == LSQ_MAT_CSC && J->srows.active && !no_spec && !lsq_dbg_serial;
-            LsmrTail tail{guardable ? last_inner : 0, tail_fn, &tc, guardable};
+            // (diagnostic, LSQ_TAIL_ORACLE_SEQ="1,1,6,5,3,1": the inner counts of a solve that is being REPEATED, fed back as perfect
+            //  first guesses -- the A/B that prices a wrong guess: profiles/r06/ab_tail_oracle.txt; never set in a measured run)
+            static const std::vector<int> oracle_seq = [] {
+                std::vector<int> v;
+                if (const char *e = getenv("LSQ_TAIL_ORACLE_SEQ"))
+                    for (const char *p = e; *p;) {
+                        v.push_back(atoi(p));
+                        while (*p && *p != ',') ++p;
+                        if (*p == ',') ++p;
+                    }
+                return v;
+            }();
+            const int first_guess = oracle_seq.empty() ? last_inner : oracle_seq[(size_t)(iter - 1) % oracle_seq.size()];
+            LsmrTail tail{guardable ? first_guess : 0, tail_fn, &tc, guardable && oracle_seq.empty()};
             LSQ_TRY(lsq_lsmr_solve(sv, J, fcur, b.dtd, b.dx, &lmiter, b.grad, ssr, lm_prep ? &prep : nullptr,
                                    tail_ok ? &tail : nullptr));  // :87
             tail_done = tail_ok;

@@ -41,7 +41,6 @@ static_assert(S64_MAT + S64_TMP >= 64 * CQ_QST, "slab image over R + scratch");
 constexpr size_t CQ_LDS = (size_t)CQ_LDS_DOUBLES * sizeof(double);
 constexpr size_t CQ_LDS_LU = (size_t)(4 * S64_MAT + S64_TMP) * sizeof(double);
 constexpr size_t CQ_LDS_TW = (size_t)(2 * S64_MAT) * sizeof(double);
-constexpr size_t CQ_LDS_TW_Q1 = (size_t)(4 * S64_MAT) * sizeof(double);
 #ifdef CQ_TIMING   // phase time stamps of workgroup 0 (tools/micro/cqr_bench.hip only)
 __device__ unsigned long long cq_tbuf[64];
 #define CQ_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) cq_tbuf[k] = wall_clock64(); } while (0)
@@ -70,11 +69,10 @@ __device__ __forceinline__ void cq_load64(double *__restrict__ dst, const double
 // ||E||_F > 1/2: cond(Q1)^2 eps is no longer O(eps) -- *bad is set (as for a Cholesky breakdown).
 template <int PASS>
 __device__ __forceinline__ void cq_factor(const double *__restrict__ G, double *__restrict__ M1, double *__restrict__ M2,
-                                          double *__restrict__ T, int *s_fail, double *s_red, int *bad, int tid) {
+                                          double *__restrict__ T, int *s_fail, double *s_red, int *bad, int tid, int ngroups = 0) {
     const int lane = tid & 63, wv = tid >> 6;
     double g[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) g[q] = G[tid + 256 * q];         // entry e = tid + 256 q: row e >> 6, column e & 63
+    cq_gram_entries(G, ngroups, g, tid);                          // entry e = tid + 256 q: row e >> 6, column e & 63
     *bad = 0;
     bool series = false;
     if (PASS == 2) {
@@ -133,19 +131,22 @@ __device__ __forceinline__ void cq_factor(const double *__restrict__ G, double *
 }
 
 // rows r0.. of a 64-column block times the upper triangular inv(R) in M2: one 16-row tile per wavefront, K = 64 (zero
-// blocks skipped); the lane's part of the product -> acc[4] (MFMA D layout: column 16 j + (lane & 15), rows (lane >> 4) + 4 r)
-__device__ __forceinline__ void cq_rows_times_inv(const double *__restrict__ P, size_t lda, int nr, const double *__restrict__ M2,
-                                                  s64_v4d acc[4], int lane, int wv) {
+// blocks skipped); the lane's part of the product -> acc[4] (MFMA D layout: column 16 j + (lane & 15), rows (lane >> 4) + 4 r).
+// In two halves, so that the rows can be requested BEFORE the factor that produces inv(R) (a memory round trip of ~2 us that
+// would otherwise follow the 18 us factor on every pass-1 workgroup's path).
+__device__ __forceinline__ void cq_rows_fetch(const double *__restrict__ P, size_t lda, int nr, double (&a)[16], int lane, int wv) {
     const int ij = lane & 15, kq = lane >> 4;
     const int row = wv * 16 + ij;
     const bool rin = row < nr;
     const double *prow = P + (rin ? row : 0);
-    double a[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const double v = prow[(size_t)(s * 4 + kq) * lda];
         a[s] = rin ? v : 0.0;
     }
+}
+__device__ __forceinline__ void cq_rows_mma(const double (&a)[16], const double *__restrict__ M2, s64_v4d acc[4], int lane) {
+    const int ij = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (s64_v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -157,6 +158,12 @@ __device__ __forceinline__ void cq_rows_times_inv(const double *__restrict__ P, 
                 acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], M2[k * S64_LS + 16 * j + ij], acc[j], 0, 0, 0);
     }
 }
+__device__ __forceinline__ void cq_rows_times_inv(const double *__restrict__ P, size_t lda, int nr, const double *__restrict__ M2,
+                                                  s64_v4d acc[4], int lane, int wv) {
+    double a[16];
+    cq_rows_fetch(P, lda, nr, a, lane, wv);
+    cq_rows_mma(a, M2, acc, lane);
+}
 
 // PASS 0: Gram partials of the raw panel.   PASS 1: R1 = chol(G), Q1 = P inv(R1) in place, Gram partials of Q1.
 // PASS 2: R2 from G2 = Q1'Q1, Q = Q1 inv(R2) -> Vb.      P = A(c0 + [0, rows), c0 + [0, 64)), column-major, ld lda.
@@ -166,7 +173,9 @@ template <int PASS, bool PRE = false>
 __global__ void __launch_bounds__(256)
 k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__restrict__ G, double *__restrict__ Gp,
            double *__restrict__ R1g, double *__restrict__ Vb, int ldv, int *__restrict__ err, int q1vb = 0 /* PASS 1: Q1 -> Vb
-           instead of in place (the Q1 form of the block reflector, round 6: no pass 2) */) {
+           instead of in place (the Q1 form of the block reflector, round 6: no pass 2) */,
+           int ngroups_in = 0 /* > 0: G holds that many group sums (cq_group_reduce), added here */,
+           double *Gq = nullptr /* non-null: this launch's own partials are summed per group into Gq */, unsigned *gcnt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *M2 = sm, *M1 = sm + S64_MAT, *T = sm + 2 * S64_MAT, *Qs = M1;   // (Qs aliases R and the scratch: used after them)
     __shared__ int s_fail;
@@ -187,15 +196,21 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
         for (int q = 0; q < 16; ++q) Qs[(cq + 4 * q) * CQ_QST + row] = rin ? t[q] : 0.0;
         __syncthreads();
         CQ_T(1);
-        cq_slab_gram(Qs, Gp + (size_t)slab * 4096, tid);
+        if (Gq) {
+            cq_slab_gram<true>(Qs, Gp + (size_t)slab * 4096, tid);
+            cq_group_reduce(Gp, Gq, gcnt, slab, (int)gridDim.x, tid);
+        } else
+            cq_slab_gram(Qs, Gp + (size_t)slab * 4096, tid);
         CQ_T(2);
         return;
     }
+    double prow[16];                                              // this wavefront's 16 rows of the slab: requested before the factor
+    cq_rows_fetch(P, (size_t)lda, nr, prow, lane, wv);
     if (PRE) {
         cq_load64(M2, G, tid);                                    // inv(R), row-major 64 x 64
     } else {
         int bad;
-        cq_factor<PASS>(G, M1, M2, T, &s_fail, s_red, &bad, tid);     // every workgroup, identically
+        cq_factor<PASS>(G, M1, M2, T, &s_fail, s_red, &bad, tid, ngroups_in);     // every workgroup, identically
         if (bad && slab == 0 && tid == 0) atomicOr(err, CQ_FAIL);
         CQ_T(PASS * 16 + 2);
         if (PASS == 1 && slab == 0)
@@ -206,7 +221,7 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
     CQ_T(PASS * 16 + 3);
     {
         s64_v4d acc[4];
-        cq_rows_times_inv(P, (size_t)lda, nr, M2, acc, lane, wv);
+        cq_rows_mma(prow, M2, acc, lane);
         const int ij = lane & 15, kq = lane >> 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -226,7 +241,13 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
         }
     }
     CQ_T(PASS * 16 + 5);
-    if (PASS == 1) cq_slab_gram(Qs, Gp + (size_t)slab * 4096, tid);
+    if (PASS == 1) {
+        if (Gq) {
+            cq_slab_gram<true>(Qs, Gp + (size_t)slab * 4096, tid);
+            cq_group_reduce(Gp, Gq, gcnt, slab, (int)gridDim.x, tid);
+        } else
+            cq_slab_gram(Qs, Gp + (size_t)slab * 4096, tid);
+    }
     CQ_T(PASS * 16 + 6);
 }
 
@@ -295,27 +316,33 @@ __global__ void __launch_bounds__(256) k_cqr_reduce(const double *__restrict__ G
 __global__ void __launch_bounds__(256)
 k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, const double *__restrict__ Q1top, int ldq,
           double *__restrict__ Binv, double *__restrict__ Sg, double *__restrict__ SRg, int *__restrict__ err,
-          double *__restrict__ R2inv) {
+          double *__restrict__ R2inv, int lu_only, int ngroups) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *B0 = sm, *B1 = sm + S64_MAT, *B2 = sm + 2 * S64_MAT, *B3 = sm + 3 * S64_MAT, *T = sm + 4 * S64_MAT;
     __shared__ double sS[64], sR[64], s_red[4];
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     CQ_T(48);
+    // (this workgroup is a chain of latencies on every panel's path: what comes from memory -- Q1's top rows, R1 -- is requested
+    //  before the factor, together with G2)
+    double qtop[16], r1v[16];
+    cq_rows_fetch(Q1top, (size_t)ldq, 64, qtop, lane, wv);         // Q1's top rows (pass 1: in place in A, or in Vb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r1v[q] = R1g[tid + 256 * q];
     int bad;
-    cq_factor<2>(G2, B0, B1, T, &s_fail, s_red, &bad, tid);       // B0 = R2, B1 = inv(R2)  (old form: the flag is raised by pass 2)
+    cq_factor<2>(G2, B0, B1, T, &s_fail, s_red, &bad, tid, ngroups);   // B0 = R2, B1 = inv(R2)  (old form: the flag is raised by pass 2)
     if (R2inv) {
         if (bad && tid == 0) atomicOr(err, CQ_FAIL);
 #pragma unroll
         for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q; R2inv[e] = B1[(e >> 6) * S64_LS + (e & 63)]; }
     }
-    cq_load64(B2, R1g, tid);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q; B2[(e >> 6) * S64_LS + (e & 63)] = r1v[q]; }
     __syncthreads();
     s64_gemm<false, false, S64_UU>(B3, B0, B2, 1.0, tid);          // B3 = R = R2 R1
     {   // Q_top (row-major) -> B2
-        const double *P = Q1top;                                   // Q1's top rows (pass 1: in place in A, or in Vb)
         s64_v4d acc[4];
-        cq_rows_times_inv(P, (size_t)ldq, 64, B1, acc, lane, wv);
+        cq_rows_mma(qtop, B1, acc, lane);
         __syncthreads();                                           // (the product above has read B2 = R1)
         const int ij = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -325,6 +352,82 @@ k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, const d
     }
     __syncthreads();
     CQ_T(49);
+    // ---- TALL PANELS (round 6): the kernel of the block reflector WITHOUT a dependent chain -------------------------------
+    // Q has orthonormal columns, so ||Q_top||_2 <= 1, and for a panel of many rows it is small (~2 sqrt(64 / rows)).  The
+    // basis-kernel form  Qfull = I - V T V',  V = Q - [S; 0],  T' = inv(I - S Q_top)  is an orthogonal matrix with Qfull [S; 0]
+    // = Q for ANY diagonal sign matrix S for which N = I - S Q_top is regular (T^-1 + T^-T = V'V = N + N') -- the sequential
+    // sign choice of the modified LU only serves stability (pivots >= 1 when Q_top is not small).  So with E = S Q_top,
+    // S_j = -sign(Q_top[j][j]) taken up front (diag(N) >= 1), and rho(E) <= 1/2 PROVEN by ||E^2||_F <= 1/4:
+    //      inv(N) = (I + E)(I + E^2)(I + E^4) ...       inv(B) = inv(Q_top - S) = -inv(N) S
+    // by repeated squaring on the MFMA unit, until the measured ||E^(2^k)||_F^2 says that the next factor is below 1e-34
+    // (cond(N) <= (1 + 1)(4/3)): ~8 products of 64^3 at C3 instead of the 64-step LU + two triangular inversions + a product.
+    // Otherwise (short panels: Q_top is a sizeable part of Q) the modified LU below.  LSQ_QR_TOP_LU=1 (lu_only) forces it.
+    if (!lu_only) {
+        double *E = B0, *P = B1, *F = B3, *Tm = B2;                // (B3 = R until S R is stored; B2 = Q_top until the decision)
+        double ev[16];
+        if (tid < 64) sS[tid] = B2[tid * S64_LS + tid] >= 0.0 ? -1.0 : 1.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            ev[q] = (B2[r * S64_LS + r] >= 0.0 ? -1.0 : 1.0) * B2[r * S64_LS + c];      // E = S Q_top
+            E[r * S64_LS + c] = ev[q];
+        }
+        __syncthreads();
+        s64_gemm<false, false, S64_FULL>(P, E, E, 1.0, tid);       // E^2 -> P for now (R still sits in F's buffer)
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q; const double v = P[(e >> 6) * S64_LS + (e & 63)]; acc += v * v; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) s_red[wv] = acc;
+        __syncthreads();
+        double fro2 = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (fro2 <= 0.0625) {                                      // (uniform; NaN fails the test and takes the LU path, which reports)
+            // the panel's part of the factor, S R, and S -- with the signs chosen above
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = tid + 256 * q, col = e >> 6, row = e & 63;
+                SRg[e] = row <= col ? sS[row] * B3[row * S64_LS + col] : 0.0;
+            }
+            if (tid < 64) Sg[tid] = sS[tid];
+            __syncthreads();                                       // (R and Q_top are dead from here on)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {                         // F = E^2 (moved out of P), P = I + E
+                const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+                F[r * S64_LS + c] = P[r * S64_LS + c];
+                P[r * S64_LS + c] = (r == c ? 1.0 : 0.0) + ev[q];
+            }
+            __syncthreads();
+            double *Fc = F, *Fn = E;                               // (E itself is no longer needed)
+            for (int it = 0; it < 8; ++it) {
+                s64_gemm<false, false, S64_FULL>(Tm, P, Fc, 1.0, tid);     // P <- P (I + F)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q, o = (e >> 6) * S64_LS + (e & 63); P[o] += Tm[o]; }
+                // ||F^2||_F <= ||F||_F^2: once that is below 1e-34 the next factor would not change a bit of P
+                if (fro2 <= 1e-17) break;                           // (uniform)
+                __syncthreads();
+                s64_gemm<false, false, S64_FULL>(Fn, Fc, Fc, 1.0, tid);    // F <- F^2
+                acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q; const double v = Fn[(e >> 6) * S64_LS + (e & 63)]; acc += v * v; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+                if (lane == 0) s_red[wv] = acc;                     // (the previous round's readers are past two barriers)
+                __syncthreads();
+                fro2 = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+                double *sw = Fc; Fc = Fn; Fn = sw;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {                         // inv(B) = -inv(N) S: column c scaled by -S_c (row-major, to global)
+                const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+                Binv[e] = -P[r * S64_LS + c] * sS[c];
+            }
+            CQ_T(52);
+            return;
+        }
+        __syncthreads();                                           // (P, E are scratch again; B2 = Q_top and B3 = R are intact)
+    }
     double *M = B2, *Li = B0;
     s64_lu_modified(M, Li, sS, sR, tid);
     CQ_T(50);
@@ -428,14 +531,42 @@ k_cqr_tw(const double *__restrict__ W, int ncolsB, const double *__restrict__ Bi
 //      WQ = inv(R2)' W;   W2 = inv(B)(A2_top - S WQ);   A2_top += S W2  (written back: every workgroup owns its 64 columns);
 //      W3 = inv(R2) W2 -> the update kernel's operand (it then subtracts Q1 W3 from ALL rows of A2, the top ones included).
 // R2inv, Binv, S, SR: k_cqr_top on the side stream (ev_lu).  The extra workgroup puts the panel's part of R into A.
+// SIXTEEN columns per workgroup (the first form took 64, like k_cqr_tw: three dependent 64^3 products by one CU -- 144 MFMAs per
+// wavefront at one per ~100 clocks -- made the launch 15 us on every panel's path; with 16 columns a wavefront owns ONE 16 x 16 tile
+// of each product, at most 16 MFMAs, and four times as many CUs share the work).
+constexpr int TQ_NC = 16;                  // columns of [A2 | b] per workgroup
+constexpr int TQ_XS = TQ_NC + 1;           // row stride of the 64 x 16 images
+constexpr size_t CQ_LDS_TW_Q1 = (size_t)(2 * S64_MAT + 2 * 64 * TQ_XS) * sizeof(double);
+// Y (64 x 16) = op(A) (64 x 64, LDS, stride S64_LS) * X (64 x 16): wavefront wv forms rows 16 wv .. 16 wv + 15.
+//   SHAPE S64_LF: op(A) = A' with A upper triangular (k tiles 0 .. wv);  S64_FULL;  S64_UF: A upper triangular (k tiles wv .. 3)
+template <bool TA, int SHAPE>
+__device__ __forceinline__ void tq_gemm16(double *__restrict__ Y, const double *__restrict__ A, const double *__restrict__ X, int tid) {
+    const int lane = tid & 63, wv = tid >> 6, ij = lane & 15, kq = lane >> 4;
+    const int k0 = SHAPE == S64_UF ? wv : 0, k1 = SHAPE == S64_LF ? wv + 1 : 4;
+    s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kt = k0; kt < k1; ++kt) {
+        double a[4], b[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = kt * 16 + kk * 4 + kq;
+            a[kk] = TA ? A[k * S64_LS + 16 * wv + ij] : A[(16 * wv + ij) * S64_LS + k];
+            b[kk] = X[k * TQ_XS + ij];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Y[(16 * wv + kq + 4 * r) * TQ_XS + ij] = acc[r];
+    __syncthreads();
+}
 __global__ void __launch_bounds__(256)
 k_cqr_tw_q1(const double *__restrict__ W, int ncolsB, const double *__restrict__ Binv, const double *__restrict__ Sg,
             const double *__restrict__ SRg, const double *__restrict__ R2inv, double *A, int lda, int c0, int cend, int n,
             double *rhs, double *__restrict__ W2) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *sBi = sm, *sRi = sm + S64_MAT, *X = sm + 2 * S64_MAT, *Y = sm + 3 * S64_MAT;
+    double *sBi = sm, *sRi = sm + S64_MAT, *X = sm + 2 * S64_MAT, *Y = X + 64 * TQ_XS;
     const int tid = threadIdx.x;
-    const int ncols = ncolsB - 64, j0 = blockIdx.x * 64;
+    const int ncols = ncolsB - 64, j0 = blockIdx.x * TQ_NC;
     if ((int)blockIdx.x == (int)gridDim.x - 1) {
         double t[16];
 #pragma unroll
@@ -447,48 +578,54 @@ k_cqr_tw_q1(const double *__restrict__ W, int ncolsB, const double *__restrict__
         }
         return;
     }
-    cq_load64(sBi, Binv, tid);
-    cq_load64(sRi, R2inv, tid);
-    double top[16];
     const int k = tid & 63;                       // (e = tid + 256 q: row k = e & 63 is the thread's own, column j = e >> 6)
+    double top[4], wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                 // (requested with the two 64 x 64 factors: one memory round trip in all)
+        const int j = (tid >> 6) + 4 * q, col = min(j0 + j, ncols - 1), a = cend + col;
+        top[q] = a < n ? A[(size_t)a * lda + c0 + k] : rhs[c0 + k];
+        wq[q] = W[(size_t)(64 + col) * 64 + k];
+    }
     const double sk = Sg[k];
     {
-        double wq[16];
+        double tb[16], tr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { tb[q] = Binv[tid + 256 * q]; tr[q] = R2inv[tid + 256 * q]; }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int j = (tid >> 6) + 4 * q, col = min(j0 + j, ncols - 1), a = cend + col;
-            top[q] = a < n ? A[(size_t)a * lda + c0 + k] : rhs[c0 + k];
-            wq[q] = W[(size_t)(64 + col) * 64 + k];
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int j = (tid >> 6) + 4 * q;
-            X[k * S64_LS + j] = j0 + j < ncols ? wq[q] : 0.0;
+            const int e = tid + 256 * q, o = (e >> 6) * S64_LS + (e & 63);
+            sBi[o] = tb[q];
+            sRi[o] = tr[q];
         }
     }
-    __syncthreads();
-    s64_gemm<true, false, S64_LF>(Y, sRi, X, 1.0, tid);            // Y = WQ = inv(R2)' (Q1'[A2 | b])
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 4; ++q) {
         const int j = (tid >> 6) + 4 * q;
-        Y[k * S64_LS + j] = j0 + j < ncols ? top[q] - sk * Y[k * S64_LS + j] : 0.0;
+        X[k * TQ_XS + j] = j0 + j < ncols ? wq[q] : 0.0;
     }
     __syncthreads();
-    s64_gemm<false, false, S64_FULL>(X, sBi, Y, 1.0, tid);         // X = W2 = inv(B)(A2_top - S WQ)
+    tq_gemm16<true, S64_LF>(Y, sRi, X, tid);                       // Y = WQ = inv(R2)' (Q1'[A2 | b])
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {                                 // A2_top += S W2: the [S W2; 0] part of V W2
+    for (int q = 0; q < 4; ++q) {
+        const int j = (tid >> 6) + 4 * q;
+        Y[k * TQ_XS + j] = j0 + j < ncols ? top[q] - sk * Y[k * TQ_XS + j] : 0.0;
+    }
+    __syncthreads();
+    tq_gemm16<false, S64_FULL>(X, sBi, Y, tid);                    // X = W2 = inv(B)(A2_top - S WQ)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                  // A2_top += S W2: the [S W2; 0] part of V W2
         const int j = (tid >> 6) + 4 * q, col = j0 + j, a = cend + col;
         if (col < ncols) {
-            const double v = top[q] + sk * X[k * S64_LS + j];
+            const double v = top[q] + sk * X[k * TQ_XS + j];
             if (a < n) A[(size_t)a * lda + c0 + k] = v;
             else rhs[c0 + k] = v;
         }
     }
-    s64_gemm<false, false, S64_UF>(Y, sRi, X, 1.0, tid);           // Y = W3 = inv(R2) W2
+    tq_gemm16<false, S64_UF>(Y, sRi, X, tid);                      // Y = W3 = inv(R2) W2
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 4; ++q) {
         const int j = (tid >> 6) + 4 * q;
-        if (j0 + j < ncols) W2[(size_t)(j0 + j) * 64 + k] = Y[k * S64_LS + j];
+        if (j0 + j < ncols) W2[(size_t)(j0 + j) * 64 + k] = Y[k * TQ_XS + j];
     }
 }
 
@@ -504,6 +641,12 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
     LSQ_HIP(hipMalloc(&w->Binv, 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->Minv, 2 * 4096 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->R2inv, 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->Gq1, (size_t)CQ_HIER_MAX_GROUPS * 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->Gq2, (size_t)CQ_HIER_MAX_GROUPS * 4096 * sizeof(double)));
+    LSQ_HIP(hipMalloc(&w->gcnt, CQ_HIER_MAX_GROUPS * sizeof(unsigned)));
+    LSQ_ZERO(w->Gq1, 0, (size_t)CQ_HIER_MAX_GROUPS * 4096 * sizeof(double));     // (the strictly lower tiles are never written)
+    LSQ_ZERO(w->Gq2, 0, (size_t)CQ_HIER_MAX_GROUPS * 4096 * sizeof(double));
+    LSQ_ZERO(w->gcnt, 0, CQ_HIER_MAX_GROUPS * sizeof(unsigned));
     LSQ_HIP(hipMalloc(&w->S, 64 * sizeof(double)));
     LSQ_HIP(hipMalloc(&w->SR, 4096 * sizeof(double)));
     {   // highest priority: k_cqr_top's single workgroup (141 KB of LDS) must get a CU before the caller's V'[A2 | b] grid fills
@@ -535,7 +678,7 @@ int lsq_cqr_alloc(lsq_ctx *c, CqrWork *w, int M) {
 
 void lsq_cqr_free(CqrWork *w) {
     if (!w || !w->ready) return;
-    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->Minv); hipFree(w->R2inv); hipFree(w->S); hipFree(w->SR);
+    hipFree(w->Gp); hipFree(w->G); hipFree(w->G2); hipFree(w->R1); hipFree(w->Binv); hipFree(w->Minv); hipFree(w->R2inv); hipFree(w->Gq1); hipFree(w->Gq2); hipFree(w->gcnt); hipFree(w->S); hipFree(w->SR);
     hipEventDestroy(w->ev_q); hipEventDestroy(w->ev_lu); hipEventDestroy(w->ev_first); hipEventDestroy(w->ev_panel);
     w->side = w->ahead = nullptr;          // (the context's)
     w->ready = false;
@@ -544,13 +687,35 @@ void lsq_cqr_free(CqrWork *w) {
 // The Q1 form (default since round 6; LSQ_QR_CQR_PASS2=1 restores the three-pass panel of rounds 2-5 for A/B): read per call.
 bool lsq_cqr_q1form() { return getenv("LSQ_QR_CQR_PASS2") == nullptr; }
 
+bool lsq_cqr_hier(int nslab) {
+    return lsq_cqr_q1form() && nslab <= CQ_GS * CQ_HIER_MAX_GROUPS && !getenv("LSQ_QR_NO_HIER");
+}
+
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps,
-                  bool gram_ready) {
+                  bool gram_ready, bool hier) {
     const int rows = M - c0, nslab = (rows + CQ_RS - 1) / CQ_RS;
     (void)c;
     const bool pre = ps == w->ahead && !getenv("LSQ_QR_AHEAD_REDUNDANT");     // one factor kernel instead of one factor per workgroup
     const bool q1 = lsq_cqr_q1form();
     w->q1form = q1;
+    const int lu_only = getenv("LSQ_QR_TOP_LU") ? 1 : 0;      // (A/B: the modified LU for every panel, as in rounds 2-5)
+    if (hier && q1 && !pre) {
+        // NO reduce launches (cq_group_reduce): the producers of the Gram partials leave group sums, the consumers add them
+        const int ng = (nslab + CQ_GS - 1) / CQ_GS;
+        if (!gram_ready)
+            LSQ_LAUNCH(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
+                               w->R1, Vb, ldv, d_err, 0, 0, w->Gq1, w->gcnt);
+        LSQ_LAUNCH(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->Gq1, w->Gp,
+                           w->R1, Vb, ldv, d_err, 1, ng, w->Gq2, w->gcnt);
+        LSQ_HIP(hipGetLastError());
+        LSQ_HIP(hipEventRecord(w->ev_q, ps));
+        LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
+        LSQ_LAUNCH(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->Gq2, (const double *)w->R1,
+                           (const double *)Vb, ldv, w->Binv, w->S, w->SR, d_err, w->R2inv, lu_only, ng);
+        LSQ_HIP(hipGetLastError());
+        LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
+        return LSQ_OK;
+    }
     // (gram_ready: the update of the previous panel left the Gram partials of this panel's slabs in w->Gp itself)
     if (!gram_ready)
         LSQ_LAUNCH(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
@@ -572,7 +737,7 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
         LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
         LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, w->side, (const double *)w->Gp, nslab, w->G2);
         LSQ_LAUNCH(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1,
-                           (const double *)Vb, ldv, w->Binv, w->S, w->SR, d_err, w->R2inv);
+                           (const double *)Vb, ldv, w->Binv, w->S, w->SR, d_err, w->R2inv, lu_only, 0);
         LSQ_HIP(hipGetLastError());
         LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
         return LSQ_OK;
@@ -584,7 +749,7 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
     LSQ_HIP(hipEventRecord(w->ev_q, ps));
     LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
     LSQ_LAUNCH(k_cqr_top, dim3(1), dim3(256), CQ_LDS_LU, w->side, (const double *)w->G2, (const double *)w->R1,
-                       (const double *)(A + (size_t)c0 * M + c0), M, w->Binv, w->S, w->SR, d_err, (double *)nullptr);
+                       (const double *)(A + (size_t)c0 * M + c0), M, w->Binv, w->S, w->SR, d_err, (double *)nullptr, lu_only, 0);
     LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
     if (pre) {
         LSQ_LAUNCH(k_cqr_factor<2>, dim3(1), dim3(256), CQ_LDS, ps, (const double *)w->G2, w->Minv + 4096, w->R1, d_err);
@@ -602,7 +767,7 @@ int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, i
     LSQ_HIP(hipStreamWaitEvent(c->stream, w->ev_lu, 0));
     const int ncols = ncolsB - 64;
     if (w->q1form) {
-        LSQ_LAUNCH(k_cqr_tw_q1, dim3(std::max(1, (ncols + 63) / 64) + 1), dim3(256), CQ_LDS_TW_Q1, c->stream, W, ncolsB,
+        LSQ_LAUNCH(k_cqr_tw_q1, dim3(std::max(1, (ncols + TQ_NC - 1) / TQ_NC) + 1), dim3(256), CQ_LDS_TW_Q1, c->stream, W, ncolsB,
                            (const double *)w->Binv, (const double *)w->S, (const double *)w->SR, (const double *)w->R2inv, A, M, c0, cend,
                            n, rhs, W2);
         LSQ_HIP(hipGetLastError());

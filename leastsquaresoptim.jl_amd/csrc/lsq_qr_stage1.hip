@@ -856,7 +856,7 @@ template <int DBG, bool GRAM = false>     // DBG 0: the product; 1: no MFMAs (me
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int M, int c0, int cend, int n,
                double *__restrict__ rhs, int ncols /* n - cend + 1 */, const double *__restrict__ W2, int jbeg, int jend, int tpw,
-               double *__restrict__ gram_out = nullptr) {
+               double *gram_out = nullptr, double *gram_q = nullptr /* group sums too (cq_group_reduce) */, unsigned *gram_cnt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double u3_qs[];      // GRAM: the slab image [col][row], CQ_QST apart
     const int rows = M - c0;
     const int nrg = (rows + Q2_NB - 1) / Q2_NB;         // row groups of 64 rows: waves 0,1 the upper half, 2,3 the lower
@@ -1003,7 +1003,13 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
 #undef U3_STEP
     if (GRAM && narrow) {
         __syncthreads();                               // the slab's 64 x 64 block of the next panel is in the image
-        if (rg >= 1 && gram_out) cq_slab_gram(u3_qs, gram_out + (size_t)(rg - 1) * 4096, tid);
+        if (rg >= 1 && gram_out) {                     // (uniform over the workgroup)
+            if (gram_q) {
+                cq_slab_gram<true>(u3_qs, gram_out + (size_t)(rg - 1) * 4096, tid);
+                cq_group_reduce(gram_out, gram_q, gram_cnt, rg - 1, nrg - 1, tid);
+            } else
+                cq_slab_gram(u3_qs, gram_out + (size_t)(rg - 1) * 4096, tid);
+        }
     }
 }
 
@@ -1026,7 +1032,7 @@ k_qr1_extract(const double *__restrict__ A, int M, int n, const double *__restri
 // those workgroups alone).
 static int qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int M, int c0, int cend, int n, double *rhs,
                            int ncols, const double *W2, bool *taken, int jbeg = 0, int jend = -1, bool beside_passes = false,
-                           double *gram_out = nullptr) {
+                           double *gram_out = nullptr, double *gram_q = nullptr, unsigned *gram_cnt = nullptr) {
     const char *e = getenv("LSQ_QR_UPDATE_W");
     const int mode = e ? atoi(e) : 1;
     *taken = mode != 0;
@@ -1049,7 +1055,8 @@ static int qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int
     const int grid = nrg * ncg + (gram_out ? nrg : 0);
     auto go = [&](auto kern) -> int {
         if (lds > 48 * 1024) LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
-        LSQ_LAUNCH(kern, dim3(grid), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncols, W2, jbeg, jend, tpw, gram_out);
+        LSQ_LAUNCH(kern, dim3(grid), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncols, W2, jbeg, jend, tpw, gram_out,
+                   gram_q, gram_cnt);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     };
@@ -1234,7 +1241,10 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     // 7.55 ms.  The wave-private update holds no LDS.)  Only with the wave-private update (it takes a column range).
     const char *lae = getenv("LSQ_QR_LOOKAHEAD");
     const char *uwe = getenv("LSQ_QR_UPDATE_W");
-    const bool la_on = cq_ok && (lae ? atoi(lae) != 0 : true) && (uwe ? atoi(uwe) == 1 : true);
+    // Round 6: in the Q1 form of the panel (one pass, the rest on the side stream) the chain that the look-ahead would hide is
+    // already short and runs beside the V'[A2 | b] product; measured with it 6.82 / 7.91 ms (C3 / LM's stacked operand), without
+    // 6.77 / 7.92 -- so it is taken only where asked for (LSQ_QR_LOOKAHEAD=1) or in the three-pass form (LSQ_QR_CQR_PASS2=1).
+    const bool la_on = cq_ok && (lae ? atoi(lae) != 0 : !lsq_cqr_q1form()) && (uwe ? atoi(uwe) == 1 : true);
     // worth it while the update of the other columns outlasts most of the passes (which run 1.5-2x slower beside it):
     // measured at C3 7.20 -> 7.06 ms, 18432 x 2048 8.94 -> 8.22; 4096 x 512 and 3000 x 700 lose 3-5 % with it
     const char *lmc = getenv("LSQ_QR_LOOKAHEAD_MINCOLS");
@@ -1244,6 +1254,9 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     // launch less on every panel's chain); only the wave-private update does it (mode 1, no timing experiment)
     const bool gram_on = cq_ok && !getenv("LSQ_QR_NO_FUSED_GRAM") && (uwe ? atoi(uwe) == 1 : true);
     bool gram_ready = false;                 // ... and did so for the panel at hand
+    // GROUP-LEVEL GRAM SUMS (round 6, cq_group_reduce): no reduce launches; Q1 form without look-ahead
+    const bool hier_on = cq_ok && !la_on && !getenv("LSQ_QR_NO_HIER");
+    bool hier_ready = false;                 // the partials at hand came with their group sums
     double *vcur = q->Vb;
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
@@ -1255,10 +1268,12 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             if (pre) LSQ_HIP(hipStreamWaitEvent(c->stream, q->cq.ev_panel, 0));
             else {
                 vcur = q->Vb;
-                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, vcur, ldv, q->d_err, c->stream, gram_ready));
+                const bool hier = hier_on && lsq_cqr_hier((rows + CQ_RS - 1) / CQ_RS) && (!gram_ready || hier_ready);
+                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, vcur, ldv, q->d_err, c->stream, gram_ready, hier));
             }
             pre = false;
             gram_ready = false;
+            hier_ready = false;
             const int ncols = n - cend + 1, ncolsB = Q2_NB + ncols;
             const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
             // (V'V, tile 0, is not formed: the basis-kernel form needs V'[A2 | b] only.  Measured and dropped in round 4: the sum
@@ -1294,8 +1309,11 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
                 const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
                 bool tk = false;
                 if (gram_out) {
-                    LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, ncols, false, gram_out));
+                    const bool hn = hier_on && lsq_cqr_hier((M - c1 + CQ_RS - 1) / CQ_RS);      // (the NEXT panel's slabs)
+                    LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, ncols, false, gram_out,
+                                            hn ? q->cq.Gq1 : nullptr, hn ? q->cq.gcnt : nullptr));
                     gram_ready = true;
+                    hier_ready = hn;
                 } else
                 LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk));
                 if (!tk)

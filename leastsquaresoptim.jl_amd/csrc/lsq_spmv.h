@@ -781,6 +781,12 @@ constexpr int LSQ_CMB_COLS = 32;
 constexpr int LSQ_CMB_GROUPS = LSQ_NT / LSQ_CMB_COLS;
 // cscale (or null): every combined dot is multiplied by cscale[j] before the epilogue sees it -- J'y = s .* (V'y) for a
 // column-scaled Jacobian J = V diag(s) (lsq_mat::d_colscale).
+// has_col_prefetch: the epilogue's own per-column operands (EpiV: P, sqrt(damp), u~x, v) are requested with the first round of
+// partials instead of after the sums -- this kernel is two memory round trips long, not three (round 6)
+template <class E, class = void>
+struct EpiHasColPrefetch : std::false_type {};
+template <class E>
+struct EpiHasColPrefetch<E, std::void_t<typename E::has_col_prefetch>> : std::true_type {};
 template <class Epi>
 __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ part, int n, int nwin, Epi epi,
                                                      int ncolblocks, const double *__restrict__ cscale = nullptr) {
@@ -796,6 +802,10 @@ __global__ void __launch_bounds__(LSQ_NT) k_combine(const double *__restrict__ p
     if (pre0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) t0[q] = part[(size_t)(g + q * LSQ_CMB_GROUPS) * n + blockIdx.x * LSQ_CMB_COLS + cidx];
+    }
+    if constexpr (EpiHasColPrefetch<Epi>::value) {
+        if (g == 0 && (int)blockIdx.x < ncolblocks && (int)blockIdx.x * LSQ_CMB_COLS + cidx < n)
+            epi.col_prefetch((int)blockIdx.x * LSQ_CMB_COLS + cidx);
     }
     if constexpr (EpiHasBlockPrepare<Epi>::value) epi.block_prepare();
     if (dflag) return;   // launches queued behind a finished solve stop here
