@@ -45,6 +45,7 @@ int lsq_rccl_comm_stats(void *comm, long long *calls, long long *doubles);
  *     void *comm, *x;  lsq_rccl_comm_create(id, rank, world, &comm);  lsq_rccl_xchg_create(comm, rank, world, &x);
  *     opt.allreduce = (lsq_allreduce_callback)lsq_rccl_xchg_callback();  opt.allreduce_user = x;
  *     lsq_optimize(...);  lsq_rccl_xchg_drain(x);  (before a barrier / before destroying the communicator)
+ *     lsq_rccl_xchg_reset(x);  lsq_optimize(...);   (another run on the same handle)
  * The communicator stays the caller's (destroy the exchange first). */
 int lsq_rccl_xchg_create(void *comm, int rank, int world, void **xchg_out);
 int lsq_rccl_xchg_destroy(void *xchg);
@@ -53,6 +54,11 @@ int lsq_rccl_xchg_destroy(void *xchg);
 void *lsq_rccl_xchg_callback(void);
 /* completes the exchange an active rank left in flight */
 int lsq_rccl_xchg_drain(void *xchg);
+/* between two lsq_optimize runs on the SAME handle (every rank, at the same point of its call sequence; no collective is
+ * issued): drains, then forgets the previous run's last result and a seen abort -- the protocol state is per RUN: without it
+ * an active rank's first call of the next run would return the previous run's final {sum ssr, max |g|, all converged}, and a
+ * handle that has seen one abort would return 2 for ever */
+int lsq_rccl_xchg_reset(void *xchg);
 /* collectives issued, how many of them were waited for on the spot, and whether an abort has been seen */
 int lsq_rccl_xchg_stats(void *xchg, long long *collectives, long long *synchronous, int *aborted);
 /* The same protocol over ANY transport -- what the CPU tests use to run it over gloo next to its Python twin

@@ -719,6 +719,8 @@ def _run_native(ctx, optimizer_kind, solver_kind, Jd, dx, dy, fcb, gcb, user, x_
         keep.append(hi)
     if allreduce is not None:
         if hasattr(allreduce, "callback"):      # an exchange served in C (sharding.RcclScalarExchange): function + handle
+            if hasattr(allreduce, "reset"):
+                allreduce.reset()               # (the protocol state is per run: include/lsqrccl.h)
             opt.allreduce = allreduce.callback
             opt.allreduce_user = allreduce.user
         else:                                   # a ctypes callback (sharding.make_allreduce_callback)

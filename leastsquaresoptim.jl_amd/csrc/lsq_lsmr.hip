@@ -22,6 +22,7 @@
 #include "lsq_spmv.h"
 
 static constexpr int LSQ_LOOKAHEAD_DEFAULT = 2;
+static constexpr bool LSQ_TAIL_REACT_DEFAULT = true;       // (lsq_lsmr_solve, three-launch iteration: react to a cautious launch instead of pre-placing the tail)
 
 // mailbox word: [63:41] epoch | [40] done | [39:32] istop | [31:0] iter
 __device__ __forceinline__ void publish(LsqMailbox *mail, const LsmrState *st) {
@@ -750,6 +751,16 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
         const bool spec = tail && tail->fn && (tail->predict > 0 || dynamic);
         int planned = spec ? tail->predict : 0;
         int tail_at = 0, tail_ran_at = 0, hint_it = 0;
+        // REACT instead of PRE-PLACE (round 6, LSQ_TAIL_REACT; profiles/r06/ab_tail_react.txt).  A guarded tail queued behind the
+        // launch that is expected to commit the stop costs nothing when the guess holds, but ~50 us when it does not: five
+        // launches of full grids that skip themselves stand between the solve's next product and the queue's head (measured:
+        // perfect first guesses would gain 3.6 % on C4, LSQ_TAIL_ORACLE_SEQ).  In this mode the expected stop only makes that
+        // launch CAUTIOUS, and nothing more is queued until it has reported (~8 us into it): if the solve is over the host
+        // queues the tail, unguarded, while the cautious launch winds down; if not, the product of that launch is still
+        // streaming for 20 us and the next launches are queued behind it as usual.  A wrong guess then costs a late product.
+        static const bool react = [] { const char *e = getenv("LSQ_TAIL_REACT"); return e ? atoi(e) != 0 : LSQ_TAIL_REACT_DEFAULT; }();
+        int wait_at = 0;             // react: the iteration whose commit (by a cautious launch) is awaited before anything else is queued
+        bool wait_is_guess = false;  //   ... and that launch was cautious because of a PREDICTION (counted), not only because nothing was known
         double t1_prev = -1.0, t2_prev = -1.0, ratio2 = s->lsmr_ratio2;
         LsmrState *stb[2] = {s->d_state, s->d_state + 1};
         const LsqSell &S = J->srows;
@@ -840,6 +851,14 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                 tail_at = 0;
                 planned = 0;
             }
+            if (wait_at > 0 && reported && it >= wait_at) {           // react: the cautious launch found the solve unfinished
+                if (wait_is_guess) {
+                    c->tail_spec[0]++;
+                    c->tail_spec[1]++;
+                    planned = 0;
+                }
+                wait_at = 0;
+            }
             if (dynamic && reported && it > hint_it && it >= 1) {
                 const double h1 = c->h_mail->test1, h2 = c->h_mail->test2;
                 const unsigned long long w2 = *(volatile unsigned long long *)c->h_mail;
@@ -853,7 +872,8 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                     t1_prev = h1; t2_prev = h2; hint_it = it;
                 }
             }
-            const bool hold = tail_at > 0 && it < tail_at;       // a guarded tail sits behind the commit of iteration tail_at
+            // a guarded tail sits behind the commit of iteration tail_at / react: a cautious launch is deciding iteration wait_at
+            const bool hold = (tail_at > 0 && it < tail_at) || (wait_at > 0 && it < wait_at);
             if (!hold) {
                 if (k1 == enq + 1 && need_product) {             // the tail behind a commit-only launch skipped itself: the solve goes on
                     LSQ_TRY(launch_k1(2));
@@ -861,7 +881,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                     continue;
                 }
                 if (k1 == enq + 1) {                             // the rest of iteration enq + 1
-                    if (spec && tail_at == 0 && planned > 0 && enq >= planned && enq >= 1 && enq > it) {
+                    if (!react && spec && tail_at == 0 && planned > 0 && enq >= planned && enq >= 1 && enq > it) {
                         // (the prediction arrived between the two halves: the launch that commits its iteration is the newest one)
                         LSQ_TRY(tail->fn(&stb[k1 & 1]->notdone, tail->user));
                         tail_at = enq;
@@ -882,7 +902,10 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
                     const bool unknown = spec && enq == 1 && hint_it == 0 && tail->predict <= 3;
                     const int mode = no_cautious ? 0 : (place ? (use_halves ? 1 : 3) : (unknown && !use_halves ? 3 : 0));
                     LSQ_TRY(launch_k1(mode));
-                    if (place) {
+                    if (react && mode == 3) {                    // nothing behind it until it has decided
+                        wait_at = enq;
+                        wait_is_guess = place;
+                    } else if (place) {
                         LSQ_TRY(tail->fn(&stb[k1 & 1]->notdone, tail->user));
                         tail_at = enq;
                     }
@@ -934,6 +957,7 @@ int lsq_lsmr_solve(lsq_solver *s, lsq_mat *J, const double *d_y, double *d_damp,
             if (it > tail_at) c->tail_spec[1]++;
             else tail_ran_at = tail_at;
         }
+        if (wait_at > 0 && wait_is_guess) c->tail_spec[0]++;      // react: the predicted stop was the stop (a right guess)
         if (dynamic && t2_prev > 0.0) s->lsmr_ratio2 = ratio2;
         if (tail && tail->fn && tail_ran_at == 0) LSQ_TRY(tail->fn(nullptr, tail->user));
         return LSQ_OK;

@@ -152,7 +152,8 @@ void lsq_cqr_free(CqrWork *w);
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps,
                   bool gram_ready = false, bool hier = false);
 bool lsq_cqr_q1form();
-// the group-level Gram sums apply to a panel of nslab slabs (Q1 form, <= CQ_GS * CQ_HIER_MAX_GROUPS slabs, LSQ_QR_NO_HIER unset)
+// the group-level Gram sums apply to a panel of nslab slabs (Q1 form, <= CQ_GS * CQ_HIER_MAX_GROUPS slabs, LSQ_QR_HIER=1: an
+// experiment that measured slower than the reduce launches -- see lsq_cqr_hier)
 bool lsq_cqr_hier(int nslab);
 // after W = Vb'[Vb | A2 | b] (k_qr1_vtb + k_qr1_wreduce):  the update kernel's 64 x N operand for the trailing columns and b.
 // Q1 form: A2 -= Vb W2 over ALL rows finishes the block step (the [S W2; 0] part has been added to A2's top rows here);

@@ -687,8 +687,12 @@ void lsq_cqr_free(CqrWork *w) {
 // The Q1 form (default since round 6; LSQ_QR_CQR_PASS2=1 restores the three-pass panel of rounds 2-5 for A/B): read per call.
 bool lsq_cqr_q1form() { return getenv("LSQ_QR_CQR_PASS2") == nullptr; }
 
+// MEASURED AND NOT TAKEN (round 6, profiles/r06/ab_c3_hier.txt): with the group sums k_cqr_pass<1> takes 42 instead of 24 us,
+// k_cqr_top 69 instead of 49, the Gram-forming update 68 instead of 62 -- the agent-scope stores of the partials, the last
+// arrivers' uncached re-reads and four rounds of loads in every consumer cost more than the two 9-19 us reduce launches they
+// replace: C3 7.38 ms against 6.83.  Kept behind LSQ_QR_HIER=1 (the GPU suite passes with it).
 bool lsq_cqr_hier(int nslab) {
-    return lsq_cqr_q1form() && nslab <= CQ_GS * CQ_HIER_MAX_GROUPS && !getenv("LSQ_QR_NO_HIER");
+    return lsq_cqr_q1form() && nslab <= CQ_GS * CQ_HIER_MAX_GROUPS && getenv("LSQ_QR_HIER") != nullptr;
 }
 
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps,

@@ -1254,8 +1254,9 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     // launch less on every panel's chain); only the wave-private update does it (mode 1, no timing experiment)
     const bool gram_on = cq_ok && !getenv("LSQ_QR_NO_FUSED_GRAM") && (uwe ? atoi(uwe) == 1 : true);
     bool gram_ready = false;                 // ... and did so for the panel at hand
-    // GROUP-LEVEL GRAM SUMS (round 6, cq_group_reduce): no reduce launches; Q1 form without look-ahead
-    const bool hier_on = cq_ok && !la_on && !getenv("LSQ_QR_NO_HIER");
+    // GROUP-LEVEL GRAM SUMS (round 6, cq_group_reduce: no reduce launches; Q1 form without look-ahead) -- measured slower,
+    // LSQ_QR_HIER=1 only (lsq_cqr_hier)
+    const bool hier_on = cq_ok && !la_on && getenv("LSQ_QR_HIER") != nullptr;
     bool hier_ready = false;                 // the partials at hand came with their group sums
     double *vcur = q->Vb;
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {

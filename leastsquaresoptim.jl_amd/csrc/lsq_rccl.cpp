@@ -302,6 +302,20 @@ extern "C" int lsq_rccl_xchg_drain(void *xchg) {
     return 0;
 }
 
+// A new run on the same handle: completes what the previous run left in flight, then forgets the previous run's
+// last result and a seen abort, so that "every rank's first call waits for its exchange" holds for EVERY run (an active rank's
+// first call would otherwise return the previous run's {sum ssr, max |g|, all converged = 1}).  Issues no collective; every
+// rank calls it at the same point of its call sequence (between two lsq_optimize runs).
+extern "C" int lsq_rccl_xchg_reset(void *xchg) {
+    Xchg *x = (Xchg *)xchg;
+    if (!x) return 0;
+    const int rc = lsq_rccl_xchg_drain(xchg);
+    x->have_last = false;
+    x->last[0] = x->last[1] = x->last[2] = 0.0;
+    x->aborted = false;
+    return rc;
+}
+
 extern "C" int lsq_rccl_xchg_destroy(void *xchg) {
     Xchg *x = (Xchg *)xchg;
     if (!x) return 0;

@@ -196,6 +196,7 @@ def rccl_shim():
     L.lsq_rccl_xchg_create_custom.argtypes = [i, i, XCHG_ISSUE_FN, XCHG_FINISH_FN, vp, pvp]
     L.lsq_rccl_xchg_destroy.argtypes = [vp]
     L.lsq_rccl_xchg_drain.argtypes = [vp]
+    L.lsq_rccl_xchg_reset.argtypes = [vp]
     L.lsq_rccl_xchg_callback.restype = vp
     L.lsq_rccl_xchg_stats.argtypes = [vp, pll, pll, C.POINTER(i)]
     _RL = L
@@ -223,6 +224,11 @@ class _XchgBase:
 
     def drain(self):
         if self.h and self._L.lsq_rccl_xchg_drain(self.h) != 0:
+            raise RuntimeError("exchange: " + self._L.lsq_rccl_last_error().decode())
+
+    def reset(self):
+        """Before another run on the same handle (lsq_rccl_xchg_reset: the protocol state is per run); api._run_native calls it."""
+        if self.h and self._L.lsq_rccl_xchg_reset(self.h) != 0:
             raise RuntimeError("exchange: " + self._L.lsq_rccl_last_error().decode())
 
     def stats(self):
