@@ -67,7 +67,9 @@ __device__ __forceinline__ void cq_load64(double *__restrict__ dst, const double
 // PASS 1: R1 = chol(G).   PASS 2: G = Q1'Q1 = I + E -- ||E||_F <= 1e-5: second-order expansion (no dependent chain: two
 // structured MFMA products, the element-wise steps on 16 register-resident entries per thread); larger: Cholesky again;
 // ||E||_F > 1/2: cond(Q1)^2 eps is no longer O(eps) -- *bad is set (as for a Cholesky breakdown).
-template <int PASS>
+// NOINV (pass 1, round 6): M2 keeps what s64_chol leaves there -- the four inv(U_kk)' diagonal blocks -- instead of the explicit
+// inverse; the caller substitutes (cq_rows_trsm).
+template <int PASS, bool NOINV = false>
 __device__ __forceinline__ void cq_factor(const double *__restrict__ G, double *__restrict__ M1, double *__restrict__ M2,
                                           double *__restrict__ T, int *s_fail, double *s_red, int *bad, int tid, int ngroups = 0) {
     const int lane = tid & 63, wv = tid >> 6;
@@ -126,7 +128,36 @@ __device__ __forceinline__ void cq_factor(const double *__restrict__ G, double *
         for (int q = 0; q < 16; ++q) { const int e = tid + 256 * q; M1[(e >> 6) * S64_LS + (e & 63)] = g[q]; }
         __syncthreads();
         if (s64_chol(M1, M2, s_fail, tid)) *bad = 1;
-        s64_chol_inverse(M1, M2, T, tid);
+        if (!NOINV) s64_chol_inverse(M1, M2, T, tid);
+    }
+}
+
+// Qslab = Pslab inv(U) WITHOUT the explicit inverse (round 6): the wavefront's 16 rows of the slab, fetched in the A-operand
+// layout (cq_rows_fetch: a[4 r + rr] = P[row][16 r + 4 rr + kq]), are exactly the B-operand fragments of X = P' that
+// s64_trsm_blocks (lsq_dense_mfma.hip) loads from LDS: X <- inv(U)' X by forward substitution over the four 16-column blocks,
+// the four stages carried in registers (the accumulator layout of one product is the B-operand layout of the next).  Needs U and
+// the inv(U_kk)' blocks s64_chol leaves in W; saves s64_chol_inverse (two levels of tile products behind five barriers: ~5 us of
+// the 18 us every pass-1 workgroup spends on its factor).  x[r][rr] = Q[row 16 wv + ij][column 16 r + kq + 4 rr].
+__device__ __forceinline__ void cq_rows_trsm(const double (&a)[16], const double *__restrict__ U, const double *__restrict__ W,
+                                             s64_v4d x[4], int lane) {
+    const int ij = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s64_v4d t = {a[4 * r], a[4 * r + 1], a[4 * r + 2], a[4 * r + 3]};
+        if (r > 0) {
+            s64_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < r; ++q)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)      // U(q, r)' X_q : A[i][k] = U[16 q + k][16 r + i]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[(16 * q + 4 * kk + kq) * S64_LS + 16 * r + ij], x[q][kk], acc, 0, 0, 0);
+            t -= acc;
+        }
+        s64_v4d y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            y = __builtin_amdgcn_mfma_f64_16x16x4f64(W[(16 * r + ij) * S64_LS + 16 * r + 4 * kk + kq], t[kk], y, 0, 0, 0);
+        x[r] = y;
     }
 }
 
@@ -210,16 +241,26 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
         cq_load64(M2, G, tid);                                    // inv(R), row-major 64 x 64
     } else {
         int bad;
-        cq_factor<PASS>(G, M1, M2, T, &s_fail, s_red, &bad, tid, ngroups_in);     // every workgroup, identically
+        cq_factor<PASS, PASS == 1>(G, M1, M2, T, &s_fail, s_red, &bad, tid, ngroups_in);     // every workgroup, identically
         if (bad && slab == 0 && tid == 0) atomicOr(err, CQ_FAIL);
         CQ_T(PASS * 16 + 2);
         if (PASS == 1 && slab == 0)
             for (int e = tid; e < 4096; e += 256) R1g[e] = M1[(e >> 6) * S64_LS + (e & 63)];
     }
-    __syncthreads();                                              // R is dead from here on: its LDS becomes the slab image
+    __syncthreads();                                              // (PRE / pass 2: R is dead from here on: its LDS becomes the slab image)
     // ---- slab product  Qslab = Pslab * inv(R) ------------------------------------------------------------------
     CQ_T(PASS * 16 + 3);
-    {
+    if (PASS == 1 && !PRE) {
+        // by substitution with R itself and its inverted 16 x 16 diagonal blocks (cq_rows_trsm), from the prefetched rows
+        s64_v4d x[4];
+        cq_rows_trsm(prow, M1, M2, x, lane);
+        __syncthreads();                                          // every wavefront has read R: the slab image may overwrite it
+        const int ij = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) Qs[(16 * r + kq + 4 * rr) * CQ_QST + wv * 16 + ij] = x[r][rr];
+    } else {
         s64_v4d acc[4];
         cq_rows_mma(prow, M2, acc, lane);
         const int ij = lane & 15, kq = lane >> 4;

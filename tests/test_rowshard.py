@@ -354,7 +354,7 @@ def test_rccl_shim_exports_its_header():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "lsqrccl.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(lsq_rccl_\w+)\s*\(", txt)))
-    assert len(names) == 13, names      # 7 of the row-sharded hook + 6 of the scalar exchange (lsq_rccl_xchg_*)
+    assert len(names) == 14, names      # 7 of the row-sharded hook + 7 of the scalar exchange (lsq_rccl_xchg_*; _reset: round 6)
     L = C.CDLL(os.path.join(root, "leastsquaresoptim.jl_amd", "liblsqrccl.so"))
     for nme in names:
         assert hasattr(L, nme), nme

@@ -236,12 +236,17 @@ def test_c_exchange_symbols_and_one_rank_protocol():
     import ctypes as C
     L = lsq.sharding.rccl_shim()
     for name in ("lsq_rccl_xchg_create", "lsq_rccl_xchg_create_custom", "lsq_rccl_xchg_destroy", "lsq_rccl_xchg_callback",
-                 "lsq_rccl_xchg_drain", "lsq_rccl_xchg_stats"):
+                 "lsq_rccl_xchg_drain", "lsq_rccl_xchg_reset", "lsq_rccl_xchg_stats"):
         assert hasattr(L, name), name
     x = lsq.sharding.TorchTransportExchange(None, 0, 1)
     seq = _drive(x, [(2.5, 0.3, 0.0), (1.5, 0.2, 0.0), (1.25, 0.1, 0.0), (1.0, 0.05, 1.0)])
     assert seq == [(0, 2.5, 0.3, 0.0), (0, 2.5, 0.3, 0.0), (0, 1.5, 0.2, 0.0), (0, 1.0, 0.05, 1.0)]
     assert x.stats() == {"collectives": 4, "synchronous": 2, "aborted": False}
+    # the protocol state is per RUN.  Without a reset an active rank's first call of the next run returns the previous
+    # run's final result; lsq_rccl_xchg_reset (api._run_native calls it before every run) makes that call synchronous again
+    assert _drive(x, [(3.0, 0.7, 0.0)]) == [(0, 1.0, 0.05, 1.0)]
+    x.reset()
+    assert _drive(x, [(3.0, 0.7, 0.0), (2.0, 0.6, 0.0)]) == [(0, 3.0, 0.7, 0.0), (0, 3.0, 0.7, 0.0)]
     x.close()
 
 
