@@ -739,7 +739,6 @@ bool lsq_cqr_hier(int nslab) {
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps,
                   bool gram_ready, bool hier) {
     const int rows = M - c0, nslab = (rows + CQ_RS - 1) / CQ_RS;
-    (void)c;
     const bool pre = ps == w->ahead && !getenv("LSQ_QR_AHEAD_REDUNDANT");     // one factor kernel instead of one factor per workgroup
     const bool q1 = lsq_cqr_q1form();
     w->q1form = q1;
@@ -767,7 +766,12 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
                            w->R1, Vb, ldv, d_err, 0);
     LSQ_LAUNCH(k_cqr_reduce, dim3(256), dim3(256), 0, ps, (const double *)w->Gp, nslab, w->G);
     if (pre) {
-        LSQ_LAUNCH(k_cqr_factor<1>, dim3(1), dim3(256), CQ_LDS, ps, (const double *)w->G, w->Minv, w->R1, d_err);
+        // (LSQ_QR_FACTOR_LDS: an LDS reservation beyond what the kernel uses -- with more than 160 - 84 KB it cannot share a CU
+        //  with a workgroup of the look-ahead's update (84 KB reserved) and is placed on a free one)
+        static const size_t flds = [] { const char *e = getenv("LSQ_QR_FACTOR_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
+        const size_t fl = std::max(CQ_LDS, flds);
+        if (fl > CQ_LDS) LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_factor<1>, fl));
+        LSQ_LAUNCH(k_cqr_factor<1>, dim3(1), dim3(256), fl, ps, (const double *)w->G, w->Minv, w->R1, d_err);
         LSQ_LAUNCH((k_cqr_pass<1, true>), dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->Minv, w->Gp,
                            w->R1, Vb, ldv, d_err, q1 ? 1 : 0);
     } else

@@ -856,7 +856,8 @@ template <int DBG, bool GRAM = false>     // DBG 0: the product; 1: no MFMAs (me
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int M, int c0, int cend, int n,
                double *__restrict__ rhs, int ncols /* n - cend + 1 */, const double *__restrict__ W2, int jbeg, int jend, int tpw,
-               double *gram_out = nullptr, double *gram_q = nullptr /* group sums too (cq_group_reduce) */, unsigned *gram_cnt = nullptr) {
+               double *gram_out = nullptr, double *gram_q = nullptr /* group sums too (cq_group_reduce) */, unsigned *gram_cnt = nullptr,
+               int flat_g = 0 /* > 0: that many workgroups share the (row group, tile pair) units evenly, see qr1_update_wave */) {
     extern __shared__ __attribute__((aligned(16))) double u3_qs[];      // GRAM: the slab image [col][row], CQ_QST apart
     const int rows = M - c0;
     const int nrg = (rows + Q2_NB - 1) / Q2_NB;         // row groups of 64 rows: waves 0,1 the upper half, 2,3 the lower
@@ -865,34 +866,62 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
     if (GRAM) {
         narrow = bid < nrg;
         if (!narrow) bid -= nrg;
-        else { jbeg = 0; jend = Q2_NB; tpw = 2; }
+        else { jbeg = 0; jend = Q2_NB; tpw = 2; flat_g = 0; }
     }
-    const int rg = bid % nrg, cg = bid / nrg;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ij = lane & 15, kq = lane >> 4;
-    const int rbase = rg * Q2_NB;
-    const int r0 = rbase + 32 * (w >> 1);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ncolsA = n - cend;                        // columns of A proper; column ncolsA is the right-hand side
-    const bool rfull = r0 + 32 <= rows;
-    const int row0 = r0 + ij, row1 = r0 + 16 + ij;
-    const bool in0 = row0 < rows, in1 = row1 < rows;
-    // tiles of this wave: jfirst + 32 t, t = 0 .. nt - 1 (the two waves of a row half take alternate 16-column tiles)
-    const int jfirst = jbeg + cg * 32 * tpw + 16 * (w & 1);
-    const int jstop = min(jend, jbeg + (cg + 1) * 32 * tpw);
     if (GRAM && narrow) {
         // rows past the end of the matrix (the ragged last slab) count as zeros; every wavefront stays for the Gram
         for (int e = tid; e < Q2_NB * CQ_QST; e += 256) u3_qs[e] = 0.0;
         __syncthreads();
     }
+    // SEGMENTS: a workgroup takes tile pairs [p0, pe) of one row group at a time.  Legacy mapping (flat_g == 0): one segment,
+    // row group bid % nrg, pairs of column group bid / nrg.  Flat mapping: the nrg x npair units in row-group-major order are
+    // cut into flat_g equal runs; a run that crosses into the next row group reloads the V fragment there.
+    const int npair = (max(jend - jbeg, 0) + 31) >> 5;
+    long long u = 0, uend = 0;
+    if (flat_g > 0) {
+        const long long U = (long long)nrg * npair;
+        u = U * bid / flat_g;
+        uend = U * (bid + 1) / flat_g;
+    }
+    for (bool first = true;; first = false) {
+    // (the lane's coordinates are re-derived per segment behind an opaque move: addresses hoisted out of this loop would cost
+    //  the 14 registers the kernel has to spare -- 23-37 VGPRs spilled without it)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int ij = lane_o & 15, kq = lane_o >> 4;
+    int rg, p0, pe;
+    if (flat_g > 0) {
+        if (u >= uend) break;
+        rg = (int)(u / npair);
+        p0 = (int)(u - (long long)rg * npair);
+        pe = (int)min((long long)npair, p0 + (uend - u));
+        u += pe - p0;
+    } else {
+        if (!first) break;
+        rg = bid % nrg;
+        p0 = (bid / nrg) * tpw;
+        pe = min(npair, p0 + tpw);
+    }
+    const int rbase = rg * Q2_NB;
+    const int r0 = rbase + 32 * (w >> 1);
+    const bool rfull = r0 + 32 <= rows;
+    const int row0 = r0 + ij, row1 = r0 + 16 + ij;
+    const bool in0 = row0 < rows, in1 = row1 < rows;
+    // tiles of this wave: jfirst + 32 t, t = 0 .. nt - 1 (the two waves of a row half take alternate 16-column tiles)
+    const int jfirst = jbeg + 32 * p0 + 16 * (w & 1);
+    const int jstop = min(jend, jbeg + 32 * pe);
     const bool idle = r0 >= rows || jfirst >= jstop;
-    if (idle && !(GRAM && narrow)) return;
-    const int nt = idle ? 0 : (jstop - jfirst + 31) >> 5;
+    if (idle) continue;
+    const int nt = (jstop - jfirst + 31) >> 5;
     double v0[16], v1[16];                              // the wave's V fragment: 32 rows x 64, for all its tiles
-    if (!idle) {
-        const double *p0 = Vb + (in0 ? row0 : 0), *p1 = Vb + (in1 ? row1 : 0);
+    {
+        const double *p0v = Vb + (in0 ? row0 : 0), *p1v = Vb + (in1 ? row1 : 0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const size_t k = 16 * (s >> 2) + 4 * kq + (s & 3);
-            const double x0 = p0[k * ldv], x1 = p1[k * ldv];
+            const double x0 = p0v[k * ldv], x1 = p1v[k * ldv];
             v0[s] = in0 ? x0 : 0.0;
             v1[s] = in1 ? x1 : 0.0;
         }
@@ -1001,7 +1030,9 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
         U3_STEP(t + 3, wb, wa, a3)
     }
 #undef U3_STEP
+    }   // segments
     if (GRAM && narrow) {
+        const int rg = bid;
         __syncthreads();                               // the slab's 64 x 64 block of the next panel is in the image
         if (rg >= 1 && gram_out) {                     // (uniform over the workgroup)
             if (gram_q) {
@@ -1045,18 +1076,47 @@ static int qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int
     // CU 60.1)
     const char *t = getenv("LSQ_QR_UPDATE_TPW");
     const int npair = (std::max(jend - jbeg, 0) + 31) / 32, want = std::max(1, c->num_cus / nrg);
-    const int tpw = t ? std::max(1, atoi(t)) : std::max(2, std::min(beside_passes ? 64 : 32, (npair + want - 1) / want));
-    const int ncg = (npair + tpw - 1) / tpw;
+    int tpw = t ? std::max(1, atoi(t)) : std::max(2, std::min(beside_passes ? 64 : 32, (npair + want - 1) / want));
+    int ncg = (npair + tpw - 1) / tpw;
     // beside the next panel's passes (look-ahead): ONE workgroup per CU, by an LDS reservation it does not use -- two of them
     // fill a CU's registers (242 VGPRs per wave) and the pass workgroups (75 KB of LDS, 4 waves) would wait for them to end
     const char *le = getenv("LSQ_QR_UPDATE_LDS");
     size_t lds = beside_passes ? (le ? (size_t)atoi(le) : (size_t)84 * 1024) : 0;
     if (gram_out) lds = std::max(lds, (size_t)Q2_NB * CQ_QST * sizeof(double));
-    const int grid = nrg * ncg + (gram_out ? nrg : 0);
+    // FLAT MAPPING (round 6, later): with one workgroup per (row group, column group) the grid is a multiple of nrg, and once
+    // nrg does not divide the CUs some CUs run a workgroup more than the others -- at 18432 rows (288 row groups, 576
+    // workgroups of 31 pairs on 256 CUs: 3 against 2) the launch took 94 us where 16384 rows take 62, 1.52 x for 1.125 x the
+    // work; 200 row groups x 40 pairs became 200 workgroups of 32 pairs and 200 of 8.  In the flat mapping num_cus (or
+    // 2 num_cus, beyond 32 pairs each) workgroups take equal runs of the nrg x npair units in row-group-major order; a run that
+    // crosses a row group starts its pipeline again (about 1.5 pairs' time), so the rectangular grid stays where it is even:
+    // both are priced in pair times -- a CU's rate does not depend on how many workgroups it holds (the 1.52 above), a
+    // workgroup costs half a pair on top of its tiles (32 / 16 / 8 / 4 pairs: 57.8 / 58.9 / 61.0 / 62.3 us) -- and flat must
+    // win by 3 %.  Measured (ms, rectangular rule of round 5 -> this): 12000 x 2048 6.20 -> 5.97, 18432 x 2048 7.81 -> 7.42,
+    // 24000 x 2048 8.86 -> 8.56.  LSQ_QR_UPDATE_FLAT=0: round 5's grid; 1 / 2: flat with that many workgroups per CU.
+    const char *fe = getenv("LSQ_QR_UPDATE_FLAT");
+    const long long units = (long long)nrg * npair;
+    int flat_g = 0;
+    if (!(fe && atoi(fe) == 0) && !t && units > 0) {
+        const int cap = beside_passes ? 64 : 32;
+        double t_rect = 1e30;
+        int tpw_rect = tpw;
+        for (int g = 1; g <= npair; ++g) {
+            const int tp = (npair + g - 1) / g;
+            if (tp > cap) continue;
+            if (tp < 2 && g > 1) break;
+            const double tt = (double)(((long long)nrg * ((npair + tp - 1) / tp) + c->num_cus - 1) / c->num_cus) * (tp + 0.5);
+            if (tt < t_rect) { t_rect = tt; tpw_rect = tp; }
+        }
+        const int per_cu = fe ? std::max(1, atoi(fe)) : (beside_passes || units <= (long long)cap * c->num_cus ? 1 : 2);
+        const double t_flat = (double)units / c->num_cus + 0.5 * per_cu + 1.5;
+        if (fe || t_flat < 0.97 * t_rect) flat_g = (int)std::max(1LL, std::min((long long)per_cu * c->num_cus, units / 2));
+        else { tpw = tpw_rect; ncg = (npair + tpw - 1) / tpw; }
+    }
+    const int grid = (flat_g > 0 ? flat_g : units > 0 ? nrg * ncg : 0) + (gram_out ? nrg : 0);
     auto go = [&](auto kern) -> int {
         if (lds > 48 * 1024) LSQ_TRY(lsq_set_lds(c, (const void *)kern, lds));
         LSQ_LAUNCH(kern, dim3(grid), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncols, W2, jbeg, jend, tpw, gram_out,
-                   gram_q, gram_cnt);
+                   gram_q, gram_cnt, flat_g);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     };
@@ -1244,11 +1304,19 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     // Round 6: in the Q1 form of the panel (one pass, the rest on the side stream) the chain that the look-ahead would hide is
     // already short and runs beside the V'[A2 | b] product; measured with it 6.82 / 7.91 ms (C3 / LM's stacked operand), without
     // 6.77 / 7.92 -- so it is taken only where asked for (LSQ_QR_LOOKAHEAD=1) or in the three-pass form (LSQ_QR_CQR_PASS2=1).
-    const bool la_on = cq_ok && (lae ? atoi(lae) != 0 : !lsq_cqr_q1form()) && (uwe ? atoi(uwe) == 1 : true);
+    // ... EXCEPT for panels with more 64-row slabs than the device has CUs (round 6, later): their passes no longer fit one round
+    // of workgroups, the chain grows by a half and there it pays to hide it.  With every panel factored ahead (no minimum of
+    // other columns) 20000 x 1000 takes 3.04 instead of 3.32 ms, 40000 x 512 1.76 / 1.94, 24000 x 2048 8.81 / 9.35, LM's stacked
+    // 18432 x 2048 operand 7.80 / 8.32 -- while C3's 16384 rows (256 slabs) are a wash (6.76 / 6.88) and 4096 x 512, 3000 x 700,
+    // 8192 x 1024 lose 5-10 % (profiles/r06/ab_c3_lookahead_tall.txt).  So in the Q1 form, unless LSQ_QR_LOOKAHEAD says otherwise,
+    // a panel is factored ahead iff it has more than num_cus * CQ_RS rows.
+    const int la_q1_min_rows = c->num_cus * CQ_RS + 1;
+    const bool la_auto = !lae && lsq_cqr_q1form();
+    const bool la_on = cq_ok && (lae ? atoi(lae) != 0 : true) && (uwe ? atoi(uwe) == 1 : true);
     // worth it while the update of the other columns outlasts most of the passes (which run 1.5-2x slower beside it):
     // measured at C3 7.20 -> 7.06 ms, 18432 x 2048 8.94 -> 8.22; 4096 x 512 and 3000 x 700 lose 3-5 % with it
     const char *lmc = getenv("LSQ_QR_LOOKAHEAD_MINCOLS");
-    const int la_min_cols = lmc ? atoi(lmc) : 1024;
+    const int la_min_cols = lmc ? atoi(lmc) : (la_auto ? 0 : 1024);
     bool pre = false;                        // this panel was factored ahead (its Q is in vcur, ev_panel says when)
     // FUSED GRAM (round 6): the update of panel k forms the Gram partials of panel k + 1 (its first pass, k_cqr_pass<0>, is one
     // launch less on every panel's chain); only the wave-private update does it (mode 1, no timing experiment)
@@ -1256,7 +1324,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     bool gram_ready = false;                 // ... and did so for the panel at hand
     // GROUP-LEVEL GRAM SUMS (round 6, cq_group_reduce: no reduce launches; Q1 form without look-ahead) -- measured slower,
     // LSQ_QR_HIER=1 only (lsq_cqr_hier)
-    const bool hier_on = cq_ok && !la_on && getenv("LSQ_QR_HIER") != nullptr;
+    const bool hier_on = cq_ok && (!la_on || la_auto) && getenv("LSQ_QR_HIER") != nullptr;   // (panels not factored ahead)
     bool hier_ready = false;                 // the partials at hand came with their group sums
     double *vcur = q->Vb;
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
@@ -1291,7 +1359,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             // is the next panel a CholeskyQR2 panel too, with enough other columns beside it?
             const int c1 = cend;
             const bool next_cq = n - c1 >= Q2_NB && M - c1 >= 256;       // the next panel is a CholeskyQR panel too
-            const bool ahead = la_on && next_cq && ncols - 1 >= Q2_NB + la_min_cols;
+            const bool ahead = la_on && next_cq && ncols - 1 >= Q2_NB + la_min_cols && (!la_auto || M - c1 >= la_q1_min_rows);
             double *const gram_out = gram_on && next_cq ? q->cq.Gp : nullptr;
             if (ahead) {
                 if (!q->Vb2) LSQ_HIP(hipMalloc(&q->Vb2, ((size_t)q->M * Q2_NB + 64) * sizeof(double)));

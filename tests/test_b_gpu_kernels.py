@@ -521,9 +521,10 @@ def test_ldiv_qr_two_stage(ctx, m, n, rank, monkeypatch):
         assert np.allclose(v, ref, rtol=1e-8, atol=1e-10), k
 
 
-@pytest.mark.parametrize("m,n", [(2049, 321), (1500, 700), (777, 513), (4099, 200), (1030, 1030)])
+@pytest.mark.parametrize("m,n", [(2049, 321), (1500, 700), (777, 513), (4099, 200), (1030, 1030), (12000, 200), (16500, 200)])
 def test_qr_wave_private_kernels_and_lookahead(ctx, m, n, monkeypatch):
-    """Round 5's trailing kernels of the blocked QR (k_qr1_vtb_w, k_qr1_update_w: wave-private tiles, no LDS) and the
+    """Round 5's trailing kernels of the blocked QR (k_qr1_vtb_w, k_qr1_update_w: wave-private tiles, no LDS), round 6's panel forms
+    (Q1 form / three passes, Neumann product / modified LU, Gram partials from the update / from pass 0, group sums) and the
     look-ahead of the next panel against the LDS-staged kernels of rounds 2-4 and against the oracle (dense_qr.jl:30-88), on
     shapes that exercise every ragged edge: rows not a multiple of 32 / 64, trailing columns not a multiple of 16, odd leading
     dimensions (8-byte aligned fragments), the right-hand side as the last column of the last tile, the stacked damped
@@ -538,13 +539,25 @@ def test_qr_wave_private_kernels_and_lookahead(ctx, m, n, monkeypatch):
     xr, rk, *_ = O.qr_solve(A, y)
     st, xd, _, _ = O.ldiv(O.QR, O.Mat(dense=A), y, damp)
     monkeypatch.setenv("LSQ_QR_TWO_STAGE", "1")
+    # round 6: the default is the Q1 form of the panel (no pass 2, Gram partials of the next panel formed by the update, Neumann
+    # product for tall panels' reflector kernel, look-ahead for panels of more slabs than CUs only); every switch that selects another
+    # form is exercised here
+    LA = {"LSQ_QR_LOOKAHEAD": "1", "LSQ_QR_LOOKAHEAD_MINCOLS": "0"}
     combos = {"default": {},
-              "lookahead_everywhere": {"LSQ_QR_LOOKAHEAD_MINCOLS": "0"},
               "no_lookahead": {"LSQ_QR_LOOKAHEAD": "0"},
+              "q1_lookahead_everywhere": dict(LA),
+              "q1_redundant_factor_ahead": dict(LA, LSQ_QR_AHEAD_REDUNDANT="1"),
+              "q1_top_lu": {"LSQ_QR_TOP_LU": "1"},
+              "q1_no_fused_gram": {"LSQ_QR_NO_FUSED_GRAM": "1"},
+              "q1_no_vtb_lds": {"LSQ_QR_VTB_LDS": "0"},
+              "q1_group_sums": {"LSQ_QR_HIER": "1"},
+              "update_grid_per_row_group": {"LSQ_QR_UPDATE_FLAT": "0"},
+              "update_two_runs_per_cu": {"LSQ_QR_UPDATE_FLAT": "2"},
+              "three_pass": {"LSQ_QR_CQR_PASS2": "1", "LSQ_QR_LOOKAHEAD": "0"},
+              "three_pass_lookahead_everywhere": dict(LA, LSQ_QR_CQR_PASS2="1"),
               "lds_update": {"LSQ_QR_UPDATE_W": "0"},
               "lds_vtb": {"LSQ_QR_VTB_W": "0"},
-              "lds_both": {"LSQ_QR_UPDATE_W": "0", "LSQ_QR_VTB_W": "0"},
-              "redundant_factor_ahead": {"LSQ_QR_LOOKAHEAD_MINCOLS": "0", "LSQ_QR_AHEAD_REDUNDANT": "1"}}
+              "lds_both": {"LSQ_QR_UPDATE_W": "0", "LSQ_QR_VTB_W": "0"}}
     got, gotd = {}, {}
     for name, env in combos.items():
         for k, v in env.items():
@@ -565,8 +578,20 @@ def test_qr_wave_private_kernels_and_lookahead(ctx, m, n, monkeypatch):
         assert np.max(np.abs(gotd[name] - xd)) <= 1e-9 * scaled, name
         assert np.max(np.abs(got[name] - got["lds_both"])) <= 1e-11 * scale, name
         assert np.max(np.abs(gotd[name] - gotd["lds_both"])) <= 1e-11 * scaled, name
-    for a, b in (("default", "no_lookahead"), ("lookahead_everywhere", "no_lookahead"), ("redundant_factor_ahead", "no_lookahead")):
+    # same kernels, same order => same bits: the default has no look-ahead for panels of at most 256 slabs of 64 rows (one per CU;
+    # at 16500 x 200 the first panel after the leading one is factored ahead, the next is not: the rule's transition); the Gram
+    # partials formed by the update are the ones pass 0 forms; the LDS reservation changes placement only.  (With look-ahead
+    # pass 1 multiplies by the explicit inverse that one workgroup formed instead of substituting: agreement to 1e-11, above.)
+    pairs = [("q1_no_fused_gram", "default"), ("q1_no_vtb_lds", "default"),
+             # (which workgroup takes a tile changes nothing about the tile)
+             ("update_grid_per_row_group", "default"), ("update_two_runs_per_cu", "default")]
+    tall = m - 64 > 256 * 64
+    if m + n - 64 <= 256 * 64:
+        pairs.append(("default", "no_lookahead"))
+    for a, b in pairs:
         assert np.array_equal(got[a], got[b]) and np.array_equal(gotd[a], gotd[b]), (a, b)
+    if tall:
+        assert not np.array_equal(got["default"], got["no_lookahead"])      # (the rule did select the other path)
 
 
 @pytest.mark.parametrize("m", [3000, 6000, 12000, 18000, 22000])
