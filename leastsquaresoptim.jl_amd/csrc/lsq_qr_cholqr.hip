@@ -440,6 +440,7 @@ k_cqr_top(const double *__restrict__ G2, const double *__restrict__ R1g, const d
             }
             __syncthreads();
             double *Fc = F, *Fn = E;                               // (E itself is no longer needed)
+            CQ_T(53);
             for (int it = 0; it < 8; ++it) {
                 s64_gemm<false, false, S64_FULL>(Tm, P, Fc, 1.0, tid);     // P <- P (I + F)
 #pragma unroll

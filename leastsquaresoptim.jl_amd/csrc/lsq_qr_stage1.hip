@@ -1109,7 +1109,14 @@ static int qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int
         }
         const int per_cu = fe ? std::max(1, atoi(fe)) : (beside_passes || units <= (long long)cap * c->num_cus ? 1 : 2);
         const double t_flat = (double)units / c->num_cus + 0.5 * per_cu + 1.5;
-        if (fe || t_flat < 0.97 * t_rect) flat_g = (int)std::max(1LL, std::min((long long)per_cu * c->num_cus, units / 2));
+        // (beside the next panel's passes: LSQ_QR_UPDATE_SPARE CUs, default 2, are left without a workgroup of this launch --
+        //  the look-ahead's one-workgroup kernels find a quieter CU: 7.41 -> 7.34 ms on LM's stacked C3 operand, 24000 x 2048
+        //  8.59 -> 8.46; forcing the factor kernel onto a FREE CU by an LDS reservation, LSQ_QR_FACTOR_LDS=102400, loses 3 %;
+        //  profiles/r06/ab_c3_lookahead_spare_cus.txt)
+        static const int spare = [] { const char *e = getenv("LSQ_QR_UPDATE_SPARE"); return e ? std::max(0, atoi(e)) : 2; }();
+        const int sp = beside_passes ? std::min(spare, c->num_cus / 2) : 0;
+        if (fe || sp > 0 || t_flat < 0.97 * t_rect)
+            flat_g = (int)std::max(1LL, std::min((long long)per_cu * c->num_cus - sp, units / 2));
         else { tpw = tpw_rect; ncg = (npair + tpw - 1) / tpw; }
     }
     const int grid = (flat_g > 0 ? flat_g : units > 0 ? nrg * ncg : 0) + (gram_out ? nrg : 0);
