@@ -429,6 +429,7 @@ def main():
             "c2_lm_cholesky_outer_ms": g(dense, "c2_lm_cholesky_4096x512", "outer_iteration_ms"),
             "c3_ldiv_ms": g(dense, "c3_qr_16384x2048", "ldiv_ms"),
             "c3_frac": g(dense, "c3_qr_16384x2048", "roofline", "frac"),
+            "c3_lm_stacked_ldiv_ms": g(dense, "c3_qr_lm_stacked_18432x2048", "ldiv_ms"),
             "c3_dogleg_qr_outer_ms": g(dense, "c3_dogleg_qr_16384x2048", "outer_iteration_ms"),
             "wide_jv_frac": g(wide, "jv", "roofline", "frac"), "wide_jtu_frac": g(wide, "jtu", "roofline", "frac"),
             "wide_lm_lsmr_outer_ms": g(wide, "lm_lsmr_outer_iteration_ms"),
@@ -733,7 +734,10 @@ def dense_secondary(ctx, lsq, probe=lambda stage: None):
     probe("dense_secondary: start")
     rng = np.random.default_rng(lsq.synthetic.BASE_SEED)
     for name, m, n, solver, for_lm in (("c2_cholesky_damped_4096x512", 4096, 512, lsq.Cholesky(), True),
-                                       ("c3_qr_16384x2048", 16384, 2048, lsq.QR(), False)):
+                                       ("c3_qr_16384x2048", 16384, 2048, lsq.QR(), False),
+                                       # LM's own use of the QR solver: the stacked operand [J; sqrt(damp)] (18432 x 2048)
+                                       ("c3_qr_lm_stacked_18432x2048", 16384, 2048, lsq.QR(), True)):
+        is_qr = name.startswith("c3_qr")
         A = rng.standard_normal((m, n)) / np.sqrt(m)
         yh = rng.standard_normal(m)
         J = lsq.DeviceMatrix(ctx, A)
@@ -780,7 +784,9 @@ def dense_secondary(ctx, lsq, probe=lambda stage: None):
             ht.append((time.perf_counter() - t0) * 1e3)
         cpu_ms = sorted(ht)[len(ht) // 2]
         err = float(np.linalg.norm(x.get() - ref) / np.linalg.norm(ref))
-        if for_lm:    # J'J m n (n+1) + Cholesky n^3/3 + J'y 2mn + two triangular solves 2 n^2
+        if is_qr and for_lm:    # Householder QR of the (m + n) x n stacked operand
+            flops, dom = 2 * (m + n) * n * n - 2 * n ** 3 / 3 + 4 * (m + n) * n, "k_qr1_vtb / k_qr1_update (block reflector), k_cqr_pass (panel; look-ahead)"
+        elif for_lm:    # J'J m n (n+1) + Cholesky n^3/3 + J'y 2mn + two triangular solves 2 n^2
             flops, dom = m * n * (n + 1) + n ** 3 / 3 + 2 * m * n + 2 * n * n, "k_syrk_mfma (J'J), k_chol_chain"
         else:         # Householder QR 2mn^2 - 2n^3/3 (+ Q'b riding along)
             flops, dom = 2 * m * n * n - 2 * n ** 3 / 3 + 4 * m * n, "k_qr1_vtb / k_qr1_update (block reflector), k_cqr_pass (panel)"
