@@ -150,7 +150,12 @@ void lsq_cqr_free(CqrWork *w);
 // hier: the Gram partials are summed per group inside the producing launches (cq_group_reduce) -- then, with gram_ready, the
 // producer of this panel's partials must have left w->Gq1 as well.
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps,
-                  bool gram_ready = false, bool hier = false);
+                  bool gram_ready = false, bool hier = false, double *Vs = nullptr /* Q1 form: Q1 also in fragment order */);
+// ... and Q1 (the panel's V) for k_qr1_vtb_w: per 16-row chunk c of the panel, 16-column tile it and half h, 64 lanes x 16 bytes,
+//   lane = ij + 16 kq  holds  Q1[row 16 c + 4 kq + 2 h + (0, 1)][column 16 it + ij]      (full chunks only)
+__host__ __device__ inline size_t lsq_cqr_vs_index(int chunk, int it, int h, int lane) {
+    return ((size_t)((chunk * 4 + it) * 2 + h) * 64 + (size_t)lane) * 2;
+}
 bool lsq_cqr_q1form();
 // the group-level Gram sums apply to a panel of nslab slabs (Q1 form, <= CQ_GS * CQ_HIER_MAX_GROUPS slabs, LSQ_QR_HIER=1: an
 // experiment that measured slower than the reduce launches -- see lsq_cqr_hier)
@@ -159,4 +164,14 @@ bool lsq_cqr_hier(int nslab);
 // Q1 form: A2 -= Vb W2 over ALL rows finishes the block step (the [S W2; 0] part has been added to A2's top rows here);
 // three-pass form: Vb becomes V = Q - [S; 0] here.
 int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, int M, int c0, int cend, int n,
-               double *rhs, double *Vb, int ldv, double *W2);
+               double *rhs, double *Vb, int ldv, double *W2, double *W2s = nullptr);
+// FRAGMENT ORDER of W2 (round 6, late).  A load instruction costs the MFMA stream of its SIMD about two clocks per (4-lane group,
+// cache line) pair it touches (profiles/r06/ab_c3_vtb_overlap.txt, section 4): a wave in which every lane reads 32 bytes of its OWN
+// column -- the natural way to fetch an MFMA operand from a column-major matrix -- touches 64 of them per instruction, a wave
+// that reads 1 KB contiguous 16.  So the producer of W2 (k_cqr_tw_q1, Q1 form) also stores it in the order in which the trailing
+// update's lanes consume it: per 16-column tile T and k group g (16 k values) and half h, 64 lanes x 16 bytes contiguous,
+//   lane = ij + 16 kq  holds  W2[column 16 T + ij][k = 16 g + 4 kq + 2 h + (0, 1)].
+__host__ __device__ inline size_t lsq_cqr_w2s_index(int T, int ij, int k) {
+    const int g = k >> 4, kq = (k >> 2) & 3, h = (k >> 1) & 1, u = k & 1;
+    return ((size_t)((T * 4 + g) * 2 + h) * 64 + (size_t)(ij + 16 * kq)) * 2 + u;
+}

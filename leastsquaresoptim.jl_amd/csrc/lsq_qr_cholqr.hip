@@ -206,7 +206,8 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
            double *__restrict__ R1g, double *__restrict__ Vb, int ldv, int *__restrict__ err, int q1vb = 0 /* PASS 1: Q1 -> Vb
            instead of in place (the Q1 form of the block reflector, round 6: no pass 2) */,
            int ngroups_in = 0 /* > 0: G holds that many group sums (cq_group_reduce), added here */,
-           double *Gq = nullptr /* non-null: this launch's own partials are summed per group into Gq */, unsigned *gcnt = nullptr) {
+           double *Gq = nullptr /* non-null: this launch's own partials are summed per group into Gq */, unsigned *gcnt = nullptr,
+           double *__restrict__ Vs = nullptr /* PASS 1, q1vb: Q1 also in V'B's fragment order (lsq_cqr_vs_index) */) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *M2 = sm, *M1 = sm + S64_MAT, *T = sm + 2 * S64_MAT, *Qs = M1;   // (Qs aliases R and the scratch: used after them)
     __shared__ int s_fail;
@@ -279,6 +280,22 @@ k_cqr_pass(double *__restrict__ A, int lda, int c0, int rows, const double *__re
         if (row < nr) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) dst[(cq + 4 * q) * ldd + row] = Qs[(cq + 4 * q) * CQ_QST + row];
+        }
+    }
+    if (PASS == 1 && Vs && q1vb) {
+        // the slab's full 16-row chunks once more, in the order in which k_qr1_vtb_w's lanes consume them (1 KB contiguous per
+        // load instruction there): block = (chunk, 16-column tile it, half h), lane = ij + 16 kq, two doubles per lane
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + 256 * q, ln = idx & 63, blk = idx >> 6, h = blk & 1, it = (blk >> 1) & 3, cc = blk >> 3;
+            if (16 * (cc + 1) <= nr) {
+                const int ij = ln & 15, kq = ln >> 4;
+                const double *src = Qs + (16 * it + ij) * CQ_QST + 16 * cc + 4 * kq + 2 * h;
+                double2 v;
+                v.x = src[0];
+                v.y = src[1];
+                *reinterpret_cast<double2 *>(Vs + lsq_cqr_vs_index(slab * 4 + cc, it, h, ln)) = v;
+            }
         }
     }
     CQ_T(PASS * 16 + 5);
@@ -604,7 +621,7 @@ __device__ __forceinline__ void tq_gemm16(double *__restrict__ Y, const double *
 __global__ void __launch_bounds__(256)
 k_cqr_tw_q1(const double *__restrict__ W, int ncolsB, const double *__restrict__ Binv, const double *__restrict__ Sg,
             const double *__restrict__ SRg, const double *__restrict__ R2inv, double *A, int lda, int c0, int cend, int n,
-            double *rhs, double *__restrict__ W2) {
+            double *rhs, double *__restrict__ W2, double *__restrict__ W2s /* or null: lsq_cqr_w2s_index */) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *sBi = sm, *sRi = sm + S64_MAT, *X = sm + 2 * S64_MAT, *Y = X + 64 * TQ_XS;
     const int tid = threadIdx.x;
@@ -668,6 +685,9 @@ k_cqr_tw_q1(const double *__restrict__ W, int ncolsB, const double *__restrict__
     for (int q = 0; q < 4; ++q) {
         const int j = (tid >> 6) + 4 * q;
         if (j0 + j < ncols) W2[(size_t)(j0 + j) * 64 + k] = Y[k * TQ_XS + j];
+        // the same values in the trailing update's FRAGMENT order (this workgroup's 16 columns are one of its 16-column tiles;
+        // columns past the end are zeros here)
+        if (W2s) W2s[lsq_cqr_w2s_index((int)blockIdx.x, j, k)] = Y[k * TQ_XS + j];
     }
 }
 
@@ -738,7 +758,7 @@ bool lsq_cqr_hier(int nslab) {
 }
 
 int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, int ldv, int *d_err, hipStream_t ps,
-                  bool gram_ready, bool hier) {
+                  bool gram_ready, bool hier, double *Vs) {
     const int rows = M - c0, nslab = (rows + CQ_RS - 1) / CQ_RS;
     const bool pre = ps == w->ahead && !getenv("LSQ_QR_AHEAD_REDUNDANT");     // one factor kernel instead of one factor per workgroup
     const bool q1 = lsq_cqr_q1form();
@@ -751,7 +771,7 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
             LSQ_LAUNCH(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
                                w->R1, Vb, ldv, d_err, 0, 0, w->Gq1, w->gcnt);
         LSQ_LAUNCH(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->Gq1, w->Gp,
-                           w->R1, Vb, ldv, d_err, 1, ng, w->Gq2, w->gcnt);
+                           w->R1, Vb, ldv, d_err, 1, ng, w->Gq2, w->gcnt, Vs);
         LSQ_HIP(hipGetLastError());
         LSQ_HIP(hipEventRecord(w->ev_q, ps));
         LSQ_HIP(hipStreamWaitEvent(w->side, w->ev_q, 0));
@@ -761,6 +781,8 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
         LSQ_HIP(hipEventRecord(w->ev_lu, w->side));
         return LSQ_OK;
     }
+    // (measured and not kept, round 6 late: group sums for pass 1's Gram ALONE -- no reduce launch on the side chain, k_cqr_top adds
+    //  the <= 32 group sums -- 6.82 against 6.43 ms at C3: the last arrivers' sums at pass 1's tail cost more than the launch)
     // (gram_ready: the update of the previous panel left the Gram partials of this panel's slabs in w->Gp itself)
     if (!gram_ready)
         LSQ_LAUNCH(k_cqr_pass<0>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)nullptr, w->Gp,
@@ -774,10 +796,10 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
         if (fl > CQ_LDS) LSQ_TRY(lsq_set_lds(c, (const void *)k_cqr_factor<1>, fl));
         LSQ_LAUNCH(k_cqr_factor<1>, dim3(1), dim3(256), fl, ps, (const double *)w->G, w->Minv, w->R1, d_err);
         LSQ_LAUNCH((k_cqr_pass<1, true>), dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->Minv, w->Gp,
-                           w->R1, Vb, ldv, d_err, q1 ? 1 : 0);
+                           w->R1, Vb, ldv, d_err, q1 ? 1 : 0, 0, (double *)nullptr, (unsigned *)nullptr, q1 ? Vs : nullptr);
     } else
         LSQ_LAUNCH(k_cqr_pass<1>, dim3(nslab), dim3(256), CQ_LDS, ps, A, M, c0, rows, (const double *)w->G, w->Gp,
-                           w->R1, Vb, ldv, d_err, q1 ? 1 : 0);
+                           w->R1, Vb, ldv, d_err, q1 ? 1 : 0, 0, (double *)nullptr, (unsigned *)nullptr, q1 ? Vs : nullptr);
     if (q1) {
         // Q1 form: the panel is DONE on this stream -- Q1 is in Vb, the caller's V'[A2 | b] product may start.  The Gram reduce of
         // pass 1's partials and everything that hangs on G2 (R2, the 64-step LU of Q_top, inv(B), S R) run on the side stream
@@ -813,13 +835,13 @@ int lsq_cqr_panel(lsq_ctx *c, CqrWork *w, double *A, int M, int c0, double *Vb, 
 }
 
 int lsq_cqr_tw(lsq_ctx *c, CqrWork *w, const double *W, int ncolsB, double *A, int M, int c0, int cend, int n,
-               double *rhs, double *Vb, int ldv, double *W2) {
+               double *rhs, double *Vb, int ldv, double *W2, double *W2s) {
     LSQ_HIP(hipStreamWaitEvent(c->stream, w->ev_lu, 0));
     const int ncols = ncolsB - 64;
     if (w->q1form) {
         LSQ_LAUNCH(k_cqr_tw_q1, dim3(std::max(1, (ncols + TQ_NC - 1) / TQ_NC) + 1), dim3(256), CQ_LDS_TW_Q1, c->stream, W, ncolsB,
                            (const double *)w->Binv, (const double *)w->S, (const double *)w->SR, (const double *)w->R2inv, A, M, c0, cend,
-                           n, rhs, W2);
+                           n, rhs, W2, W2s);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }

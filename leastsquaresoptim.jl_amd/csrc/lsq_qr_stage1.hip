@@ -491,11 +491,16 @@ k_qr1_vtb(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, 
 //   leave in 128-byte pieces.  Chunks of the next V3_D steps are in flight (register ring).  The four waves of a workgroup
 //   take neighbouring 32-column groups over the SAME rows, so that three of their four reads of V hit the CU's L1; workgroups
 //   of one k slice sit behind one L2 (slice = blockIdx % kslices).
+// SWZ (round 6, late): the full chunks of V come from its fragment-order copy Vs (lsq_cqr_vs_index, written by pass 1 of the Q1
+// form): eight loads of 1 KB contiguous per chunk instead of eight in which every lane reads 32 bytes of its own column -- a load
+// costs the MFMA stream about two clocks per (4-lane group, cache line) pair it touches, 64 against 16 here
+// (profiles/r06/ab_c3_vtb_overlap.txt, section 4).  The ragged last chunk still reads Vb.
 constexpr int V3_D = 3;
-template <int DBG>
+template <int DBG, bool SWZ = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_qr1_vtb_w(const double *__restrict__ Vb, int ldv, const double *__restrict__ A, int M, int c0, int cend, int n,
-            const double *__restrict__ rhs, int ncolsB, int kslices, double *__restrict__ Wp, int tile0) {
+            const double *__restrict__ rhs, int ncolsB, int kslices, double *__restrict__ Wp, int tile0,
+            const double *__restrict__ Vs = nullptr) {
     const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
     const int rows = M - c0;
     const int slice = blockIdx.x % kslices, cgrp = blockIdx.x / kslices;
@@ -520,6 +525,16 @@ k_qr1_vtb_w(const double *__restrict__ Vb, int ldv, const double *__restrict__ A
         for (int s = 0; s < 4; ++s) {
             af[0][s] = pa0[R + s];
             af[1][s] = pa1[R + s];
+        }
+        if (SWZ) {
+            const double *ps = Vs + lsq_cqr_vs_index(R >> 4, 0, 0, lane);        // (R is a multiple of 16: a chunk of the panel)
+#pragma unroll
+            for (int ih = 0; ih < 8; ++ih) {                                     // ih = 2 it + h
+                const double2 v = *reinterpret_cast<const double2 *>(ps + ih * 128);
+                bf[ih >> 1][2 * (ih & 1)] = v.x;
+                bf[ih >> 1][2 * (ih & 1) + 1] = v.y;
+            }
+            return;
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -852,7 +867,9 @@ constexpr int U3_DA = 4;                    // depth of the A2 ring
 // panel's CholeskyQR pass (what k_cqr_pass<0> would read back from memory one launch later: same values, same cq_slab_gram,
 // same bits) -- row group rg of this panel is slab rg - 1 of the next (its first 64 rows become rows of R).  The other
 // workgroups take columns jbeg..jend as before (the caller passes jbeg >= 64).
-template <int DBG, bool GRAM = false>     // DBG 0: the product; 1: no MFMAs (memory side alone); 2: no A2 traffic (MFMA side alone) -- timing experiments only
+// SWZ: W2 is read from its fragment-order copy (lsq_cqr_w2s_index: 1 KB contiguous per load instruction instead of 64 pieces of
+// 32 bytes -- the pieces cost the MFMA stream four times as many clocks, lsq_qr_cholqr.h); W2 then points at that copy.
+template <int DBG, bool GRAM = false, bool SWZ = false>     // DBG 0: the product; 1: no MFMAs (memory side alone); 2: no A2 traffic (MFMA side alone) -- timing experiments only
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int M, int c0, int cend, int n,
                double *__restrict__ rhs, int ncols /* n - cend + 1 */, const double *__restrict__ W2, int jbeg, int jend, int tpw,
@@ -928,6 +945,16 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
     }
     auto colptr = [&](int col) -> double * { return (col < ncolsA ? A + (size_t)(cend + col) * M : rhs) + c0; };
     auto fetch_w = [&](int t, double *wf) {
+        if (SWZ) {
+            const double *pw = W2 + (size_t)((jfirst + 32 * t) >> 4) * 1024 + (size_t)lane_o * 2;
+#pragma unroll
+            for (int gh = 0; gh < 8; ++gh) {          // gh = 2 g + h: k = 16 g + 4 kq + 2 h + (0, 1) = wf index 4 g + 2 h + (0, 1)
+                const double2 v = *reinterpret_cast<const double2 *>(pw + gh * 128);
+                wf[2 * gh] = v.x;
+                wf[2 * gh + 1] = v.y;
+            }
+            return;
+        }
         const int col = min(jfirst + 32 * t + ij, ncols - 1);
         const double *pw = W2 + (size_t)col * Q2_NB + 4 * kq;
 #pragma unroll
@@ -1063,7 +1090,8 @@ k_qr1_extract(const double *__restrict__ A, int M, int n, const double *__restri
 // those workgroups alone).
 static int qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int M, int c0, int cend, int n, double *rhs,
                            int ncols, const double *W2, bool *taken, int jbeg = 0, int jend = -1, bool beside_passes = false,
-                           double *gram_out = nullptr, double *gram_q = nullptr, unsigned *gram_cnt = nullptr) {
+                           double *gram_out = nullptr, double *gram_q = nullptr, unsigned *gram_cnt = nullptr,
+                           const double *W2s = nullptr /* W2 in fragment order too (lsq_cqr_w2s_index): the kernel reads that copy */) {
     const char *e = getenv("LSQ_QR_UPDATE_W");
     const int mode = e ? atoi(e) : 1;
     *taken = mode != 0;
@@ -1127,6 +1155,11 @@ static int qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     };
+    if (W2s && mode == 1) {
+        W2 = W2s;
+        if (gram_out) return go(k_qr1_update_w<0, true, true>);
+        return go(k_qr1_update_w<0, false, true>);
+    }
     if (gram_out) return go(k_qr1_update_w<0, true>);
     if (mode == 2) return go(k_qr1_update_w<1>);
     if (mode == 3) return go(k_qr1_update_w<2>);
@@ -1136,7 +1169,7 @@ static int qr1_update_wave(lsq_ctx *c, const double *Vb, int ldv, double *A, int
 static void qr2_free(void *p) {
     Qr2Work *q = (Qr2Work *)p;
     if (!q) return;
-    hipFree(q->Vb); hipFree(q->Vb2); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
+    hipFree(q->Vb); hipFree(q->Vb2); hipFree(q->Vs); hipFree(q->Vs2); hipFree(q->Wp); hipFree(q->W); hipFree(q->W2); hipFree(q->W2s); hipFree(q->R); hipFree(q->rhs2); hipFree(q->tau1);
     hipFree(q->vn); hipFree(q->colat); hipFree(q->ice); hipFree(q->lazy);
     hipFree(q->Xinv); hipFree(q->T2); hipFree(q->fro); hipFree(q->xslot); hipFree(q->bslot); hipFree(q->d_err); hipFree(q->Pn); hipFree(q->tsS[0]); hipFree(q->tsS[1]); hipFree(q->tsr[0]); hipFree(q->tsr[1]);
     if (q->h_fro) hipHostFree(q->h_fro);
@@ -1161,7 +1194,7 @@ static int qr1_vtb_slices(const lsq_ctx *c, const Qr2Work *q, int rows, int nt, 
 // V'[A2 | b] partials by the wave-private kernel (default; LSQ_QR_VTB_W=0: k_qr1_vtb; 2: timing experiment without MFMAs).
 // Returns the number of k slices written (for k_qr1_wreduce), or -1 if the launch failed.
 static int qr1_vtb_launch(lsq_ctx *c, Qr2Work *q, const double *Vb, int ldv, const double *A, int M, int c0, int cend, int n,
-                          const double *rhs, int ncolsB, int tile0) {
+                          const double *rhs, int ncolsB, int tile0, const double *Vs = nullptr /* V in fragment order too */) {
     const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB, rows = M - c0;
     const char *e = getenv("LSQ_QR_VTB_W");
     const int mode = e ? atoi(e) : 1;
@@ -1189,6 +1222,10 @@ static int qr1_vtb_launch(lsq_ctx *c, Qr2Work *q, const double *Vb, int ldv, con
     if (mode == 2) {
         if (lds > 48 * 1024 && lsq_set_lds(c, (const void *)k_qr1_vtb_w<1>, lds) != LSQ_OK) return -1;
         LSQ_LAUNCH(k_qr1_vtb_w<1>, dim3(ncgrp * ks), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp, tile0);
+    } else if (Vs) {
+        if (lds > 48 * 1024 && lsq_set_lds(c, (const void *)k_qr1_vtb_w<0, true>, lds) != LSQ_OK) return -1;
+        LSQ_LAUNCH((k_qr1_vtb_w<0, true>), dim3(ncgrp * ks), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp,
+                   tile0, Vs);
     } else {
         if (lds > 48 * 1024 && lsq_set_lds(c, (const void *)k_qr1_vtb_w<0>, lds) != LSQ_OK) return -1;
         LSQ_LAUNCH(k_qr1_vtb_w<0>, dim3(ncgrp * ks), dim3(256), lds, c->stream, Vb, ldv, A, M, c0, cend, n, rhs, ncolsB, ks, q->Wp, tile0);
@@ -1267,12 +1304,14 @@ static int qr2_workspace(lsq_solver *s, int M, int n) {
         const int ntile = (ncolsB + Q2_NB - 1) / Q2_NB;
         q->kslices = std::max(1, std::min(64, (4 * c->num_cus + ntile - 1) / ntile));   // (4 workgroups per CU: their barriers and LDS phases interleave)
         LSQ_HIP(hipMalloc(&q->Vb, ((size_t)M * Q2_NB + 64) * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->Vs, ((size_t)(M + 16) * Q2_NB + 64) * sizeof(double)));
         // split-K partials of V'[A2 | b]: room for the widest panel at q->kslices slices AND for the narrow last panels at many
         // more slices each (qr1_vtb_slices)
         q->wp_slots = std::max(q->kslices * ntile, 4 * c->num_cus + 2 * ntile + 256);
         LSQ_HIP(hipMalloc(&q->Wp, (size_t)q->wp_slots * Q2_NB * Q2_NB * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->W, (size_t)ntile * Q2_NB * Q2_NB * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->W2, (size_t)ntile * Q2_NB * Q2_NB * sizeof(double)));
+        LSQ_HIP(hipMalloc(&q->W2s, ((size_t)ntile * Q2_NB * Q2_NB + 1024) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->R, ((size_t)n * n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->rhs2, ((size_t)n + 8) * sizeof(double)));
         LSQ_HIP(hipMalloc(&q->tau1, ((size_t)n + 8) * sizeof(double)));
@@ -1324,6 +1363,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     // measured at C3 7.20 -> 7.06 ms, 18432 x 2048 8.94 -> 8.22; 4096 x 512 and 3000 x 700 lose 3-5 % with it
     const char *lmc = getenv("LSQ_QR_LOOKAHEAD_MINCOLS");
     const int la_min_cols = lmc ? atoi(lmc) : (la_auto ? 0 : 1024);
+    const bool swz_on = !getenv("LSQ_QR_NO_SWIZZLE");
     bool pre = false;                        // this panel was factored ahead (its Q is in vcur, ev_panel says when)
     // FUSED GRAM (round 6): the update of panel k forms the Gram partials of panel k + 1 (its first pass, k_cqr_pass<0>, is one
     // launch less on every panel's chain); only the wave-private update does it (mode 1, no timing experiment)
@@ -1334,6 +1374,7 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
     const bool hier_on = cq_ok && (!la_on || la_auto) && getenv("LSQ_QR_HIER") != nullptr;   // (panels not factored ahead)
     bool hier_ready = false;                 // the partials at hand came with their group sums
     double *vcur = q->Vb;
+    double *vscur = nullptr;                 // vcur's fragment-order copy (Q1 form), or null
     for (int c0 = 0; c0 < n; c0 += Q2_NB) {
         const int nb = std::min(Q2_NB, n - c0), cend = c0 + nb;
         if (cq_ok && nb == Q2_NB && M - c0 >= 256) {
@@ -1344,8 +1385,9 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             if (pre) LSQ_HIP(hipStreamWaitEvent(c->stream, q->cq.ev_panel, 0));
             else {
                 vcur = q->Vb;
+                vscur = swz_on && lsq_cqr_q1form() ? q->Vs : nullptr;
                 const bool hier = hier_on && lsq_cqr_hier((rows + CQ_RS - 1) / CQ_RS) && (!gram_ready || hier_ready);
-                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, vcur, ldv, q->d_err, c->stream, gram_ready, hier));
+                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c0, vcur, ldv, q->d_err, c->stream, gram_ready, hier, vscur));
             }
             pre = false;
             gram_ready = false;
@@ -1355,14 +1397,16 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             // (V'V, tile 0, is not formed: the basis-kernel form needs V'[A2 | b] only.  Measured and dropped in round 4: the sum
             //  over the k slices taken by k_cqr_tw itself instead of the k_qr1_wreduce launch -- 32 workgroups reading 1 MB of
             //  partials each take longer than the 10 us launch over 256: C3 7.83 against 7.60 ms, profiles/r04/ab_c3_tw.txt)
-            const int ks = qr1_vtb_launch(c, q, vcur, ldv, A, M, c0, cend, n, rhs, ncolsB, 1);
+            const int ks = qr1_vtb_launch(c, q, vcur, ldv, A, M, c0, cend, n, rhs, ncolsB, 1, vscur);
             if (ks < 0) { lsq_set_error("qr: the V'[A2 | b] launch failed"); return LSQ_EHIP; }
             {
                 long long tot = (long long)(ntile - 1) * Q2_NB * Q2_NB;
                 int g = (int)std::min<long long>((tot + 255) / 256, (long long)c->num_cus * 4);
                 LSQ_LAUNCH(k_qr1_wreduce, dim3(g), dim3(256), 0, c->stream, q->Wp, ncolsB, ks, q->W, 1);
             }
-            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, vcur, ldv, q->W2));
+            // (Q1 form: W2 also in the update's fragment order -- LSQ_QR_NO_SWIZZLE=1: round 5's loads, A/B)
+            const double *w2s = q->cq.q1form && swz_on ? q->W2s : nullptr;
+            LSQ_TRY(lsq_cqr_tw(c, &q->cq, q->W, ncolsB, A, M, c0, cend, n, rhs, vcur, ldv, q->W2, const_cast<double *>(w2s)));
             // is the next panel a CholeskyQR2 panel too, with enough other columns beside it?
             const int c1 = cend;
             const bool next_cq = n - c1 >= Q2_NB && M - c1 >= 256;       // the next panel is a CholeskyQR panel too
@@ -1371,15 +1415,21 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
             if (ahead) {
                 if (!q->Vb2) LSQ_HIP(hipMalloc(&q->Vb2, ((size_t)q->M * Q2_NB + 64) * sizeof(double)));
                 double *vnext = vcur == q->Vb ? q->Vb2 : q->Vb;
+                double *vsnext = nullptr;
+                if (swz_on && lsq_cqr_q1form()) {
+                    if (!q->Vs2) LSQ_HIP(hipMalloc(&q->Vs2, ((size_t)(q->M + 16) * Q2_NB + 64) * sizeof(double)));
+                    vsnext = vnext == q->Vb ? q->Vs : q->Vs2;
+                }
                 bool tk = false;
-                if (gram_out) LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, Q2_NB, false, gram_out));
-                else LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, 0, Q2_NB));
+                if (gram_out) LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, Q2_NB, false, gram_out, nullptr, nullptr, w2s));
+                else LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, 0, Q2_NB, false, nullptr, nullptr, nullptr, w2s));
                 LSQ_HIP(hipEventRecord(q->cq.ev_first, c->stream));
                 LSQ_HIP(hipStreamWaitEvent(q->cq.ahead, q->cq.ev_first, 0));
-                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c1, vnext, M - c1, q->d_err, q->cq.ahead, gram_out != nullptr));
+                LSQ_TRY(lsq_cqr_panel(c, &q->cq, A, M, c1, vnext, M - c1, q->d_err, q->cq.ahead, gram_out != nullptr, false, vsnext));
                 LSQ_HIP(hipEventRecord(q->cq.ev_panel, q->cq.ahead));
-                LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, ncols, true));
+                LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, ncols, true, nullptr, nullptr, nullptr, w2s));
                 vcur = vnext;
+                vscur = vsnext;
                 pre = true;
             } else {
                 const int nrt = (rows + Q2_NB - 1) / Q2_NB, nct = (ncols + Q2_NB - 1) / Q2_NB;
@@ -1387,11 +1437,11 @@ static int qr2_factor_core(lsq_solver *s, double *A, double *rhs, int M, int n, 
                 if (gram_out) {
                     const bool hn = hier_on && lsq_cqr_hier((M - c1 + CQ_RS - 1) / CQ_RS);      // (the NEXT panel's slabs)
                     LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, Q2_NB, ncols, false, gram_out,
-                                            hn ? q->cq.Gq1 : nullptr, hn ? q->cq.gcnt : nullptr));
+                                            hn ? q->cq.Gq1 : nullptr, hn ? q->cq.gcnt : nullptr, w2s));
                     gram_ready = true;
                     hier_ready = hn;
                 } else
-                LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk));
+                LSQ_TRY(qr1_update_wave(c, vcur, ldv, A, M, c0, cend, n, rhs, ncols, q->W2, &tk, 0, -1, false, nullptr, nullptr, nullptr, w2s));
                 if (!tk)
                 LSQ_LAUNCH(k_qr1_update, dim3(nrt * ((nct + Q2_UCT - 1) / Q2_UCT)), dim3(256), 0, c->stream, vcur, ldv, A, M,
                                    c0, cend, n, rhs, ncols, q->W2);

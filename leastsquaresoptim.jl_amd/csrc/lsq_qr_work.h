@@ -23,7 +23,7 @@ __device__ __forceinline__ double blk_sum_qr(double v, double *sh) {
 }
 
 struct Qr2Work {
-    double *Vb = nullptr, *Vb2 = nullptr /* look-ahead: the next panel's Q */, *Wp = nullptr, *W = nullptr, *W2 = nullptr, *R = nullptr, *rhs2 = nullptr, *tau1 = nullptr;
+    double *Vb = nullptr, *Vb2 = nullptr /* look-ahead: the next panel's Q */, *Vs = nullptr, *Vs2 = nullptr /* Vb / Vb2 in V'B's fragment order (lsq_cqr_vs_index) */, *Wp = nullptr, *W = nullptr, *W2 = nullptr, *W2s = nullptr /* W2 in the update's fragment order (lsq_cqr_w2s_index) */, *R = nullptr, *rhs2 = nullptr, *tau1 = nullptr;
     double *vn = nullptr;     // stage 2: vn1/vn2 double-buffered (4n)
     double *ice = nullptr;    // stage 2: condition-estimate vectors + scalars (2n + 8)
     double *lazy = nullptr;   // stage 1, lazy reflectors: beta[n] | scale[n]

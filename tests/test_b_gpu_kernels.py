@@ -553,6 +553,7 @@ def test_qr_wave_private_kernels_and_lookahead(ctx, m, n, monkeypatch):
               "q1_group_sums": {"LSQ_QR_HIER": "1"},
               "update_grid_per_row_group": {"LSQ_QR_UPDATE_FLAT": "0"},
               "update_two_runs_per_cu": {"LSQ_QR_UPDATE_FLAT": "2"},
+              "operands_in_matrix_order": {"LSQ_QR_NO_SWIZZLE": "1"},
               "three_pass": {"LSQ_QR_CQR_PASS2": "1", "LSQ_QR_LOOKAHEAD": "0"},
               "three_pass_lookahead_everywhere": dict(LA, LSQ_QR_CQR_PASS2="1"),
               "lds_update": {"LSQ_QR_UPDATE_W": "0"},
@@ -584,7 +585,9 @@ def test_qr_wave_private_kernels_and_lookahead(ctx, m, n, monkeypatch):
     # pass 1 multiplies by the explicit inverse that one workgroup formed instead of substituting: agreement to 1e-11, above.)
     pairs = [("q1_no_fused_gram", "default"), ("q1_no_vtb_lds", "default"),
              # (which workgroup takes a tile changes nothing about the tile)
-             ("update_grid_per_row_group", "default"), ("update_two_runs_per_cu", "default")]
+             ("update_grid_per_row_group", "default"), ("update_two_runs_per_cu", "default"),
+             # (W2 and Q1 read from their fragment-order copies or from the matrices themselves: the same numbers)
+             ("operands_in_matrix_order", "default")]
     tall = m - 64 > 256 * 64
     if m + n - 64 <= 256 * 64:
         pairs.append(("default", "no_lookahead"))
