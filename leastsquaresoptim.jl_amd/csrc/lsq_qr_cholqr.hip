@@ -47,6 +47,9 @@ __device__ unsigned long long cq_tbuf[64];
 #else
 #define CQ_T(k) do { } while (0)
 #endif
+#ifndef CQ_NO_FIRST_ORDER
+#define CQ_NO_FIRST_ORDER 0                // (A/B builds: -DCQ_NO_FIRST_ORDER=1 keeps the second-order expansion for every panel)
+#endif
 constexpr int CQ_FAIL = 2;                 // bit of the solver's error word (bit 0: an in-kernel exchange timed out)
 
 // 64 x 64 row-major matrix in global memory -> LDS image (stride S64_LS): all 16 loads of a thread in flight at once
@@ -76,7 +79,7 @@ __device__ __forceinline__ void cq_factor(const double *__restrict__ G, double *
     double g[16];
     cq_gram_entries(G, ngroups, g, tid);                          // entry e = tid + 256 q: row e >> 6, column e & 63
     *bad = 0;
-    bool series = false;
+    bool series = false, first_order = false;
     if (PASS == 2) {
         double acc = 0.0;
 #pragma unroll
@@ -92,8 +95,22 @@ __device__ __forceinline__ void cq_factor(const double *__restrict__ G, double *
         const double fro2 = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
         if (!(fro2 <= 0.25)) *bad = 1;                                 // (NaN lands here too)
         series = fro2 <= 1e-10;
+        first_order = fro2 <= 1e-22 && !CQ_NO_FIRST_ORDER;
     }
-    if (series) {
+    if (series && first_order) {
+        // ||E||_F <= 1e-11 (the usual case: Q1 of a well-conditioned panel is orthonormal to a few ulps): the second-order terms
+        // X1'X1 and X2 X2 are below 1e-22 beside entries of size 1 -- R2 = I + Phi(E), inv(R2) = I - Phi(E) to the last bit
+        // that matters, and two 64^3 products + three barriers leave k_cqr_top's chain (round 6, late: that chain decides most
+        // panels since V'B reads its operands in fragment order)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            const double x = r < c ? g[q] : (r == c ? 0.5 * (g[q] - 1.0) : 0.0), d = r == c ? 1.0 : 0.0;
+            M2[r * S64_LS + c] = d - x;
+            M1[r * S64_LS + c] = d + x;
+        }
+        __syncthreads();
+    } else if (series) {
         // X1 = Phi(E);  X2 = X1 - Phi(X1'X1);  inv(R2) = I - X2 + X2 X2;  R2 = I + X2      (Phi: strict upper + half diagonal)
         double x[16];
 #pragma unroll
