@@ -862,6 +862,7 @@ k_qr1_update(const double *__restrict__ Vb, int ldv, double *__restrict__ A, int
 //   lane (ij = lane & 15, kq = lane >> 4), step s: k = 16 (s >> 2) + 4 kq + (s & 3)
 //   a operand  W2[col jj + ij][k]      b operand  V[row r0 + 16 b + ij][k]      D'[col jj + kq + 4 r][row r0 + 16 b + ij]
 constexpr int U3_DA = 4;                    // depth of the A2 ring
+typedef double u3_d2 __attribute__((ext_vector_type(2), aligned(8)));     // two adjacent rows of a column (8-byte aligned: M may be odd)
 // GRAM (round 6): the launch carries nrg extra workgroups AT ITS FRONT that update the NEXT panel's 64 columns (trailing columns
 // 0..63, whatever jbeg says) and, with the updated 64 x 64 block still at hand, form the Gram partial of that slab for the next
 // panel's CholeskyQR pass (what k_cqr_pass<0> would read back from memory one launch later: same values, same cq_slab_gram,
@@ -924,7 +925,11 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
     const int rbase = rg * Q2_NB;
     const int r0 = rbase + 32 * (w >> 1);
     const bool rfull = r0 + 32 <= rows;
-    const int row0 = r0 + ij, row1 = r0 + 16 + ij;
+    // (round 6, late) the wave's two 16-row MFMA tiles are the EVEN and the ODD rows of its 32: lane ij holds rows r0 + 2 ij and
+    // r0 + 2 ij + 1, adjacent in memory, so V and A2 travel as 16-byte pieces -- half the load / store instructions, each still
+    // one cache line per 4-lane group (a load or store costs the MFMA stream ~2 clocks per (lane group, line) pair).  Which
+    // physical row an MFMA row is changes nothing about an element's dot product: same bits as rows r0 + ij / r0 + 16 + ij.
+    const int row0 = r0 + 2 * ij, row1 = row0 + 1;
     const bool in0 = row0 < rows, in1 = row1 < rows;
     // tiles of this wave: jfirst + 32 t, t = 0 .. nt - 1 (the two waves of a row half take alternate 16-column tiles)
     const int jfirst = jbeg + 32 * p0 + 16 * (w & 1);
@@ -934,6 +939,16 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
     const int nt = (jstop - jfirst + 31) >> 5;
     double v0[16], v1[16];                              // the wave's V fragment: 32 rows x 64, for all its tiles
     {
+        if (rfull) {
+            const double *pv2 = Vb + row0;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const size_t k = 16 * (s >> 2) + 4 * kq + (s & 3);
+                const u3_d2 x = *reinterpret_cast<const u3_d2 *>(pv2 + k * ldv);
+                v0[s] = x[0];
+                v1[s] = x[1];
+            }
+        } else {
         const double *p0v = Vb + (in0 ? row0 : 0), *p1v = Vb + (in1 ? row1 : 0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -941,6 +956,7 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
             const double x0 = p0v[k * ldv], x1 = p1v[k * ldv];
             v0[s] = in0 ? x0 : 0.0;
             v1[s] = in1 ? x1 : 0.0;
+        }
         }
     }
     auto colptr = [&](int col) -> double * { return (col < ncolsA ? A + (size_t)(cend + col) * M : rhs) + c0; };
@@ -971,8 +987,9 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
             const double *pa = A + (size_t)(cend + jj + kq) * M + c0 + row0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                at[r] = pa[(size_t)4 * r * M];
-                at[4 + r] = pa[(size_t)4 * r * M + 16];
+                const u3_d2 x = *reinterpret_cast<const u3_d2 *>(pa + (size_t)4 * r * M);
+                at[r] = x[0];
+                at[4 + r] = x[1];
             }
         } else {
 #pragma unroll
@@ -1007,12 +1024,14 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double n0 = at[r] - (c00[r] + c01[r]), n1 = at[4 + r] - (c10[r] + c11[r]);
-                pa[(size_t)4 * r * M] = n0;
-                pa[(size_t)4 * r * M + 16] = n1;
+                u3_d2 y;
+                y[0] = n0;
+                y[1] = n1;
+                *reinterpret_cast<u3_d2 *>(pa + (size_t)4 * r * M) = y;
                 if (GRAM && narrow) {       // (column jj + kq + 4 r of the next panel, rows of this slab)
-                    double *qs = u3_qs + (jj + kq + 4 * r) * CQ_QST + 32 * (w >> 1) + ij;
+                    double *qs = u3_qs + (jj + kq + 4 * r) * CQ_QST + 32 * (w >> 1) + 2 * ij;
                     qs[0] = n0;
-                    qs[16] = n1;
+                    qs[1] = n1;
                 }
             }
         } else {
@@ -1025,9 +1044,9 @@ k_qr1_update_w(const double *__restrict__ Vb, int ldv, double *__restrict__ A, i
                     if (in0) pc[row0] = n0;
                     if (in1) pc[row1] = n1;
                     if (GRAM && narrow && col < Q2_NB) {
-                        double *qs = u3_qs + col * CQ_QST + 32 * (w >> 1) + ij;
+                        double *qs = u3_qs + col * CQ_QST + 32 * (w >> 1) + 2 * ij;
                         if (in0) qs[0] = n0;
-                        if (in1) qs[16] = n1;
+                        if (in1) qs[1] = n1;
                     }
                 }
             }
